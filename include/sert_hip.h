@@ -1,0 +1,200 @@
+/*
+ * sert_hip.h -- C ABI of libsert_hip.so, the MI355X (gfx950) execution engine
+ * behind the sert.models / sert.inference Python surface.
+ *
+ * The reference (cvangysel/SERT) has no FFI: its hot path is the body of four
+ * compiled Theano functions created in sert/models.py:530-608 (train_fn,
+ * test_fn, validate_fn, predict_fn).  Each entry point below replaces one of
+ * those functions or one Theano primitive they rely on; the file:line it
+ * replaces is cited next to it.  The Python host (sert_amd/models.py) binds
+ * these with ctypes; INTEGRATION.md shows the stub a SERT maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; the message is
+ *     available from sert_last_error() (thread-local, valid until the next call)
+ *   - plain pointers and sizes only; host pointers are borrowed for the
+ *     duration of the call; device memory is owned by the sert_model handle
+ *   - one handle = one model replica on one HIP device with one HIP stream;
+ *     a handle is not thread-safe
+ *   - all floating point data is IEEE fp32 (floatX=float32, product-search.sh:95)
+ */
+#ifndef SERT_HIP_H
+#define SERT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sert_model sert_model;
+
+/* model kind: bin/train.py:21-24 */
+enum {
+    SERT_KIND_LOGLINEAR = 0,   /* sert.models.LanguageModel            (models.py:804) */
+    SERT_KIND_VECTORSPACE = 1  /* sert.models.VectorSpaceLanguageModel (models.py:1024) */
+};
+
+/* data split: ModelBase.TRAIN / VALIDATE givens (models.py:482-522) */
+enum { SERT_SPLIT_TRAIN = 0, SERT_SPLIT_VALIDATE = 1 };
+
+/* tensors addressable through sert_get_tensor / sert_set_tensor */
+enum {
+    SERT_T_RW = 0,      /* word representations   (V_w, d_w)  models.py:167-171 */
+    SERT_T_RE = 1,      /* entity representations (V_e, d_e)  models.py:940     */
+    SERT_T_W = 2,       /* dense weights: VS (d_w, d_e) models.py:1057; LL (d_w, V_e) :846 */
+    SERT_T_B = 3,       /* dense bias:    VS (d_e);  LL (V_e)                    */
+    /* optimiser state, same shapes: Adam m / Adadelta accu  = STATE0,
+     *                               Adam v / Adadelta delta = STATE1 */
+    SERT_T_STATE0_RW = 4, SERT_T_STATE0_RE = 5, SERT_T_STATE0_W = 6, SERT_T_STATE0_B = 7,
+    SERT_T_STATE1_RW = 8, SERT_T_STATE1_RE = 9, SERT_T_STATE1_W = 10, SERT_T_STATE1_B = 11,
+    /* last-step gradients (data term + L2 term), only kept when cfg.keep_grads */
+    SERT_T_GRAD_RW = 12, SERT_T_GRAD_RE = 13, SERT_T_GRAD_W = 14, SERT_T_GRAD_B = 15,
+    /* last-step activations (debug / parity): */
+    SERT_T_ACT_H = 16,   /* VS mean-pooled window (B, d_w)      models.py:226  */
+    SERT_T_ACT_T = 17,   /* VS tanh(hW+b)         (B, d_e)      models.py:1057 */
+    SERT_T_ACT_DA = 18,  /* VS dL/d(hW+b)         (B, d_e)                     */
+    SERT_T_ACT_DH = 19,  /* VS dL/dh              (B, d_w)                     */
+    SERT_T_ACT_ROWLOSS = 20 /* per-instance loss  (B,)          models.py:1098, :292 */
+};
+
+typedef struct sert_config {
+    uint32_t struct_size;     /* = sizeof(sert_config), checked */
+    int32_t kind;             /* SERT_KIND_* */
+    int32_t batch_size;       /* rows this replica processes per step (B_local) */
+    int32_t global_batch_size;/* B of the model: divisor of the loss mean and of the
+                                 L2 term lambda/(2B) (models.py:281-282, :773-791).
+                                 == batch_size unless data-parallel */
+    int32_t window_size;      /* n,   models.py:697 */
+    int32_t vocab_size;       /* V_w, models.py:701 */
+    int32_t num_entities;     /* V_e, models.py:924 / output_layer_size :809 */
+    int32_t word_dim;         /* d_w, models.py:702 */
+    int32_t entity_dim;       /* d_e, models.py:925 (vectorspace only) */
+    int32_t num_negatives;    /* z,   models.py:961 (vectorspace only) */
+    int32_t id_bytes;         /* width of token ids in x: 1, 2 or 4
+                                 (np.min_scalar_type, bin/prepare.py:380) */
+    int32_t device;           /* HIP device ordinal */
+    int32_t keep_grads;       /* keep SERT_T_GRAD_* readable after a step (debug) */
+    int32_t deterministic;    /* 1: order-fixed reductions everywhere */
+    float lambda_;            /* regularization_lambda, models.py:704 */
+    /* optimiser hyper-parameters.  vectorspace: Adam (models.py:922)
+     * lr, beta1, beta2, eps.  loglinear: Adadelta (models.py:820) lr, rho(beta1), eps. */
+    float lr, beta1, beta2, eps;
+    uint64_t seed;            /* device negative sampler (replaces RandomStreams
+                                 seeding, models.py:958-959) */
+} sert_config;
+
+/* ---- lifetime ----------------------------------------------------------- */
+
+/* Replaces model construction + theano.function compilation
+ * (models.py:422-480, :530-608). Allocates parameters (zero), optimiser state,
+ * gradient and activation buffers on cfg->device. */
+int sert_create(const sert_config* cfg, sert_model** out);
+int sert_destroy(sert_model* m);
+
+const char* sert_last_error(void);
+
+/* Human-readable device description ("gfx950 ... 256 CUs ..."); returns the
+ * number of bytes written (excluding NUL) or <0 on error. */
+int sert_device_info(int device, char* buf, size_t buflen);
+/* Number of visible HIP devices, <0 on error. */
+int sert_device_count(void);
+
+/* ---- parameters and state ---------------------------------------------- */
+
+/* theano.shared(...).set_value / get_value (models.py:183, :328-330, :945).
+ * `count` must equal the tensor's element count. */
+int sert_set_tensor(sert_model* m, int which, const float* host, size_t count);
+int sert_get_tensor(sert_model* m, int which, float* host, size_t count);
+/* element count of a tensor (0 if not present for this model kind) */
+size_t sert_tensor_size(sert_model* m, int which);
+
+/* Adam's shared step counter t (Lasagne adam t_prev); resume support. */
+int sert_set_step(sert_model* m, int64_t t);
+int64_t sert_get_step(sert_model* m);
+
+/* ---- data set ---------------------------------------------------------- */
+
+/* Replaces theano.shared(x/y/w) of the whole data set (models.py:470-480):
+ * one H2D upload, batches are then slices [i*B, (i+1)*B) (models.py:322-326).
+ *   x        (N, n) token ids, id_bytes wide, row-major
+ *   y_int    (N,) int32 labels, or NULL when the labels are CSR
+ *   csr_*    CSR label matrix (N, V_e) f32 (loglinear without --one_hot_classes,
+ *            models.py:66-89 densifies it per batch); NULL when y_int given
+ *   w        (N,) f32 instance weights, NULL = all ones (train split only)
+ * In data-parallel mode every rank uploads the rows it owns of every global
+ * batch (see sert_amd/distributed.py). */
+int sert_upload_dataset(sert_model* m, int split, const void* x, const int32_t* y_int,
+                        const int64_t* csr_indptr, const int32_t* csr_indices,
+                        const float* csr_data, const float* w, int64_t num_instances);
+
+/* ---- the hot path ------------------------------------------------------- */
+
+/* train_fn(batch_index) (models.py:581-588): forward, backward, L2, optimiser
+ * update on rows [batch_index*B, (batch_index+1)*B) of the train split.
+ * *loss_out receives the training loss evaluated BEFORE the update.
+ *   negatives  (B, z) int64 entity ids (vectorspace; models.py:970-973) or NULL
+ *              to let the device sampler draw them (iid uniform, with
+ *              replacement, keyed by (seed, step, global row, j)).
+ * With a communicator attached (sert_comm_init) the gradients are summed over
+ * ranks before the (replicated) update, and *loss_out is the global loss. */
+int sert_train_batch(sert_model* m, int64_t batch_index, const int64_t* negatives,
+                     float* loss_out);
+
+/* Same, for `count` batches back to back with no host synchronisation in
+ * between (device sampler only).  losses_out[count]. */
+int sert_train_batches(sert_model* m, const int64_t* batch_indices, int64_t count,
+                       float* losses_out);
+
+/* test_fn / validate_fn (models.py:593-608): unweighted, unregularised mean
+ * loss of one batch of `split`; no parameter change. */
+int sert_eval_batch(sert_model* m, int split, int64_t batch_index,
+                    const int64_t* negatives, float* loss_out);
+
+/* vectorspace predict_fn (models.py:1107-1118), batched over Q queries:
+ * out[q] = tanh(avg[q] . W + b)   (no clip).  avg (Q, d_w), out (Q, d_e). */
+int sert_predict_project(sert_model* m, const float* avg, int64_t num_queries, float* out);
+
+/* loglinear predict_fn (models.py:880-890): ids (rows, n) -> per-token
+ * distributions out (rows, n, V_e).  rows need not equal batch_size. */
+int sert_predict_tokens(sert_model* m, const void* ids, int64_t rows, float* out);
+
+/* ---- entity scoring (bin/query.py:239-370, batched) --------------------- */
+
+/* For each of Q query projections: L2-normalise it (query.py:333-336), score
+ * every entity with (cos + 1)/2 against the L2-normalised entity table
+ * (query.py:270-274, :352-357) and return the k best, sorted by score
+ * descending, ties by lowest entity index.
+ *   entities (V_e, d) f32 host (un-normalised), proj (Q, d) f32 host
+ *   idx_out (Q, k) int32, score_out (Q, k) f32 */
+int sert_score_topk(int device, const float* entities, int64_t num_entities, int32_t dim,
+                    const float* proj, int64_t num_queries, int32_t k,
+                    int32_t* idx_out, float* score_out);
+
+/* ---- data parallel (new: the reference is single-device) ---- */
+
+#define SERT_COMM_ID_BYTES 128
+/* ncclGetUniqueId; rank 0 calls it and ships the bytes to the other ranks. */
+int sert_comm_unique_id(char id[SERT_COMM_ID_BYTES]);
+/* ncclCommInitRank on this handle's device/stream. */
+int sert_comm_init(sert_model* m, const char id[SERT_COMM_ID_BYTES], int rank, int world);
+int sert_comm_destroy(sert_model* m);
+
+/* ---- diagnostics -------------------------------------------------------- */
+
+/* hipStreamSynchronize on the handle's stream. */
+int sert_synchronize(sert_model* m);
+/* Average duration in microseconds of the named kernel group over the steps
+ * since the last sert_timing_reset (HIP events on the handle's stream).
+ * Enabled with sert_timing_enable(m, 1).  Groups: see sert_timing_names(). */
+int sert_timing_enable(sert_model* m, int on);
+int sert_timing_reset(sert_model* m);
+int sert_timing_count(sert_model* m);
+const char* sert_timing_name(sert_model* m, int i);
+double sert_timing_avg_us(sert_model* m, int i);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SERT_HIP_H */

@@ -1,0 +1,44 @@
+"""Build recipe for libsert_hip.so (hipcc, gfx950 only, in-tree)."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB = os.path.join(HERE, 'libsert_hip.so')
+INCLUDE = os.path.join(os.path.dirname(HERE), 'include')
+
+SOURCES = ['sert_hip.hip']
+HEADERS = ['common.h', 'gemm.h', 'kernels_vs.h', 'kernels_ll.h', 'kernels_opt.h',
+           'kernels_score.h', 'model.h']
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    deps.append(os.path.join(INCLUDE, 'sert_hip.h'))
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source for gfx950 into sert_amd/libsert_hip.so."""
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    if not os.path.exists(hipcc):
+        if os.path.exists(LIB):
+            return LIB  # GPU box without a toolchain: use the prebuilt library
+        raise RuntimeError('hipcc not found and no prebuilt libsert_hip.so')
+    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
+           '-munsafe-fp-atomics', '-I' + INCLUDE]
+    cmd += [os.path.join(CSRC, s) for s in SOURCES]
+    cmd += ['-o', LIB, '-ldl']
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force=True, verbose=True))

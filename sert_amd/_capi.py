@@ -1,0 +1,295 @@
+"""ctypes binding of include/sert_hip.h (libsert_hip.so).
+
+There is deliberately no fallback: if the HIP library is missing or a call
+fails, an exception is raised.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libsert_hip.so')
+
+KIND_LOGLINEAR, KIND_VECTORSPACE = 0, 1
+SPLIT_TRAIN, SPLIT_VALIDATE = 0, 1
+
+T_RW, T_RE, T_W, T_B = 0, 1, 2, 3
+T_STATE0_RW, T_STATE0_RE, T_STATE0_W, T_STATE0_B = 4, 5, 6, 7
+T_STATE1_RW, T_STATE1_RE, T_STATE1_W, T_STATE1_B = 8, 9, 10, 11
+T_GRAD_RW, T_GRAD_RE, T_GRAD_W, T_GRAD_B = 12, 13, 14, 15
+T_ACT_H, T_ACT_T, T_ACT_DA, T_ACT_DH, T_ACT_ROWLOSS = 16, 17, 18, 19, 20
+
+COMM_ID_BYTES = 128
+
+# every symbol include/sert_hip.h declares
+EXPORTS = [
+    'sert_create', 'sert_destroy', 'sert_last_error', 'sert_device_info', 'sert_device_count',
+    'sert_set_tensor', 'sert_get_tensor', 'sert_tensor_size', 'sert_set_step', 'sert_get_step',
+    'sert_upload_dataset', 'sert_train_batch', 'sert_train_batches', 'sert_eval_batch',
+    'sert_predict_project', 'sert_predict_tokens', 'sert_score_topk',
+    'sert_comm_unique_id', 'sert_comm_init', 'sert_comm_destroy',
+    'sert_synchronize', 'sert_timing_enable', 'sert_timing_reset', 'sert_timing_count',
+    'sert_timing_name', 'sert_timing_avg_us',
+]
+
+
+class SertConfig(ctypes.Structure):
+    _fields_ = [
+        ('struct_size', ctypes.c_uint32),
+        ('kind', ctypes.c_int32),
+        ('batch_size', ctypes.c_int32),
+        ('global_batch_size', ctypes.c_int32),
+        ('window_size', ctypes.c_int32),
+        ('vocab_size', ctypes.c_int32),
+        ('num_entities', ctypes.c_int32),
+        ('word_dim', ctypes.c_int32),
+        ('entity_dim', ctypes.c_int32),
+        ('num_negatives', ctypes.c_int32),
+        ('id_bytes', ctypes.c_int32),
+        ('device', ctypes.c_int32),
+        ('keep_grads', ctypes.c_int32),
+        ('deterministic', ctypes.c_int32),
+        ('lambda_', ctypes.c_float),
+        ('lr', ctypes.c_float),
+        ('beta1', ctypes.c_float),
+        ('beta2', ctypes.c_float),
+        ('eps', ctypes.c_float),
+        ('seed', ctypes.c_uint64),
+    ]
+
+
+class SertError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libsert_hip.so (once) and declare the signatures."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SertError(
+            'libsert_hip.so not found at %s; build it with '
+            '`python -m sert_amd._build` (hipcc --offload-arch=gfx950). '
+            'There is no CPU fallback.' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64, sz = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t
+    fp = ctypes.c_void_p  # host float*/int* passed as raw addresses
+    lib.sert_create.argtypes = [ctypes.POINTER(SertConfig), ctypes.POINTER(vp)]
+    lib.sert_destroy.argtypes = [vp]
+    lib.sert_last_error.restype = ctypes.c_char_p
+    lib.sert_device_info.argtypes = [ctypes.c_int, ctypes.c_char_p, sz]
+    lib.sert_device_count.argtypes = []
+    lib.sert_set_tensor.argtypes = [vp, ctypes.c_int, fp, sz]
+    lib.sert_get_tensor.argtypes = [vp, ctypes.c_int, fp, sz]
+    lib.sert_tensor_size.argtypes = [vp, ctypes.c_int]
+    lib.sert_tensor_size.restype = sz
+    lib.sert_set_step.argtypes = [vp, i64]
+    lib.sert_get_step.argtypes = [vp]
+    lib.sert_get_step.restype = i64
+    lib.sert_upload_dataset.argtypes = [vp, ctypes.c_int, fp, fp, fp, fp, fp, fp, i64]
+    lib.sert_train_batch.argtypes = [vp, i64, fp, ctypes.POINTER(ctypes.c_float)]
+    lib.sert_train_batches.argtypes = [vp, fp, i64, fp]
+    lib.sert_eval_batch.argtypes = [vp, ctypes.c_int, i64, fp, ctypes.POINTER(ctypes.c_float)]
+    lib.sert_predict_project.argtypes = [vp, fp, i64, fp]
+    lib.sert_predict_tokens.argtypes = [vp, fp, i64, fp]
+    lib.sert_score_topk.argtypes = [ctypes.c_int, fp, i64, i32, fp, i64, i32, fp, fp]
+    lib.sert_comm_unique_id.argtypes = [ctypes.c_char_p]
+    lib.sert_comm_init.argtypes = [vp, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
+    lib.sert_comm_destroy.argtypes = [vp]
+    lib.sert_synchronize.argtypes = [vp]
+    lib.sert_timing_enable.argtypes = [vp, ctypes.c_int]
+    lib.sert_timing_reset.argtypes = [vp]
+    lib.sert_timing_count.argtypes = [vp]
+    lib.sert_timing_name.argtypes = [vp, ctypes.c_int]
+    lib.sert_timing_name.restype = ctypes.c_char_p
+    lib.sert_timing_avg_us.argtypes = [vp, ctypes.c_int]
+    lib.sert_timing_avg_us.restype = ctypes.c_double
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise SertError(load().sert_last_error().decode('utf-8', 'replace'))
+
+
+def _addr(a):
+    return None if a is None else a.ctypes.data
+
+
+def device_count():
+    return load().sert_device_count()
+
+
+def device_info(device=0):
+    buf = ctypes.create_string_buffer(512)
+    n = load().sert_device_info(device, buf, 512)
+    if n < 0:
+        raise SertError(load().sert_last_error().decode())
+    return buf.value.decode()
+
+
+def require_gpu():
+    """Raise unless a HIP device is visible (the product has no CPU path)."""
+    n = device_count()
+    if n is None or n <= 0:
+        raise SertError('no HIP device visible: sert_amd runs on MI355X (gfx950) only; '
+                        'there is no CPU fallback.')
+    return n
+
+
+class Engine(object):
+    """Thin owner of one sert_model handle."""
+
+    def __init__(self, **cfg):
+        lib = load()
+        c = SertConfig()
+        c.struct_size = ctypes.sizeof(SertConfig)
+        for k, v in cfg.items():
+            if not hasattr(c, k):
+                raise TypeError('unknown sert_config field %r' % k)
+            setattr(c, k, v)
+        self.cfg = c
+        self._h = ctypes.c_void_p()
+        self._lib = lib
+        check(lib.sert_create(ctypes.byref(c), ctypes.byref(self._h)))
+
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h:
+            self._lib.sert_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # tensors
+    def tensor_size(self, which):
+        return int(self._lib.sert_tensor_size(self._h, which))
+
+    def set_tensor(self, which, array):
+        a = np.ascontiguousarray(array, dtype=np.float32)
+        check(self._lib.sert_set_tensor(self._h, which, a.ctypes.data, a.size))
+
+    def get_tensor(self, which, shape=None, out=None):
+        n = self.tensor_size(which)
+        if out is None:
+            out = np.empty(n, dtype=np.float32)
+        assert out.dtype == np.float32 and out.size == n and out.flags['C_CONTIGUOUS']
+        check(self._lib.sert_get_tensor(self._h, which, out.ctypes.data, n))
+        return out.reshape(shape) if shape is not None else out
+
+    def set_step(self, t):
+        check(self._lib.sert_set_step(self._h, int(t)))
+
+    def get_step(self):
+        return int(self._lib.sert_get_step(self._h))
+
+    # data
+    def upload_dataset(self, split, x, y_int=None, csr=None, w=None):
+        x = np.ascontiguousarray(x)
+        n = x.shape[0]
+        keep = [x]
+        y_addr = ip = ix = da = None
+        if y_int is not None:
+            y_int = np.ascontiguousarray(y_int, dtype=np.int32)
+            keep.append(y_int)
+            y_addr = y_int.ctypes.data
+        if csr is not None:
+            indptr = np.ascontiguousarray(csr.indptr, dtype=np.int64)
+            indices = np.ascontiguousarray(csr.indices, dtype=np.int32)
+            data = np.ascontiguousarray(csr.data, dtype=np.float32)
+            keep += [indptr, indices, data]
+            ip, ix, da = indptr.ctypes.data, indices.ctypes.data, data.ctypes.data
+        w_addr = None
+        if w is not None:
+            w = np.ascontiguousarray(w, dtype=np.float32)
+            keep.append(w)
+            w_addr = w.ctypes.data
+        check(self._lib.sert_upload_dataset(self._h, split, x.ctypes.data if n else None,
+                                            y_addr, ip, ix, da, w_addr, n))
+        del keep
+
+    # hot path
+    def train_batch(self, batch_index, negatives=None):
+        loss = ctypes.c_float()
+        if negatives is not None:
+            negatives = np.ascontiguousarray(negatives, dtype=np.int64)
+        check(self._lib.sert_train_batch(self._h, int(batch_index), _addr(negatives),
+                                         ctypes.byref(loss)))
+        return np.float32(loss.value)
+
+    def train_batches(self, batch_indices):
+        idx = np.ascontiguousarray(batch_indices, dtype=np.int64)
+        out = np.empty(idx.size, dtype=np.float32)
+        check(self._lib.sert_train_batches(self._h, idx.ctypes.data, idx.size, out.ctypes.data))
+        return out
+
+    def eval_batch(self, split, batch_index, negatives=None):
+        loss = ctypes.c_float()
+        if negatives is not None:
+            negatives = np.ascontiguousarray(negatives, dtype=np.int64)
+        check(self._lib.sert_eval_batch(self._h, split, int(batch_index), _addr(negatives),
+                                        ctypes.byref(loss)))
+        return np.float32(loss.value)
+
+    def predict_project(self, avg):
+        avg = np.ascontiguousarray(avg, dtype=np.float32)
+        q = avg.shape[0]
+        out = np.empty((q, self.cfg.entity_dim), dtype=np.float32)
+        check(self._lib.sert_predict_project(self._h, avg.ctypes.data, q, out.ctypes.data))
+        return out
+
+    def predict_tokens(self, ids):
+        ids = np.ascontiguousarray(ids)
+        assert ids.dtype.itemsize == self.cfg.id_bytes
+        rows = ids.shape[0]
+        out = np.empty((rows, self.cfg.window_size, self.cfg.num_entities), dtype=np.float32)
+        check(self._lib.sert_predict_tokens(self._h, ids.ctypes.data, rows, out.ctypes.data))
+        return out
+
+    # data parallel
+    def comm_init(self, unique_id, rank, world):
+        assert len(unique_id) == COMM_ID_BYTES
+        check(self._lib.sert_comm_init(self._h, unique_id, rank, world))
+
+    # diagnostics
+    def synchronize(self):
+        check(self._lib.sert_synchronize(self._h))
+
+    def timing_enable(self, on=True):
+        check(self._lib.sert_timing_enable(self._h, 1 if on else 0))
+
+    def timing_reset(self):
+        check(self._lib.sert_timing_reset(self._h))
+
+    def timings(self):
+        n = self._lib.sert_timing_count(self._h)
+        return {self._lib.sert_timing_name(self._h, i).decode():
+                self._lib.sert_timing_avg_us(self._h, i) for i in range(n)}
+
+
+def comm_unique_id():
+    buf = ctypes.create_string_buffer(COMM_ID_BYTES)
+    check(load().sert_comm_unique_id(buf))
+    return buf.raw
+
+
+def score_topk(entities, projections, k, device=0):
+    """Batched VectorSpaceCallback scoring (bin/query.py:239-370)."""
+    e = np.ascontiguousarray(entities, dtype=np.float32)
+    p = np.ascontiguousarray(projections, dtype=np.float32)
+    assert e.ndim == 2 and p.ndim == 2 and e.shape[1] == p.shape[1]
+    q = p.shape[0]
+    idx = np.empty((q, k), dtype=np.int32)
+    val = np.empty((q, k), dtype=np.float32)
+    check(load().sert_score_topk(device, e.ctypes.data, e.shape[0], e.shape[1], p.ctypes.data, q,
+                                 k, idx.ctypes.data, val.ctypes.data))
+    return idx, val

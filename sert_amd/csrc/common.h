@@ -1,0 +1,82 @@
+// Shared helpers for the gfx950 kernels of libsert_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+namespace sert {
+
+constexpr int kWave = 64;  // CDNA wavefront width (hard-coded: warpSize folds to 64 on gfx950)
+
+// ---- error plumbing (messages surface through sert_last_error()) ----------
+extern thread_local std::string g_last_error;
+
+inline int fail(const char* file, int line, const std::string& msg) {
+    char buf[64];
+    snprintf(buf, sizeof buf, "%s:%d: ", file, line);
+    g_last_error = std::string(buf) + msg;
+    return 1;
+}
+
+#define SERT_FAIL(msg) return ::sert::fail(__FILE__, __LINE__, (msg))
+#define SERT_HIP(expr)                                                              \
+    do {                                                                            \
+        hipError_t _e = (expr);                                                     \
+        if (_e != hipSuccess)                                                       \
+            return ::sert::fail(__FILE__, __LINE__,                                 \
+                                std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+#define SERT_TRY(expr)            \
+    do {                          \
+        int _rc = (expr);         \
+        if (_rc != 0) return _rc; \
+    } while (0)
+
+// ---- wave-level reductions -------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, kWave));
+    return v;
+}
+
+// Block-wide sum for blockDim.x == 256 (4 waves). `red` is >= 4 floats of LDS.
+// Result valid in every thread.
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__device__ __forceinline__ float block_max_256(float v, float* red) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// clip bounds of the reference as fp32 constants: 1e-7 and float32(1 - 1e-7)
+// = 1 - 2^-23 (sert/models.py:200, :290, :900, :1067-1068)
+#define SERT_CLIP_LO 1e-7f
+#define SERT_CLIP_HI 0.99999988079071044921875f
+
+// T.nnet.sigmoid, float32 C implementation of Theano 0.8.2 [upstream]:
+// x < -88 -> 0 ; x > 15 -> 1 ; else 1/(1+exp(-x))
+__device__ __forceinline__ float theano_sigmoid(float x) {
+    if (x < -88.0f) return 0.0f;
+    if (x > 15.0f) return 1.0f;
+    return 1.0f / (1.0f + expf(-x));
+}
+
+inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+}  // namespace sert

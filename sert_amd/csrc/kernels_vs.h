@@ -1,0 +1,187 @@
+// vectorspace / LSE kernels (sert/models.py:1024-1118), gfx950.
+#pragma once
+#include "common.h"
+
+namespace sert {
+
+// ---- K2+K3: embedding gather + window mean-pool ----------------------------
+// h[i,:] = (sum_k R_w[X[i,k],:]) / n         sert/models.py:180 + :226
+// One thread per (row, VEC-wide column chunk): consecutive lanes read
+// consecutive 16-byte pieces of one embedding row (coalesced); the (B,n,d)
+// gathered tensor is never materialised.
+template <typename IdT, int VEC>
+__global__ __launch_bounds__(256) void vs_gather_mean(const IdT* __restrict__ X,
+                                                      const float* __restrict__ Rw,
+                                                      float* __restrict__ H, int B, int n, int d) {
+    const int chunks = d / VEC;
+    const int64_t total = (int64_t)B * chunks;
+    const float fn = (float)n;
+    for (int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; tid < total;
+         tid += (int64_t)gridDim.x * blockDim.x) {
+        const int row = (int)(tid / chunks);
+        const int c = (int)(tid - (int64_t)row * chunks) * VEC;
+        const IdT* xr = X + (size_t)row * n;
+        if (VEC == 4) {
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = 0; k < n; ++k) {
+                const size_t id = (size_t)xr[k];
+                const float4 v = *reinterpret_cast<const float4*>(Rw + id * d + c);
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            }
+            a.x /= fn; a.y /= fn; a.z /= fn; a.w /= fn;
+            *reinterpret_cast<float4*>(H + (size_t)row * d + c) = a;
+        } else {
+            float a = 0.f;
+            for (int k = 0; k < n; ++k) a += Rw[(size_t)xr[k] * d + c];
+            H[(size_t)row * d + c] = a / fn;
+        }
+    }
+}
+
+// ---- K5: negative sampler (Philox4x32-10) ----------------------------------
+// iid uniform entity ids with replacement, target not excluded
+// (sert/models.py:961-973).  Keyed by (seed, step, global row*z + j) so the
+// stream does not depend on how rows are split over ranks.
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+__global__ void vs_sample_negatives(int32_t* __restrict__ neg, int64_t count, int64_t global_offset,
+                                    uint32_t num_entities, uint64_t seed, uint64_t step) {
+    // one thread owns one Philox counter = 4 consecutive GLOBAL sample indices
+    const int64_t q_first = global_offset >> 2;
+    const int64_t q_last = (global_offset + count - 1) >> 2;
+    const int64_t quads = q_last - q_first + 1;
+    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < quads;
+         q += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t ctr = (uint64_t)(q_first + q);
+        uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), (uint32_t)step,
+                         (uint32_t)(step >> 32)};
+        philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t local = (int64_t)(ctr * 4 + j) - global_offset;
+            if (local >= 0 && local < count)
+                neg[local] = (int32_t)(((uint64_t)c[j] * num_entities) >> 32);
+        }
+    }
+}
+
+__global__ void convert_i64_to_i32(const int64_t* __restrict__ in, int32_t* __restrict__ out,
+                                   int64_t count) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < count;
+         i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (int32_t)in[i];
+}
+
+// ---- K6: fused NCE score + loss + gradient ----------------------------------
+// One wave per batch row i.  With p = clip(t) (models.py:1065-1068):
+//   u_j   = <R_e[c_j], p>                 c_0 = y_i, c_1..z = negatives (:990, :897)
+//   s_j   = clip(sigmoid(u_j), eps, 1-eps)                                (:896-900)
+//   loss  = -(log s_0 + sum_{j>0} log(1 - s_j))                           (:1091-1098)
+// TRAIN additionally produces, with g = w_i / B (models.py:278-282):
+//   du_j  = d loss/d u_j (clip gradient mask inclusive, [upstream Clip.grad])
+//   dR_e[c_j] += du_j * p   (fp32 atomics; duplicates accumulate)
+//   da    = (sum_j du_j R_e[c_j]) * [|t| <= 1-eps] * (1 - t^2)
+// rowloss[i] = (TRAIN ? w_i : 1) * loss.
+template <int NPL, bool TRAIN>
+__global__ __launch_bounds__(256) void vs_nce(const float* __restrict__ T,
+                                              const float* __restrict__ Re,
+                                              const int32_t* __restrict__ y,
+                                              const int32_t* __restrict__ neg,
+                                              const float* __restrict__ w, float* __restrict__ DA,
+                                              float* __restrict__ GRe, float* __restrict__ rowloss,
+                                              int B, int z, int de, float inv_batch) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= B) return;
+    float t[NPL], p[NPL], dp[NPL];
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+        const int c = lane + 64 * q;
+        t[q] = (c < de) ? T[(size_t)i * de + c] : 0.f;
+        p[q] = fminf(fmaxf(t[q], -SERT_CLIP_HI), SERT_CLIP_HI);
+        dp[q] = 0.f;
+    }
+    const float wi = TRAIN ? w[i] : 1.f;
+    const float g = wi * inv_batch;
+    float loss = 0.f;
+    for (int j = 0; j <= z; ++j) {
+        const int e = (j == 0) ? y[i] : neg[(size_t)i * z + (j - 1)];
+        float er[NPL];
+        float part = 0.f;
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+            const int c = lane + 64 * q;
+            er[q] = (c < de) ? Re[(size_t)e * de + c] : 0.f;
+            part += er[q] * p[q];
+        }
+        const float u = wave_sum(part);
+        const float sig = theano_sigmoid(u);
+        const float s = fminf(fmaxf(sig, SERT_CLIP_LO), SERT_CLIP_HI);
+        loss -= (j == 0) ? logf(s) : logf(1.0f - s);
+        if (TRAIN) {
+            const bool inside = (sig >= SERT_CLIP_LO) && (sig <= SERT_CLIP_HI);
+            float du = 0.f;
+            if (inside) {
+                const float ds = sig * (1.0f - sig);
+                du = (j == 0) ? -(g / s) * ds : (g / (1.0f - s)) * ds;
+            }
+#pragma unroll
+            for (int q = 0; q < NPL; ++q) {
+                const int c = lane + 64 * q;
+                dp[q] += du * er[q];
+                if (c < de) atomicAdd(&GRe[(size_t)e * de + c], du * p[q]);
+            }
+        }
+    }
+    if (TRAIN) {
+#pragma unroll
+        for (int q = 0; q < NPL; ++q) {
+            const int c = lane + 64 * q;
+            const bool inside = (t[q] >= -SERT_CLIP_HI) && (t[q] <= SERT_CLIP_HI);
+            if (c < de) DA[(size_t)i * de + c] = inside ? dp[q] * (1.0f - t[q] * t[q]) : 0.f;
+        }
+    }
+    if (lane == 0) rowloss[i] = wi * loss;
+}
+
+// ---- K9: scatter-add of the window gradient into the word table -------------
+// dR_w[X[i,k],:] += dh[i,:] / n     (autodiff of models.py:180 + :226;
+// Theano AdvancedIncSubtensor1: duplicates accumulate)
+template <typename IdT, int VEC>
+__global__ __launch_bounds__(256) void vs_scatter_dh(const IdT* __restrict__ X,
+                                                     const float* __restrict__ DH,
+                                                     float* __restrict__ GRw, int B, int n, int d) {
+    const int chunks = d / VEC;
+    const int64_t total = (int64_t)B * n * chunks;
+    const float fn = (float)n;
+    for (int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; tid < total;
+         tid += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t rk = tid / chunks;            // row*n + k
+        const int c = (int)(tid - rk * chunks) * VEC;
+        const int row = (int)(rk / n);
+        const size_t id = (size_t)X[rk];
+        float* dst = GRw + id * d + c;
+        const float* src = DH + (size_t)row * d + c;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) atomicAdd(dst + v, src[v] / fn);
+    }
+}
+
+// out = tanh(avg.W + b) is done by the GEMM with the EPI_BIAS_TANH epilogue.
+
+}  // namespace sert

@@ -1,0 +1,93 @@
+// Device-side model state for libsert_hip.so.
+#pragma once
+#include <vector>
+#include <string>
+#include "common.h"
+#include "../../include/sert_hip.h"
+
+namespace sert {
+
+struct DataSplit {
+    int64_t N = 0;
+    void* x = nullptr;          // (N, n) ids, id_bytes wide
+    int32_t* y = nullptr;       // (N,) int labels, or null
+    int64_t* csr_indptr = nullptr;   // (N+1)
+    int32_t* csr_indices = nullptr;  // (nnz)
+    float* csr_data = nullptr;       // (nnz)
+    int64_t nnz = 0;
+    float* w = nullptr;         // (N,) instance weights (train split)
+};
+
+// Timed kernel groups (HIP events on the model's stream).
+enum TimingGroup {
+    TG_GATHER = 0,    // embedding gather (+ mean-pool)
+    TG_GEMM_FWD,      // projection / logits GEMM
+    TG_LOSS,          // NCE or softmax/window/CE forward+backward
+    TG_GEMM_BWD,      // dW, dh/dG GEMMs, db
+    TG_SCATTER,       // scatter-add into the word table
+    TG_ALLREDUCE,     // RCCL gradient exchange
+    TG_OPTIMIZER,     // fused L2 + Adam/Adadelta over all tensors
+    TG_FINALIZE,      // loss reduction
+    TG_COUNT
+};
+
+struct Timing {
+    bool enabled = false;
+    hipEvent_t ev[TG_COUNT][2] = {};
+    bool created = false;
+    bool used[TG_COUNT] = {};
+    double total_us[TG_COUNT] = {};
+    int64_t samples[TG_COUNT] = {};
+};
+
+}  // namespace sert
+
+struct sert_model {
+    sert_config cfg;
+    hipStream_t stream = nullptr;
+
+    // shapes
+    size_t n_rw = 0, n_re = 0, n_w = 0, n_b = 0;
+
+    // parameters + optimiser state
+    float *rw = nullptr, *re = nullptr, *W = nullptr, *b = nullptr;
+    float *s0_rw = nullptr, *s0_re = nullptr, *s0_w = nullptr, *s0_b = nullptr;
+    float *s1_rw = nullptr, *s1_re = nullptr, *s1_w = nullptr, *s1_b = nullptr;
+
+    // gradients: ONE flat allocation [g_re | g_rw | g_w | g_b | loss_sum(1) | pad]
+    // so that the data-parallel exchange is a single all-reduce.
+    float* gflat = nullptr;
+    size_t gflat_count = 0;
+    float *g_re = nullptr, *g_rw = nullptr, *g_w = nullptr, *g_b = nullptr, *g_loss = nullptr;
+
+    // per-batch activations
+    float *H = nullptr, *T = nullptr, *DA = nullptr, *DH = nullptr, *rowloss = nullptr;
+    int32_t* neg = nullptr;       // (B, z) device negatives
+    int64_t* neg_stage = nullptr; // (B, z) int64 staging for host-supplied negatives
+    // loglinear activations
+    float *G = nullptr;           // (B*n, d) gathered rows
+    float *Z = nullptr;           // (B*n, V_e) logits -> probabilities -> dZ
+    float *J = nullptr;           // (B, V_e) window log-product -> dJ
+    float *DG = nullptr;          // (B*n, d)
+
+    // scratch
+    float* part = nullptr;        // split-K partials
+    size_t part_count = 0;
+    float* red_loss = nullptr;    // loss partials [kOptBlocks]
+    float* red_sq = nullptr;      // sumsq partials [3 * kOptBlocks]
+    float* d_loss = nullptr;      // [3] loss, data term, reg term (device)
+    float* h_loss = nullptr;      // pinned host mirror
+    float* d_losses = nullptr;    // multi-step loss ring
+    int64_t d_losses_cap = 0;
+
+    sert::DataSplit split[2];
+
+    int64_t step = 0;             // optimiser step counter t (Adam) / training sampler position
+    int64_t eval_draws = 0;       // evaluation sampler position
+
+    // data parallel
+    int rank = 0, world = 1;
+    void* comm = nullptr;         // ncclComm_t
+
+    sert::Timing timing;
+};

@@ -1,0 +1,848 @@
+// libsert_hip.so -- C ABI (include/sert_hip.h) over the gfx950 kernels.
+// Host orchestration of one training / evaluation / prediction step: the body of
+// the reference's compiled Theano functions (sert/models.py:581-608).
+#include <dlfcn.h>
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "gemm.h"
+#include "kernels_ll.h"
+#include "kernels_opt.h"
+#include "kernels_score.h"
+#include "kernels_vs.h"
+#include "model.h"
+
+namespace sert {
+thread_local std::string g_last_error;
+
+static const char* kTimingNames[TG_COUNT] = {"gather",  "gemm_fwd",  "loss",      "gemm_bwd",
+                                             "scatter", "allreduce", "optimizer", "finalize"};
+
+// ---- timing ----------------------------------------------------------------
+struct ScopedTimer {
+    sert_model* m;
+    int g;
+    ScopedTimer(sert_model* m_, int g_) : m(m_), g(g_) {
+        if (m->timing.enabled) {
+            (void)hipEventRecord(m->timing.ev[g][0], m->stream);
+        }
+    }
+    ~ScopedTimer() {
+        if (m->timing.enabled) {
+            (void)hipEventRecord(m->timing.ev[g][1], m->stream);
+            m->timing.used[g] = true;
+        }
+    }
+};
+
+static void timing_collect(sert_model* m) {
+    if (!m->timing.enabled) return;
+    for (int g = 0; g < TG_COUNT; ++g) {
+        if (!m->timing.used[g]) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, m->timing.ev[g][0], m->timing.ev[g][1]) == hipSuccess) {
+            m->timing.total_us[g] += 1000.0 * ms;
+            m->timing.samples[g] += 1;
+        }
+        m->timing.used[g] = false;
+    }
+}
+
+// ---- RCCL, loaded lazily (single-GPU runs never touch it) --------------------
+struct UniqueId {
+    char internal[SERT_COMM_ID_BYTES];
+};
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, /*ncclUniqueId by value*/ UniqueId, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+static Rccl g_rccl;
+
+static int rccl_load() {
+    if (g_rccl.lib) return 0;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1",
+                           "/opt/rocm/lib/librccl.so"};
+    void* lib = nullptr;
+    for (const char* n : names) {
+        lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (lib) break;
+    }
+    if (!lib) SERT_FAIL(std::string("cannot dlopen librccl: ") + dlerror());
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(lib, "ncclCommInitRank");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(lib, "ncclCommDestroy");
+    g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(lib, "ncclAllReduce");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(lib, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllReduce)
+        SERT_FAIL("librccl is missing ncclGetUniqueId/ncclCommInitRank/ncclCommDestroy/ncclAllReduce");
+    g_rccl.lib = lib;
+    return 0;
+}
+#define SERT_NCCL(expr)                                                                       \
+    do {                                                                                      \
+        int _r = (expr);                                                                      \
+        if (_r != 0)                                                                          \
+            SERT_FAIL(std::string(#expr) + ": " +                                             \
+                      (g_rccl.GetErrorString ? g_rccl.GetErrorString(_r) : "rccl error"));    \
+    } while (0)
+
+// ---- small helpers -----------------------------------------------------------
+template <typename T>
+static int dmalloc(T** p, size_t count) {
+    *p = nullptr;
+    if (count == 0) return 0;
+    SERT_HIP(hipMalloc((void**)p, count * sizeof(T)));
+    return 0;
+}
+template <typename T>
+static int dzalloc(T** p, size_t count, hipStream_t s) {
+    SERT_TRY(dmalloc(p, count));
+    if (count) SERT_HIP(hipMemsetAsync(*p, 0, count * sizeof(T), s));
+    return 0;
+}
+static inline int grid_for(int64_t work_items, int block = 256, int cap = 256 * 8) {
+    int64_t g = (work_items + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+static inline size_t round_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
+
+static bool is_vs(const sert_model* m) { return m->cfg.kind == SERT_KIND_VECTORSPACE; }
+
+struct TensorRef {
+    float* ptr;
+    size_t count;
+};
+static TensorRef tensor_ref(sert_model* m, int which) {
+    const size_t B = m->cfg.batch_size;
+    switch (which) {
+        case SERT_T_RW: return {m->rw, m->n_rw};
+        case SERT_T_RE: return {m->re, m->n_re};
+        case SERT_T_W: return {m->W, m->n_w};
+        case SERT_T_B: return {m->b, m->n_b};
+        case SERT_T_STATE0_RW: return {m->s0_rw, m->n_rw};
+        case SERT_T_STATE0_RE: return {m->s0_re, m->n_re};
+        case SERT_T_STATE0_W: return {m->s0_w, m->n_w};
+        case SERT_T_STATE0_B: return {m->s0_b, m->n_b};
+        case SERT_T_STATE1_RW: return {m->s1_rw, m->n_rw};
+        case SERT_T_STATE1_RE: return {m->s1_re, m->n_re};
+        case SERT_T_STATE1_W: return {m->s1_w, m->n_w};
+        case SERT_T_STATE1_B: return {m->s1_b, m->n_b};
+        case SERT_T_GRAD_RW: return {m->g_rw, m->n_rw};
+        case SERT_T_GRAD_RE: return {m->g_re, m->n_re};
+        case SERT_T_GRAD_W: return {m->g_w, m->n_w};
+        case SERT_T_GRAD_B: return {m->g_b, m->n_b};
+        case SERT_T_ACT_H: return {m->H, m->H ? B * m->cfg.word_dim : 0};
+        case SERT_T_ACT_T: return {m->T, m->T ? B * m->cfg.entity_dim : 0};
+        case SERT_T_ACT_DA: return {m->DA, m->DA ? B * m->cfg.entity_dim : 0};
+        case SERT_T_ACT_DH: return {m->DH, m->DH ? B * m->cfg.word_dim : 0};
+        case SERT_T_ACT_ROWLOSS: return {m->rowloss, B};
+        default: return {nullptr, 0};
+    }
+}
+
+// Dispatch on the token-id width (np.min_scalar_type, bin/prepare.py:380).
+#define SERT_ID_DISPATCH(id_bytes, ...)                                  \
+    do {                                                                 \
+        if ((id_bytes) == 1) { typedef uint8_t IdT; __VA_ARGS__; }       \
+        else if ((id_bytes) == 2) { typedef uint16_t IdT; __VA_ARGS__; } \
+        else { typedef uint32_t IdT; __VA_ARGS__; }                      \
+    } while (0)
+
+// ---- the vectorspace step -----------------------------------------------------
+static int vs_negatives(sert_model* m, const int64_t* negatives, uint64_t stream_pos) {
+    const auto& c = m->cfg;
+    const int64_t count = (int64_t)c.batch_size * c.num_negatives;
+    if (count == 0) return 0;
+    if (negatives) {
+        SERT_HIP(hipMemcpyAsync(m->neg_stage, negatives, count * sizeof(int64_t),
+                                hipMemcpyHostToDevice, m->stream));
+        hipLaunchKernelGGL(convert_i64_to_i32, dim3(grid_for(count)), dim3(256), 0, m->stream,
+                           m->neg_stage, m->neg, count);
+    } else {
+        const int64_t global_offset = (int64_t)m->rank * count;
+        // Philox stream position: even = training draws, odd = evaluation draws
+        // (the reference keeps two independent RandomStreams, models.py:745-752).
+        hipLaunchKernelGGL(vs_sample_negatives, dim3(grid_for((count + 3) / 4)), dim3(256), 0,
+                           m->stream, m->neg, count, global_offset, (uint32_t)c.num_entities,
+                           c.seed, stream_pos);
+    }
+    return 0;
+}
+
+template <bool TRAIN>
+static int vs_forward(sert_model* m, const DataSplit& ds, int64_t batch_index) {
+    const auto& c = m->cfg;
+    const int B = c.batch_size, n = c.window_size, dw = c.word_dim, de = c.entity_dim;
+    const size_t row0 = (size_t)batch_index * B;
+    {
+        ScopedTimer t(m, TG_GATHER);
+        SERT_ID_DISPATCH(c.id_bytes, {
+            const IdT* X = (const IdT*)ds.x + row0 * n;
+            if (dw % 4 == 0)
+                hipLaunchKernelGGL((vs_gather_mean<IdT, 4>), dim3(grid_for((int64_t)B * dw / 4, 256, 1 << 20)),
+                                   dim3(256), 0, m->stream, X, m->rw, m->H, B, n, dw);
+            else
+                hipLaunchKernelGGL((vs_gather_mean<IdT, 1>), dim3(grid_for((int64_t)B * dw, 256, 1 << 20)),
+                                   dim3(256), 0, m->stream, X, m->rw, m->H, B, n, dw);
+        });
+    }
+    {
+        ScopedTimer t(m, TG_GEMM_FWD);
+        // t = tanh(h.W + b)   (models.py:1057-1061)
+        launch_gemm<false, false, EPI_BIAS_TANH>(m->stream, m->H, m->W, m->T, m->b, B, de, dw, dw,
+                                                 de, de);
+    }
+    {
+        ScopedTimer t(m, TG_LOSS);
+        const int32_t* y = ds.y + row0;
+        const float* w = TRAIN ? ds.w + row0 : nullptr;
+        const float inv_batch = 1.0f / (float)c.global_batch_size;
+        const int npl = cdiv(de, 64);
+        dim3 grid(cdiv(B, 4)), block(256);
+#define SERT_NCE_CASE(N)                                                                     \
+    case N:                                                                                  \
+        hipLaunchKernelGGL((vs_nce<N, TRAIN>), grid, block, 0, m->stream, m->T, m->re, y,   \
+                           m->neg, w, m->DA, m->g_re, m->rowloss, B, c.num_negatives, de,   \
+                           inv_batch);                                                       \
+        break;
+        switch (npl) {
+            SERT_NCE_CASE(1) SERT_NCE_CASE(2) SERT_NCE_CASE(3) SERT_NCE_CASE(4)
+            SERT_NCE_CASE(5) SERT_NCE_CASE(6) SERT_NCE_CASE(7) SERT_NCE_CASE(8)
+            default: SERT_FAIL("entity_dim > 512 is not supported");
+        }
+#undef SERT_NCE_CASE
+    }
+    return 0;
+}
+
+static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) {
+    const auto& c = m->cfg;
+    const int B = c.batch_size, n = c.window_size, dw = c.word_dim, de = c.entity_dim;
+    const size_t row0 = (size_t)batch_index * B;
+    {
+        ScopedTimer t(m, TG_GEMM_BWD);
+        // dW = h^T.da : reduction over the batch, split-K with order-fixed combine
+        int splits = std::min(256, cdiv(B, GK));
+        int kper = (int)round_up(cdiv(B, splits), GK);
+        splits = cdiv(B, kper);
+        const size_t mn = (size_t)dw * de;
+        launch_gemm<true, false, EPI_STORE>(m->stream, m->H, m->DA, m->part, nullptr, dw, de, B, dw,
+                                            de, de, splits, kper, mn);
+        hipLaunchKernelGGL(reduce_partials, dim3(grid_for(mn)), dim3(256), 0, m->stream, m->part,
+                           splits, mn, m->g_w);
+        // db = sum_i da_i
+        const int rpb = cdiv(B, 256);
+        const int nb = cdiv(B, rpb);
+        hipLaunchKernelGGL(colsum_partial, dim3(nb), dim3(256), 0, m->stream, m->DA, B, de, rpb,
+                           m->part);
+        hipLaunchKernelGGL(reduce_partials, dim3(grid_for(de)), dim3(256), 0, m->stream, m->part,
+                           nb, (size_t)de, m->g_b);
+        // dh = da.W^T
+        launch_gemm<false, true, EPI_STORE>(m->stream, m->DA, m->W, m->DH, nullptr, B, dw, de, de,
+                                            de, dw);
+    }
+    {
+        ScopedTimer t(m, TG_SCATTER);
+        SERT_ID_DISPATCH(c.id_bytes, {
+            const IdT* X = (const IdT*)ds.x + row0 * n;
+            if (dw % 4 == 0)
+                hipLaunchKernelGGL((vs_scatter_dh<IdT, 4>),
+                                   dim3(grid_for((int64_t)B * n * dw / 4, 256, 1 << 20)), dim3(256), 0,
+                                   m->stream, X, m->DH, m->g_rw, B, n, dw);
+            else
+                hipLaunchKernelGGL((vs_scatter_dh<IdT, 1>),
+                                   dim3(grid_for((int64_t)B * n * dw, 256, 1 << 20)), dim3(256), 0,
+                                   m->stream, X, m->DH, m->g_rw, B, n, dw);
+        });
+    }
+    return 0;
+}
+
+// ---- the loglinear step -------------------------------------------------------
+template <bool TRAIN>
+static int ll_forward(sert_model* m, const DataSplit& ds, int64_t batch_index) {
+    const auto& c = m->cfg;
+    const int B = c.batch_size, n = c.window_size, d = c.word_dim, V = c.num_entities;
+    const size_t row0 = (size_t)batch_index * B;
+    const int64_t rows = (int64_t)B * n;
+    {
+        ScopedTimer t(m, TG_GATHER);
+        SERT_ID_DISPATCH(c.id_bytes, {
+            const IdT* X = (const IdT*)ds.x + row0 * n;
+            if (d % 4 == 0)
+                hipLaunchKernelGGL((ll_gather_rows<IdT, 4>), dim3(grid_for(rows * d / 4, 256, 1 << 20)),
+                                   dim3(256), 0, m->stream, X, m->rw, m->G, rows, d);
+            else
+                hipLaunchKernelGGL((ll_gather_rows<IdT, 1>), dim3(grid_for(rows * d, 256, 1 << 20)),
+                                   dim3(256), 0, m->stream, X, m->rw, m->G, rows, d);
+        });
+    }
+    {
+        ScopedTimer t(m, TG_GEMM_FWD);
+        launch_gemm<false, false, EPI_BIAS>(m->stream, m->G, m->W, m->Z, m->b, (int)rows, V, d, d, V,
+                                            V);
+        hipLaunchKernelGGL(ll_softmax_rows, dim3(cdiv(rows, 4)), dim3(256), 0, m->stream, m->Z, rows,
+                           V);
+    }
+    {
+        ScopedTimer t(m, TG_LOSS);
+        const float inv_batch = 1.0f / (float)c.global_batch_size;
+        const int32_t* y = ds.y ? ds.y + row0 : nullptr;
+        const int64_t* indptr = ds.csr_indptr ? ds.csr_indptr + row0 : nullptr;
+        const float* w = TRAIN ? ds.w + row0 : nullptr;
+        hipLaunchKernelGGL((ll_window<TRAIN>), dim3(B), dim3(256), 0, m->stream, m->Z, m->J, y,
+                           indptr, ds.csr_indices, ds.csr_data, w, m->rowloss, n, V, inv_batch);
+    }
+    return 0;
+}
+
+static int ll_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) {
+    const auto& c = m->cfg;
+    const int B = c.batch_size, n = c.window_size, d = c.word_dim, V = c.num_entities;
+    const size_t row0 = (size_t)batch_index * B;
+    const int64_t rows = (int64_t)B * n;
+    {
+        ScopedTimer t(m, TG_GEMM_BWD);
+        // dW (d, V) = G^T.dZ, reduction over the B*n tokens
+        const int tiles = cdiv(V, GN) * cdiv(d, GM);
+        int splits = std::max(1, std::min(cdiv(rows, GK), cdiv(1024, tiles)));
+        int kper = (int)round_up(cdiv(rows, splits), GK);
+        splits = cdiv(rows, kper);
+        const size_t mn = (size_t)d * V;
+        launch_gemm<true, false, EPI_STORE>(m->stream, m->G, m->Z, m->part, nullptr, d, V, (int)rows,
+                                            d, V, V, splits, kper, mn);
+        hipLaunchKernelGGL(reduce_partials, dim3(grid_for(mn)), dim3(256), 0, m->stream, m->part,
+                           splits, mn, m->g_w);
+        // db = column sums of dZ
+        const int rpb = cdiv(rows, 256);
+        const int nb = cdiv(rows, rpb);
+        hipLaunchKernelGGL(colsum_partial, dim3(nb), dim3(256), 0, m->stream, m->Z, (int)rows, V, rpb,
+                           m->part);
+        hipLaunchKernelGGL(reduce_partials, dim3(grid_for(V)), dim3(256), 0, m->stream, m->part, nb,
+                           (size_t)V, m->g_b);
+        // dG (rows, d) = dZ.W^T
+        launch_gemm<false, true, EPI_STORE>(m->stream, m->Z, m->W, m->DG, nullptr, (int)rows, d, V, V,
+                                            V, d);
+    }
+    {
+        ScopedTimer t(m, TG_SCATTER);
+        SERT_ID_DISPATCH(c.id_bytes, {
+            const IdT* X = (const IdT*)ds.x + row0 * n;
+            if (d % 4 == 0)
+                hipLaunchKernelGGL((ll_scatter_rows<IdT, 4>), dim3(grid_for(rows * d / 4, 256, 1 << 20)),
+                                   dim3(256), 0, m->stream, X, m->DG, m->g_rw, rows, d);
+            else
+                hipLaunchKernelGGL((ll_scatter_rows<IdT, 1>), dim3(grid_for(rows * d, 256, 1 << 20)),
+                                   dim3(256), 0, m->stream, X, m->DG, m->g_rw, rows, d);
+        });
+    }
+    return 0;
+}
+
+// ---- shared tail: loss sum, exchange, optimiser, loss ---------------------------
+static int reduce_rowloss(sert_model* m, float* dst_sum /* device, 1 float */) {
+    const int B = m->cfg.batch_size;
+    const int nb = std::min(kOptBlocks, cdiv(B, 256));
+    hipLaunchKernelGGL(sum_partial, dim3(nb), dim3(256), 0, m->stream, m->rowloss, (size_t)B,
+                       m->red_loss);
+    // single-block fp64 combine, result (sum, not mean) to dst_sum[0]
+    hipLaunchKernelGGL(finalize_loss, dim3(1), dim3(256), 0, m->stream, m->red_loss, nb,
+                       m->red_loss, 0, 1.0f, 0.0f, m->d_loss);
+    SERT_HIP(hipMemcpyAsync(dst_sum, m->d_loss, sizeof(float), hipMemcpyDeviceToDevice, m->stream));
+    return 0;
+}
+
+static int optimizer_and_loss(sert_model* m, float* loss_dst /* device [3] */) {
+    const auto& c = m->cfg;
+    const bool keep = c.keep_grads != 0;
+    const float l2k = c.lambda_ > 0.f ? c.lambda_ / (float)c.global_batch_size : 0.f;
+    m->step += 1;
+    int n_sq = 0;
+    {
+        ScopedTimer t(m, TG_OPTIMIZER);
+        struct Item { float *p, *g, *s0, *s1; size_t count; bool l2; };
+        // update order of the reference: [R_e, R_w, W, b] (models.py:542-543, :1105)
+        Item items[4] = {{m->re, m->g_re, m->s0_re, m->s1_re, m->n_re, true},
+                         {m->rw, m->g_rw, m->s0_rw, m->s1_rw, m->n_rw, true},
+                         {m->W, m->g_w, m->s0_w, m->s1_w, m->n_w, true},
+                         {m->b, m->g_b, m->s0_b, m->s1_b, m->n_b, false}};
+        float a_t = 0.f;
+        if (is_vs(m)) {
+            const float t = (float)m->step;
+            a_t = c.lr * sqrtf(1.0f - powf(c.beta2, t)) / (1.0f - powf(c.beta1, t));
+        }
+        for (auto& it : items) {
+            if (it.count == 0) continue;
+            const int nb = std::min<int64_t>(kOptBlocks, cdiv(it.count, 256));
+            float* sq = m->red_sq + n_sq;
+            if (is_vs(m)) {
+                AdamArgs a{it.l2 ? l2k : 0.f, a_t, c.beta1, c.beta2, c.eps};
+                if (keep) hipLaunchKernelGGL((adam_l2<true>), dim3(nb), dim3(256), 0, m->stream, it.p, it.g, it.s0, it.s1, it.count, a, sq);
+                else      hipLaunchKernelGGL((adam_l2<false>), dim3(nb), dim3(256), 0, m->stream, it.p, it.g, it.s0, it.s1, it.count, a, sq);
+            } else {
+                AdadeltaArgs a{it.l2 ? l2k : 0.f, c.lr, c.beta1, c.eps};
+                if (keep) hipLaunchKernelGGL((adadelta_l2<true>), dim3(nb), dim3(256), 0, m->stream, it.p, it.g, it.s0, it.s1, it.count, a, sq);
+                else      hipLaunchKernelGGL((adadelta_l2<false>), dim3(nb), dim3(256), 0, m->stream, it.p, it.g, it.s0, it.s1, it.count, a, sq);
+            }
+            if (it.l2) n_sq += nb;  // bias partials are overwritten by the next tensor / ignored
+        }
+    }
+    {
+        ScopedTimer t(m, TG_FINALIZE);
+        const float inv_batch = 1.0f / (float)c.global_batch_size;
+        const float reg_scale = c.lambda_ > 0.f ? c.lambda_ / (2.0f * (float)c.global_batch_size) : 0.f;
+        hipLaunchKernelGGL(finalize_loss, dim3(1), dim3(256), 0, m->stream, m->g_loss, 1, m->red_sq,
+                           n_sq, inv_batch, reg_scale, loss_dst);
+    }
+    return 0;
+}
+
+static int train_step_async(sert_model* m, int64_t batch_index, const int64_t* negatives,
+                            float* loss_dst) {
+    const DataSplit& ds = m->split[SERT_SPLIT_TRAIN];
+    const int B = m->cfg.batch_size;
+    if (ds.N == 0) SERT_FAIL("no training data uploaded");
+    if (batch_index < 0 || (batch_index + 1) * (int64_t)B > ds.N) SERT_FAIL("batch_index out of range");
+    SERT_HIP(hipMemsetAsync(m->gflat, 0, m->gflat_count * sizeof(float), m->stream));
+    if (is_vs(m)) {
+        SERT_TRY(vs_negatives(m, negatives, (uint64_t)m->step * 2));
+        SERT_TRY(vs_forward<true>(m, ds, batch_index));
+        SERT_TRY(vs_backward(m, ds, batch_index));
+    } else {
+        SERT_TRY(ll_forward<true>(m, ds, batch_index));
+        SERT_TRY(ll_backward(m, ds, batch_index));
+    }
+    SERT_TRY(reduce_rowloss(m, m->g_loss));
+    if (m->comm) {
+        ScopedTimer t(m, TG_ALLREDUCE);
+        SERT_NCCL(g_rccl.AllReduce(m->gflat, m->gflat, m->gflat_count, /*ncclFloat32*/ 7,
+                                   /*ncclSum*/ 0, m->comm, m->stream));
+    }
+    SERT_TRY(optimizer_and_loss(m, loss_dst));
+    return 0;
+}
+
+}  // namespace sert
+
+using namespace sert;
+
+// =============================== C ABI ===========================================
+extern "C" {
+
+const char* sert_last_error(void) { return g_last_error.c_str(); }
+
+int sert_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return -1;
+    return n;
+}
+
+int sert_device_info(int device, char* buf, size_t buflen) {
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) != hipSuccess) {
+        g_last_error = "hipGetDeviceProperties failed";
+        return -1;
+    }
+    return snprintf(buf, buflen, "%s %s: %d CUs, %.0f MHz, %.1f GiB, LDS/block %zu KiB", p.name,
+                    p.gcnArchName, p.multiProcessorCount, p.clockRate / 1000.0,
+                    p.totalGlobalMem / (1024.0 * 1024.0 * 1024.0), p.sharedMemPerBlock / 1024);
+}
+
+int sert_create(const sert_config* cfg, sert_model** out) {
+    if (!cfg || !out) SERT_FAIL("null argument");
+    if (cfg->struct_size != sizeof(sert_config)) SERT_FAIL("sert_config size mismatch (ABI)");
+    if (cfg->kind != SERT_KIND_LOGLINEAR && cfg->kind != SERT_KIND_VECTORSPACE) SERT_FAIL("bad kind");
+    if (cfg->batch_size <= 0 || cfg->window_size <= 0 || cfg->vocab_size <= 0 ||
+        cfg->num_entities <= 0 || cfg->word_dim <= 0)
+        SERT_FAIL("sizes must be positive");
+    if (cfg->global_batch_size < cfg->batch_size) SERT_FAIL("global_batch_size < batch_size");
+    if (cfg->id_bytes != 1 && cfg->id_bytes != 2 && cfg->id_bytes != 4) SERT_FAIL("id_bytes must be 1, 2 or 4");
+    if (cfg->kind == SERT_KIND_VECTORSPACE) {
+        if (cfg->entity_dim <= 0 || cfg->entity_dim > 512) SERT_FAIL("entity_dim must be in [1, 512]");
+        if (cfg->num_negatives < 0) SERT_FAIL("num_negatives must be >= 0");
+    }
+    SERT_HIP(hipSetDevice(cfg->device));
+    sert_model* m = new sert_model();
+    m->cfg = *cfg;
+    const auto& c = m->cfg;
+    SERT_HIP(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+    const size_t B = c.batch_size, n = c.window_size, dw = c.word_dim, V = c.num_entities;
+    const bool vs = is_vs(m);
+    const size_t de = vs ? c.entity_dim : 0;
+    m->n_rw = (size_t)c.vocab_size * dw;
+    m->n_re = vs ? V * de : 0;
+    m->n_w = vs ? dw * de : dw * V;
+    m->n_b = vs ? de : V;
+    hipStream_t s = m->stream;
+    SERT_TRY(dzalloc(&m->rw, m->n_rw, s));  SERT_TRY(dzalloc(&m->re, m->n_re, s));
+    SERT_TRY(dzalloc(&m->W, m->n_w, s));    SERT_TRY(dzalloc(&m->b, m->n_b, s));
+    SERT_TRY(dzalloc(&m->s0_rw, m->n_rw, s)); SERT_TRY(dzalloc(&m->s0_re, m->n_re, s));
+    SERT_TRY(dzalloc(&m->s0_w, m->n_w, s));   SERT_TRY(dzalloc(&m->s0_b, m->n_b, s));
+    SERT_TRY(dzalloc(&m->s1_rw, m->n_rw, s)); SERT_TRY(dzalloc(&m->s1_re, m->n_re, s));
+    SERT_TRY(dzalloc(&m->s1_w, m->n_w, s));   SERT_TRY(dzalloc(&m->s1_b, m->n_b, s));
+    // flat gradient buffer, every sub-tensor 16-byte aligned
+    const size_t o_re = 0, o_rw = o_re + round_up(m->n_re, 4), o_w = o_rw + round_up(m->n_rw, 4),
+                 o_b = o_w + round_up(m->n_w, 4), o_l = o_b + round_up(m->n_b, 4);
+    m->gflat_count = o_l + 4;
+    SERT_TRY(dzalloc(&m->gflat, m->gflat_count, s));
+    m->g_re = m->n_re ? m->gflat + o_re : nullptr;
+    m->g_rw = m->gflat + o_rw;
+    m->g_w = m->gflat + o_w;
+    m->g_b = m->gflat + o_b;
+    m->g_loss = m->gflat + o_l;
+    SERT_TRY(dzalloc(&m->rowloss, B, s));
+    size_t part = 0;
+    if (vs) {
+        SERT_TRY(dzalloc(&m->H, B * dw, s));  SERT_TRY(dzalloc(&m->T, B * de, s));
+        SERT_TRY(dzalloc(&m->DA, B * de, s)); SERT_TRY(dzalloc(&m->DH, B * dw, s));
+        SERT_TRY(dzalloc(&m->neg, std::max<size_t>(4, B * c.num_negatives), s));
+        SERT_TRY(dzalloc(&m->neg_stage, std::max<size_t>(4, B * c.num_negatives), s));
+        part = std::max((size_t)256 * dw * de, (size_t)256 * de);
+    } else {
+        SERT_TRY(dzalloc(&m->G, B * n * dw, s));  SERT_TRY(dzalloc(&m->Z, B * n * V, s));
+        SERT_TRY(dzalloc(&m->J, B * V, s));       SERT_TRY(dzalloc(&m->DG, B * n * dw, s));
+        const size_t tiles = (size_t)cdiv(V, GN) * cdiv(dw, GM);
+        const size_t splits = std::max<size_t>(1, cdiv(1024, tiles)) + 1;
+        part = std::max(splits * dw * V, (size_t)256 * V);
+    }
+    m->part_count = part;
+    SERT_TRY(dzalloc(&m->part, part, s));
+    SERT_TRY(dzalloc(&m->red_loss, (size_t)kOptBlocks, s));
+    SERT_TRY(dzalloc(&m->red_sq, (size_t)4 * kOptBlocks, s));
+    SERT_TRY(dzalloc(&m->d_loss, (size_t)4, s));
+    SERT_HIP(hipHostMalloc((void**)&m->h_loss, 4 * sizeof(float), hipHostMallocDefault));
+    for (int g = 0; g < TG_COUNT; ++g)
+        for (int k = 0; k < 2; ++k) SERT_HIP(hipEventCreate(&m->timing.ev[g][k]));
+    m->timing.created = true;
+    SERT_HIP(hipStreamSynchronize(s));
+    *out = m;
+    return 0;
+}
+
+static void free_split(DataSplit& d) {
+    (void)hipFree(d.x); (void)hipFree(d.y); (void)hipFree(d.csr_indptr);
+    (void)hipFree(d.csr_indices); (void)hipFree(d.csr_data); (void)hipFree(d.w);
+    d = DataSplit();
+}
+
+int sert_destroy(sert_model* m) {
+    if (!m) return 0;
+    (void)hipSetDevice(m->cfg.device);
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    if (m->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(m->comm);
+    float* bufs[] = {m->rw, m->re, m->W, m->b, m->s0_rw, m->s0_re, m->s0_w, m->s0_b, m->s1_rw,
+                     m->s1_re, m->s1_w, m->s1_b, m->gflat, m->H, m->T, m->DA, m->DH, m->rowloss,
+                     m->G, m->Z, m->J, m->DG, m->part, m->red_loss, m->red_sq, m->d_loss,
+                     m->d_losses};
+    for (float* p : bufs) (void)hipFree(p);
+    (void)hipFree(m->neg); (void)hipFree(m->neg_stage);
+    if (m->h_loss) (void)hipHostFree(m->h_loss);
+    free_split(m->split[0]); free_split(m->split[1]);
+    if (m->timing.created)
+        for (int g = 0; g < TG_COUNT; ++g)
+            for (int k = 0; k < 2; ++k) (void)hipEventDestroy(m->timing.ev[g][k]);
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+    return 0;
+}
+
+size_t sert_tensor_size(sert_model* m, int which) {
+    if (!m) return 0;
+    return tensor_ref(m, which).count;
+}
+
+int sert_set_tensor(sert_model* m, int which, const float* host, size_t count) {
+    if (!m || !host) SERT_FAIL("null argument");
+    SERT_HIP(hipSetDevice(m->cfg.device));
+    TensorRef t = tensor_ref(m, which);
+    if (!t.ptr || t.count == 0) SERT_FAIL("tensor not present for this model kind");
+    if (t.count != count) SERT_FAIL("element count mismatch");
+    SERT_HIP(hipMemcpyAsync(t.ptr, host, count * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    SERT_HIP(hipStreamSynchronize(m->stream));
+    return 0;
+}
+
+int sert_get_tensor(sert_model* m, int which, float* host, size_t count) {
+    if (!m || !host) SERT_FAIL("null argument");
+    SERT_HIP(hipSetDevice(m->cfg.device));
+    TensorRef t = tensor_ref(m, which);
+    if (!t.ptr || t.count == 0) SERT_FAIL("tensor not present for this model kind");
+    if (t.count != count) SERT_FAIL("element count mismatch");
+    SERT_HIP(hipMemcpyAsync(host, t.ptr, count * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+    SERT_HIP(hipStreamSynchronize(m->stream));
+    return 0;
+}
+
+int sert_set_step(sert_model* m, int64_t t) {
+    if (!m || t < 0) SERT_FAIL("bad argument");
+    m->step = t;
+    return 0;
+}
+int64_t sert_get_step(sert_model* m) { return m ? m->step : -1; }
+
+int sert_upload_dataset(sert_model* m, int split, const void* x, const int32_t* y_int,
+                        const int64_t* csr_indptr, const int32_t* csr_indices,
+                        const float* csr_data, const float* w, int64_t N) {
+    if (!m) SERT_FAIL("null model");
+    if (split != SERT_SPLIT_TRAIN && split != SERT_SPLIT_VALIDATE) SERT_FAIL("bad split");
+    if (N < 0) SERT_FAIL("negative instance count");
+    if (N > 0 && !x) SERT_FAIL("x is null");
+    if (N > 0 && !y_int && !(csr_indptr && csr_indices && csr_data)) SERT_FAIL("no labels given");
+    if (is_vs(m) && N > 0 && !y_int) SERT_FAIL("vectorspace requires int labels (models.py:933-934)");
+    SERT_HIP(hipSetDevice(m->cfg.device));
+    DataSplit& d = m->split[split];
+    free_split(d);
+    d.N = N;
+    if (N == 0) return 0;
+    hipStream_t s = m->stream;
+    const size_t xbytes = (size_t)N * m->cfg.window_size * m->cfg.id_bytes;
+    SERT_HIP(hipMalloc(&d.x, xbytes));
+    SERT_HIP(hipMemcpyAsync(d.x, x, xbytes, hipMemcpyHostToDevice, s));
+    if (y_int) {
+        SERT_TRY(dmalloc(&d.y, (size_t)N));
+        SERT_HIP(hipMemcpyAsync(d.y, y_int, N * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    } else {
+        d.nnz = csr_indptr[N];
+        SERT_TRY(dmalloc(&d.csr_indptr, (size_t)N + 1));
+        SERT_TRY(dmalloc(&d.csr_indices, (size_t)std::max<int64_t>(1, d.nnz)));
+        SERT_TRY(dmalloc(&d.csr_data, (size_t)std::max<int64_t>(1, d.nnz)));
+        SERT_HIP(hipMemcpyAsync(d.csr_indptr, csr_indptr, (N + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
+        if (d.nnz) {
+            SERT_HIP(hipMemcpyAsync(d.csr_indices, csr_indices, d.nnz * sizeof(int32_t), hipMemcpyHostToDevice, s));
+            SERT_HIP(hipMemcpyAsync(d.csr_data, csr_data, d.nnz * sizeof(float), hipMemcpyHostToDevice, s));
+        }
+    }
+    if (split == SERT_SPLIT_TRAIN) {
+        SERT_TRY(dmalloc(&d.w, (size_t)N));
+        if (w) {
+            SERT_HIP(hipMemcpyAsync(d.w, w, N * sizeof(float), hipMemcpyHostToDevice, s));
+        } else {
+            std::vector<float> ones((size_t)N, 1.0f);
+            SERT_HIP(hipMemcpyAsync(d.w, ones.data(), N * sizeof(float), hipMemcpyHostToDevice, s));
+            SERT_HIP(hipStreamSynchronize(s));
+        }
+    }
+    SERT_HIP(hipStreamSynchronize(s));
+    return 0;
+}
+
+int sert_train_batch(sert_model* m, int64_t batch_index, const int64_t* negatives, float* loss_out) {
+    if (!m) SERT_FAIL("null model");
+    SERT_HIP(hipSetDevice(m->cfg.device));
+    SERT_TRY(train_step_async(m, batch_index, negatives, m->d_loss));
+    SERT_HIP(hipMemcpyAsync(m->h_loss, m->d_loss, 3 * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+    SERT_HIP(hipStreamSynchronize(m->stream));
+    timing_collect(m);
+    if (loss_out) *loss_out = m->h_loss[0];
+    return 0;
+}
+
+int sert_train_batches(sert_model* m, const int64_t* batch_indices, int64_t count, float* losses_out) {
+    if (!m || !batch_indices || count < 0) SERT_FAIL("bad argument");
+    SERT_HIP(hipSetDevice(m->cfg.device));
+    if (count == 0) return 0;
+    if (m->d_losses_cap < count) {
+        (void)hipFree(m->d_losses);
+        SERT_TRY(dmalloc(&m->d_losses, (size_t)count * 3));
+        m->d_losses_cap = count;
+    }
+    for (int64_t i = 0; i < count; ++i) {
+        SERT_TRY(train_step_async(m, batch_indices[i], nullptr, m->d_losses + 3 * i));
+        if (m->timing.enabled) {  // events are single-slot: drain per step when timing
+            SERT_HIP(hipStreamSynchronize(m->stream));
+            timing_collect(m);
+        }
+    }
+    std::vector<float> tmp((size_t)count * 3);
+    SERT_HIP(hipMemcpyAsync(tmp.data(), m->d_losses, count * 3 * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+    SERT_HIP(hipStreamSynchronize(m->stream));
+    if (losses_out)
+        for (int64_t i = 0; i < count; ++i) losses_out[i] = tmp[3 * i];
+    return 0;
+}
+
+int sert_eval_batch(sert_model* m, int split, int64_t batch_index, const int64_t* negatives, float* loss_out) {
+    if (!m) SERT_FAIL("null model");
+    if (split != SERT_SPLIT_TRAIN && split != SERT_SPLIT_VALIDATE) SERT_FAIL("bad split");
+    SERT_HIP(hipSetDevice(m->cfg.device));
+    const DataSplit& ds = m->split[split];
+    const int B = m->cfg.batch_size;
+    if (batch_index < 0 || (batch_index + 1) * (int64_t)B > ds.N) SERT_FAIL("batch_index out of range");
+    if (is_vs(m)) {
+        SERT_TRY(vs_negatives(m, negatives, (uint64_t)(m->eval_draws++) * 2 + 1));
+        SERT_TRY(vs_forward<false>(m, ds, batch_index));
+    } else {
+        SERT_TRY(ll_forward<false>(m, ds, batch_index));
+    }
+    // mean over the batch, no weights, no regulariser (models.py:751-752)
+    const int nb = std::min(kOptBlocks, cdiv(B, 256));
+    hipLaunchKernelGGL(sum_partial, dim3(nb), dim3(256), 0, m->stream, m->rowloss, (size_t)B, m->red_loss);
+    hipLaunchKernelGGL(finalize_loss, dim3(1), dim3(256), 0, m->stream, m->red_loss, nb, m->red_loss, 0,
+                       1.0f / (float)B, 0.0f, m->d_loss);
+    SERT_HIP(hipMemcpyAsync(m->h_loss, m->d_loss, 3 * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+    SERT_HIP(hipStreamSynchronize(m->stream));
+    float v = m->h_loss[0];
+    if (m->comm) {
+        // eval loss of the global batch = mean of the per-rank means (equal shares)
+        float* tmp = m->d_loss + 3;
+        SERT_HIP(hipMemcpyAsync(tmp, m->d_loss, sizeof(float), hipMemcpyDeviceToDevice, m->stream));
+        SERT_NCCL(g_rccl.AllReduce(tmp, tmp, 1, 7, 0, m->comm, m->stream));
+        SERT_HIP(hipMemcpyAsync(m->h_loss, tmp, sizeof(float), hipMemcpyDeviceToHost, m->stream));
+        SERT_HIP(hipStreamSynchronize(m->stream));
+        v = m->h_loss[0] / (float)m->world;
+    }
+    timing_collect(m);
+    if (loss_out) *loss_out = v;
+    return 0;
+}
+
+int sert_predict_project(sert_model* m, const float* avg, int64_t Q, float* out) {
+    if (!m || !avg || !out) SERT_FAIL("null argument");
+    if (!is_vs(m)) SERT_FAIL("sert_predict_project is the vectorspace predict_fn");
+    if (Q <= 0) return 0;
+    SERT_HIP(hipSetDevice(m->cfg.device));
+    const int dw = m->cfg.word_dim, de = m->cfg.entity_dim;
+    float *d_in = nullptr, *d_out = nullptr;
+    SERT_TRY(dmalloc(&d_in, (size_t)Q * dw));
+    SERT_TRY(dmalloc(&d_out, (size_t)Q * de));
+    SERT_HIP(hipMemcpyAsync(d_in, avg, (size_t)Q * dw * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    launch_gemm<false, false, EPI_BIAS_TANH>(m->stream, d_in, m->W, d_out, m->b, (int)Q, de, dw, dw, de, de);
+    SERT_HIP(hipMemcpyAsync(out, d_out, (size_t)Q * de * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+    SERT_HIP(hipStreamSynchronize(m->stream));
+    (void)hipFree(d_in); (void)hipFree(d_out);
+    return 0;
+}
+
+int sert_predict_tokens(sert_model* m, const void* ids, int64_t rows, float* out) {
+    if (!m || !ids || !out) SERT_FAIL("null argument");
+    if (is_vs(m)) SERT_FAIL("sert_predict_tokens is the loglinear predict_fn");
+    if (rows <= 0) return 0;
+    SERT_HIP(hipSetDevice(m->cfg.device));
+    const auto& c = m->cfg;
+    const int n = c.window_size, d = c.word_dim, V = c.num_entities;
+    const int64_t toks = rows * n;
+    void* d_ids = nullptr;
+    float *dG = nullptr, *dZ = nullptr;
+    SERT_HIP(hipMalloc(&d_ids, (size_t)toks * c.id_bytes));
+    SERT_TRY(dmalloc(&dG, (size_t)toks * d));
+    SERT_TRY(dmalloc(&dZ, (size_t)toks * V));
+    SERT_HIP(hipMemcpyAsync(d_ids, ids, (size_t)toks * c.id_bytes, hipMemcpyHostToDevice, m->stream));
+    SERT_ID_DISPATCH(c.id_bytes, {
+        const IdT* X = (const IdT*)d_ids;
+        if (d % 4 == 0)
+            hipLaunchKernelGGL((ll_gather_rows<IdT, 4>), dim3(grid_for(toks * d / 4, 256, 1 << 20)), dim3(256), 0, m->stream, X, m->rw, dG, toks, d);
+        else
+            hipLaunchKernelGGL((ll_gather_rows<IdT, 1>), dim3(grid_for(toks * d, 256, 1 << 20)), dim3(256), 0, m->stream, X, m->rw, dG, toks, d);
+    });
+    launch_gemm<false, false, EPI_BIAS>(m->stream, dG, m->W, dZ, m->b, (int)toks, V, d, d, V, V);
+    hipLaunchKernelGGL(ll_softmax_rows, dim3(cdiv(toks, 4)), dim3(256), 0, m->stream, dZ, toks, V);
+    SERT_HIP(hipMemcpyAsync(out, dZ, (size_t)toks * V * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+    SERT_HIP(hipStreamSynchronize(m->stream));
+    (void)hipFree(d_ids); (void)hipFree(dG); (void)hipFree(dZ);
+    return 0;
+}
+
+int sert_score_topk(int device, const float* entities, int64_t V, int32_t dim, const float* proj,
+                    int64_t Q, int32_t k, int32_t* idx_out, float* score_out) {
+    if (!entities || !proj || !idx_out || !score_out) SERT_FAIL("null argument");
+    if (V <= 0 || dim <= 0 || Q < 0 || k <= 0) SERT_FAIL("bad sizes");
+    if (k > V) SERT_FAIL("k exceeds the number of entities");
+    if (k > kTopKMax) SERT_FAIL("k > 1024 is not supported");
+    if (Q == 0) return 0;
+    SERT_HIP(hipSetDevice(device));
+    hipStream_t s;
+    SERT_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    float *dE = nullptr, *dP = nullptr, *dS = nullptr, *dVal = nullptr;
+    int32_t* dIdx = nullptr;
+    const int64_t QT = std::min<int64_t>(Q, std::max<int64_t>(128, (int64_t)(1ll << 28) / V / 128 * 128));
+    SERT_TRY(dmalloc(&dE, (size_t)V * dim));
+    SERT_TRY(dmalloc(&dP, (size_t)Q * dim));
+    SERT_TRY(dmalloc(&dS, (size_t)QT * V));
+    SERT_TRY(dmalloc(&dVal, (size_t)Q * k));
+    SERT_TRY(dmalloc(&dIdx, (size_t)Q * k));
+    SERT_HIP(hipMemcpyAsync(dE, entities, (size_t)V * dim * sizeof(float), hipMemcpyHostToDevice, s));
+    SERT_HIP(hipMemcpyAsync(dP, proj, (size_t)Q * dim * sizeof(float), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(l2_normalize_rows, dim3(cdiv(V, 4)), dim3(256), 0, s, dE, V, dim);
+    hipLaunchKernelGGL(l2_normalize_rows, dim3(cdiv(Q, 4)), dim3(256), 0, s, dP, Q, dim);
+    for (int64_t q0 = 0; q0 < Q; q0 += QT) {
+        const int64_t qn = std::min(QT, Q - q0);
+        // S = P.E^T
+        launch_gemm<false, true, EPI_STORE>(s, dP + q0 * dim, dE, dS, nullptr, (int)qn, (int)V, dim, dim, dim, (int)V);
+        hipLaunchKernelGGL(topk_rows, dim3((unsigned)qn), dim3(256), 0, s, dS, (int)V, k,
+                           dIdx + q0 * k, dVal + q0 * k);
+    }
+    SERT_HIP(hipMemcpyAsync(idx_out, dIdx, (size_t)Q * k * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    SERT_HIP(hipMemcpyAsync(score_out, dVal, (size_t)Q * k * sizeof(float), hipMemcpyDeviceToHost, s));
+    SERT_HIP(hipStreamSynchronize(s));
+    (void)hipFree(dE); (void)hipFree(dP); (void)hipFree(dS); (void)hipFree(dVal); (void)hipFree(dIdx);
+    (void)hipStreamDestroy(s);
+    return 0;
+}
+
+int sert_comm_unique_id(char id[SERT_COMM_ID_BYTES]) {
+    SERT_TRY(rccl_load());
+    SERT_NCCL(g_rccl.GetUniqueId(id));
+    return 0;
+}
+
+int sert_comm_init(sert_model* m, const char id[SERT_COMM_ID_BYTES], int rank, int world) {
+    if (!m || !id) SERT_FAIL("null argument");
+    if (world < 1 || rank < 0 || rank >= world) SERT_FAIL("bad rank/world");
+    if ((int64_t)m->cfg.batch_size * world != m->cfg.global_batch_size)
+        SERT_FAIL("global_batch_size must equal batch_size * world");
+    SERT_TRY(rccl_load());
+    SERT_HIP(hipSetDevice(m->cfg.device));
+    UniqueId uid;
+    memcpy(uid.internal, id, SERT_COMM_ID_BYTES);
+    SERT_NCCL(g_rccl.CommInitRank(&m->comm, world, uid, rank));
+    m->rank = rank;
+    m->world = world;
+    return 0;
+}
+
+int sert_comm_destroy(sert_model* m) {
+    if (m && m->comm) {
+        SERT_NCCL(g_rccl.CommDestroy(m->comm));
+        m->comm = nullptr;
+        m->rank = 0;
+        m->world = 1;
+    }
+    return 0;
+}
+
+int sert_synchronize(sert_model* m) {
+    if (!m) SERT_FAIL("null model");
+    SERT_HIP(hipSetDevice(m->cfg.device));
+    SERT_HIP(hipStreamSynchronize(m->stream));
+    return 0;
+}
+
+int sert_timing_enable(sert_model* m, int on) {
+    if (!m) SERT_FAIL("null model");
+    m->timing.enabled = on != 0;
+    return 0;
+}
+int sert_timing_reset(sert_model* m) {
+    if (!m) SERT_FAIL("null model");
+    for (int g = 0; g < TG_COUNT; ++g) { m->timing.total_us[g] = 0; m->timing.samples[g] = 0; m->timing.used[g] = false; }
+    return 0;
+}
+int sert_timing_count(sert_model*) { return TG_COUNT; }
+const char* sert_timing_name(sert_model*, int i) { return (i >= 0 && i < TG_COUNT) ? kTimingNames[i] : ""; }
+double sert_timing_avg_us(sert_model* m, int i) {
+    if (!m || i < 0 || i >= TG_COUNT || m->timing.samples[i] == 0) return 0.0;
+    return m->timing.total_us[i] / (double)m->timing.samples[i];
+}
+
+}  // extern "C"

@@ -1,0 +1,261 @@
+#!/usr/bin/env python
+"""bench.py -- training (word-window, entity) pairs/s of the SERT hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one call of train_fn(batch_index) (sert/models.py:581-588): forward,
+backward, L2, dense optimiser update on one batch of synthetic (window, entity)
+pairs, INCLUDING the per-step loss read-back the reference's epoch loop performs
+(sert/models.py:369-379).  Workload at N=1: BASELINE.json configs[1] -- the LSE
+config |V_w|=100k, |V_e|=1k, d=128, window=10, batch=65536 -- run with the
+reference's LSE model (VectorSpaceLanguageModel: NCE, z=10, Adam).  N>1: weak
+scaling, one process per GPU (launched by torch.distributed.run), per-GPU batch
+fixed at 65536, gradients summed by one RCCL all-reduce per step.
+
+Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel group
+(HIP events on the model's stream, measured live in the timed region),
+`cpu_baseline` the oracle (numpy restatement of the reference graph) timed on
+this node's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 MFMA dense peak
+
+
+def synth_data(rng, N, n, Vw, Ve):
+    """Zipf(1.1) token ranks clipped to V_w then permuted once,
+    labels ~ U[0,V_e), weights = 1."""
+    ranks = np.minimum(rng.zipf(1.1, size=(N, n)) - 1, Vw - 1)
+    perm = rng.permutation(Vw).astype(np.uint32)
+    X = perm[ranks].astype(np.min_scalar_type(Vw - 1))
+    y = rng.randint(0, Ve, size=N).astype(np.int32)
+    w = np.ones(N, dtype=np.float32)
+    return X, y, w
+
+
+def glorot(rng, shape):
+    a = np.sqrt(6.0 / (shape[0] + shape[1]))
+    return rng.uniform(-a, a, size=shape).astype(np.float32)
+
+
+def group_work(kind, B, n, s, dw, de, Ve, Vw, z):
+    """Algorithmic bytes / flops per launch group (SURVEY 8(d) per-pair figures
+    x the pairs one step processes; per-step optimiser term 32*P)."""
+    if kind == 'vectorspace':
+        P = Vw * dw + Ve * de + dw * de + de
+        return {
+            'gather':    ('hbm', B * (n * s + 4 * n * dw)),
+            'gemm_fwd':  ('mfma', 2.0 * B * dw * de),
+            'loss':      ('hbm', B * (8 + 12 * (1 + z) * de)),
+            'gemm_bwd':  ('mfma', 4.0 * B * dw * de),
+            'scatter':   ('hbm', B * (8 * n * dw)),
+            'optimizer': ('hbm', 32.0 * P),
+        }
+    P = Vw * dw + dw * Ve + Ve
+    return {
+        'gather':    ('hbm', B * (n * s + 4 * n * dw)),
+        'gemm_fwd':  ('mfma', 2.0 * B * n * dw * Ve),
+        'loss':      ('hbm', B * (12.0 * n * Ve)),
+        'gemm_bwd':  ('mfma', 4.0 * B * n * dw * Ve),
+        'scatter':   ('hbm', B * (8 * n * dw)),
+        'optimizer': ('hbm', 32.0 * P),
+    }
+
+
+def build_model(kind, models, B_global, n, Vw, Ve, dw, de, z, X, y, w, seed):
+    np.random.seed(seed)
+    rng = np.random.RandomState(seed + 1)
+    Rw = glorot(rng, (Vw, dw))
+    empty_x = np.zeros((0, n), dtype=X.dtype)
+    empty_y = np.zeros((0,), dtype=np.int32)
+    if kind == 'vectorspace':
+        Re = glorot(rng, (Ve, de))
+        m = models.VectorSpaceLanguageModel(
+            batch_size=B_global, window_size=n, num_negative_samples=z,
+            representations_init=Rw, entity_representations_init=Re,
+            regularization_lambda=0.01, training_set=(X, y, w),
+            validation_set=(empty_x, empty_y))
+    else:
+        m = models.LanguageModel(
+            batch_size=B_global, window_size=n, representations_init=Rw,
+            output_layer_size=Ve, regularization_lambda=0.01,
+            training_set=(X, y, w), validation_set=(empty_x, empty_y))
+    return m
+
+
+def timed_steps(model, dist, num_batches, steps, warmup, timing=True):
+    eng = model._engine
+    for i in range(warmup):
+        model.train_fn(i % num_batches)
+    eng.timing_reset()
+    eng.timing_enable(timing)
+    eng.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    last = 0.0
+    for i in range(steps):
+        last = model.train_fn((warmup + i) % num_batches)
+    eng.synchronize()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    eng.timing_enable(False)
+    if not np.isfinite(last):
+        raise RuntimeError('non-finite loss in the timed region')
+    return dist.all_reduce_max(dt), eng.timings(), float(last)
+
+
+def cpu_baseline(kind, B, n, Vw, Ve, dw, de, z, budget_s=15.0):
+    """The oracle (numpy restatement of the reference graph -- NOT Theano, which
+    cannot run here) timed on this node's host cores."""
+    from oracle import sert_oracle as O
+    rng = np.random.RandomState(123)
+    X, y, w = synth_data(rng, B, n, Vw, Ve)
+    Rw = glorot(rng, (Vw, dw))
+    if kind == 'vectorspace':
+        ora = O.VectorSpaceOracle(B, n, z, Rw, glorot(rng, (Ve, de)), glorot(rng, (dw, de)),
+                                  np.zeros(de, np.float32), 0.01)
+        step = lambda: ora.train_step(X, y, w, rng.randint(0, Ve, size=(B, z)))
+    else:
+        ora = O.LogLinearOracle(B, n, Rw, glorot(rng, (dw, Ve)), np.zeros(Ve, np.float32), 0.01)
+        step = lambda: ora.train_step(X, y, w)
+    t0 = time.perf_counter()
+    steps = 0
+    while True:
+        step()
+        steps += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or steps >= 8:
+            break
+    return dict(value=steps * B / dt, unit='pairs/s',
+                cores=len(os.sched_getaffinity(0)), kind='port',
+                sample='%d steps of B=%d (%d pairs, %.1f s) of the same workload; numpy+BLAS '
+                       'restatement of the reference graph (oracle/), not Theano' %
+                       (steps, B, steps * B, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--model', choices=['vectorspace', 'loglinear'], default='vectorspace')
+    ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default 65536; loglinear 8192)')
+    ap.add_argument('--vocab', type=int, default=100000)
+    ap.add_argument('--entities', type=int, default=1000)
+    ap.add_argument('--dim', type=int, default=128)
+    ap.add_argument('--window', type=int, default=10)
+    ap.add_argument('--negatives', type=int, default=10)
+    ap.add_argument('--num-batches', type=int, default=8)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-budget', type=float, default=15.0)
+    ap.add_argument('--no-loglinear-extra', action='store_true')
+    args = ap.parse_args()
+
+    from sert_amd import _build
+    _build.build()
+    from sert_amd import distributed as dist
+    from sert_amd import models, _capi
+
+    ctx = dist.init_from_env()
+    if ctx.world_size != args.gpus and not (args.gpus == 1 and ctx.world_size == 1):
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run '
+                         '--nproc-per-node %d' % (args.gpus, ctx.world_size, args.gpus))
+    N = ctx.world_size
+    kind = args.model
+    Bl = args.batch or (65536 if kind == 'vectorspace' else 8192)
+    Bg = Bl * N
+    n, Vw, Ve, d, z = args.window, args.vocab, args.entities, args.dim, args.negatives
+    rng = np.random.RandomState(0)
+    X, y, w = synth_data(rng, args.num_batches * Bg, n, Vw, Ve)
+    model = build_model(kind, models, Bg, n, Vw, Ve, d, d, z, X, y, w, seed=0)
+
+    dt, timings, last_loss = timed_steps(model, dist, args.num_batches, args.steps, args.warmup)
+    value = args.steps * Bg / dt
+
+    out = None
+    if ctx.rank == 0:
+        s = X.dtype.itemsize
+        work = group_work(kind, Bl, n, s, d, d, Ve, Vw, z)
+        kernels = {}
+        for name, us in timings.items():
+            if us <= 0 or name not in work:
+                continue
+            bound, amount = work[name]
+            if bound == 'hbm':
+                ach = amount / (us * 1e-6) / 1e9
+                kernels[name] = dict(us=round(us, 2), bound='hbm', achieved=round(ach, 1),
+                                     unit='GB/s', frac=round(ach / HBM_PEAK_GBS, 4))
+            else:
+                ach = amount / (us * 1e-6) / 1e12
+                kernels[name] = dict(us=round(us, 2), bound='mfma', achieved=round(ach, 2),
+                                     unit='TFLOP/s', frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4))
+        for name in ('allreduce', 'finalize'):
+            if timings.get(name, 0) > 0:
+                kernels[name] = dict(us=round(timings[name], 2))
+        dom = max((k for k in kernels if 'bound' in kernels[k]), key=lambda k: kernels[k]['us'])
+        kd = kernels[dom]
+        roofline = dict(kernel=dom, bound=kd['bound'], achieved=kd['achieved'],
+                        peak=HBM_PEAK_GBS if kd['bound'] == 'hbm' else MFMA_F32_PEAK_TFLOPS,
+                        unit=kd['unit'], frac=kd['frac'], traffic=None,
+                        avg_us=kd['us'])
+        out = {
+            'metric': 'training_pairs_per_sec', 'value': value, 'unit': 'pairs/s',
+            'n_gpus': N, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': 1000.0 * dt / args.steps, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {
+                'workload': ('C2 LSE: %s V_w=%d V_e=%d d=%d window=%d batch/GPU=%d%s' % (
+                    'VectorSpaceLanguageModel (NCE z=%d, Adam)' % z if kind == 'vectorspace'
+                    else 'LanguageModel (full softmax, Adadelta)',
+                    Vw, Ve, d, n, Bl, '' if N == 1 else ' global_batch=%d' % Bg)),
+                'global_batch': Bg, 'parallelism': 'dp%d' % N,
+                'id_dtype': str(X.dtype), 'lambda': 0.01,
+            },
+            'roofline': roofline,
+            'kernels': kernels,
+            'last_loss': last_loss,
+            'device': _capi.device_info(model._engine.cfg.device),
+        }
+
+    # extra: the reference's full-softmax model (loglinear) at the same dims
+    if N == 1 and kind == 'vectorspace' and not args.no_loglinear_extra:
+        del model
+        Bll = 8192
+        rng2 = np.random.RandomState(1)
+        X2, y2, w2 = synth_data(rng2, 4 * Bll, n, Vw, Ve)
+        m2 = build_model('loglinear', models, Bll, n, Vw, Ve, d, d, z, X2, y2, w2, seed=1)
+        st = max(5, min(20, args.steps))
+        dt2, tm2, _ = timed_steps(m2, dist, 4, st, 3)
+        work2 = group_work('loglinear', Bll, n, X2.dtype.itemsize, d, d, Ve, Vw, z)
+        fl = sum(v for k, (b, v) in work2.items() if b == 'mfma')
+        out['loglinear'] = {
+            'workload': 'LanguageModel (full softmax over V_e, Adadelta) V_w=%d V_e=%d d=%d window=%d batch=%d' % (Vw, Ve, d, n, Bll),
+            'value': st * Bll / dt2, 'unit': 'pairs/s', 'ms_per_step': 1000 * dt2 / st,
+            'kernels_us': {k: round(v, 1) for k, v in tm2.items() if v > 0},
+            'mfma_tflops_whole_step': fl / (dt2 / st) / 1e12,
+        }
+        del m2
+
+    if ctx.rank == 0 and N == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(kind, Bl, n, Vw, Ve, d, d, z, args.cpu_budget)
+    elif ctx.rank == 0:
+        out['cpu_baseline'] = None
+
+    if ctx.rank == 0:
+        print(json.dumps(out))
+    dist.barrier()
+    dist.shutdown()
+
+
+if __name__ == '__main__':
+    main()

@@ -77,6 +77,8 @@ typedef struct sert_config {
     int32_t device;           /* HIP device ordinal */
     int32_t keep_grads;       /* keep SERT_T_GRAD_* readable after a step (debug) */
     int32_t deterministic;    /* 1: order-fixed reductions everywhere */
+    int32_t inference_only;   /* 1: parameters only (no optimiser state, gradients or
+                                 activations); only sert_predict_* and tensor I/O work */
     float lambda_;            /* regularization_lambda, models.py:704 */
     /* optimiser hyper-parameters.  vectorspace: Adam (models.py:922)
      * lr, beta1, beta2, eps.  loglinear: Adadelta (models.py:820) lr, rho(beta1), eps. */

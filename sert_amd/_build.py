@@ -9,7 +9,7 @@ INCLUDE = os.path.join(os.path.dirname(HERE), 'include')
 
 SOURCES = ['sert_hip.hip']
 HEADERS = ['common.h', 'gemm.h', 'kernels_vs.h', 'kernels_ll.h', 'kernels_opt.h',
-           'kernels_score.h', 'model.h']
+           'kernels_score.h', 'kernels_seg.h', 'word_index.h', 'model.h']
 
 
 def _stale():

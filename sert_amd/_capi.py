@@ -50,6 +50,7 @@ class SertConfig(ctypes.Structure):
         ('device', ctypes.c_int32),
         ('keep_grads', ctypes.c_int32),
         ('deterministic', ctypes.c_int32),
+        ('inference_only', ctypes.c_int32),
         ('lambda_', ctypes.c_float),
         ('lr', ctypes.c_float),
         ('beta1', ctypes.c_float),

@@ -1,0 +1,78 @@
+// Order-fixed segmented gather-reduce (replaces fp32 atomic scatter-add), gfx950.
+#pragma once
+#include "common.h"
+#include "word_index.h"
+
+namespace sert {
+
+// For every item: acc = sum_{e in [begin,end)} src[row(e), :]  (e ascending),
+// then  dst >= 0 : final[dst, :]    = acc / divisor  (gradient table row)
+//       dst <  0 : partial[-(dst+1), :] = acc        (next level's input)
+// row(e) = rows ? rows[e] : e.  LPI lanes cooperate on one item (LPI = 32 when
+// d/4 <= 32 so a wave carries two items), each lane owns float4 column chunks.
+template <int LPI>
+__global__ __launch_bounds__(256) void segsum_rows(const float* __restrict__ src,
+                                                   const int32_t* __restrict__ rows,
+                                                   const int4* __restrict__ items, int nitems,
+                                                   float* __restrict__ final_dst,
+                                                   float* __restrict__ partial_dst, int d,
+                                                   float divisor) {
+    constexpr int IPB = 256 / LPI;  // items per block
+    const int sub = threadIdx.x / LPI, l = threadIdx.x % LPI;
+    const int item = blockIdx.x * IPB + sub;
+    if (item >= nitems) return;
+    const int4 it = items[item];
+    const int chunks = d >> 2;
+    for (int c = l; c < chunks; c += LPI) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        int e = it.x;
+        for (; e + 4 <= it.y; e += 4) {
+            int r0, r1, r2, r3;
+            if (rows) { r0 = rows[e]; r1 = rows[e + 1]; r2 = rows[e + 2]; r3 = rows[e + 3]; }
+            else      { r0 = e; r1 = e + 1; r2 = e + 2; r3 = e + 3; }
+            const float4 v0 = *reinterpret_cast<const float4*>(src + (size_t)r0 * d + 4 * c);
+            const float4 v1 = *reinterpret_cast<const float4*>(src + (size_t)r1 * d + 4 * c);
+            const float4 v2 = *reinterpret_cast<const float4*>(src + (size_t)r2 * d + 4 * c);
+            const float4 v3 = *reinterpret_cast<const float4*>(src + (size_t)r3 * d + 4 * c);
+            a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
+            a.x += v1.x; a.y += v1.y; a.z += v1.z; a.w += v1.w;
+            a.x += v2.x; a.y += v2.y; a.z += v2.z; a.w += v2.w;
+            a.x += v3.x; a.y += v3.y; a.z += v3.z; a.w += v3.w;
+        }
+        for (; e < it.y; ++e) {
+            const int r = rows ? rows[e] : e;
+            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)r * d + 4 * c);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        if (it.z >= 0) {
+            a.x /= divisor; a.y /= divisor; a.z /= divisor; a.w /= divisor;
+            *reinterpret_cast<float4*>(final_dst + (size_t)it.z * d + 4 * c) = a;
+        } else {
+            *reinterpret_cast<float4*>(partial_dst + (size_t)(-(it.z + 1)) * d + 4 * c) = a;
+        }
+    }
+}
+
+// Scalar variant for d % 4 != 0: one wave per item, lanes stride over columns.
+__global__ __launch_bounds__(256) void segsum_rows_scalar(const float* __restrict__ src,
+                                                          const int32_t* __restrict__ rows,
+                                                          const int4* __restrict__ items,
+                                                          int nitems, float* __restrict__ final_dst,
+                                                          float* __restrict__ partial_dst, int d,
+                                                          float divisor) {
+    const int lane = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= nitems) return;
+    const int4 it = items[item];
+    for (int c = lane; c < d; c += 64) {
+        float a = 0.f;
+        for (int e = it.x; e < it.y; ++e) {
+            const int r = rows ? rows[e] : e;
+            a += src[(size_t)r * d + c];
+        }
+        if (it.z >= 0) final_dst[(size_t)it.z * d + c] = a / divisor;
+        else partial_dst[(size_t)(-(it.z + 1)) * d + c] = a;
+    }
+}
+
+}  // namespace sert

@@ -3,6 +3,7 @@
 #include <vector>
 #include <string>
 #include "common.h"
+#include "word_index.h"
 #include "../../include/sert_hip.h"
 
 namespace sert {
@@ -16,6 +17,10 @@ struct DataSplit {
     float* csr_data = nullptr;       // (nnz)
     int64_t nnz = 0;
     float* w = nullptr;         // (N,) instance weights (train split)
+    // inverted index word -> rows of every complete batch (train split only)
+    int32_t* idx_rows = nullptr;
+    int4* idx_items = nullptr;
+    std::vector<BatchIndex> idx_batches;
 };
 
 // Timed kernel groups (HIP events on the model's stream).
@@ -71,6 +76,8 @@ struct sert_model {
     float *DG = nullptr;          // (B*n, d)
 
     // scratch
+    float* wpart = nullptr;       // segmented-reduce partial rows (word gradient tree)
+    size_t wpart_rows = 0;
     float* part = nullptr;        // split-K partials
     size_t part_count = 0;
     float* red_loss = nullptr;    // loss partials [kOptBlocks]

@@ -14,6 +14,7 @@
 #include "kernels_ll.h"
 #include "kernels_opt.h"
 #include "kernels_score.h"
+#include "kernels_seg.h"
 #include "kernels_vs.h"
 #include "model.h"
 
@@ -159,6 +160,36 @@ static TensorRef tensor_ref(sert_model* m, int which) {
         else { typedef uint32_t IdT; __VA_ARGS__; }                      \
     } while (0)
 
+
+// dR_w = scatter-add of `src` rows into the word table, as an order-fixed
+// segmented reduction over the batch's prebuilt inverted index (word_index.h).
+static int word_grad_segsum(sert_model* m, const DataSplit& ds, int64_t batch_index,
+                            const float* src, float divisor) {
+    const int d = m->cfg.word_dim;
+    if ((size_t)batch_index >= ds.idx_batches.size()) SERT_FAIL("batch has no word index");
+    const BatchIndex& bx = ds.idx_batches[(size_t)batch_index];
+    for (int l = 0; l < bx.nlevels; ++l) {
+        const int nitems = bx.item_cnt[l];
+        if (nitems == 0) continue;
+        const float* in = (l == 0) ? src : m->wpart + (size_t)bx.part_off[l - 1] * d;
+        const int32_t* rows = (l == 0) ? ds.idx_rows + bx.rows_off : nullptr;
+        const int4* items = ds.idx_items + bx.item_off[l];
+        float* pout = m->wpart + (size_t)bx.part_off[l] * d;
+        if (d % 4 == 0) {
+            if (d / 4 <= 32)
+                hipLaunchKernelGGL((segsum_rows<32>), dim3(cdiv(nitems, 8)), dim3(256), 0, m->stream,
+                                   in, rows, items, nitems, m->g_rw, pout, d, divisor);
+            else
+                hipLaunchKernelGGL((segsum_rows<64>), dim3(cdiv(nitems, 4)), dim3(256), 0, m->stream,
+                                   in, rows, items, nitems, m->g_rw, pout, d, divisor);
+        } else {
+            hipLaunchKernelGGL(segsum_rows_scalar, dim3(cdiv(nitems, 4)), dim3(256), 0, m->stream, in,
+                               rows, items, nitems, m->g_rw, pout, d, divisor);
+        }
+    }
+    return 0;
+}
+
 // ---- the vectorspace step -----------------------------------------------------
 static int vs_negatives(sert_model* m, const int64_t* negatives, uint64_t stream_pos) {
     const auto& c = m->cfg;
@@ -254,18 +285,10 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
     }
     {
         ScopedTimer t(m, TG_SCATTER);
-        SERT_ID_DISPATCH(c.id_bytes, {
-            const IdT* X = (const IdT*)ds.x + row0 * n;
-            if (dw % 4 == 0)
-                hipLaunchKernelGGL((vs_scatter_dh<IdT, 4>),
-                                   dim3(grid_for((int64_t)B * n * dw / 4, 256, 1 << 20)), dim3(256), 0,
-                                   m->stream, X, m->DH, m->g_rw, B, n, dw);
-            else
-                hipLaunchKernelGGL((vs_scatter_dh<IdT, 1>),
-                                   dim3(grid_for((int64_t)B * n * dw, 256, 1 << 20)), dim3(256), 0,
-                                   m->stream, X, m->DH, m->g_rw, B, n, dw);
-        });
+        // dR_w[X[i,k],:] += dh[i,:] / n
+        SERT_TRY(word_grad_segsum(m, ds, batch_index, m->DH, (float)n));
     }
+    (void)row0;
     return 0;
 }
 
@@ -337,16 +360,10 @@ static int ll_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
     }
     {
         ScopedTimer t(m, TG_SCATTER);
-        SERT_ID_DISPATCH(c.id_bytes, {
-            const IdT* X = (const IdT*)ds.x + row0 * n;
-            if (d % 4 == 0)
-                hipLaunchKernelGGL((ll_scatter_rows<IdT, 4>), dim3(grid_for(rows * d / 4, 256, 1 << 20)),
-                                   dim3(256), 0, m->stream, X, m->DG, m->g_rw, rows, d);
-            else
-                hipLaunchKernelGGL((ll_scatter_rows<IdT, 1>), dim3(grid_for(rows * d, 256, 1 << 20)),
-                                   dim3(256), 0, m->stream, X, m->DG, m->g_rw, rows, d);
-        });
+        // dR_w[X[r],:] += dG[r,:]
+        SERT_TRY(word_grad_segsum(m, ds, batch_index, m->DG, 1.0f));
     }
+    (void)row0;
     return 0;
 }
 
@@ -412,6 +429,7 @@ static int train_step_async(sert_model* m, int64_t batch_index, const int64_t* n
                             float* loss_dst) {
     const DataSplit& ds = m->split[SERT_SPLIT_TRAIN];
     const int B = m->cfg.batch_size;
+    if (m->cfg.inference_only) SERT_FAIL("model was created inference_only");
     if (ds.N == 0) SERT_FAIL("no training data uploaded");
     if (batch_index < 0 || (batch_index + 1) * (int64_t)B > ds.N) SERT_FAIL("batch_index out of range");
     SERT_HIP(hipMemsetAsync(m->gflat, 0, m->gflat_count * sizeof(float), m->stream));
@@ -487,40 +505,42 @@ int sert_create(const sert_config* cfg, sert_model** out) {
     hipStream_t s = m->stream;
     SERT_TRY(dzalloc(&m->rw, m->n_rw, s));  SERT_TRY(dzalloc(&m->re, m->n_re, s));
     SERT_TRY(dzalloc(&m->W, m->n_w, s));    SERT_TRY(dzalloc(&m->b, m->n_b, s));
-    SERT_TRY(dzalloc(&m->s0_rw, m->n_rw, s)); SERT_TRY(dzalloc(&m->s0_re, m->n_re, s));
-    SERT_TRY(dzalloc(&m->s0_w, m->n_w, s));   SERT_TRY(dzalloc(&m->s0_b, m->n_b, s));
-    SERT_TRY(dzalloc(&m->s1_rw, m->n_rw, s)); SERT_TRY(dzalloc(&m->s1_re, m->n_re, s));
-    SERT_TRY(dzalloc(&m->s1_w, m->n_w, s));   SERT_TRY(dzalloc(&m->s1_b, m->n_b, s));
-    // flat gradient buffer, every sub-tensor 16-byte aligned
-    const size_t o_re = 0, o_rw = o_re + round_up(m->n_re, 4), o_w = o_rw + round_up(m->n_rw, 4),
-                 o_b = o_w + round_up(m->n_w, 4), o_l = o_b + round_up(m->n_b, 4);
-    m->gflat_count = o_l + 4;
-    SERT_TRY(dzalloc(&m->gflat, m->gflat_count, s));
-    m->g_re = m->n_re ? m->gflat + o_re : nullptr;
-    m->g_rw = m->gflat + o_rw;
-    m->g_w = m->gflat + o_w;
-    m->g_b = m->gflat + o_b;
-    m->g_loss = m->gflat + o_l;
-    SERT_TRY(dzalloc(&m->rowloss, B, s));
-    size_t part = 0;
-    if (vs) {
-        SERT_TRY(dzalloc(&m->H, B * dw, s));  SERT_TRY(dzalloc(&m->T, B * de, s));
-        SERT_TRY(dzalloc(&m->DA, B * de, s)); SERT_TRY(dzalloc(&m->DH, B * dw, s));
-        SERT_TRY(dzalloc(&m->neg, std::max<size_t>(4, B * c.num_negatives), s));
-        SERT_TRY(dzalloc(&m->neg_stage, std::max<size_t>(4, B * c.num_negatives), s));
-        part = std::max((size_t)256 * dw * de, (size_t)256 * de);
-    } else {
-        SERT_TRY(dzalloc(&m->G, B * n * dw, s));  SERT_TRY(dzalloc(&m->Z, B * n * V, s));
-        SERT_TRY(dzalloc(&m->J, B * V, s));       SERT_TRY(dzalloc(&m->DG, B * n * dw, s));
-        const size_t tiles = (size_t)cdiv(V, GN) * cdiv(dw, GM);
-        const size_t splits = std::max<size_t>(1, cdiv(1024, tiles)) + 1;
-        part = std::max(splits * dw * V, (size_t)256 * V);
+    if (!c.inference_only) {
+        SERT_TRY(dzalloc(&m->s0_rw, m->n_rw, s)); SERT_TRY(dzalloc(&m->s0_re, m->n_re, s));
+        SERT_TRY(dzalloc(&m->s0_w, m->n_w, s));   SERT_TRY(dzalloc(&m->s0_b, m->n_b, s));
+        SERT_TRY(dzalloc(&m->s1_rw, m->n_rw, s)); SERT_TRY(dzalloc(&m->s1_re, m->n_re, s));
+        SERT_TRY(dzalloc(&m->s1_w, m->n_w, s));   SERT_TRY(dzalloc(&m->s1_b, m->n_b, s));
+        // flat gradient buffer, every sub-tensor 16-byte aligned
+        const size_t o_re = 0, o_rw = o_re + round_up(m->n_re, 4), o_w = o_rw + round_up(m->n_rw, 4),
+                     o_b = o_w + round_up(m->n_w, 4), o_l = o_b + round_up(m->n_b, 4);
+        m->gflat_count = o_l + 4;
+        SERT_TRY(dzalloc(&m->gflat, m->gflat_count, s));
+        m->g_re = m->n_re ? m->gflat + o_re : nullptr;
+        m->g_rw = m->gflat + o_rw;
+        m->g_w = m->gflat + o_w;
+        m->g_b = m->gflat + o_b;
+        m->g_loss = m->gflat + o_l;
+        SERT_TRY(dzalloc(&m->rowloss, B, s));
+        size_t part = 0;
+        if (vs) {
+            SERT_TRY(dzalloc(&m->H, B * dw, s));  SERT_TRY(dzalloc(&m->T, B * de, s));
+            SERT_TRY(dzalloc(&m->DA, B * de, s)); SERT_TRY(dzalloc(&m->DH, B * dw, s));
+            SERT_TRY(dzalloc(&m->neg, std::max<size_t>(4, B * c.num_negatives), s));
+            SERT_TRY(dzalloc(&m->neg_stage, std::max<size_t>(4, B * c.num_negatives), s));
+            part = std::max((size_t)256 * dw * de, (size_t)256 * de);
+        } else {
+            SERT_TRY(dzalloc(&m->G, B * n * dw, s));  SERT_TRY(dzalloc(&m->Z, B * n * V, s));
+            SERT_TRY(dzalloc(&m->J, B * V, s));       SERT_TRY(dzalloc(&m->DG, B * n * dw, s));
+            const size_t tiles = (size_t)cdiv(V, GN) * cdiv(dw, GM);
+            const size_t splits = std::max<size_t>(1, cdiv(1024, tiles)) + 1;
+            part = std::max(splits * dw * V, (size_t)256 * V);
+        }
+        m->part_count = part;
+        SERT_TRY(dzalloc(&m->part, part, s));
+        SERT_TRY(dzalloc(&m->red_loss, (size_t)kOptBlocks, s));
+        SERT_TRY(dzalloc(&m->red_sq, (size_t)4 * kOptBlocks, s));
+        SERT_TRY(dzalloc(&m->d_loss, (size_t)4, s));
     }
-    m->part_count = part;
-    SERT_TRY(dzalloc(&m->part, part, s));
-    SERT_TRY(dzalloc(&m->red_loss, (size_t)kOptBlocks, s));
-    SERT_TRY(dzalloc(&m->red_sq, (size_t)4 * kOptBlocks, s));
-    SERT_TRY(dzalloc(&m->d_loss, (size_t)4, s));
     SERT_HIP(hipHostMalloc((void**)&m->h_loss, 4 * sizeof(float), hipHostMallocDefault));
     for (int g = 0; g < TG_COUNT; ++g)
         for (int k = 0; k < 2; ++k) SERT_HIP(hipEventCreate(&m->timing.ev[g][k]));
@@ -533,6 +553,7 @@ int sert_create(const sert_config* cfg, sert_model** out) {
 static void free_split(DataSplit& d) {
     (void)hipFree(d.x); (void)hipFree(d.y); (void)hipFree(d.csr_indptr);
     (void)hipFree(d.csr_indices); (void)hipFree(d.csr_data); (void)hipFree(d.w);
+    (void)hipFree(d.idx_rows); (void)hipFree(d.idx_items);
     d = DataSplit();
 }
 
@@ -543,7 +564,7 @@ int sert_destroy(sert_model* m) {
     if (m->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(m->comm);
     float* bufs[] = {m->rw, m->re, m->W, m->b, m->s0_rw, m->s0_re, m->s0_w, m->s0_b, m->s1_rw,
                      m->s1_re, m->s1_w, m->s1_b, m->gflat, m->H, m->T, m->DA, m->DH, m->rowloss,
-                     m->G, m->Z, m->J, m->DG, m->part, m->red_loss, m->red_sq, m->d_loss,
+                     m->G, m->Z, m->J, m->DG, m->part, m->wpart, m->red_loss, m->red_sq, m->d_loss,
                      m->d_losses};
     for (float* p : bufs) (void)hipFree(p);
     (void)hipFree(m->neg); (void)hipFree(m->neg_stage);
@@ -633,6 +654,29 @@ int sert_upload_dataset(sert_model* m, int split, const void* x, const int32_t* 
             SERT_HIP(hipStreamSynchronize(s));
         }
     }
+    if (split == SERT_SPLIT_TRAIN && !m->cfg.inference_only) {
+        const int B = m->cfg.batch_size, n = m->cfg.window_size;
+        const int64_t nb = N / B;
+        WordIndex wi;
+        const bool row_is_pos = !is_vs(m);
+        bool ids_ok = true;
+        SERT_ID_DISPATCH(m->cfg.id_bytes,
+                         ids_ok = build_word_index<IdT>((const IdT*)x, nb, B, n, m->cfg.vocab_size, row_is_pos, wi));
+        if (!ids_ok) SERT_FAIL("token id >= vocab_size in x");
+        if (!wi.rows.empty()) {
+            SERT_TRY(dmalloc(&d.idx_rows, wi.rows.size()));
+            SERT_HIP(hipMemcpyAsync(d.idx_rows, wi.rows.data(), wi.rows.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+            SERT_HIP(hipMalloc((void**)&d.idx_items, std::max<size_t>(1, wi.items.size()) * sizeof(SegItem)));
+            SERT_HIP(hipMemcpyAsync(d.idx_items, wi.items.data(), wi.items.size() * sizeof(SegItem), hipMemcpyHostToDevice, s));
+            SERT_HIP(hipStreamSynchronize(s));
+        }
+        d.idx_batches = wi.batches;
+        if ((size_t)wi.max_part_rows + 1 > m->wpart_rows) {
+            (void)hipFree(m->wpart);
+            m->wpart_rows = (size_t)wi.max_part_rows + 1;
+            SERT_TRY(dmalloc(&m->wpart, m->wpart_rows * m->cfg.word_dim));
+        }
+    }
     SERT_HIP(hipStreamSynchronize(s));
     return 0;
 }
@@ -678,6 +722,7 @@ int sert_eval_batch(sert_model* m, int split, int64_t batch_index, const int64_t
     SERT_HIP(hipSetDevice(m->cfg.device));
     const DataSplit& ds = m->split[split];
     const int B = m->cfg.batch_size;
+    if (m->cfg.inference_only) SERT_FAIL("model was created inference_only");
     if (batch_index < 0 || (batch_index + 1) * (int64_t)B > ds.N) SERT_FAIL("batch_index out of range");
     if (is_vs(m)) {
         SERT_TRY(vs_negatives(m, negatives, (uint64_t)(m->eval_draws++) * 2 + 1));

@@ -1,0 +1,127 @@
+// Host-side builder of the per-batch inverted index word -> batch rows.
+//
+// The reference's backward of the embedding lookup is Theano's
+// AdvancedIncSubtensor1 into zeros_like(R_w) (autodiff of sert/models.py:180):
+// a scatter-add with heavy duplicates (Zipfian tokens).  Batches are fixed
+// slices [i*B, (i+1)*B) of the data set (models.py:322-326), so the sorted
+// (word -> rows) lists can be built ONCE at upload; the device then does an
+// order-fixed segmented gather-reduce instead of fp32 atomics: deterministic
+// and free of hot-row serialisation.
+//
+// Levels: a word with more than kSegChunk occurrences is split into chunks whose
+// partial sums are reduced again at the next level (tree), so no single wave
+// walks more than kSegChunk rows.
+#pragma once
+#include <stdint.h>
+#include <algorithm>
+#include <vector>
+
+namespace sert {
+
+constexpr int kSegChunk = 64;
+constexpr int kSegMaxLevels = 6;
+
+struct SegItem {       // 16 bytes, read as int4 on the device
+    int32_t begin;     // first entry (level 0: index into rows[]; level>0: partial row)
+    int32_t end;       // one past the last entry
+    int32_t dst;       // >= 0: destination row in the gradient table (final)
+                       // <  0: partial row -(dst+1) of this level's output space
+    int32_t pad;
+};
+
+struct BatchIndex {
+    int64_t rows_off = 0;                 // offset of this batch's level-0 entries in rows[]
+    int nlevels = 0;
+    int64_t item_off[kSegMaxLevels] = {}; // offset into items[]
+    int32_t item_cnt[kSegMaxLevels] = {};
+    int64_t part_off[kSegMaxLevels] = {}; // partial-row offset of level l's OUTPUT space
+    int64_t part_rows = 0;                // total partial rows of this batch
+};
+
+struct WordIndex {
+    std::vector<int32_t> rows;            // all batches, level-0 entries (source row ids)
+    std::vector<SegItem> items;           // all batches, all levels
+    std::vector<BatchIndex> batches;
+    int64_t max_part_rows = 0;
+};
+
+// ids: (num_batches*B*n) token ids of the complete batches, IdT wide.
+// row_of_pos: entry value = pos / n (vectorspace: row of dh) or pos (loglinear: row of dG).
+template <typename IdT>
+bool build_word_index(const IdT* ids, int64_t num_batches, int B, int n, int vocab,
+                      bool row_is_pos, WordIndex& out) {
+    const int64_t T = (int64_t)B * n;
+    out.rows.resize((size_t)(num_batches * T));
+    out.batches.resize((size_t)num_batches);
+    std::vector<int32_t> count((size_t)vocab + 1, 0);
+    std::vector<int32_t> touched;
+    touched.reserve((size_t)std::min<int64_t>(T, vocab));
+    std::vector<int32_t> start;  // per touched word
+    for (int64_t bi = 0; bi < num_batches; ++bi) {
+        const IdT* x = ids + bi * T;
+        BatchIndex& bx = out.batches[(size_t)bi];
+        bx.rows_off = bi * T;
+        // counting sort by word id (stable in position)
+        touched.clear();
+        for (int64_t p = 0; p < T; ++p) {
+            const int64_t wid64 = (int64_t)x[p];
+            if (wid64 >= vocab) return false;  // token id outside the vocabulary
+            const int32_t wid = (int32_t)wid64;
+            if (count[wid]++ == 0) touched.push_back(wid);
+        }
+        std::sort(touched.begin(), touched.end());
+        // exclusive offsets, stored back into count[] as write cursors
+        start.resize(touched.size() + 1);
+        int32_t acc = 0;
+        for (size_t t = 0; t < touched.size(); ++t) {
+            start[t] = acc;
+            const int32_t c = count[touched[t]];
+            count[touched[t]] = acc;   // cursor
+            acc += c;
+        }
+        start[touched.size()] = acc;
+        int32_t* rows = out.rows.data() + bx.rows_off;
+        for (int64_t p = 0; p < T; ++p) {
+            const int32_t wid = (int32_t)x[p];
+            rows[count[wid]++] = (int32_t)(row_is_pos ? p : p / n);
+        }
+        for (int32_t wid : touched) count[wid] = 0;
+
+        // level 0 items
+        struct Seg { int32_t begin, end, word; };
+        std::vector<Seg> segs(touched.size());
+        for (size_t t = 0; t < touched.size(); ++t) segs[t] = {start[t], start[t + 1], touched[t]};
+        int level = 0;
+        int64_t part_base = 0;
+        while (!segs.empty() && level < kSegMaxLevels) {
+            bx.item_off[level] = (int64_t)out.items.size();
+            bx.part_off[level] = part_base;
+            std::vector<Seg> next;
+            int32_t nparts = 0;
+            for (const Seg& s : segs) {
+                const int32_t len = s.end - s.begin;
+                if (len <= kSegChunk || level == kSegMaxLevels - 1) {
+                    out.items.push_back({s.begin, s.end, s.word, 0});
+                } else {
+                    const int32_t first = nparts;
+                    for (int32_t b = s.begin; b < s.end; b += kSegChunk) {
+                        const int32_t e = std::min(s.end, b + kSegChunk);
+                        out.items.push_back({b, e, -(nparts + 1), 0});
+                        ++nparts;
+                    }
+                    next.push_back({first, nparts, s.word});
+                }
+            }
+            bx.item_cnt[level] = (int32_t)((int64_t)out.items.size() - bx.item_off[level]);
+            part_base += nparts;
+            segs.swap(next);
+            ++level;
+        }
+        bx.nlevels = level;
+        bx.part_rows = part_base;
+        if (part_base > out.max_part_rows) out.max_part_rows = part_base;
+    }
+    return true;
+}
+
+}  // namespace sert

@@ -56,7 +56,8 @@ def group_work(kind, B, n, s, dw, de, Ve, Vw, z):
         return {
             'gather':    ('hbm', B * (n * s + 4 * n * dw)),
             'gemm_fwd':  ('mfma', 2.0 * B * dw * de),
-            'loss':      ('hbm', B * (8 + 12 * (1 + z) * de)),
+            'loss':      ('hbm', B * (8 + 4 * (1 + z) * de)),
+            'entity_grad': ('hbm', B * (8 * (1 + z) * de)),
             'gemm_bwd':  ('mfma', 4.0 * B * dw * de),
             'scatter':   ('hbm', B * (8 * n * dw)),
             'optimizer': ('hbm', 32.0 * P),

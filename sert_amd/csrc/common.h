@@ -45,6 +45,20 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Sum over each aligned group of 16 lanes (one DPP "row"); pure VALU, no LDS
+// traffic.  Every lane of the group receives the total.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]  (xor 1)
+    v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]  (xor 2)
+    v += dpp_mov<0x124>(v);   // row_ror:4
+    v += dpp_mov<0x128>(v);   // row_ror:8
+    return v;
+}
+
 // Block-wide sum for blockDim.x == 256 (4 waves). `red` is >= 4 floats of LDS.
 // Result valid in every thread.
 __device__ __forceinline__ float block_sum_256(float v, float* red) {

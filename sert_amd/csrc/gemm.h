@@ -87,7 +87,10 @@ __device__ __forceinline__ void gemm_load_cmajor(const float* __restrict__ src, 
 //   TB=false: B row-major (K,N)      TB=true: B stored (N,K)  -> computes A.B^T
 // gridDim = (ceil(N/128), ceil(M/128), splits); split z covers k in
 // [z*kper, min(K,(z+1)*kper)) and writes to C + z*c_split_stride.
-template <bool TA, bool TB, int EPI>
+// CSB: additionally emit the column sums of op(B) over this split's k range
+// (row tile 0 only) at C[z] + M*N .. +N  -- used for db = sum_i da_i, which
+// rides along with the dW = h^T.da GEMM for free (the da tile is in LDS anyway).
+template <bool TA, bool TB, int EPI, bool CSB = false>
 __global__ __launch_bounds__(256) void gemm_f32_mfma(const float* __restrict__ A,
                                                      const float* __restrict__ B,
                                                      float* __restrict__ C,
@@ -103,6 +106,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const float* __restrict__ A
     const int wr = w >> 1, wc = w & 1;
     const int li = lane & 31, lh = lane >> 5;
 
+    float csum = 0.f;
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -117,6 +121,13 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const float* __restrict__ A
         if (TB) gemm_load_cmajor(B, ldb, k0, kend, n0, N, Bs, vecB);
         else    gemm_load_kmajor(B, ldb, k0, kend, n0, N, Bs, vecB);
         __syncthreads();
+        if (CSB && blockIdx.y == 0) {
+            const int col = threadIdx.x & 127, half = threadIdx.x >> 7;
+            float cs = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < GK / 2; ++kk) cs += Bs[half * (GK / 2) + kk][col];
+            csum += cs;
+        }
 #pragma unroll
         for (int kk = 0; kk < GK; kk += 2) {
             const int k = kk + lh;
@@ -134,6 +145,13 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const float* __restrict__ A
 
     // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     float* Cz = C + (size_t)blockIdx.z * c_split_stride;
+    if (CSB && blockIdx.y == 0) {
+        // the k loop ended with a barrier: As is free to reuse
+        const int col = threadIdx.x & 127, half = threadIdx.x >> 7;
+        if (half == 1) As[0][col] = csum;
+        __syncthreads();
+        if (half == 0 && n0 + col < N) Cz[(size_t)M * N + n0 + col] = csum + As[0][col];
+    }
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
 #pragma unroll
@@ -156,7 +174,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const float* __restrict__ A
     }
 }
 
-template <bool TA, bool TB, int EPI>
+template <bool TA, bool TB, int EPI, bool CSB = false>
 inline void launch_gemm(hipStream_t s, const float* A, const float* B, float* C, const float* bias,
                         int M, int N, int K, int lda, int ldb, int ldc, int splits = 1,
                         int kper = 0, size_t c_split_stride = 0) {
@@ -164,32 +182,30 @@ inline void launch_gemm(hipStream_t s, const float* A, const float* B, float* C,
     dim3 grid(cdiv(N, GN), cdiv(M, GM), splits);
     const int vecA = (lda % 4 == 0) && (((uintptr_t)A) % 16 == 0);
     const int vecB = (ldb % 4 == 0) && (((uintptr_t)B) % 16 == 0);
-    hipLaunchKernelGGL((gemm_f32_mfma<TA, TB, EPI>), grid, dim3(256), 0, s, A, B, C, bias, M, N, K,
+    hipLaunchKernelGGL((gemm_f32_mfma<TA, TB, EPI, CSB>), grid, dim3(256), 0, s, A, B, C, bias, M, N, K,
                        lda, ldb, ldc, kper, c_split_stride, vecA, vecB);
 }
 
-// out[i] = sum_s part[s*count + i], s ascending (order-fixed => deterministic)
-__global__ void reduce_partials(const float* __restrict__ part, int splits, size_t count,
-                                float* __restrict__ out) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count;
-         i += (size_t)gridDim.x * blockDim.x) {
-        float a = 0.f;
-        for (int s = 0; s < splits; ++s) a += part[(size_t)s * count + i];
-        out[i] = a;
-    }
-}
-
-// part[b][c] = sum over the rows of block b's slice of X (rows, cols); then
-// reduce_partials gives the column sums (db = sum_i da_i).
-__global__ __launch_bounds__(256) void colsum_partial(const float* __restrict__ X, int rows,
-                                                      int cols, int rows_per_block,
-                                                      float* __restrict__ part) {
-    const int r0 = blockIdx.x * rows_per_block;
-    const int r1 = min(rows, r0 + rows_per_block);
-    for (int c = threadIdx.x; c < cols; c += blockDim.x) {
-        float a = 0.f;
-        for (int r = r0; r < r1; ++r) a += X[(size_t)r * cols + c];
-        part[(size_t)blockIdx.x * cols + c] = a;
+// out[i] = sum_s part[s*stride + i] over the split-K partial slabs, in a fixed
+// association (4 interleaved groups of ascending s, then a fixed 4-way add)
+// => deterministic.  Elements i < n1 go to out1[i], the rest to out2[i-n1]
+// (dW followed by the fused db column sums).  64 elements per workgroup.
+__global__ __launch_bounds__(256) void reduce_partials(const float* __restrict__ part, int splits,
+                                                       size_t stride, size_t count,
+                                                       float* __restrict__ out1, size_t n1,
+                                                       float* __restrict__ out2) {
+    __shared__ float red[4][64];
+    const int l = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const size_t i = (size_t)blockIdx.x * 64 + l;
+    float a = 0.f;
+    if (i < count)
+        for (int s = g; s < splits; s += 4) a += part[(size_t)s * stride + i];
+    red[g][l] = a;
+    __syncthreads();
+    if (g == 0 && i < count) {
+        const float v = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+        if (i < n1) out1[i] = v;
+        else out2[i - n1] = v;
     }
 }
 

@@ -150,22 +150,4 @@ __global__ __launch_bounds__(256) void ll_window(float* __restrict__ P, float* _
     }
 }
 
-// dR_w[X[r],:] += dG[r,:]   (autodiff of models.py:180; duplicates accumulate)
-template <typename IdT, int VEC>
-__global__ __launch_bounds__(256) void ll_scatter_rows(const IdT* __restrict__ X,
-                                                       const float* __restrict__ DG,
-                                                       float* __restrict__ GRw, int64_t rows,
-                                                       int d) {
-    const int chunks = d / VEC;
-    const int64_t total = rows * chunks;
-    for (int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; tid < total;
-         tid += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = tid / chunks;
-        const int c = (int)(tid - r * chunks) * VEC;
-        const size_t id = (size_t)X[r];
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) atomicAdd(GRw + id * d + c + v, DG[(size_t)r * d + c + v]);
-    }
-}
-
 }  // namespace sert

@@ -88,23 +88,110 @@ __global__ void convert_i64_to_i32(const int64_t* __restrict__ in, int32_t* __re
 }
 
 // ---- K6: fused NCE score + loss + gradient ----------------------------------
-// One wave per batch row i.  With p = clip(t) (models.py:1065-1068):
+// 16 lanes per batch row i (16 rows per 256-thread workgroup); lane l owns the
+// float4 column chunks l, l+16, ... of the d_e-wide vectors, so one candidate's
+// entity row is a single coalesced 16-lane x 16-byte read and the dot product
+// closes with a 4-step DPP row reduction (no LDS).  With p = clip(t)
+// (models.py:1065-1068):
 //   u_j   = <R_e[c_j], p>                 c_0 = y_i, c_1..z = negatives (:990, :897)
 //   s_j   = clip(sigmoid(u_j), eps, 1-eps)                                (:896-900)
 //   loss  = -(log s_0 + sum_{j>0} log(1 - s_j))                           (:1091-1098)
 // TRAIN additionally produces, with g = w_i / B (models.py:278-282):
 //   du_j  = d loss/d u_j (clip gradient mask inclusive, [upstream Clip.grad])
-//   dR_e[c_j] += du_j * p   (fp32 atomics; duplicates accumulate)
+//   coef[i,j] = du_j, cand[i,j] = c_j   -> dR_e[c_j] += du_j * p is done by the
+//           order-fixed sorted reduction in kernels_egrad.h (no atomics)
 //   da    = (sum_j du_j R_e[c_j]) * [|t| <= 1-eps] * (1 - t^2)
 // rowloss[i] = (TRAIN ? w_i : 1) * loss.
-template <int NPL, bool TRAIN>
+template <int NCH, bool TRAIN>
 __global__ __launch_bounds__(256) void vs_nce(const float* __restrict__ T,
                                               const float* __restrict__ Re,
                                               const int32_t* __restrict__ y,
                                               const int32_t* __restrict__ neg,
                                               const float* __restrict__ w, float* __restrict__ DA,
-                                              float* __restrict__ GRe, float* __restrict__ rowloss,
-                                              int B, int z, int de, float inv_batch) {
+                                              float* __restrict__ coef, int32_t* __restrict__ cand,
+                                              float* __restrict__ rowloss, int B, int z, int de,
+                                              float inv_batch) {
+    const int l = threadIdx.x & 15;
+    const int i = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (i >= B) return;
+    const int chunks = de >> 2;  // de % 4 == 0 on this path
+    float4 t[NCH], p[NCH], dp[NCH];
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+        const int c = l + 16 * q;
+        t[q] = (c < chunks) ? *reinterpret_cast<const float4*>(T + (size_t)i * de + 4 * c)
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
+        p[q].x = fminf(fmaxf(t[q].x, -SERT_CLIP_HI), SERT_CLIP_HI);
+        p[q].y = fminf(fmaxf(t[q].y, -SERT_CLIP_HI), SERT_CLIP_HI);
+        p[q].z = fminf(fmaxf(t[q].z, -SERT_CLIP_HI), SERT_CLIP_HI);
+        p[q].w = fminf(fmaxf(t[q].w, -SERT_CLIP_HI), SERT_CLIP_HI);
+        dp[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float wi = TRAIN ? w[i] : 1.f;
+    const float g = wi * inv_batch;
+    float loss = 0.f;
+#pragma unroll 2
+    for (int j = 0; j <= z; ++j) {
+        const int e = (j == 0) ? y[i] : neg[(size_t)i * z + (j - 1)];
+        float4 er[NCH];
+        float part = 0.f;
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            const int c = l + 16 * q;
+            er[q] = (c < chunks) ? *reinterpret_cast<const float4*>(Re + (size_t)e * de + 4 * c)
+                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+            part += er[q].x * p[q].x + er[q].y * p[q].y + er[q].z * p[q].z + er[q].w * p[q].w;
+        }
+        const float u = row16_sum(part);
+        const float sig = theano_sigmoid(u);
+        const float s = fminf(fmaxf(sig, SERT_CLIP_LO), SERT_CLIP_HI);
+        loss -= (j == 0) ? logf(s) : logf(1.0f - s);
+        if (TRAIN) {
+            const bool inside = (sig >= SERT_CLIP_LO) && (sig <= SERT_CLIP_HI);
+            float du = 0.f;
+            if (inside) {
+                const float ds = sig * (1.0f - sig);
+                du = (j == 0) ? -(g / s) * ds : (g / (1.0f - s)) * ds;
+            }
+#pragma unroll
+            for (int q = 0; q < NCH; ++q) {
+                dp[q].x += du * er[q].x; dp[q].y += du * er[q].y;
+                dp[q].z += du * er[q].z; dp[q].w += du * er[q].w;
+            }
+            if (l == 0) {
+                coef[(size_t)i * (z + 1) + j] = du;
+                cand[(size_t)i * (z + 1) + j] = e;
+            }
+        }
+    }
+    if (TRAIN) {
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            const int c = l + 16 * q;
+            if (c >= chunks) continue;
+            float4 o;
+            o.x = (t[q].x >= -SERT_CLIP_HI && t[q].x <= SERT_CLIP_HI) ? dp[q].x * (1.0f - t[q].x * t[q].x) : 0.f;
+            o.y = (t[q].y >= -SERT_CLIP_HI && t[q].y <= SERT_CLIP_HI) ? dp[q].y * (1.0f - t[q].y * t[q].y) : 0.f;
+            o.z = (t[q].z >= -SERT_CLIP_HI && t[q].z <= SERT_CLIP_HI) ? dp[q].z * (1.0f - t[q].z * t[q].z) : 0.f;
+            o.w = (t[q].w >= -SERT_CLIP_HI && t[q].w <= SERT_CLIP_HI) ? dp[q].w * (1.0f - t[q].w * t[q].w) : 0.f;
+            *reinterpret_cast<float4*>(DA + (size_t)i * de + 4 * c) = o;
+        }
+    }
+    if (l == 0) rowloss[i] = wi * loss;
+}
+
+// Generic-width fallback (d_e % 4 != 0): one wave per row, scalar columns.
+template <int NPL, bool TRAIN>
+__global__ __launch_bounds__(256) void vs_nce_scalar(const float* __restrict__ T,
+                                                     const float* __restrict__ Re,
+                                                     const int32_t* __restrict__ y,
+                                                     const int32_t* __restrict__ neg,
+                                                     const float* __restrict__ w,
+                                                     float* __restrict__ DA,
+                                                     float* __restrict__ coef,
+                                                     int32_t* __restrict__ cand,
+                                                     float* __restrict__ rowloss, int B, int z,
+                                                     int de, float inv_batch) {
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= B) return;
@@ -141,10 +228,10 @@ __global__ __launch_bounds__(256) void vs_nce(const float* __restrict__ T,
                 du = (j == 0) ? -(g / s) * ds : (g / (1.0f - s)) * ds;
             }
 #pragma unroll
-            for (int q = 0; q < NPL; ++q) {
-                const int c = lane + 64 * q;
-                dp[q] += du * er[q];
-                if (c < de) atomicAdd(&GRe[(size_t)e * de + c], du * p[q]);
+            for (int q = 0; q < NPL; ++q) dp[q] += du * er[q];
+            if (lane == 0) {
+                coef[(size_t)i * (z + 1) + j] = du;
+                cand[(size_t)i * (z + 1) + j] = e;
             }
         }
     }
@@ -157,29 +244,6 @@ __global__ __launch_bounds__(256) void vs_nce(const float* __restrict__ T,
         }
     }
     if (lane == 0) rowloss[i] = wi * loss;
-}
-
-// ---- K9: scatter-add of the window gradient into the word table -------------
-// dR_w[X[i,k],:] += dh[i,:] / n     (autodiff of models.py:180 + :226;
-// Theano AdvancedIncSubtensor1: duplicates accumulate)
-template <typename IdT, int VEC>
-__global__ __launch_bounds__(256) void vs_scatter_dh(const IdT* __restrict__ X,
-                                                     const float* __restrict__ DH,
-                                                     float* __restrict__ GRw, int B, int n, int d) {
-    const int chunks = d / VEC;
-    const int64_t total = (int64_t)B * n * chunks;
-    const float fn = (float)n;
-    for (int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; tid < total;
-         tid += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t rk = tid / chunks;            // row*n + k
-        const int c = (int)(tid - rk * chunks) * VEC;
-        const int row = (int)(rk / n);
-        const size_t id = (size_t)X[rk];
-        float* dst = GRw + id * d + c;
-        const float* src = DH + (size_t)row * d + c;
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) atomicAdd(dst + v, src[v] / fn);
-    }
 }
 
 // out = tanh(avg.W + b) is done by the GEMM with the EPI_BIAS_TANH epilogue.

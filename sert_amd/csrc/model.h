@@ -28,6 +28,7 @@ enum TimingGroup {
     TG_GATHER = 0,    // embedding gather (+ mean-pool)
     TG_GEMM_FWD,      // projection / logits GEMM
     TG_LOSS,          // NCE or softmax/window/CE forward+backward
+    TG_EGRAD,         // entity-table gradient: sort + chunk reduce + fix-up (vectorspace)
     TG_GEMM_BWD,      // dW, dh/dG GEMMs, db
     TG_SCATTER,       // scatter-add into the word table
     TG_ALLREDUCE,     // RCCL gradient exchange
@@ -69,6 +70,13 @@ struct sert_model {
     float *H = nullptr, *T = nullptr, *DA = nullptr, *DH = nullptr, *rowloss = nullptr;
     int32_t* neg = nullptr;       // (B, z) device negatives
     int64_t* neg_stage = nullptr; // (B, z) int64 staging for host-supplied negatives
+    // entity-gradient machinery (kernels_egrad.h), all (B*(1+z)) long
+    int32_t *cand = nullptr, *cand_sorted = nullptr, *iota = nullptr, *pair_sorted = nullptr;
+    float* coef = nullptr;
+    float *ehead = nullptr, *etail = nullptr;  // (chunks, d_e) carries
+    void* sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+    int sort_bits = 1;
     // loglinear activations
     float *G = nullptr;           // (B*n, d) gathered rows
     float *Z = nullptr;           // (B*n, V_e) logits -> probabilities -> dZ

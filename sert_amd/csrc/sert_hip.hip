@@ -11,6 +11,7 @@
 
 #include "common.h"
 #include "gemm.h"
+#include "kernels_egrad.h"
 #include "kernels_ll.h"
 #include "kernels_opt.h"
 #include "kernels_score.h"
@@ -21,8 +22,9 @@
 namespace sert {
 thread_local std::string g_last_error;
 
-static const char* kTimingNames[TG_COUNT] = {"gather",  "gemm_fwd",  "loss",      "gemm_bwd",
-                                             "scatter", "allreduce", "optimizer", "finalize"};
+static const char* kTimingNames[TG_COUNT] = {"gather",   "gemm_fwd", "loss",      "entity_grad",
+                                             "gemm_bwd", "scatter",  "allreduce", "optimizer",
+                                             "finalize"};
 
 // ---- timing ----------------------------------------------------------------
 struct ScopedTimer {
@@ -239,20 +241,38 @@ static int vs_forward(sert_model* m, const DataSplit& ds, int64_t batch_index) {
         const int32_t* y = ds.y + row0;
         const float* w = TRAIN ? ds.w + row0 : nullptr;
         const float inv_batch = 1.0f / (float)c.global_batch_size;
-        const int npl = cdiv(de, 64);
-        dim3 grid(cdiv(B, 4)), block(256);
+        dim3 block(256);
+        if (de % 4 == 0) {
+            const int nch = cdiv(de / 4, 16);
+            dim3 grid(cdiv(B, 16));
 #define SERT_NCE_CASE(N)                                                                     \
     case N:                                                                                  \
         hipLaunchKernelGGL((vs_nce<N, TRAIN>), grid, block, 0, m->stream, m->T, m->re, y,   \
-                           m->neg, w, m->DA, m->g_re, m->rowloss, B, c.num_negatives, de,   \
-                           inv_batch);                                                       \
+                           m->neg, w, m->DA, m->coef, m->cand, m->rowloss, B,               \
+                           c.num_negatives, de, inv_batch);                                  \
         break;
-        switch (npl) {
-            SERT_NCE_CASE(1) SERT_NCE_CASE(2) SERT_NCE_CASE(3) SERT_NCE_CASE(4)
-            SERT_NCE_CASE(5) SERT_NCE_CASE(6) SERT_NCE_CASE(7) SERT_NCE_CASE(8)
-            default: SERT_FAIL("entity_dim > 512 is not supported");
-        }
+            switch (nch) {
+                SERT_NCE_CASE(1) SERT_NCE_CASE(2) SERT_NCE_CASE(3) SERT_NCE_CASE(4)
+                SERT_NCE_CASE(5) SERT_NCE_CASE(6) SERT_NCE_CASE(7) SERT_NCE_CASE(8)
+                default: SERT_FAIL("entity_dim > 512 is not supported");
+            }
 #undef SERT_NCE_CASE
+        } else {
+            const int npl = cdiv(de, 64);
+            dim3 grid(cdiv(B, 4));
+#define SERT_NCE_CASE(N)                                                                     \
+    case N:                                                                                  \
+        hipLaunchKernelGGL((vs_nce_scalar<N, TRAIN>), grid, block, 0, m->stream, m->T,      \
+                           m->re, y, m->neg, w, m->DA, m->coef, m->cand, m->rowloss, B,     \
+                           c.num_negatives, de, inv_batch);                                  \
+        break;
+            switch (npl) {
+                SERT_NCE_CASE(1) SERT_NCE_CASE(2) SERT_NCE_CASE(3) SERT_NCE_CASE(4)
+                SERT_NCE_CASE(5) SERT_NCE_CASE(6) SERT_NCE_CASE(7) SERT_NCE_CASE(8)
+                default: SERT_FAIL("entity_dim > 512 is not supported");
+            }
+#undef SERT_NCE_CASE
+        }
     }
     return 0;
 }
@@ -262,23 +282,45 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
     const int B = c.batch_size, n = c.window_size, dw = c.word_dim, de = c.entity_dim;
     const size_t row0 = (size_t)batch_index * B;
     {
+        ScopedTimer t(m, TG_EGRAD);
+        // dR_e: stable sort of the (entity, pair) keys, chunked reduce, carry fix-up
+        const int total = B * (c.num_negatives + 1);
+        const int V = c.num_entities;
+        if (sort_pairs(m->sort_tmp, m->sort_tmp_bytes, m->cand, m->cand_sorted, m->iota,
+                       m->pair_sorted, total, m->sort_bits, m->stream) != 0)
+            SERT_FAIL("radix sort of the entity keys failed");
+        const int chunks = cdiv(total, kEChunk);
+        dim3 cgrid(cdiv(chunks, 16)), fgrid(cdiv(V, 16)), blk(256);
+#define SERT_EG_ARGS m->cand_sorted, m->pair_sorted, m->coef, m->T, total, c.num_negatives + 1, de, \
+                     m->g_re, m->ehead, m->etail
+        if (de % 4 == 0) {
+            const int nch = cdiv(de / 4, 16);
+            if (nch <= 1)      hipLaunchKernelGGL((egrad_chunk_reduce<4, 1>), cgrid, blk, 0, m->stream, SERT_EG_ARGS);
+            else if (nch <= 2) hipLaunchKernelGGL((egrad_chunk_reduce<4, 2>), cgrid, blk, 0, m->stream, SERT_EG_ARGS);
+            else if (nch <= 5) hipLaunchKernelGGL((egrad_chunk_reduce<4, 5>), cgrid, blk, 0, m->stream, SERT_EG_ARGS);
+            else               hipLaunchKernelGGL((egrad_chunk_reduce<4, 8>), cgrid, blk, 0, m->stream, SERT_EG_ARGS);
+            hipLaunchKernelGGL((egrad_fixup<4>), fgrid, blk, 0, m->stream, m->cand_sorted, total, V, de,
+                               m->ehead, m->etail, m->g_re);
+        } else {
+            hipLaunchKernelGGL((egrad_chunk_reduce<1, 4>), cgrid, blk, 0, m->stream, SERT_EG_ARGS);
+            hipLaunchKernelGGL((egrad_fixup<1>), fgrid, blk, 0, m->stream, m->cand_sorted, total, V, de,
+                               m->ehead, m->etail, m->g_re);
+        }
+#undef SERT_EG_ARGS
+    }
+    {
         ScopedTimer t(m, TG_GEMM_BWD);
-        // dW = h^T.da : reduction over the batch, split-K with order-fixed combine
+        // dW = h^T.da (reduction over the batch: split-K, order-fixed combine);
+        // db = sum_i da_i rides along as the column sums of the da operand
         int splits = std::min(256, cdiv(B, GK));
         int kper = (int)round_up(cdiv(B, splits), GK);
         splits = cdiv(B, kper);
         const size_t mn = (size_t)dw * de;
-        launch_gemm<true, false, EPI_STORE>(m->stream, m->H, m->DA, m->part, nullptr, dw, de, B, dw,
-                                            de, de, splits, kper, mn);
-        hipLaunchKernelGGL(reduce_partials, dim3(grid_for(mn)), dim3(256), 0, m->stream, m->part,
-                           splits, mn, m->g_w);
-        // db = sum_i da_i
-        const int rpb = cdiv(B, 256);
-        const int nb = cdiv(B, rpb);
-        hipLaunchKernelGGL(colsum_partial, dim3(nb), dim3(256), 0, m->stream, m->DA, B, de, rpb,
-                           m->part);
-        hipLaunchKernelGGL(reduce_partials, dim3(grid_for(de)), dim3(256), 0, m->stream, m->part,
-                           nb, (size_t)de, m->g_b);
+        const size_t stride = mn + de;
+        launch_gemm<true, false, EPI_STORE, true>(m->stream, m->H, m->DA, m->part, nullptr, dw, de,
+                                                  B, dw, de, de, splits, kper, stride);
+        hipLaunchKernelGGL(reduce_partials, dim3(cdiv(stride, 64)), dim3(256), 0, m->stream, m->part,
+                           splits, stride, stride, m->g_w, mn, m->g_b);
         // dh = da.W^T
         launch_gemm<false, true, EPI_STORE>(m->stream, m->DA, m->W, m->DH, nullptr, B, dw, de, de,
                                             de, dw);
@@ -337,23 +379,17 @@ static int ll_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
     const int64_t rows = (int64_t)B * n;
     {
         ScopedTimer t(m, TG_GEMM_BWD);
-        // dW (d, V) = G^T.dZ, reduction over the B*n tokens
+        // dW (d, V) = G^T.dZ, reduction over the B*n tokens; db = column sums of dZ
         const int tiles = cdiv(V, GN) * cdiv(d, GM);
         int splits = std::max(1, std::min(cdiv(rows, GK), cdiv(1024, tiles)));
         int kper = (int)round_up(cdiv(rows, splits), GK);
         splits = cdiv(rows, kper);
         const size_t mn = (size_t)d * V;
-        launch_gemm<true, false, EPI_STORE>(m->stream, m->G, m->Z, m->part, nullptr, d, V, (int)rows,
-                                            d, V, V, splits, kper, mn);
-        hipLaunchKernelGGL(reduce_partials, dim3(grid_for(mn)), dim3(256), 0, m->stream, m->part,
-                           splits, mn, m->g_w);
-        // db = column sums of dZ
-        const int rpb = cdiv(rows, 256);
-        const int nb = cdiv(rows, rpb);
-        hipLaunchKernelGGL(colsum_partial, dim3(nb), dim3(256), 0, m->stream, m->Z, (int)rows, V, rpb,
-                           m->part);
-        hipLaunchKernelGGL(reduce_partials, dim3(grid_for(V)), dim3(256), 0, m->stream, m->part, nb,
-                           (size_t)V, m->g_b);
+        const size_t stride = mn + V;
+        launch_gemm<true, false, EPI_STORE, true>(m->stream, m->G, m->Z, m->part, nullptr, d, V,
+                                                  (int)rows, d, V, V, splits, kper, stride);
+        hipLaunchKernelGGL(reduce_partials, dim3(cdiv(stride, 64)), dim3(256), 0, m->stream, m->part,
+                           splits, stride, stride, m->g_w, mn, m->g_b);
         // dG (rows, d) = dZ.W^T
         launch_gemm<false, true, EPI_STORE>(m->stream, m->Z, m->W, m->DG, nullptr, (int)rows, d, V, V,
                                             V, d);
@@ -527,13 +563,24 @@ int sert_create(const sert_config* cfg, sert_model** out) {
             SERT_TRY(dzalloc(&m->DA, B * de, s)); SERT_TRY(dzalloc(&m->DH, B * dw, s));
             SERT_TRY(dzalloc(&m->neg, std::max<size_t>(4, B * c.num_negatives), s));
             SERT_TRY(dzalloc(&m->neg_stage, std::max<size_t>(4, B * c.num_negatives), s));
-            part = std::max((size_t)256 * dw * de, (size_t)256 * de);
+            part = (size_t)256 * (dw * de + de);
+            const size_t total = B * (c.num_negatives + 1);
+            SERT_TRY(dzalloc(&m->cand, total, s));        SERT_TRY(dzalloc(&m->cand_sorted, total + 1, s));
+            SERT_TRY(dzalloc(&m->iota, total, s));        SERT_TRY(dzalloc(&m->pair_sorted, total, s));
+            SERT_TRY(dzalloc(&m->coef, total, s));
+            const size_t chunks = (total + kEChunk - 1) / kEChunk;
+            SERT_TRY(dzalloc(&m->ehead, chunks * de, s)); SERT_TRY(dzalloc(&m->etail, chunks * de, s));
+            hipLaunchKernelGGL(fill_iota, dim3(grid_for((int64_t)total)), dim3(256), 0, s, m->iota, (int64_t)total);
+            m->sort_bits = 1;
+            while ((1ll << m->sort_bits) < (long long)V) ++m->sort_bits;
+            m->sort_tmp_bytes = sort_pairs_temp_bytes((int)total, m->sort_bits);
+            SERT_HIP(hipMalloc(&m->sort_tmp, std::max<size_t>(16, m->sort_tmp_bytes)));
         } else {
             SERT_TRY(dzalloc(&m->G, B * n * dw, s));  SERT_TRY(dzalloc(&m->Z, B * n * V, s));
             SERT_TRY(dzalloc(&m->J, B * V, s));       SERT_TRY(dzalloc(&m->DG, B * n * dw, s));
             const size_t tiles = (size_t)cdiv(V, GN) * cdiv(dw, GM);
             const size_t splits = std::max<size_t>(1, cdiv(1024, tiles)) + 1;
-            part = std::max(splits * dw * V, (size_t)256 * V);
+            part = splits * (dw * V + V);
         }
         m->part_count = part;
         SERT_TRY(dzalloc(&m->part, part, s));
@@ -568,6 +615,9 @@ int sert_destroy(sert_model* m) {
                      m->d_losses};
     for (float* p : bufs) (void)hipFree(p);
     (void)hipFree(m->neg); (void)hipFree(m->neg_stage);
+    (void)hipFree(m->cand); (void)hipFree(m->cand_sorted); (void)hipFree(m->iota);
+    (void)hipFree(m->pair_sorted); (void)hipFree(m->coef); (void)hipFree(m->ehead);
+    (void)hipFree(m->etail); (void)hipFree(m->sort_tmp);
     if (m->h_loss) (void)hipHostFree(m->h_loss);
     free_split(m->split[0]); free_split(m->split[1]);
     if (m->timing.created)

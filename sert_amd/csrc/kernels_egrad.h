@@ -2,7 +2,7 @@
 //
 // dR_e[e] = sum over all (row i, candidate j) with c_ij = e of du_ij * clip(t_i)
 // (autodiff of sert/models.py:990 + :897; Theano AdvancedIncSubtensor1).
-// The B*(1+z) (entity, pair) keys are radix-sorted by entity (stable, so the
+// The B*(1+z) (entity, pair) keys are counting-sorted by entity (kernels_sort.h; stable, so the
 // order inside an entity is the pair order), then reduced in fixed 16-pair
 // chunks; runs that cross a chunk boundary leave per-chunk carries that a
 // second kernel adds in chunk order.  Same association every run => the result
@@ -140,16 +140,5 @@ __global__ __launch_bounds__(256) void egrad_fixup(const int32_t* __restrict__ k
         }
     }
 }
-
-__global__ void fill_iota(int32_t* __restrict__ out, int64_t count) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < count;
-         i += (int64_t)gridDim.x * blockDim.x)
-        out[i] = (int32_t)i;
-}
-
-// segsort.hip (hipCUB radix sort, stable)
-size_t sort_pairs_temp_bytes(int n, int end_bit);
-int sort_pairs(void* tmp, size_t tmp_bytes, const int32_t* keys_in, int32_t* keys_out,
-               const int32_t* vals_in, int32_t* vals_out, int n, int end_bit, hipStream_t s);
 
 }  // namespace sert

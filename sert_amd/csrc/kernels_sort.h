@@ -1,0 +1,152 @@
+// Stable LSD counting sort of (key, value) int32 pairs by an up-to-11-bit digit,
+// gfx950.  Purpose-built for the entity-gradient keys (kernels_egrad.h):
+// B*(1+z) ~ 10^5..10^6 keys, key range = V_e.  Generic library radix sorts fall
+// back to a ~20-launch merge sort at this size (145 us measured with rocPRIM);
+// this is 3 launches per digit.
+//
+//   csort_hist      per 2048-key tile: digit histogram (LDS int atomics: the
+//                   COUNTS are order-independent)        -> hist[bin][tile]
+//   csort_scan_bins per bin: exclusive scan over tiles   -> hist (in place), bin_total
+//   csort_scatter   per tile: exclusive scan of bin totals (LDS), per-wave
+//                   private histograms, then ranks by ballot matching in program
+//                   order => positions are a pure function of the input: stable
+//                   and deterministic.
+#pragma once
+#include "common.h"
+
+namespace sert {
+
+constexpr int kSortTile = 2048;      // keys per workgroup (256 threads x 8)
+constexpr int kSortMaxBits = 11;
+constexpr int kSortMaxBins = 1 << kSortMaxBits;
+
+__global__ __launch_bounds__(256) void csort_hist(const int32_t* __restrict__ keys, int n,
+                                                  int shift, int nbins, int tiles,
+                                                  int32_t* __restrict__ hist) {
+    __shared__ int32_t h[kSortMaxBins];
+    const int tile = blockIdx.x;
+    for (int b = threadIdx.x; b < nbins; b += 256) h[b] = 0;
+    __syncthreads();
+    const int base = tile * kSortTile;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int i = base + r * 256 + threadIdx.x;
+        if (i < n) atomicAdd(&h[(keys[i] >> shift) & (nbins - 1)], 1);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < nbins; b += 256) hist[(size_t)b * tiles + tile] = h[b];
+}
+
+// one wave per bin
+__global__ __launch_bounds__(256) void csort_scan_bins(int32_t* __restrict__ hist, int nbins,
+                                                       int tiles, int32_t* __restrict__ bin_total) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= nbins) return;
+    int32_t* row = hist + (size_t)b * tiles;
+    int32_t carry = 0;
+    for (int t0 = 0; t0 < tiles; t0 += 64) {
+        const int t = t0 + lane;
+        const int32_t v = (t < tiles) ? row[t] : 0;
+        int32_t inc = v;  // inclusive wave scan
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int32_t o = __shfl_up(inc, off, kWave);
+            if (lane >= off) inc += o;
+        }
+        if (t < tiles) row[t] = carry + inc - v;
+        carry += __shfl(inc, 63, kWave);
+    }
+    if (lane == 0) bin_total[b] = carry;
+}
+
+// vals_in == nullptr: the value of element i is i (first pass over iota).
+__global__ __launch_bounds__(256) void csort_scatter(const int32_t* __restrict__ keys_in,
+                                                     const int32_t* __restrict__ vals_in,
+                                                     int32_t* __restrict__ keys_out,
+                                                     int32_t* __restrict__ vals_out, int n,
+                                                     int shift, int nbits, int tiles,
+                                                     const int32_t* __restrict__ hist,
+                                                     const int32_t* __restrict__ bin_total) {
+    __shared__ int32_t wh[4][kSortMaxBins];   // per-wave digit counts -> start positions
+    __shared__ int32_t bin_base[kSortMaxBins];
+    __shared__ int32_t scan_tmp[256];
+    const int nbins = 1 << nbits;
+    const int tile = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+
+    // exclusive scan of the bin totals -> first output position of every bin
+    const int per = (nbins + 255) / 256;     // consecutive bins per thread (<= 8)
+    int32_t local[8];
+    int32_t sum = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int b = tid * per + q;
+        local[q] = (q < per && b < nbins) ? bin_total[b] : 0;
+        sum += local[q];
+    }
+    scan_tmp[tid] = sum;
+    for (int b = tid; b < 4 * kSortMaxBins; b += 256) (&wh[0][0])[b] = 0;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const int32_t v = (tid >= off) ? scan_tmp[tid - off] : 0;
+        __syncthreads();
+        scan_tmp[tid] += v;
+        __syncthreads();
+    }
+    int32_t run = scan_tmp[tid] - sum;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int b = tid * per + q;
+        if (q < per && b < nbins) bin_base[b] = run;
+        run += local[q];
+    }
+
+    // phase A: per-wave histograms over the wave's 512-key segment
+    const int seg = tile * kSortTile + w * 512;
+    int32_t key[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int i = seg + r * 64 + lane;
+        key[r] = (i < n) ? keys_in[i] : 0;
+        if (i < n) atomicAdd(&wh[w][(key[r] >> shift) & (nbins - 1)], 1);
+    }
+    __syncthreads();
+    // phase B: counts -> absolute start positions (tile offset + waves before)
+    for (int b = tid; b < nbins; b += 256) {
+        int32_t g = bin_base[b] + hist[(size_t)b * tiles + tile];
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) {
+            const int32_t c = wh[ww][b];
+            wh[ww][b] = g;
+            g += c;
+        }
+    }
+    __syncthreads();
+    // phase C: stable ranks, 64 keys at a time in program order
+    volatile int32_t* mine = wh[w];
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int i = seg + r * 64 + lane;
+        const bool active = i < n;
+        const int d = (key[r] >> shift) & (nbins - 1);
+        unsigned long long peers = __ballot(active);
+        for (int bit = 0; bit < nbits; ++bit) {
+            const bool one = (d >> bit) & 1;
+            const unsigned long long bal = __ballot(one);
+            peers &= one ? bal : ~bal;
+        }
+        if (active) {
+            const int rank = __popcll(peers & lt_mask);
+            const int32_t pos = mine[d] + rank;
+            keys_out[pos] = key[r];
+            vals_out[pos] = vals_in ? vals_in[i] : i;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (active && (peers & lt_mask) == 0) mine[d] += __popcll(peers);  // group leader
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+}  // namespace sert

@@ -71,11 +71,11 @@ struct sert_model {
     int32_t* neg = nullptr;       // (B, z) device negatives
     int64_t* neg_stage = nullptr; // (B, z) int64 staging for host-supplied negatives
     // entity-gradient machinery (kernels_egrad.h), all (B*(1+z)) long
-    int32_t *cand = nullptr, *cand_sorted = nullptr, *iota = nullptr, *pair_sorted = nullptr;
+    int32_t *cand = nullptr, *cand_sorted = nullptr, *pair_sorted = nullptr;
     float* coef = nullptr;
     float *ehead = nullptr, *etail = nullptr;  // (chunks, d_e) carries
-    void* sort_tmp = nullptr;
-    size_t sort_tmp_bytes = 0;
+    int32_t *sort_hist = nullptr, *sort_bin_total = nullptr;   // counting-sort scratch
+    int32_t *sort_k_tmp = nullptr, *sort_v_tmp = nullptr;       // ping-pong (only if > 11 key bits)
     int sort_bits = 1;
     // loglinear activations
     float *G = nullptr;           // (B*n, d) gathered rows

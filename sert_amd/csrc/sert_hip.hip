@@ -16,6 +16,7 @@
 #include "kernels_opt.h"
 #include "kernels_score.h"
 #include "kernels_seg.h"
+#include "kernels_sort.h"
 #include "kernels_vs.h"
 #include "model.h"
 
@@ -192,6 +193,33 @@ static int word_grad_segsum(sert_model* m, const DataSplit& ds, int64_t batch_in
     return 0;
 }
 
+// Stable sort of the (entity id, pair index) keys of this step: cand -> cand_sorted,
+// iota -> pair_sorted (kernels_sort.h), LSD over ceil(bits/11) digits.
+static int entity_key_sort(sert_model* m, int total) {
+    const int tiles = cdiv(total, kSortTile);
+    const int bits = m->sort_bits;
+    const int passes = cdiv(bits, kSortMaxBits);
+    const int width = cdiv(bits, passes);
+    const int32_t* kin = m->cand;
+    const int32_t* vin = nullptr;  // value of element i is i
+    for (int p = 0; p < passes; ++p) {
+        const int shift = p * width;
+        const int nb = std::min(width, bits - shift);
+        const bool to_final = ((passes - 1 - p) % 2) == 0;
+        int32_t* kout = to_final ? m->cand_sorted : m->sort_k_tmp;
+        int32_t* vout = to_final ? m->pair_sorted : m->sort_v_tmp;
+        hipLaunchKernelGGL(csort_hist, dim3(tiles), dim3(256), 0, m->stream, kin, total, shift, 1 << nb,
+                           tiles, m->sort_hist);
+        hipLaunchKernelGGL(csort_scan_bins, dim3(cdiv(1 << nb, 4)), dim3(256), 0, m->stream,
+                           m->sort_hist, 1 << nb, tiles, m->sort_bin_total);
+        hipLaunchKernelGGL(csort_scatter, dim3(tiles), dim3(256), 0, m->stream, kin, vin, kout, vout,
+                           total, shift, nb, tiles, m->sort_hist, m->sort_bin_total);
+        kin = kout;
+        vin = vout;
+    }
+    return 0;
+}
+
 // ---- the vectorspace step -----------------------------------------------------
 static int vs_negatives(sert_model* m, const int64_t* negatives, uint64_t stream_pos) {
     const auto& c = m->cfg;
@@ -286,9 +314,7 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         // dR_e: stable sort of the (entity, pair) keys, chunked reduce, carry fix-up
         const int total = B * (c.num_negatives + 1);
         const int V = c.num_entities;
-        if (sort_pairs(m->sort_tmp, m->sort_tmp_bytes, m->cand, m->cand_sorted, m->iota,
-                       m->pair_sorted, total, m->sort_bits, m->stream) != 0)
-            SERT_FAIL("radix sort of the entity keys failed");
+        SERT_TRY(entity_key_sort(m, total));
         const int chunks = cdiv(total, kEChunk);
         dim3 cgrid(cdiv(chunks, 16)), fgrid(cdiv(V, 16)), blk(256);
 #define SERT_EG_ARGS m->cand_sorted, m->pair_sorted, m->coef, m->T, total, c.num_negatives + 1, de, \
@@ -566,15 +592,19 @@ int sert_create(const sert_config* cfg, sert_model** out) {
             part = (size_t)256 * (dw * de + de);
             const size_t total = B * (c.num_negatives + 1);
             SERT_TRY(dzalloc(&m->cand, total, s));        SERT_TRY(dzalloc(&m->cand_sorted, total + 1, s));
-            SERT_TRY(dzalloc(&m->iota, total, s));        SERT_TRY(dzalloc(&m->pair_sorted, total, s));
+            SERT_TRY(dzalloc(&m->pair_sorted, total, s));
             SERT_TRY(dzalloc(&m->coef, total, s));
             const size_t chunks = (total + kEChunk - 1) / kEChunk;
             SERT_TRY(dzalloc(&m->ehead, chunks * de, s)); SERT_TRY(dzalloc(&m->etail, chunks * de, s));
-            hipLaunchKernelGGL(fill_iota, dim3(grid_for((int64_t)total)), dim3(256), 0, s, m->iota, (int64_t)total);
             m->sort_bits = 1;
             while ((1ll << m->sort_bits) < (long long)V) ++m->sort_bits;
-            m->sort_tmp_bytes = sort_pairs_temp_bytes((int)total, m->sort_bits);
-            SERT_HIP(hipMalloc(&m->sort_tmp, std::max<size_t>(16, m->sort_tmp_bytes)));
+            const size_t tiles = (total + kSortTile - 1) / kSortTile;
+            SERT_TRY(dzalloc(&m->sort_hist, (size_t)kSortMaxBins * tiles, s));
+            SERT_TRY(dzalloc(&m->sort_bin_total, (size_t)kSortMaxBins, s));
+            if (m->sort_bits > kSortMaxBits) {
+                SERT_TRY(dzalloc(&m->sort_k_tmp, total, s));
+                SERT_TRY(dzalloc(&m->sort_v_tmp, total, s));
+            }
         } else {
             SERT_TRY(dzalloc(&m->G, B * n * dw, s));  SERT_TRY(dzalloc(&m->Z, B * n * V, s));
             SERT_TRY(dzalloc(&m->J, B * V, s));       SERT_TRY(dzalloc(&m->DG, B * n * dw, s));
@@ -615,9 +645,10 @@ int sert_destroy(sert_model* m) {
                      m->d_losses};
     for (float* p : bufs) (void)hipFree(p);
     (void)hipFree(m->neg); (void)hipFree(m->neg_stage);
-    (void)hipFree(m->cand); (void)hipFree(m->cand_sorted); (void)hipFree(m->iota);
+    (void)hipFree(m->cand); (void)hipFree(m->cand_sorted); 
     (void)hipFree(m->pair_sorted); (void)hipFree(m->coef); (void)hipFree(m->ehead);
-    (void)hipFree(m->etail); (void)hipFree(m->sort_tmp);
+    (void)hipFree(m->etail); (void)hipFree(m->sort_hist); (void)hipFree(m->sort_bin_total);
+    (void)hipFree(m->sort_k_tmp); (void)hipFree(m->sort_v_tmp);
     if (m->h_loss) (void)hipHostFree(m->h_loss);
     free_split(m->split[0]); free_split(m->split[1]);
     if (m->timing.created)

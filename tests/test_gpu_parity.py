@@ -21,6 +21,8 @@ LOSS_TOL, ACT_TOL, GRAD_TOL, PARAM_TOL = 1e-5, 2e-5, 1e-4, 1e-4
     dict(B=96, n=3, z=7, Vw=200, Ve=11, dw=30, de=70),      # scalar path, NPL=2, ragged tiles
     dict(B=256, n=10, z=10, Vw=3000, Ve=1000, dw=128, de=128),  # C2-shaped
     dict(B=130, n=4, z=10, Vw=70000, Ve=300, dw=300, de=128),   # uint32 ids, d=300
+    dict(B=2100, n=2, z=5, Vw=300, Ve=5000, dw=16, de=32),      # 13 key bits: 2 sort passes, >1 tile/chunk carries
+    dict(B=300, n=2, z=20, Vw=50, Ve=3, dw=8, de=300),          # heavy duplicate entities: long carry chains
 ])
 def test_vectorspace_steps(hip_lib, dims):
     B, n, z = dims['B'], dims['n'], dims['z']

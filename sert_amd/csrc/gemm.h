@@ -198,8 +198,10 @@ __global__ __launch_bounds__(256) void reduce_partials(const float* __restrict__
     const int l = threadIdx.x & 63, g = threadIdx.x >> 6;
     const size_t i = (size_t)blockIdx.x * 64 + l;
     float a = 0.f;
-    if (i < count)
+    if (i < count) {
+#pragma unroll 8
         for (int s = g; s < splits; s += 4) a += part[(size_t)s * stride + i];
+    }
     red[g][l] = a;
     __syncthreads();
     if (g == 0 && i < count) {

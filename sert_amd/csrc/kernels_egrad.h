@@ -23,7 +23,8 @@ template <int VEC, int NCH>
 __global__ __launch_bounds__(256) void egrad_chunk_reduce(
     const int32_t* __restrict__ keys, const int32_t* __restrict__ pairs,
     const float* __restrict__ coef, const float* __restrict__ T, int total, int zp1, int de,
-    float* __restrict__ GRe, float* __restrict__ head, float* __restrict__ tail) {
+    float* __restrict__ GRe, float* __restrict__ head, float* __restrict__ tail,
+    int32_t* __restrict__ run_start, int32_t* __restrict__ run_end) {
     const int l = threadIdx.x & 15;
     const int gbase = (threadIdx.x & 63) & ~15;  // first lane of this group inside the wave
     const int chunk = blockIdx.x * 16 + (threadIdx.x >> 4);
@@ -52,8 +53,15 @@ __global__ __launch_bounds__(256) void egrad_chunk_reduce(
             for (int v = 0; v < VEC; ++v) acc[q][v] = 0.f;
         int cur = first_key;
         bool at_begin = true;
+        int jb = 0;
 
-        auto flush = [&](int e, bool touches_begin, bool touches_end) {
+        auto flush = [&](int e, bool touches_begin, bool touches_end, int jb, int je) {
+            // sorted positions of the entity's run: recorded by the chunk that
+            // holds its first / last pair (fix-up then needs no search)
+            if (p0 == 0 && l == 0) {
+                if (!touches_begin) run_start[e] = cb + jb;
+                if (!touches_end) run_end[e] = cb + je;
+            }
             float* dst;
             if (!touches_begin && !touches_end) dst = GRe + (size_t)e * de;   // sole owner
             else if (touches_end) dst = tail + (size_t)chunk * de;
@@ -76,7 +84,8 @@ __global__ __launch_bounds__(256) void egrad_chunk_reduce(
             const int row = __shfl(my_row, gbase + j, kWave);
             const float cf = __shfl(my_coef, gbase + j, kWave);
             if (k != cur) {
-                flush(cur, at_begin && prev_key == cur, false);
+                flush(cur, at_begin && prev_key == cur, false, jb, j);
+                jb = j;
 #pragma unroll
                 for (int q = 0; q < NCH; ++q)
 #pragma unroll
@@ -101,42 +110,52 @@ __global__ __launch_bounds__(256) void egrad_chunk_reduce(
                 }
             }
         }
-        flush(cur, at_begin && prev_key == cur, next_key == cur);
+        flush(cur, at_begin && prev_key == cur, next_key == cur, jb, cnt);
     }
 }
 
-// 16 lanes per entity: add the carries of the chunks its run spans.
+// One wave per entity: add the carries of the chunks its run [s,t) spans.  The
+// four 16-lane rows of the wave take every 4th chunk (independent load chains),
+// then combine in a fixed order.
 template <int VEC>
-__global__ __launch_bounds__(256) void egrad_fixup(const int32_t* __restrict__ keys, int total,
-                                                   int V, int de, const float* __restrict__ head,
+__global__ __launch_bounds__(256) void egrad_fixup(const int32_t* __restrict__ run_start,
+                                                   const int32_t* __restrict__ run_end, int V,
+                                                   int de, const float* __restrict__ head,
                                                    const float* __restrict__ tail,
                                                    float* __restrict__ GRe) {
-    const int l = threadIdx.x & 15;
-    const int e = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int lane = threadIdx.x & 63;
+    const int l = lane & 15, g = lane >> 4;
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (e >= V) return;
-    const int pieces = de / VEC;
-    // lower_bound(e) and lower_bound(e+1)
-    int lo = 0, hi = total;
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] < e) lo = mid + 1; else hi = mid; }
-    const int s = lo;
-    hi = total;
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (keys[mid] <= e) lo = mid + 1; else hi = mid; }
-    const int t = lo;
-    if (t <= s) return;
+    const int s = run_start[e], t = run_end[e];
+    if (t <= s) return;                      // entity not in this batch (arrays are zeroed)
     const int cs = s / kEChunk, cl = (t - 1) / kEChunk;
-    if (cs == cl) return;  // the run sits inside one chunk: written directly
+    if (cs == cl) return;                    // run inside one chunk: written directly
+    const int pieces = de / VEC;
     for (int c = l; c < pieces; c += 16) {
         float a[VEC];
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) a[v] = tail[(size_t)cs * de + VEC * c + v];
-        for (int k = cs + 1; k < cl; ++k)
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) a[v] += tail[(size_t)k * de + VEC * c + v];
-        // last chunk: the run touches its begin and cannot continue => head
+        for (int v = 0; v < VEC; ++v) a[v] = 0.f;
+        // chunks cs .. cl-1 carry the run in their tail slot, chunk cl in its head slot
+#pragma unroll 4
+        for (int k = cs + g; k < cl; k += 4) {
+            if (VEC == 4) {
+                const float4 v4 = *reinterpret_cast<const float4*>(tail + (size_t)k * de + 4 * c);
+                a[0] += v4.x; a[1 % VEC] += v4.y; a[2 % VEC] += v4.z; a[3 % VEC] += v4.w;
+            } else {
+                a[0] += tail[(size_t)k * de + c];
+            }
+        }
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
-            a[v] += head[(size_t)cl * de + VEC * c + v];
-            GRe[(size_t)e * de + VEC * c + v] = a[v];
+            float x = a[v];
+            x += __shfl_xor(x, 16, kWave);
+            x += __shfl_xor(x, 32, kWave);
+            a[v] = x + head[(size_t)cl * de + VEC * c + v];
+        }
+        if (g == 0) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) GRe[(size_t)e * de + VEC * c + v] = a[v];
         }
     }
 }

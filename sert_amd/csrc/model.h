@@ -65,6 +65,8 @@ struct sert_model {
     float* gflat = nullptr;
     size_t gflat_count = 0;
     float *g_re = nullptr, *g_rw = nullptr, *g_w = nullptr, *g_b = nullptr, *g_loss = nullptr;
+    size_t gflat_alloc = 0;       // allocation incl. the per-step-zeroed int tail below
+    int32_t *run_start = nullptr, *run_end = nullptr;   // (V_e) sorted-run bounds per entity
 
     // per-batch activations
     float *H = nullptr, *T = nullptr, *DA = nullptr, *DH = nullptr, *rowloss = nullptr;

@@ -316,20 +316,20 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         const int V = c.num_entities;
         SERT_TRY(entity_key_sort(m, total));
         const int chunks = cdiv(total, kEChunk);
-        dim3 cgrid(cdiv(chunks, 16)), fgrid(cdiv(V, 16)), blk(256);
+        dim3 cgrid(cdiv(chunks, 16)), fgrid(cdiv(V, 4)), blk(256);
 #define SERT_EG_ARGS m->cand_sorted, m->pair_sorted, m->coef, m->T, total, c.num_negatives + 1, de, \
-                     m->g_re, m->ehead, m->etail
+                     m->g_re, m->ehead, m->etail, m->run_start, m->run_end
         if (de % 4 == 0) {
             const int nch = cdiv(de / 4, 16);
             if (nch <= 1)      hipLaunchKernelGGL((egrad_chunk_reduce<4, 1>), cgrid, blk, 0, m->stream, SERT_EG_ARGS);
             else if (nch <= 2) hipLaunchKernelGGL((egrad_chunk_reduce<4, 2>), cgrid, blk, 0, m->stream, SERT_EG_ARGS);
             else if (nch <= 5) hipLaunchKernelGGL((egrad_chunk_reduce<4, 5>), cgrid, blk, 0, m->stream, SERT_EG_ARGS);
             else               hipLaunchKernelGGL((egrad_chunk_reduce<4, 8>), cgrid, blk, 0, m->stream, SERT_EG_ARGS);
-            hipLaunchKernelGGL((egrad_fixup<4>), fgrid, blk, 0, m->stream, m->cand_sorted, total, V, de,
+            hipLaunchKernelGGL((egrad_fixup<4>), fgrid, blk, 0, m->stream, m->run_start, m->run_end, V, de,
                                m->ehead, m->etail, m->g_re);
         } else {
             hipLaunchKernelGGL((egrad_chunk_reduce<1, 4>), cgrid, blk, 0, m->stream, SERT_EG_ARGS);
-            hipLaunchKernelGGL((egrad_fixup<1>), fgrid, blk, 0, m->stream, m->cand_sorted, total, V, de,
+            hipLaunchKernelGGL((egrad_fixup<1>), fgrid, blk, 0, m->stream, m->run_start, m->run_end, V, de,
                                m->ehead, m->etail, m->g_re);
         }
 #undef SERT_EG_ARGS
@@ -494,7 +494,7 @@ static int train_step_async(sert_model* m, int64_t batch_index, const int64_t* n
     if (m->cfg.inference_only) SERT_FAIL("model was created inference_only");
     if (ds.N == 0) SERT_FAIL("no training data uploaded");
     if (batch_index < 0 || (batch_index + 1) * (int64_t)B > ds.N) SERT_FAIL("batch_index out of range");
-    SERT_HIP(hipMemsetAsync(m->gflat, 0, m->gflat_count * sizeof(float), m->stream));
+    SERT_HIP(hipMemsetAsync(m->gflat, 0, m->gflat_alloc * sizeof(float), m->stream));
     if (is_vs(m)) {
         SERT_TRY(vs_negatives(m, negatives, (uint64_t)m->step * 2));
         SERT_TRY(vs_forward<true>(m, ds, batch_index));
@@ -576,7 +576,14 @@ int sert_create(const sert_config* cfg, sert_model** out) {
         const size_t o_re = 0, o_rw = o_re + round_up(m->n_re, 4), o_w = o_rw + round_up(m->n_rw, 4),
                      o_b = o_w + round_up(m->n_w, 4), o_l = o_b + round_up(m->n_b, 4);
         m->gflat_count = o_l + 4;
-        SERT_TRY(dzalloc(&m->gflat, m->gflat_count, s));
+        // tail of the same allocation (zeroed with the gradients every step, not
+        // part of the all-reduce): per-entity sorted-run bounds
+        m->gflat_alloc = m->gflat_count + (vs ? 2 * round_up(V, 4) : 0);
+        SERT_TRY(dzalloc(&m->gflat, m->gflat_alloc, s));
+        if (vs) {
+            m->run_start = (int32_t*)(m->gflat + m->gflat_count);
+            m->run_end = m->run_start + round_up(V, 4);
+        }
         m->g_re = m->n_re ? m->gflat + o_re : nullptr;
         m->g_rw = m->gflat + o_rw;
         m->g_w = m->gflat + o_w;

@@ -164,12 +164,29 @@ int sert_predict_tokens(sert_model* m, const void* ids, int64_t rows, float* out
 
 /* ---- entity scoring (bin/query.py:239-370, batched) --------------------- */
 
-/* For each of Q query projections: L2-normalise it (query.py:333-336), score
- * every entity with (cos + 1)/2 against the L2-normalised entity table
- * (query.py:270-274, :352-357) and return the k best, sorted by score
- * descending, ties by lowest entity index.
- *   entities (V_e, d) f32 host (un-normalised), proj (Q, d) f32 host
- *   idx_out (Q, k) int32, score_out (Q, k) f32 */
+typedef struct sert_scorer sert_scorer;
+
+/* VectorSpaceCallback.__init__ (query.py:241-302): take the entity table
+ * (V_e, d) f32 (host, un-normalised; not modified), L2-normalise a device copy
+ * (query.py:270-274).  Replaces NearestNeighbors.fit (query.py:288-293). */
+int sert_scorer_create(int device, const float* entities, int64_t num_entities, int32_t dim,
+                       sert_scorer** out);
+int sert_scorer_destroy(sert_scorer* s);
+
+/* VectorSpaceCallback.process (query.py:320-367) for Q queries at once: L2-normalise
+ * each projection (query.py:333-336), score every entity with (cos + 1)/2
+ * (query.py:352-357) and return the k best per query, sorted by score
+ * descending, ties by lowest entity index (replaces kneighbors / cdist+argsort,
+ * query.py:304-318, and the Python candidate loop :348-365).
+ *   proj (Q, d) f32 host;  idx_out (Q, k) int32;  score_out (Q, k) f32;  1 <= k <= min(V_e, 1024) */
+int sert_scorer_topk(sert_scorer* s, const float* proj, int64_t num_queries, int32_t k,
+                     int32_t* idx_out, float* score_out);
+
+/* All scores (no selection): score_out (Q, V_e) f32 = (cos + 1)/2.  For --top
+ * unset / > 1024 (query.py:250-260 ranks every entity); the caller orders them. */
+int sert_scorer_scores(sert_scorer* s, const float* proj, int64_t num_queries, float* score_out);
+
+/* Convenience: create + topk + destroy. */
 int sert_score_topk(int device, const float* entities, int64_t num_entities, int32_t dim,
                     const float* proj, int64_t num_queries, int32_t k,
                     int32_t* idx_out, float* score_out);

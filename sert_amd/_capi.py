@@ -28,6 +28,7 @@ EXPORTS = [
     'sert_set_tensor', 'sert_get_tensor', 'sert_tensor_size', 'sert_set_step', 'sert_get_step',
     'sert_upload_dataset', 'sert_train_batch', 'sert_train_batches', 'sert_eval_batch',
     'sert_predict_project', 'sert_predict_tokens', 'sert_score_topk',
+    'sert_scorer_create', 'sert_scorer_destroy', 'sert_scorer_topk', 'sert_scorer_scores',
     'sert_comm_unique_id', 'sert_comm_init', 'sert_comm_destroy',
     'sert_synchronize', 'sert_timing_enable', 'sert_timing_reset', 'sert_timing_count',
     'sert_timing_name', 'sert_timing_avg_us',
@@ -99,6 +100,10 @@ def load():
     lib.sert_predict_project.argtypes = [vp, fp, i64, fp]
     lib.sert_predict_tokens.argtypes = [vp, fp, i64, fp]
     lib.sert_score_topk.argtypes = [ctypes.c_int, fp, i64, i32, fp, i64, i32, fp, fp]
+    lib.sert_scorer_create.argtypes = [ctypes.c_int, fp, i64, i32, ctypes.POINTER(vp)]
+    lib.sert_scorer_destroy.argtypes = [vp]
+    lib.sert_scorer_topk.argtypes = [vp, fp, i64, i32, fp, fp]
+    lib.sert_scorer_scores.argtypes = [vp, fp, i64, fp]
     lib.sert_comm_unique_id.argtypes = [ctypes.c_char_p]
     lib.sert_comm_init.argtypes = [vp, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
     lib.sert_comm_destroy.argtypes = [vp]
@@ -294,3 +299,59 @@ def score_topk(entities, projections, k, device=0):
     check(load().sert_score_topk(device, e.ctypes.data, e.shape[0], e.shape[1], p.ctypes.data, q,
                                  k, idx.ctypes.data, val.ctypes.data))
     return idx, val
+
+
+class Scorer(object):
+    """Persistent device copy of the (L2-normalised) entity table + top-k scoring
+    (sert_scorer_* in include/sert_hip.h)."""
+
+    def __init__(self, entities, device=0):
+        e = np.ascontiguousarray(entities, dtype=np.float32)
+        assert e.ndim == 2
+        self.num_entities, self.dim = e.shape
+        self._lib = load()
+        self._h = ctypes.c_void_p()
+        check(self._lib.sert_scorer_create(device, e.ctypes.data, e.shape[0], e.shape[1],
+                                           ctypes.byref(self._h)))
+
+    def topk(self, projections, k):
+        p = np.ascontiguousarray(projections, dtype=np.float32)
+        if p.ndim == 1:
+            p = p.reshape(1, -1)
+        assert p.shape[1] == self.dim
+        q = p.shape[0]
+        idx = np.empty((q, k), dtype=np.int32)
+        val = np.empty((q, k), dtype=np.float32)
+        check(self._lib.sert_scorer_topk(self._h, p.ctypes.data, q, k, idx.ctypes.data,
+                                         val.ctypes.data))
+        return idx, val
+
+    def scores(self, projections):
+        p = np.ascontiguousarray(projections, dtype=np.float32)
+        if p.ndim == 1:
+            p = p.reshape(1, -1)
+        assert p.shape[1] == self.dim
+        out = np.empty((p.shape[0], self.num_entities), dtype=np.float32)
+        check(self._lib.sert_scorer_scores(self._h, p.ctypes.data, p.shape[0], out.ctypes.data))
+        return out
+
+    def rank(self, projections, k=None):
+        """(idx, score) per query, best first; k=None ranks every entity."""
+        if k is not None and k <= min(self.num_entities, 1024):
+            return self.topk(projections, k)
+        sc = self.scores(projections)
+        order = np.argsort(-sc, axis=1, kind='stable')   # ties: lowest index first
+        if k is not None:
+            order = order[:, :k]
+        return order.astype(np.int32), np.take_along_axis(sc, order, axis=1)
+
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h:
+            self._lib.sert_scorer_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -20,6 +20,13 @@ __global__ __launch_bounds__(256) void l2_normalize_rows(float* __restrict__ X, 
     for (int c = lane; c < d; c += 64) x[c] = x[c] / nrm;
 }
 
+// S <- (S + 1) / 2, in place (query.py:352-357)
+__global__ void cos_to_score(float* __restrict__ S, size_t count) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count;
+         i += (size_t)gridDim.x * blockDim.x)
+        S[i] = (S[i] + 1.0f) / 2.0f;
+}
+
 // Order-preserving map float -> uint32 such that ascending uint == DESCENDING float.
 __device__ __forceinline__ uint32_t desc_key(float f) {
     uint32_t u = __float_as_uint(f);

@@ -108,3 +108,16 @@ struct sert_model {
 
     sert::Timing timing;
 };
+
+struct sert_scorer {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int64_t V = 0;
+    int dim = 0;
+    float* E = nullptr;      // (V, dim) L2-normalised entity table
+    float* P = nullptr;      // (Q, dim) query projections
+    float* S = nullptr;      // (QT, V) cosine slab of one query tile
+    float* val = nullptr;    // (Q, k)
+    int32_t* idx = nullptr;  // (Q, k)
+    int64_t cap_q = 0, cap_qk = 0, cap_s = 0;
+};

@@ -886,41 +886,116 @@ int sert_predict_tokens(sert_model* m, const void* ids, int64_t rows, float* out
     return 0;
 }
 
-int sert_score_topk(int device, const float* entities, int64_t V, int32_t dim, const float* proj,
-                    int64_t Q, int32_t k, int32_t* idx_out, float* score_out) {
-    if (!entities || !proj || !idx_out || !score_out) SERT_FAIL("null argument");
-    if (V <= 0 || dim <= 0 || Q < 0 || k <= 0) SERT_FAIL("bad sizes");
-    if (k > V) SERT_FAIL("k exceeds the number of entities");
+int sert_scorer_create(int device, const float* entities, int64_t V, int32_t dim, sert_scorer** out) {
+    if (!entities || !out) SERT_FAIL("null argument");
+    if (V <= 0 || dim <= 0) SERT_FAIL("bad sizes");
+    SERT_HIP(hipSetDevice(device));
+    sert_scorer* sc = new sert_scorer();
+    sc->device = device;
+    sc->V = V;
+    sc->dim = dim;
+    SERT_HIP(hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking));
+    SERT_TRY(dmalloc(&sc->E, (size_t)V * dim));
+    SERT_HIP(hipMemcpyAsync(sc->E, entities, (size_t)V * dim * sizeof(float), hipMemcpyHostToDevice, sc->stream));
+    hipLaunchKernelGGL(l2_normalize_rows, dim3(cdiv(V, 4)), dim3(256), 0, sc->stream, sc->E, V, dim);
+    SERT_HIP(hipStreamSynchronize(sc->stream));
+    *out = sc;
+    return 0;
+}
+
+int sert_scorer_destroy(sert_scorer* sc) {
+    if (!sc) return 0;
+    (void)hipSetDevice(sc->device);
+    (void)hipFree(sc->E); (void)hipFree(sc->P); (void)hipFree(sc->S); (void)hipFree(sc->val); (void)hipFree(sc->idx);
+    if (sc->stream) (void)hipStreamDestroy(sc->stream);
+    delete sc;
+    return 0;
+}
+
+int sert_scorer_topk(sert_scorer* sc, const float* proj, int64_t Q, int32_t k, int32_t* idx_out, float* score_out) {
+    if (!sc || !proj || !idx_out || !score_out) SERT_FAIL("null argument");
+    if (Q < 0 || k <= 0) SERT_FAIL("bad sizes");
+    if (k > sc->V) SERT_FAIL("k exceeds the number of entities");
     if (k > kTopKMax) SERT_FAIL("k > 1024 is not supported");
     if (Q == 0) return 0;
-    SERT_HIP(hipSetDevice(device));
-    hipStream_t s;
-    SERT_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-    float *dE = nullptr, *dP = nullptr, *dS = nullptr, *dVal = nullptr;
-    int32_t* dIdx = nullptr;
-    const int64_t QT = std::min<int64_t>(Q, std::max<int64_t>(128, (int64_t)(1ll << 28) / V / 128 * 128));
-    SERT_TRY(dmalloc(&dE, (size_t)V * dim));
-    SERT_TRY(dmalloc(&dP, (size_t)Q * dim));
-    SERT_TRY(dmalloc(&dS, (size_t)QT * V));
-    SERT_TRY(dmalloc(&dVal, (size_t)Q * k));
-    SERT_TRY(dmalloc(&dIdx, (size_t)Q * k));
-    SERT_HIP(hipMemcpyAsync(dE, entities, (size_t)V * dim * sizeof(float), hipMemcpyHostToDevice, s));
-    SERT_HIP(hipMemcpyAsync(dP, proj, (size_t)Q * dim * sizeof(float), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(l2_normalize_rows, dim3(cdiv(V, 4)), dim3(256), 0, s, dE, V, dim);
-    hipLaunchKernelGGL(l2_normalize_rows, dim3(cdiv(Q, 4)), dim3(256), 0, s, dP, Q, dim);
+    SERT_HIP(hipSetDevice(sc->device));
+    hipStream_t s = sc->stream;
+    const int64_t V = sc->V;
+    const int dim = sc->dim;
+    // query tile: bounds the materialised score slab to ~1 GiB
+    const int64_t QT = std::min<int64_t>(Q, std::max<int64_t>(128, ((int64_t)1 << 28) / V / 128 * 128));
+    if (sc->cap_q < Q) {
+        (void)hipFree(sc->P); (void)hipFree(sc->val); (void)hipFree(sc->idx);
+        SERT_TRY(dmalloc(&sc->P, (size_t)Q * dim));
+        sc->cap_q = Q;
+        sc->cap_qk = 0;
+        sc->val = nullptr; sc->idx = nullptr;
+    }
+    if (sc->cap_qk < Q * k) {
+        (void)hipFree(sc->val); (void)hipFree(sc->idx);
+        SERT_TRY(dmalloc(&sc->val, (size_t)Q * k));
+        SERT_TRY(dmalloc(&sc->idx, (size_t)Q * k));
+        sc->cap_qk = Q * k;
+    }
+    if (sc->cap_s < QT * V) {
+        (void)hipFree(sc->S);
+        SERT_TRY(dmalloc(&sc->S, (size_t)QT * V));
+        sc->cap_s = QT * V;
+    }
+    SERT_HIP(hipMemcpyAsync(sc->P, proj, (size_t)Q * dim * sizeof(float), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(l2_normalize_rows, dim3(cdiv(Q, 4)), dim3(256), 0, s, sc->P, Q, dim);
     for (int64_t q0 = 0; q0 < Q; q0 += QT) {
         const int64_t qn = std::min(QT, Q - q0);
-        // S = P.E^T
-        launch_gemm<false, true, EPI_STORE>(s, dP + q0 * dim, dE, dS, nullptr, (int)qn, (int)V, dim, dim, dim, (int)V);
-        hipLaunchKernelGGL(topk_rows, dim3((unsigned)qn), dim3(256), 0, s, dS, (int)V, k,
-                           dIdx + q0 * k, dVal + q0 * k);
+        // S = P.E^T  (cosines)
+        launch_gemm<false, true, EPI_STORE>(s, sc->P + q0 * dim, sc->E, sc->S, nullptr, (int)qn, (int)V, dim,
+                                            dim, dim, (int)V);
+        hipLaunchKernelGGL(topk_rows, dim3((unsigned)qn), dim3(256), 0, s, sc->S, (int)V, k,
+                           sc->idx + q0 * k, sc->val + q0 * k);
     }
-    SERT_HIP(hipMemcpyAsync(idx_out, dIdx, (size_t)Q * k * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    SERT_HIP(hipMemcpyAsync(score_out, dVal, (size_t)Q * k * sizeof(float), hipMemcpyDeviceToHost, s));
+    SERT_HIP(hipMemcpyAsync(idx_out, sc->idx, (size_t)Q * k * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    SERT_HIP(hipMemcpyAsync(score_out, sc->val, (size_t)Q * k * sizeof(float), hipMemcpyDeviceToHost, s));
     SERT_HIP(hipStreamSynchronize(s));
-    (void)hipFree(dE); (void)hipFree(dP); (void)hipFree(dS); (void)hipFree(dVal); (void)hipFree(dIdx);
-    (void)hipStreamDestroy(s);
     return 0;
+}
+
+int sert_scorer_scores(sert_scorer* sc, const float* proj, int64_t Q, float* score_out) {
+    if (!sc || !proj || !score_out) SERT_FAIL("null argument");
+    if (Q <= 0) return 0;
+    SERT_HIP(hipSetDevice(sc->device));
+    hipStream_t s = sc->stream;
+    const int64_t V = sc->V;
+    const int dim = sc->dim;
+    const int64_t QT = std::min<int64_t>(Q, std::max<int64_t>(128, ((int64_t)1 << 28) / V / 128 * 128));
+    if (sc->cap_q < Q) {
+        (void)hipFree(sc->P); (void)hipFree(sc->val); (void)hipFree(sc->idx);
+        SERT_TRY(dmalloc(&sc->P, (size_t)Q * dim));
+        sc->cap_q = Q; sc->cap_qk = 0; sc->val = nullptr; sc->idx = nullptr;
+    }
+    if (sc->cap_s < QT * V) {
+        (void)hipFree(sc->S);
+        SERT_TRY(dmalloc(&sc->S, (size_t)QT * V));
+        sc->cap_s = QT * V;
+    }
+    SERT_HIP(hipMemcpyAsync(sc->P, proj, (size_t)Q * dim * sizeof(float), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(l2_normalize_rows, dim3(cdiv(Q, 4)), dim3(256), 0, s, sc->P, Q, dim);
+    for (int64_t q0 = 0; q0 < Q; q0 += QT) {
+        const int64_t qn = std::min(QT, Q - q0);
+        launch_gemm<false, true, EPI_STORE>(s, sc->P + q0 * dim, sc->E, sc->S, nullptr, (int)qn, (int)V, dim,
+                                            dim, dim, (int)V);
+        hipLaunchKernelGGL(cos_to_score, dim3(grid_for(qn * V)), dim3(256), 0, s, sc->S, (size_t)(qn * V));
+        SERT_HIP(hipMemcpyAsync(score_out + q0 * V, sc->S, (size_t)qn * V * sizeof(float), hipMemcpyDeviceToHost, s));
+        SERT_HIP(hipStreamSynchronize(s));
+    }
+    return 0;
+}
+
+int sert_score_topk(int device, const float* entities, int64_t V, int32_t dim, const float* proj,
+                    int64_t Q, int32_t k, int32_t* idx_out, float* score_out) {
+    sert_scorer* sc = nullptr;
+    SERT_TRY(sert_scorer_create(device, entities, V, dim, &sc));
+    const int rc = sert_scorer_topk(sc, proj, Q, k, idx_out, score_out);
+    sert_scorer_destroy(sc);
+    return rc;
 }
 
 int sert_comm_unique_id(char id[SERT_COMM_ID_BYTES]) {

@@ -1,0 +1,131 @@
+"""CPU, world_size 2 over gloo: the data-parallel algebra the HIP engine relies on.
+
+Each rank owns rows [r*B_l, (r+1)*B_l) of every GLOBAL batch
+(distributed.shard_rows), computes the data-term gradient of its rows with the
+GLOBAL 1/B scaling, the per-rank gradients are summed (all-reduce), and the L2
+term + optimiser step are applied once, identically, on every rank.  Checked
+here with the oracle as the per-rank compute: the result must equal the
+single-process full-batch step.
+"""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+from sert_amd import distributed
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_rows_partition():
+    N, B, world = 1000, 64, 4
+    parts = [distributed.shard_rows(N, B, r, world) for r in range(world)]
+    allrows = np.sort(np.concatenate(parts))
+    assert np.array_equal(allrows, np.arange((N // B) * B))          # tail dropped
+    for r, p in enumerate(parts):
+        assert len(p) == (N // B) * (B // world)
+        # local batch j of rank r = rows [j*B + r*B_l, j*B + (r+1)*B_l)
+        assert np.array_equal(p[:B // world], np.arange(r * 16, (r + 1) * 16))
+        assert np.array_equal(p[16:32], 64 + np.arange(r * 16, (r + 1) * 16))
+
+
+WORKER = textwrap.dedent('''
+    import os, sys
+    import numpy as np
+    sys.path.insert(0, %(root)r)
+    from oracle import sert_oracle as O
+    from sert_amd import distributed as D
+
+    ctx = D.init_from_env()
+    assert ctx.world_size == 2
+    rng = np.random.RandomState(0)            # same data on every rank
+    B, n, z, Vw, Ve, dw, de = 16, 3, 4, 40, 9, 6, 5
+    lam = 0.01
+    Rw, Re = O.glorot_uniform(rng, (Vw, dw)), O.glorot_uniform(rng, (Ve, de))
+    W, b = O.glorot_uniform(rng, (dw, de)), (0.1 * rng.randn(de)).astype(np.float32)
+    X = rng.randint(0, Vw, (2 * B, n)); y = rng.randint(0, Ve, 2 * B)
+    w = rng.uniform(.5, 2, 2 * B).astype(np.float32)
+    neg = rng.randint(0, Ve, (2 * B, z))
+
+    # reference: one process, full global batches
+    full = O.VectorSpaceOracle(B, n, z, Rw, Re, W, b, lam)
+    ref_losses = [full.train_step(X[j*B:(j+1)*B], y[j*B:(j+1)*B], w[j*B:(j+1)*B], neg[j*B:(j+1)*B])
+                  for j in range(2)]
+
+    # data parallel: this rank's rows, global 1/B scaling, summed gradients
+    rows = D.shard_rows(2 * B, B, ctx.rank, ctx.world_size)
+    Bl = B // ctx.world_size
+    dp = O.VectorSpaceOracle(B, n, z, Rw, Re, W, b, lam)   # .B = GLOBAL batch: scales and L2
+    losses = []
+    for j in range(2):
+        r = rows[j*Bl:(j+1)*Bl]
+        f = dp.forward(X[r], y[r], neg[r])
+        # data term of the loss and of the gradients for the local rows only
+        lam_saved, dp.lam = dp.lam, 0.0
+        _, grads, _ = dp.loss_and_grads(X[r], y[r], w[r], neg[r])
+        dp.lam = lam_saved
+        # loss_and_grads divides by len(local rows); rescale to the GLOBAL batch
+        scale = np.float32(len(r)) / np.float32(B)
+        grads = [g * scale for g in grads]
+        local_loss_sum = np.array([np.sum(f['loss'] * w[r], dtype=np.float64)])
+        flat = np.concatenate([g.ravel() for g in grads] + [local_loss_sum.astype(np.float32)])
+        flat = D.all_reduce_sum_array(flat)                  # ONE exchange per step
+        out, o = [], 0
+        for g in grads:
+            out.append(flat[o:o + g.size].reshape(g.shape)); o += g.size
+        loss = np.float32(flat[o] / B) + dp.regularizer()
+        k = np.float32(lam) / np.float32(B)                 # L2 once, after the reduce
+        out[0] = out[0] + k * dp.R_e; out[1] = out[1] + k * dp.R_w; out[2] = out[2] + k * dp.W
+        dp.opt.update(dp.params(), out)
+        losses.append(loss)
+    for a, c in zip(losses, ref_losses):
+        assert abs(a - c) <= 2e-6 * abs(c), (a, c)
+    for p, q in zip(dp.params(), full.params()):
+        assert np.abs(p - q).max() <= 1e-5 * np.abs(q).max()
+    # replicas stay identical
+    chk = D.all_reduce_sum_array(np.concatenate([p.ravel() for p in dp.params()]).astype(np.float64))
+    mine = np.concatenate([p.ravel() for p in dp.params()]).astype(np.float64)
+    assert np.allclose(chk, 2 * mine, rtol=0, atol=0)
+    # object / array broadcast used for the ncclUniqueId and the initial parameters
+    assert D.broadcast_object('id-from-%%d' %% ctx.rank) == 'id-from-0'
+    a = D.broadcast_array(np.full(3, ctx.rank, dtype=np.float32))
+    assert np.array_equal(a, np.zeros(3, np.float32))
+    assert D.all_reduce_max(float(ctx.rank)) == 1.0
+    D.barrier()
+    D.shutdown()
+    print('rank %%d ok' %% ctx.rank)
+''')
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_two_rank_gloo_equals_single_process(tmp_path):
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER % {'root': ROOT})
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE='2',
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, _ = p.communicate()
+        outs.append(out.decode())
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, out
+        assert 'rank %d ok' % rank in out

@@ -1,0 +1,331 @@
+"""-m gpu: the sert.models / sert.inference / bin/*.py surface end to end on the
+MI355X, against the oracle and the reference-derived golden vectors."""
+import importlib.util
+import io
+import json
+import os
+import pickle
+import subprocess
+import sys
+import types
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import sert_oracle as O
+from sert_amd import _capi as C
+from sert_amd import inference, models, scoring
+from tests import util as U
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+@pytest.fixture(scope='module')
+def gold():
+    arrays = np.load(os.path.join(HERE, 'golden', 'reference_vectors.npz'))
+    with open(os.path.join(HERE, 'golden', 'reference_vectors.json')) as f:
+        meta = json.load(f)
+    return arrays, meta
+
+
+def test_vectorspace_model_epoch_matches_oracle(hip_lib):
+    """train() over a shuffled epoch + train_error()/validation_error() through
+    the class surface, explicit negatives, vs the oracle driven the same way."""
+    B, n, z, Vw, Ve, dw, de = 64, 4, 5, 400, 30, 32, 32
+    N, Nv = B * 5 + 7, B * 2
+    p = U.make_vs_problem(11, N + Nv, n, z, Vw, Ve, dw, de)
+    Xt, yt, wt = p['X'][:N], p['y'][:N], p['w'][:N]
+    Xv, yv = p['X'][N:], p['y'][N:]
+    negs = {('t', j): p['rng'].randint(0, Ve, (B, z)).astype(np.int64) for j in range(5)}
+    negs.update({('e', j): p['rng'].randint(0, Ve, (B, z)).astype(np.int64) for j in range(5)})
+    np.random.seed(3)
+    m = models.VectorSpaceLanguageModel(
+        batch_size=B, window_size=n, num_negative_samples=z, representations_init=p['Rw'],
+        entity_representations_init=p['Re'], regularization_lambda=0.01,
+        training_set=(Xt, yt, wt), validation_set=(Xv, yv))
+    m.negative_sampler = lambda j: negs[('t', j)]
+    m.eval_negative_sampler = lambda j: negs[('e', j)]
+    W0, b0 = m.get_dense_weights(), m.get_dense_bias()
+    assert isinstance(m, models.ModelInterface)
+    ora = O.VectorSpaceOracle(B, n, z, p['Rw'], p['Re'], W0, b0, 0.01)
+    order = list(range(5))
+    np.random.seed(99)
+    np.random.shuffle(order)
+    ref_losses = [ora.train_step(Xt[j*B:(j+1)*B], yt[j*B:(j+1)*B], wt[j*B:(j+1)*B], negs[('t', j)])
+                  for j in order]
+    np.random.seed(99)
+    nb, mean_loss = m.train()
+    assert nb == 5
+    assert abs(mean_loss - np.mean(ref_losses)) < 1e-5 * abs(np.mean(ref_losses))
+    Rw, Re = m.get_representations()
+    assert U.rel_err(Rw, ora.R_w) < 1e-4 and U.rel_err(Re, ora.R_e) < 1e-4
+    te_mean, te_std = m.train_error()
+    ref = [ora.eval_loss(Xt[j*B:(j+1)*B], yt[j*B:(j+1)*B], negs[('e', j)]) for j in range(5)]
+    assert abs(te_mean - np.mean(ref)) < 1e-5 * abs(np.mean(ref))
+    assert abs(te_std - np.std(ref)) < 1e-4 * max(1e-3, abs(np.std(ref)))
+    ve_mean, _ = m.validation_error()
+    refv = [ora.eval_loss(Xv[j*B:(j+1)*B], yv[j*B:(j+1)*B], negs[('e', j)]) for j in range(2)]
+    assert abs(ve_mean - np.mean(refv)) < 1e-5 * abs(np.mean(refv))
+    # get_state: [predict_fn, R_w, R_e]; predict_fn pickles and still predicts
+    state = m.get_state()
+    assert len(state) == 3 and state[1].shape == (Vw, dw) and state[2].shape == (Ve, de)
+    fn = pickle.loads(pickle.dumps(state[0]))
+    avg = Rw[[1, 2, 3]].mean(axis=0)
+    out = fn(avg)
+    assert out.shape == (1, de)
+    assert U.rel_err(out, ora.predict(avg)[None, :]) < 1e-5
+    # optimiser state round trip (additive)
+    st = m.get_optimizer_state()
+    assert st['step'] == 5 and st['m_R_w'].shape == (Vw, dw)
+    m.set_optimizer_state(st)
+    assert U.rel_err(st['m_R_w'], ora.opt.m[1]) < 1e-4
+
+
+def test_loglinear_model_csr_labels(hip_lib):
+    B, n, Vw, Ve, d = 32, 3, 200, 20, 16
+    p = U.make_ll_problem(4, B * 3, n, Vw, Ve, d, 'csr')
+    empty = (np.zeros((0, n), p['X'].dtype), sp.csr_matrix((0, Ve), dtype=np.float32))
+    np.random.seed(1)
+    m = models.LanguageModel(batch_size=B, window_size=n, representations_init=p['Rw'],
+                             output_layer_size=Ve, regularization_lambda=0.01,
+                             training_set=(p['X'], p['y'], p['w']), validation_set=empty)
+    ora = O.LogLinearOracle(B, n, p['Rw'], m.get_dense_weights(), m.get_dense_bias(), 0.01)
+    for j in range(3):
+        ref = ora.train_step(p['X'][j*B:(j+1)*B], p['ydense'][j*B:(j+1)*B], p['w'][j*B:(j+1)*B])
+        got = m.train_fn(j)
+        assert abs(got - ref) <= 1e-5 * abs(ref)
+    assert U.rel_err(m.get_representations(), ora.R_w) < 1e-4
+    # validation set empty -> mean of nothing, as in the reference (nan + warning)
+    state = m.get_state()
+    assert len(state) == 2
+    fn = pickle.loads(pickle.dumps(state[0]))
+    batch = p['X'][:B]
+    P = fn(batch, np.ones((B, n), np.int8))
+    _, Pref = ora.token_distributions(batch)
+    assert P.shape == (B, n, Ve) and U.rel_err(P, Pref) < 1e-5
+
+
+def test_vectorspace_callback_matches_reference_golden(hip_lib, gold):
+    """VectorSpaceCallback on the GPU scorer vs the reference's own callback
+    (sklearn brute kNN / cdist), captured in tests/golden."""
+    arrays, _ = gold
+    E, projs = arrays['vs_E'], arrays['vs_proj']
+    de = E.shape[1]
+    for tag, top in [('10', 10), ('all', None), ('100', 100)]:
+        ranked = []
+        cb = scoring.VectorSpaceCallback(
+            E.copy(), types.SimpleNamespace(top=top),
+            types.SimpleNamespace(entity_representation_size=de),
+            {i: 'w%d' % i for i in range(20)}, io.StringIO(),
+            lambda t, idx, val: ranked.append((t, np.array(idx), np.array(val))))
+        assert cb.should_average_input()
+        for qi in range(projs.shape[0]):
+            cb([1, 2], projs[qi][None, :].copy(), topic_id='q%d' % qi)
+        for qi, (tid, idx, val) in enumerate(ranked):
+            gidx = arrays['vs_top%s_idx_%d' % (tag, qi)]
+            gval = arrays['vs_top%s_val_%d' % (tag, qi)]
+            assert tid == 'q%d' % qi and len(idx) == len(gidx)
+            for r in np.nonzero(idx != gidx)[0]:
+                assert abs(gval[r] - val[r]) < 1e-6     # only near-ties may swap
+            assert np.abs(val - gval).max() < 1e-6
+        # batched path gives the same rankings
+        ranked_b = []
+        cb2 = scoring.VectorSpaceCallback(
+            E.copy(), types.SimpleNamespace(top=top),
+            types.SimpleNamespace(entity_representation_size=de), {}, None,
+            lambda t, idx, val: ranked_b.append((t, np.array(idx), np.array(val))))
+        cb2.process_batch([[1]] * projs.shape[0], projs.copy(),
+                          [{'topic_id': 'q%d' % i} for i in range(projs.shape[0])])
+        for a, b in zip(ranked, ranked_b):
+            assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
+def test_ndcg_parity_on_synthetic_queries(hip_lib):
+    """Query-time nDCG@100 of the GPU ranking within 1e-4 of the oracle's."""
+    rng = np.random.RandomState(12)
+    V, d, Q, k = 2000, 64, 50, 100
+    E = rng.randn(V, d).astype(np.float32)
+    Pj = np.tanh(rng.randn(Q, d)).astype(np.float32)
+    idx, val = C.score_topk(E, Pj, k)
+    diffs = []
+    for q in range(Q):
+        rel = set(rng.choice(V, 30, replace=False).tolist()) | set(idx[q][:5].tolist())
+        order, _ = O.vectorspace_rank(Pj[q].astype(np.float64), E.astype(np.float64), top=k)
+        diffs.append(abs(O.ndcg_at_k(list(idx[q]), rel, k) - O.ndcg_at_k(list(order), rel, k)))
+    assert max(diffs) <= 1e-4
+
+
+def test_large_scoring_properties(hip_lib):
+    """BASELINE configs[4]-shaped (reduced Q): sortedness, score range, and the
+    top-1 of a query equal to an entity row is that entity."""
+    rng = np.random.RandomState(13)
+    V, d, Q, k = 100000, 128, 256, 100
+    E = rng.randn(V, d).astype(np.float32)
+    Pj = np.tanh(rng.randn(Q, d)).astype(np.float32)
+    Pj[:8] = E[1000:1008]
+    idx, val = C.score_topk(E, Pj, k)
+    assert np.all(np.diff(val, axis=1) <= 0)
+    assert val.min() >= 0.0 and val.max() <= 1.0 + 1e-6
+    assert np.array_equal(idx[:8, 0], np.arange(1000, 1008))
+    assert np.all(np.abs(val[:8, 0] - 1.0) < 1e-6)
+    for q in range(8, 12):     # spot-check a few full rankings against fp64
+        order, sc = O.vectorspace_rank(Pj[q].astype(np.float64), E.astype(np.float64), top=k)
+        assert np.abs(val[q] - sc).max() < 1e-6
+        assert len(set(idx[q]) ^ set(order)) <= 2
+
+
+def test_c2_sized_training_is_deterministic_and_learns(hip_lib):
+    """BASELINE configs[1] full size: two identical runs are BIT-identical (no
+    atomics anywhere on the path) and the loss goes down."""
+    B, n, z, Vw, Ve, d = 65536, 10, 10, 100000, 1000, 128
+    rng = np.random.RandomState(0)
+    ranks = np.minimum(rng.zipf(1.1, size=(2 * B, n)) - 1, Vw - 1)
+    X = rng.permutation(Vw).astype(np.uint32)[ranks]
+    # learnable structure: the label is a function of the first token
+    y = (X[:, 0] % Ve).astype(np.int32)
+    w = np.ones(2 * B, dtype=np.float32)
+    p = dict(Rw=O.glorot_uniform(rng, (Vw, d)), Re=O.glorot_uniform(rng, (Ve, d)),
+             W=O.glorot_uniform(rng, (d, d)), b=np.zeros(d, np.float32), X=X)
+    finals, losses = [], []
+    for run in range(2):
+        eng = U.vs_engine(p, B, n, z, 0.01, keep_grads=0, seed=77, lr=0.01)
+        eng.upload_dataset(C.SPLIT_TRAIN, X, y_int=y, w=w)
+        ls = [eng.train_batch(s % 2) for s in range(12)]
+        finals.append((eng.get_tensor(C.T_RW).copy(), eng.get_tensor(C.T_RE).copy(),
+                       eng.get_tensor(C.T_W).copy()))
+        losses.append(ls)
+        eng.close()
+    assert np.all(np.isfinite(losses[0]))
+    assert losses[0] == losses[1]
+    for a, b in zip(finals[0], finals[1]):
+        assert np.array_equal(a, b)
+    assert np.mean(losses[0][-2:]) < np.mean(losses[0][:2])
+
+
+def test_device_sampler_is_uniform(hip_lib):
+    """Device Philox negatives: iid uniform over entities (models.py:970-973) --
+    chi-square over 64 entities, checked through the loss at W=0 (any sample
+    gives (1+z) log 2) and through the entity-gradient row sums."""
+    B, n, z, Vw, Ve, dw, de = 4096, 2, 16, 50, 64, 8, 8
+    p = U.make_vs_problem(21, B, n, z, Vw, Ve, dw, de, weights='ones')
+    p['W'][:] = 0
+    p['b'][:] = 0.5           # p = tanh(0.5) constant => dR_e[e] = count(e) * du * p
+    p['Re'][:] = 0
+    p['y'][:] = 0
+    eng = U.vs_engine(p, B, n, z, 0.0, seed=5)
+    eng.upload_dataset(C.SPLIT_TRAIN, p['X'], y_int=p['y'], w=p['w'])
+    loss = eng.train_batch(0)
+    assert abs(loss - (1 + z) * np.log(2)) < 1e-5
+    g = eng.get_tensor(C.T_GRAD_RE, (Ve, de))
+    per_neg = (0.5 / B) * np.tanh(0.5)           # du for a negative with sigma = 1/2
+    counts = g[:, 0] / per_neg
+    counts[0] += B                                # the positives (entity 0) pull the other way
+    assert abs(counts.sum() - B * z) < 1e-2 * B * z
+    expected = B * z / Ve
+    chi2 = ((counts - expected) ** 2 / expected).sum()
+    assert chi2 < 130.0                           # 63 dof: p(chi2 > 130) ~ 1e-6
+    eng.close()
+
+
+def test_rccl_single_rank_communicator(hip_lib):
+    """ncclCommInitRank / ncclAllReduce through the C ABI with world=1 (all a
+    1-GPU box can run): the exchange path is exercised and is the identity."""
+    B, n, z, Vw, Ve, dw, de = 64, 3, 4, 100, 12, 16, 16
+    p = U.make_vs_problem(31, B * 2, n, z, Vw, Ve, dw, de)
+    neg = p['rng'].randint(0, Ve, (B, z)).astype(np.int64)
+    outs = []
+    for use_comm in (False, True):
+        eng = U.vs_engine(p, B, n, z, 0.01)
+        if use_comm:
+            eng.comm_init(C.comm_unique_id(), 0, 1)
+        eng.upload_dataset(C.SPLIT_TRAIN, p['X'], y_int=p['y'], w=p['w'])
+        l0 = eng.train_batch(0, neg)
+        l1 = eng.train_batch(1, neg)
+        ev = eng.eval_batch(C.SPLIT_TRAIN, 0, neg)
+        outs.append((l0, l1, ev, eng.get_tensor(C.T_RW).copy()))
+        eng.close()
+    assert outs[0][:3] == outs[1][:3]
+    assert np.array_equal(outs[0][3], outs[1][3])
+
+
+def _write_tiny_corpus(tmp_path, kind):
+    """data.npz + meta in the bin/prepare.py formats (Appendix B)."""
+    rng = np.random.RandomState(5)
+    Vw, Ve, n, N, Nv = 120, 12, 4, 600, 128
+    words = {'w%d' % i: types.SimpleNamespace(id=i) for i in range(Vw)}
+    tokens = {i: 'w%d' % i for i in range(Vw)}
+    ent_inv = {i: 'E%03d' % i for i in range(Ve)}
+
+    def make(N):
+        yi = rng.randint(0, Ve, N)
+        x = np.stack([(yi * 10 + rng.randint(0, 10, N)) % Vw for _ in range(n)], axis=1)
+        y = sp.csr_matrix((np.ones(N, np.float32), (np.arange(N), yi)), shape=(N, Ve))
+        return x.astype(np.uint8), y
+    xt, yt = make(N)
+    xv, yv = make(Nv)
+    yo = np.empty((), dtype=object)
+    yo[()] = yt
+    yvo = np.empty((), dtype=object)
+    yvo[()] = yv
+    np.savez(str(tmp_path / 'data.npz'), x_train=xt, y_train=yo, x_validate=xv, y_validate=yvo)
+    with open(str(tmp_path / 'meta'), 'wb') as f:
+        for obj in (argparse_ns(window_size=n), words, tokens, ent_inv, {}):
+            pickle.dump(obj, f)
+    with open(str(tmp_path / 'topics'), 'w') as f:
+        for e in range(Ve):
+            f.write('%d;w%d w%d zzz-oov\n' % (e, e * 10 + 1, e * 10 + 2))
+    with open(str(tmp_path / 'qrel'), 'w') as f:
+        for e in range(Ve):
+            f.write('%d 0 E%03d 1.0\n' % (e, e))
+    return Ve
+
+
+def argparse_ns(**kw):
+    import argparse
+    return argparse.Namespace(**kw)
+
+
+@pytest.mark.parametrize('kind', ['vectorspace', 'loglinear'])
+def test_cli_train_then_query(hip_lib, tmp_path, kind):
+    """bin/train.py -> model_<epoch>.bin -> bin/query.py -> TREC run; the learned
+    ranking puts the right entity first for most topics."""
+    Ve = _write_tiny_corpus(tmp_path, kind)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    cmd = [sys.executable, os.path.join(ROOT, 'bin', 'train.py'), '--data', str(tmp_path / 'data.npz'),
+           '--meta', str(tmp_path / 'meta'), '--type', kind, '--iterations', '40', '--batch_size', '32',
+           '--word_representation_size', '16', '--model_output', str(tmp_path / 'model'),
+           '--seed', '1', '--loglevel', 'WARNING', '--regularization_lambda', '0.0']
+    if kind == 'vectorspace':
+        cmd += ['--num_negative_samples', '5', '--one_hot_classes', '--entity_representation_size', '16']
+    subprocess.check_call(cmd, env=env)
+    files = sorted(f for f in os.listdir(str(tmp_path)) if f.startswith('model_'))
+    assert files[0] == 'model_0.bin' and len(files) >= 2
+    last = sorted(files, key=lambda f: int(f.split('_')[1].split('.')[0]))[-1]
+    with open(str(tmp_path / last), 'rb') as f:
+        n_pickles = 0
+        while True:
+            try:
+                pickle.load(f)
+                n_pickles += 1
+            except EOFError:
+                break
+    assert n_pickles == (4 if kind == 'vectorspace' else 3)
+    cmdq = [sys.executable, os.path.join(ROOT, 'bin', 'query.py'), '--meta', str(tmp_path / 'meta'),
+            '--model', str(tmp_path / last), '--topics', str(tmp_path / 'topics'),
+            '--run_out', str(tmp_path / 'run'), '--loglevel', 'WARNING']
+    if kind == 'vectorspace':
+        cmdq += ['--top', '5']
+    subprocess.check_call(cmdq, env=env)
+    from sert_amd.utils import trec_utils
+    with open(str(tmp_path / 'run_ef')) as f:
+        run = trec_utils.parse_run(f)
+    with open(str(tmp_path / 'qrel')) as f:
+        qrels = trec_utils.parse_qrels(f)
+    assert len(run) == Ve
+    res = trec_utils.evaluate_run(run, qrels, k=100)
+    assert res['ndcg_cut_100'] > 0.5, res
+    assert os.path.exists(str(tmp_path / 'run_ep')) and os.path.exists(str(tmp_path / 'run_debug'))

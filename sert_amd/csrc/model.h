@@ -51,6 +51,8 @@ struct Timing {
 struct sert_model {
     sert_config cfg;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;   // side stream: the entity-gradient chain runs beside the GEMMs
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
     // shapes
     size_t n_rw = 0, n_re = 0, n_w = 0, n_b = 0;

@@ -31,14 +31,15 @@ static const char* kTimingNames[TG_COUNT] = {"gather",   "gemm_fwd", "loss",    
 struct ScopedTimer {
     sert_model* m;
     int g;
-    ScopedTimer(sert_model* m_, int g_) : m(m_), g(g_) {
+    hipStream_t s;
+    ScopedTimer(sert_model* m_, int g_, hipStream_t s_ = nullptr) : m(m_), g(g_), s(s_ ? s_ : m_->stream) {
         if (m->timing.enabled) {
-            (void)hipEventRecord(m->timing.ev[g][0], m->stream);
+            (void)hipEventRecord(m->timing.ev[g][0], s);
         }
     }
     ~ScopedTimer() {
         if (m->timing.enabled) {
-            (void)hipEventRecord(m->timing.ev[g][1], m->stream);
+            (void)hipEventRecord(m->timing.ev[g][1], s);
             m->timing.used[g] = true;
         }
     }
@@ -195,7 +196,7 @@ static int word_grad_segsum(sert_model* m, const DataSplit& ds, int64_t batch_in
 
 // Stable sort of the (entity id, pair index) keys of this step: cand -> cand_sorted,
 // iota -> pair_sorted (kernels_sort.h), LSD over ceil(bits/11) digits.
-static int entity_key_sort(sert_model* m, int total) {
+static int entity_key_sort(sert_model* m, int total, hipStream_t st) {
     const int tiles = cdiv(total, kSortTile);
     const int bits = m->sort_bits;
     const int passes = cdiv(bits, kSortMaxBits);
@@ -208,11 +209,11 @@ static int entity_key_sort(sert_model* m, int total) {
         const bool to_final = ((passes - 1 - p) % 2) == 0;
         int32_t* kout = to_final ? m->cand_sorted : m->sort_k_tmp;
         int32_t* vout = to_final ? m->pair_sorted : m->sort_v_tmp;
-        hipLaunchKernelGGL(csort_hist, dim3(tiles), dim3(256), 0, m->stream, kin, total, shift, 1 << nb,
+        hipLaunchKernelGGL(csort_hist, dim3(tiles), dim3(256), 0, st, kin, total, shift, 1 << nb,
                            tiles, m->sort_hist);
-        hipLaunchKernelGGL(csort_scan_bins, dim3(cdiv(1 << nb, 4)), dim3(256), 0, m->stream,
+        hipLaunchKernelGGL(csort_scan_bins, dim3(cdiv(1 << nb, 4)), dim3(256), 0, st,
                            m->sort_hist, 1 << nb, tiles, m->sort_bin_total);
-        hipLaunchKernelGGL(csort_scatter, dim3(tiles), dim3(256), 0, m->stream, kin, vin, kout, vout,
+        hipLaunchKernelGGL(csort_scatter, dim3(tiles), dim3(256), 0, st, kin, vin, kout, vout,
                            total, shift, nb, tiles, m->sort_hist, m->sort_bin_total);
         kin = kout;
         vin = vout;
@@ -310,26 +311,31 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
     const int B = c.batch_size, n = c.window_size, dw = c.word_dim, de = c.entity_dim;
     const size_t row0 = (size_t)batch_index * B;
     {
-        ScopedTimer t(m, TG_EGRAD);
+        // fork: this chain only depends on the NCE kernel and is independent of the
+        // GEMMs / word-table reduction below, so it runs on the side stream
+        hipStream_t st = m->stream2;
+        SERT_HIP(hipEventRecord(m->ev_fork, m->stream));
+        SERT_HIP(hipStreamWaitEvent(st, m->ev_fork, 0));
+        ScopedTimer t(m, TG_EGRAD, st);
         // dR_e: stable sort of the (entity, pair) keys, chunked reduce, carry fix-up
         const int total = B * (c.num_negatives + 1);
         const int V = c.num_entities;
-        SERT_TRY(entity_key_sort(m, total));
+        SERT_TRY(entity_key_sort(m, total, st));
         const int chunks = cdiv(total, kEChunk);
         dim3 cgrid(cdiv(chunks, 16)), fgrid(cdiv(V, 4)), blk(256);
 #define SERT_EG_ARGS m->cand_sorted, m->pair_sorted, m->coef, m->T, total, c.num_negatives + 1, de, \
                      m->g_re, m->ehead, m->etail, m->run_start, m->run_end
         if (de % 4 == 0) {
             const int nch = cdiv(de / 4, 16);
-            if (nch <= 1)      hipLaunchKernelGGL((egrad_chunk_reduce<4, 1>), cgrid, blk, 0, m->stream, SERT_EG_ARGS);
-            else if (nch <= 2) hipLaunchKernelGGL((egrad_chunk_reduce<4, 2>), cgrid, blk, 0, m->stream, SERT_EG_ARGS);
-            else if (nch <= 5) hipLaunchKernelGGL((egrad_chunk_reduce<4, 5>), cgrid, blk, 0, m->stream, SERT_EG_ARGS);
-            else               hipLaunchKernelGGL((egrad_chunk_reduce<4, 8>), cgrid, blk, 0, m->stream, SERT_EG_ARGS);
-            hipLaunchKernelGGL((egrad_fixup<4>), fgrid, blk, 0, m->stream, m->run_start, m->run_end, V, de,
+            if (nch <= 1)      hipLaunchKernelGGL((egrad_chunk_reduce<4, 1>), cgrid, blk, 0, st, SERT_EG_ARGS);
+            else if (nch <= 2) hipLaunchKernelGGL((egrad_chunk_reduce<4, 2>), cgrid, blk, 0, st, SERT_EG_ARGS);
+            else if (nch <= 5) hipLaunchKernelGGL((egrad_chunk_reduce<4, 5>), cgrid, blk, 0, st, SERT_EG_ARGS);
+            else               hipLaunchKernelGGL((egrad_chunk_reduce<4, 8>), cgrid, blk, 0, st, SERT_EG_ARGS);
+            hipLaunchKernelGGL((egrad_fixup<4>), fgrid, blk, 0, st, m->run_start, m->run_end, V, de,
                                m->ehead, m->etail, m->g_re);
         } else {
-            hipLaunchKernelGGL((egrad_chunk_reduce<1, 4>), cgrid, blk, 0, m->stream, SERT_EG_ARGS);
-            hipLaunchKernelGGL((egrad_fixup<1>), fgrid, blk, 0, m->stream, m->run_start, m->run_end, V, de,
+            hipLaunchKernelGGL((egrad_chunk_reduce<1, 4>), cgrid, blk, 0, st, SERT_EG_ARGS);
+            hipLaunchKernelGGL((egrad_fixup<1>), fgrid, blk, 0, st, m->run_start, m->run_end, V, de,
                                m->ehead, m->etail, m->g_re);
         }
 #undef SERT_EG_ARGS
@@ -356,6 +362,9 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         // dR_w[X[i,k],:] += dh[i,:] / n
         SERT_TRY(word_grad_segsum(m, ds, batch_index, m->DH, (float)n));
     }
+    // join the entity-gradient chain
+    SERT_HIP(hipEventRecord(m->ev_join, m->stream2));
+    SERT_HIP(hipStreamWaitEvent(m->stream, m->ev_join, 0));
     (void)row0;
     return 0;
 }
@@ -557,6 +566,9 @@ int sert_create(const sert_config* cfg, sert_model** out) {
     m->cfg = *cfg;
     const auto& c = m->cfg;
     SERT_HIP(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+    SERT_HIP(hipStreamCreateWithFlags(&m->stream2, hipStreamNonBlocking));
+    SERT_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+    SERT_HIP(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
     const size_t B = c.batch_size, n = c.window_size, dw = c.word_dim, V = c.num_entities;
     const bool vs = is_vs(m);
     const size_t de = vs ? c.entity_dim : 0;
@@ -661,6 +673,9 @@ int sert_destroy(sert_model* m) {
     if (m->timing.created)
         for (int g = 0; g < TG_COUNT; ++g)
             for (int k = 0; k < 2; ++k) (void)hipEventDestroy(m->timing.ev[g][k]);
+    if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+    if (m->ev_join) (void)hipEventDestroy(m->ev_join);
+    if (m->stream2) (void)hipStreamDestroy(m->stream2);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
     return 0;

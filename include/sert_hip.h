@@ -213,6 +213,13 @@ int sert_timing_count(sert_model* m);
 const char* sert_timing_name(sert_model* m, int i);
 double sert_timing_avg_us(sert_model* m, int i);
 
+/* Micro-benchmark of the fp32 MFMA GEMM on device-resident random operands:
+ * C (M,N) = op(A).op(B); ta/tb as in gemm.h; epi 0 = store, 1 = +bias, 2 = tanh(+bias);
+ * splits > 1 = split-K partial slabs.  Returns the average launch time in *avg_us
+ * (HIP events, `iters` launches after 2 warm-ups). */
+int sert_bench_gemm(int device, int ta, int tb, int epi, int M, int N, int K, int splits,
+                    int iters, double* avg_us);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,7 +31,7 @@ EXPORTS = [
     'sert_scorer_create', 'sert_scorer_destroy', 'sert_scorer_topk', 'sert_scorer_scores',
     'sert_comm_unique_id', 'sert_comm_init', 'sert_comm_destroy',
     'sert_synchronize', 'sert_timing_enable', 'sert_timing_reset', 'sert_timing_count',
-    'sert_timing_name', 'sert_timing_avg_us',
+    'sert_timing_name', 'sert_timing_avg_us', 'sert_bench_gemm',
 ]
 
 
@@ -115,6 +115,7 @@ def load():
     lib.sert_timing_name.restype = ctypes.c_char_p
     lib.sert_timing_avg_us.argtypes = [vp, ctypes.c_int]
     lib.sert_timing_avg_us.restype = ctypes.c_double
+    lib.sert_bench_gemm.argtypes = [ctypes.c_int] * 9 + [ctypes.POINTER(ctypes.c_double)]
     _lib = lib
     return lib
 
@@ -355,3 +356,10 @@ class Scorer(object):
             self.close()
         except Exception:
             pass
+
+
+def bench_gemm(M, N, K, ta=0, tb=0, epi=0, splits=1, iters=20, device=0):
+    """Average launch time (us) of the fp32 MFMA GEMM on random device operands."""
+    us = ctypes.c_double()
+    check(load().sert_bench_gemm(device, ta, tb, epi, M, N, K, splits, iters, ctypes.byref(us)))
+    return us.value

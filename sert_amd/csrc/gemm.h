@@ -12,102 +12,213 @@
 // staged through LDS k-major ([k][m] / [k][n], leading dim 132) so that a
 // wave's MFMA fragment read (32 consecutive m or n for one k) is one
 // conflict-free ds_read_b32 per 32-lane half.
+//
+// The shapes on this path are skinny (K = 128 for the projections, or one
+// 128x128 output with K = batch for dW), so what decides the rate is not LDS
+// bandwidth (a 32x32x2 fp32 MFMA occupies its SIMD for 64 cycles) but pipeline
+// bubbles.  Hence: (1) register-staged double buffering -- the global loads of
+// k-slab t+1 are issued before the MFMAs of slab t and written to the other LDS
+// buffer after them, one barrier per slab; (2) persistent workgroups that walk
+// a flat (tile, k-slab) sequence, so the prefetch crosses tile boundaries and
+// the epilogue stores of a tile overlap the loads of the next; (3) two
+// workgroups per CU (67.6 KB LDS each) so one computes while the other waits.
 #pragma once
+#include <stdlib.h>
+#include <algorithm>
 #include "common.h"
 
 namespace sert {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int GM = 128, GN = 128, GK = 32, GLD = 132;
+#ifndef SERT_GK
+#define SERT_GK 16
+#endif
+#ifndef SERT_GEMM_WAVES
+#define SERT_GEMM_WAVES 4
+#endif
+constexpr int GM = 128, GN = 128, GK = SERT_GK, GLD = 132;
+constexpr int GNV = GK / 8;          // float4 pieces per thread per operand slab
+constexpr int GTPR = 256 / GK;       // threads per k-row in the k-major loader
 
 enum { EPI_STORE = 0, EPI_BIAS = 1, EPI_BIAS_TANH = 2 };
 
+// tanh for the projection epilogue (sert/models.py:1055): ~15 instructions instead
+// of the libm expansion (which, inlined 64x per lane, spilled the accumulators).
+//   |x| <  0.25 : odd Taylor series through x^9   (truncation < 3e-9 relative)
+//   |x| >= 0.25 : 1 - 2/(exp(2|x|) + 1)           (<= ~4 ulp; saturates to 1 for |x| > 9)
+__device__ __forceinline__ float fast_tanh(float x) {
+    const float ax = fabsf(x);
+    const float x2 = x * x;
+    const float poly = x * (1.0f + x2 * (-0.33333334f + x2 * (0.13333334f + x2 * (-0.05396825f + x2 * 0.02186949f))));
+    const float e = __expf(2.0f * fminf(ax, 10.0f));
+    const float big = copysignf(1.0f - 2.0f / (e + 1.0f), x);
+    return ax < 0.25f ? poly : big;
+}
+
+struct GemmArgs {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;
+    int M, N, K;
+    int lda, ldb, ldc;
+    int kper;                 // k range per split (multiple of GK)
+    int splits;
+    int tiles_m, tiles_n;
+    size_t c_split_stride;    // C offset between splits
+    int vecA, vecB;           // 16-byte loads allowed
+};
+
+// --- global -> registers (zero padded) ----------------------------------------
+// VEC = true : every 4-float piece is 16-byte aligned and either fully inside or
+//              fully outside the matrix (leading dims, extents and pointers are
+//              multiples of 4 floats) -> branch-free: one float4 load from a
+//              clamped address, zeroed by select when outside.
+// VEC = false: scalar guarded loads (odd sizes; small problems only).
+//
 // Source stored [k][c], contiguous along c (the tile's M or N axis).
-__device__ __forceinline__ void gemm_load_kmajor(const float* __restrict__ src, int ld, int k0,
-                                                 int kend, int c0, int cend, float (*dst)[GLD],
-                                                 bool vec) {
+// `base` = src + k0*ld + c0 is workgroup-uniform; lane offsets are 32-bit.
+template <bool VEC>
+__device__ __forceinline__ void gload_kmajor(const float* __restrict__ base, int ld, int krem,
+                                             int crem, float4 (&r)[GNV]) {
     const int t = threadIdx.x;
-    const int kr = t >> 3;         // 0..31
-    const int cq = (t & 7) * 4;    // 0..28
-    const int k = k0 + kr;
-    const float* row = src + (size_t)k * ld;
+    const int kr = t / GTPR;
+    const int cq = (t % GTPR) * 4;
+    const bool kok = kr < krem;
+    const unsigned roff = kok ? (unsigned)kr * (unsigned)ld : 0u;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int c = cq + j * 32;
-        const int gc = c0 + c;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < kend) {
-            if (vec && gc + 3 < cend) {
-                v = *reinterpret_cast<const float4*>(row + gc);
-            } else {
-                if (gc + 0 < cend) v.x = row[gc + 0];
-                if (gc + 1 < cend) v.y = row[gc + 1];
-                if (gc + 2 < cend) v.z = row[gc + 2];
-                if (gc + 3 < cend) v.w = row[gc + 3];
+    for (int j = 0; j < GNV; ++j) {
+        const int c = cq + j * (GTPR * 4);
+        if (VEC) {
+            // unconditional load from a clamped (always valid) offset, zeroed by a
+            // multiply: a select would make hipcc branch around every load
+            const bool ok = kok && (c < crem);
+            const float okf = ok ? 1.f : 0.f;
+            const float4 v = *reinterpret_cast<const float4*>(base + (ok ? roff + (unsigned)c : 0u));
+            r[j] = make_float4(v.x * okf, v.y * okf, v.z * okf, v.w * okf);
+        } else {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (kok) {
+                if (c + 0 < crem) v.x = base[roff + c + 0];
+                if (c + 1 < crem) v.y = base[roff + c + 1];
+                if (c + 2 < crem) v.z = base[roff + c + 2];
+                if (c + 3 < crem) v.w = base[roff + c + 3];
             }
+            r[j] = v;
         }
-        *reinterpret_cast<float4*>(&dst[kr][c]) = v;
     }
+}
+__device__ __forceinline__ void lstore_kmajor(float (*dst)[GLD], const float4 (&r)[GNV]) {
+    const int t = threadIdx.x;
+    const int kr = t / GTPR, cq = (t % GTPR) * 4;
+#pragma unroll
+    for (int j = 0; j < GNV; ++j) *reinterpret_cast<float4*>(&dst[kr][cq + j * (GTPR * 4)]) = r[j];
 }
 
 // Source stored [c][k], contiguous along k: transposed on the way into LDS.
-__device__ __forceinline__ void gemm_load_cmajor(const float* __restrict__ src, int ld, int k0,
-                                                 int kend, int c0, int cend, float (*dst)[GLD],
-                                                 bool vec) {
+// `base` = src + c0*ld + k0 is workgroup-uniform.
+template <bool VEC>
+__device__ __forceinline__ void gload_cmajor(const float* __restrict__ base, int ld, int krem,
+                                             int crem, float4 (&r)[GNV]) {
     const int t = threadIdx.x;
-    const int c = t >> 1;           // 0..127
-    const int kh = (t & 1) * 16;    // 0 / 16
-    const int gc = c0 + c;
-    const float* row = src + (size_t)gc * ld;
+    const int c = t >> 1;
+    const int kh = (t & 1) * (GK / 2);
+    const bool cok = c < crem;
+    const unsigned roff = cok ? (unsigned)c * (unsigned)ld : 0u;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int kl = kh + j * 4;
-        const int k = k0 + kl;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gc < cend) {
-            if (vec && k + 3 < kend) {
-                v = *reinterpret_cast<const float4*>(row + k);
-            } else {
-                if (k + 0 < kend) v.x = row[k + 0];
-                if (k + 1 < kend) v.y = row[k + 1];
-                if (k + 2 < kend) v.z = row[k + 2];
-                if (k + 3 < kend) v.w = row[k + 3];
+    for (int j = 0; j < GNV; ++j) {
+        const int k = kh + j * 4;
+        if (VEC) {
+            const bool ok = cok && (k < krem);
+            const float okf = ok ? 1.f : 0.f;
+            const float4 v = *reinterpret_cast<const float4*>(base + (ok ? roff + (unsigned)k : 0u));
+            r[j] = make_float4(v.x * okf, v.y * okf, v.z * okf, v.w * okf);
+        } else {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (cok) {
+                if (k + 0 < krem) v.x = base[roff + k + 0];
+                if (k + 1 < krem) v.y = base[roff + k + 1];
+                if (k + 2 < krem) v.z = base[roff + k + 2];
+                if (k + 3 < krem) v.w = base[roff + k + 3];
             }
+            r[j] = v;
         }
-        dst[kl + 0][c] = v.x;
-        dst[kl + 1][c] = v.y;
-        dst[kl + 2][c] = v.z;
-        dst[kl + 3][c] = v.w;
+    }
+}
+__device__ __forceinline__ void lstore_cmajor(float (*dst)[GLD], const float4 (&r)[GNV]) {
+    const int t = threadIdx.x;
+    const int c = t >> 1, kh = (t & 1) * (GK / 2);
+#pragma unroll
+    for (int j = 0; j < GNV; ++j) {
+        const int kl = kh + j * 4;
+        dst[kl + 0][c] = r[j].x;
+        dst[kl + 1][c] = r[j].y;
+        dst[kl + 2][c] = r[j].z;
+        dst[kl + 3][c] = r[j].w;
     }
 }
 
-// C[z] (M,N) = epi( op(A) (M,K) . op(B) (K,N) ) over K range of split z.
+// C[z] (M,N) = epi( op(A) (M,K) . op(B) (K,N) ) over the K range of split z.
 //   TA=false: A row-major (M,K)      TA=true: A stored (K,M)  -> computes A^T.B
 //   TB=false: B row-major (K,N)      TB=true: B stored (N,K)  -> computes A.B^T
-// gridDim = (ceil(N/128), ceil(M/128), splits); split z covers k in
+// Work item w in [0, tiles_m*tiles_n*splits): split z = w / (tiles_m*tiles_n),
+// tile = w % (..), tile row = tile / tiles_n.  Split z covers k in
 // [z*kper, min(K,(z+1)*kper)) and writes to C + z*c_split_stride.
 // CSB: additionally emit the column sums of op(B) over this split's k range
 // (row tile 0 only) at C[z] + M*N .. +N  -- used for db = sum_i da_i, which
 // rides along with the dW = h^T.da GEMM for free (the da tile is in LDS anyway).
-template <bool TA, bool TB, int EPI, bool CSB = false>
-__global__ __launch_bounds__(256) void gemm_f32_mfma(const float* __restrict__ A,
-                                                     const float* __restrict__ B,
-                                                     float* __restrict__ C,
-                                                     const float* __restrict__ bias, int M, int N,
-                                                     int K, int lda, int ldb, int ldc, int kper,
-                                                     size_t c_split_stride, int vecA, int vecB) {
-    __shared__ __attribute__((aligned(16))) float As[GK][GLD];
-    __shared__ __attribute__((aligned(16))) float Bs[GK][GLD];
-    const int m0 = blockIdx.y * GM, n0 = blockIdx.x * GN;
-    const int kbeg = blockIdx.z * kper;
-    const int kend = min(K, kbeg + kper);
+template <bool TA, bool TB, int EPI, bool CSB, bool VEC>
+__global__ __launch_bounds__(256, SERT_GEMM_WAVES) void gemm_f32_mfma(const GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float As[2][GK][GLD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GK][GLD];
+    __shared__ float cs_lds[GN];
+
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int wr = w >> 1, wc = w & 1;
     const int li = lane & 31, lh = lane >> 5;
+    const int tiles_mn = g.tiles_m * g.tiles_n;
+    const int total = tiles_mn * g.splits;
 
-    float csum = 0.f;
+    int item = blockIdx.x;
+    if (item >= total) return;
+
+    int m0, n0, kbeg, kend, z, tm_idx;
+    auto decode = [&](int it) {
+        z = it / tiles_mn;
+        const int t = it - z * tiles_mn;
+        tm_idx = t / g.tiles_n;
+        m0 = tm_idx * GM;
+        n0 = (t - tm_idx * g.tiles_n) * GN;
+        kbeg = z * g.kper;
+        kend = min(g.K, kbeg + g.kper);
+    };
+    auto gload = [&](int mm0, int nn0, int k0, int ke, float4 (&ra)[GNV], float4 (&rb)[GNV]) {
+        // tile base pointers are workgroup-uniform (SGPRs); per-lane offsets 32-bit.
+        // The leading dimensions are made opaque here so that the lane offsets are
+        // recomputed per slab (a handful of VALU ops) instead of being hoisted out
+        // of the persistent loop and spilled (64-bit addresses x 16 loads).
+        int lda_ = g.lda, ldb_ = g.ldb;
+        asm volatile("" : "+s"(lda_), "+s"(ldb_));
+        if (TA) gload_kmajor<VEC>(g.A + (size_t)k0 * lda_ + mm0, lda_, ke - k0, g.M - mm0, ra);
+        else    gload_cmajor<VEC>(g.A + (size_t)mm0 * lda_ + k0, lda_, ke - k0, g.M - mm0, ra);
+        if (TB) gload_cmajor<VEC>(g.B + (size_t)nn0 * ldb_ + k0, ldb_, ke - k0, g.N - nn0, rb);
+        else    gload_kmajor<VEC>(g.B + (size_t)k0 * ldb_ + nn0, ldb_, ke - k0, g.N - nn0, rb);
+    };
+    auto lstore = [&](int buf, const float4 (&ra)[GNV], const float4 (&rb)[GNV]) {
+        if (TA) lstore_kmajor(As[buf], ra); else lstore_cmajor(As[buf], ra);
+        if (TB) lstore_cmajor(Bs[buf], rb); else lstore_kmajor(Bs[buf], rb);
+    };
+
+    float4 ra[GNV], rb[GNV];
+    decode(item);
+    gload(m0, n0, kbeg, kend, ra, rb);
+    lstore(0, ra, rb);
+    __syncthreads();
+    int buf = 0;
+
     f32x16 acc[2][2];
+    float csum = 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -115,62 +226,93 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const float* __restrict__ A
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    for (int k0 = kbeg; k0 < kend; k0 += GK) {
-        if (TA) gemm_load_kmajor(A, lda, k0, kend, m0, M, As, vecA);
-        else    gemm_load_cmajor(A, lda, k0, kend, m0, M, As, vecA);
-        if (TB) gemm_load_cmajor(B, ldb, k0, kend, n0, N, Bs, vecB);
-        else    gemm_load_kmajor(B, ldb, k0, kend, n0, N, Bs, vecB);
-        __syncthreads();
-        if (CSB && blockIdx.y == 0) {
-            const int col = threadIdx.x & 127, half = threadIdx.x >> 7;
-            float cs = 0.f;
+    while (true) {
+        const int next_item = item + gridDim.x;
+        const bool has_next_item = next_item < total;
+        for (int k0 = kbeg; k0 < kend; k0 += GK) {
+            const bool next_k = (k0 + GK) < kend;
+            bool staged = false;
+            // ---- prefetch the next k-slab (of this tile, or slab 0 of the next) ----
+            if (next_k) {
+                gload(m0, n0, k0 + GK, kend, ra, rb);
+                staged = true;
+            } else if (has_next_item) {
+                const int zz = next_item / tiles_mn;
+                const int t = next_item - zz * tiles_mn;
+                const int tmi = t / g.tiles_n;
+                const int kb = zz * g.kper;
+                gload(tmi * GM, (t - tmi * g.tiles_n) * GN, kb, min(g.K, kb + g.kper), ra, rb);
+                staged = true;
+            }
+            // ---- MFMAs on the current slab ----
+            if (CSB && tm_idx == 0) {
+                const int col = threadIdx.x & 127, half = threadIdx.x >> 7;
+                float cs = 0.f;
 #pragma unroll
-            for (int kk = 0; kk < GK / 2; ++kk) cs += Bs[half * (GK / 2) + kk][col];
-            csum += cs;
-        }
+                for (int kk = 0; kk < GK / 2; ++kk) cs += Bs[buf][half * (GK / 2) + kk][col];
+                csum += cs;
+            }
 #pragma unroll
-        for (int kk = 0; kk < GK; kk += 2) {
-            const int k = kk + lh;
-            const float a0 = As[k][wr * 64 + li];
-            const float a1 = As[k][wr * 64 + 32 + li];
-            const float b0 = Bs[k][wc * 64 + li];
-            const float b1 = Bs[k][wc * 64 + 32 + li];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-        }
-        __syncthreads();
-    }
+            for (int kk = 0; kk < GK; kk += 2) {
+                const int k = kk + lh;
+                const float a0 = As[buf][k][wr * 64 + li];
+                const float a1 = As[buf][k][wr * 64 + 32 + li];
+                const float b0 = Bs[buf][k][wc * 64 + li];
+                const float b1 = Bs[buf][k][wc * 64 + 32 + li];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+            // ---- stage the prefetched slab into the other buffer ----
+            if (staged) lstore(buf ^ 1, ra, rb);
 
-    // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    float* Cz = C + (size_t)blockIdx.z * c_split_stride;
-    if (CSB && blockIdx.y == 0) {
-        // the k loop ended with a barrier: As is free to reuse
-        const int col = threadIdx.x & 127, half = threadIdx.x >> 7;
-        if (half == 1) As[0][col] = csum;
-        __syncthreads();
-        if (half == 0 && n0 + col < N) Cz[(size_t)M * N + n0 + col] = csum + As[0][col];
-    }
+            if (!next_k) {
+                // ---- epilogue of this tile (its stores overlap the next tile's loads) ----
+                // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+                float* Cz = g.C + (size_t)z * g.c_split_stride;
+                if (CSB && tm_idx == 0) {
+                    const int col = threadIdx.x & 127, half = threadIdx.x >> 7;
+                    if (half == 1) cs_lds[col] = csum;
+                    __syncthreads();
+                    if (half == 0 && n0 + col < g.N)
+                        Cz[(size_t)g.M * g.N + n0 + col] = csum + cs_lds[col];
+                    csum = 0.f;
+                }
+                // tile base is workgroup-uniform; lane offsets inside the tile are 32-bit
+                float* Ct = Cz + (size_t)m0 * g.ldc + n0;
+                const int mrem = g.M - m0, nrem = g.N - n0;
+                unsigned uld = (unsigned)g.ldc;
+                asm volatile("" : "+s"(uld));   // keep the 64 store offsets out of the main loop's live set
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
+                for (int tm = 0; tm < 2; ++tm) {
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-            const int col = n0 + wc * 64 + tn * 32 + li;
-            if (col >= N) continue;
-            float bv = 0.f;
-            if (EPI != EPI_STORE) bv = bias[col];
+                    for (int tn = 0; tn < 2; ++tn) {
+                        const int col = wc * 64 + tn * 32 + li;
+                        const int row0 = wr * 64 + tm * 32 + 4 * lh;
+                        const bool cok = col < nrem;
+                        float bv = 0.f;
+                        if (EPI != EPI_STORE && cok) bv = g.bias[n0 + col];
+                        unsigned off = (unsigned)row0 * uld + (unsigned)col;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wr * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (row < M) {
-                    float v = acc[tm][tn][r];
-                    if (EPI == EPI_BIAS) v = v + bv;
-                    if (EPI == EPI_BIAS_TANH) v = tanhf(v + bv);
-                    Cz[(size_t)row * ldc + col] = v;
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = row0 + (r & 3) + 8 * (r >> 2);
+                            float v = acc[tm][tn][r];
+                            if (EPI == EPI_BIAS) v = v + bv;
+                            if (EPI == EPI_BIAS_TANH) v = fast_tanh(v + bv);
+                            if (cok && row < mrem) Ct[off] = v;
+                            acc[tm][tn][r] = 0.f;
+                            off += ((r & 3) == 3) ? 5u * uld : uld;
+                        }
+                    }
                 }
             }
+            __syncthreads();
+            buf ^= 1;
         }
+        if (!has_next_item) break;
+        item = next_item;
+        decode(item);
     }
 }
 
@@ -179,11 +321,28 @@ inline void launch_gemm(hipStream_t s, const float* A, const float* B, float* C,
                         int M, int N, int K, int lda, int ldb, int ldc, int splits = 1,
                         int kper = 0, size_t c_split_stride = 0) {
     if (splits <= 1) { splits = 1; kper = K; }
-    dim3 grid(cdiv(N, GN), cdiv(M, GM), splits);
-    const int vecA = (lda % 4 == 0) && (((uintptr_t)A) % 16 == 0);
-    const int vecB = (ldb % 4 == 0) && (((uintptr_t)B) % 16 == 0);
-    hipLaunchKernelGGL((gemm_f32_mfma<TA, TB, EPI, CSB>), grid, dim3(256), 0, s, A, B, C, bias, M, N, K,
-                       lda, ldb, ldc, kper, c_split_stride, vecA, vecB);
+    GemmArgs g;
+    g.A = A; g.B = B; g.C = C; g.bias = bias;
+    g.M = M; g.N = N; g.K = K;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.kper = kper; g.splits = splits;
+    g.tiles_m = cdiv(M, GM); g.tiles_n = cdiv(N, GN);
+    g.c_split_stride = c_split_stride;
+    g.vecA = g.vecB = 0;
+    // vector path: every 16-byte piece aligned and wholly inside or outside
+    const bool vec = (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A) % 16 == 0) &&
+                     (((uintptr_t)B) % 16 == 0) && (K % 4 == 0) && (kper % 4 == 0) &&
+                     (TA ? (M % 4 == 0) : true) && (TB ? true : (N % 4 == 0));
+    const long long total = (long long)g.tiles_m * g.tiles_n * splits;
+    // persistent: at most 2 workgroups per CU (256 CUs), each walks items w, w+grid, ...
+    static const int max_grid = [] {
+        const char* e = getenv("SERT_GEMM_GRID");   // tuning knob (default: 2 per CU)
+        const int v = e ? atoi(e) : 0;
+        return v > 0 ? v : 256 * SERT_GEMM_WAVES;
+    }();
+    const int grid = (int)std::min<long long>(total, max_grid);
+    if (vec) hipLaunchKernelGGL((gemm_f32_mfma<TA, TB, EPI, CSB, true>), dim3(grid), dim3(256), 0, s, g);
+    else     hipLaunchKernelGGL((gemm_f32_mfma<TA, TB, EPI, CSB, false>), dim3(grid), dim3(256), 0, s, g);
 }
 
 // out[i] = sum_s part[s*stride + i] over the split-K partial slabs, in a fixed

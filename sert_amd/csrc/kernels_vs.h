@@ -130,7 +130,6 @@ __global__ __launch_bounds__(256) void vs_nce(const float* __restrict__ T,
     const float wi = TRAIN ? w[i] : 1.f;
     const float g = wi * inv_batch;
     float loss = 0.f;
-#pragma unroll 2
     for (int j = 0; j <= z; ++j) {
         const int e = (j == 0) ? y[i] : neg[(size_t)i * z + (j - 1)];
         float4 er[NCH];

@@ -16,6 +16,7 @@ struct DataSplit {
     int32_t* csr_indices = nullptr;  // (nnz)
     float* csr_data = nullptr;       // (nnz)
     int64_t nnz = 0;
+    int64_t max_labels_per_row = 0;
     float* w = nullptr;         // (N,) instance weights (train split)
     // inverted index word -> rows of every complete batch (train split only)
     int32_t* idx_rows = nullptr;

@@ -344,7 +344,8 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         ScopedTimer t(m, TG_GEMM_BWD);
         // dW = h^T.da (reduction over the batch: split-K, order-fixed combine);
         // db = sum_i da_i rides along as the column sums of the da operand
-        int splits = std::min(256, cdiv(B, GK));
+        static const int want_splits = [] { const char* e = getenv("SERT_DW_SPLITS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
+        int splits = std::min(want_splits, cdiv(B, GK));
         int kper = (int)round_up(cdiv(B, splits), GK);
         splits = cdiv(B, kper);
         const size_t mn = (size_t)dw * de;
@@ -392,15 +393,21 @@ static int ll_forward(sert_model* m, const DataSplit& ds, int64_t batch_index) {
         ScopedTimer t(m, TG_GEMM_FWD);
         launch_gemm<false, false, EPI_BIAS>(m->stream, m->G, m->W, m->Z, m->b, (int)rows, V, d, d, V,
                                             V);
+    }
+    const float inv_batch = 1.0f / (float)c.global_batch_size;
+    const int32_t* y = ds.y ? ds.y + row0 : nullptr;
+    const int64_t* indptr = ds.csr_indptr ? ds.csr_indptr + row0 : nullptr;
+    const float* w = TRAIN ? ds.w + row0 : nullptr;
+    const size_t fused_lds = ((size_t)n * V + V) * sizeof(float);
+    // fused path: the row's (n, V) slab lives in LDS; CSR rows with > 1024 labels fall back
+    if (fused_lds <= 150 * 1024 && ds.max_labels_per_row <= 1024) {
+        ScopedTimer t(m, TG_LOSS);
+        hipLaunchKernelGGL((ll_fused_row<TRAIN>), dim3(B), dim3(256), fused_lds, m->stream, m->Z, y, indptr,
+                           ds.csr_indices, ds.csr_data, w, m->rowloss, n, V, inv_batch);
+    } else {
+        ScopedTimer t(m, TG_LOSS);
         hipLaunchKernelGGL(ll_softmax_rows, dim3(cdiv(rows, 4)), dim3(256), 0, m->stream, m->Z, rows,
                            V);
-    }
-    {
-        ScopedTimer t(m, TG_LOSS);
-        const float inv_batch = 1.0f / (float)c.global_batch_size;
-        const int32_t* y = ds.y ? ds.y + row0 : nullptr;
-        const int64_t* indptr = ds.csr_indptr ? ds.csr_indptr + row0 : nullptr;
-        const float* w = TRAIN ? ds.w + row0 : nullptr;
         hipLaunchKernelGGL((ll_window<TRAIN>), dim3(B), dim3(256), 0, m->stream, m->Z, m->J, y,
                            indptr, ds.csr_indices, ds.csr_data, w, m->rowloss, n, V, inv_batch);
     }
@@ -608,7 +615,7 @@ int sert_create(const sert_config* cfg, sert_model** out) {
             SERT_TRY(dzalloc(&m->DA, B * de, s)); SERT_TRY(dzalloc(&m->DH, B * dw, s));
             SERT_TRY(dzalloc(&m->neg, std::max<size_t>(4, B * c.num_negatives), s));
             SERT_TRY(dzalloc(&m->neg_stage, std::max<size_t>(4, B * c.num_negatives), s));
-            part = (size_t)256 * (dw * de + de);
+            part = (size_t)1024 * (dw * de + de);
             const size_t total = B * (c.num_negatives + 1);
             SERT_TRY(dzalloc(&m->cand, total, s));        SERT_TRY(dzalloc(&m->cand_sorted, total + 1, s));
             SERT_TRY(dzalloc(&m->pair_sorted, total, s));
@@ -625,6 +632,11 @@ int sert_create(const sert_config* cfg, sert_model** out) {
                 SERT_TRY(dzalloc(&m->sort_v_tmp, total, s));
             }
         } else {
+            // the fused loss kernel may ask for more than the default 64 KB of dynamic LDS
+            SERT_HIP(hipFuncSetAttribute((const void*)ll_fused_row<true>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            SERT_HIP(hipFuncSetAttribute((const void*)ll_fused_row<false>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
             SERT_TRY(dzalloc(&m->G, B * n * dw, s));  SERT_TRY(dzalloc(&m->Z, B * n * V, s));
             SERT_TRY(dzalloc(&m->J, B * V, s));       SERT_TRY(dzalloc(&m->DG, B * n * dw, s));
             const size_t tiles = (size_t)cdiv(V, GN) * cdiv(dw, GM);
@@ -734,10 +746,13 @@ int sert_upload_dataset(sert_model* m, int split, const void* x, const int32_t* 
     SERT_HIP(hipMalloc(&d.x, xbytes));
     SERT_HIP(hipMemcpyAsync(d.x, x, xbytes, hipMemcpyHostToDevice, s));
     if (y_int) {
+        d.max_labels_per_row = 1;
         SERT_TRY(dmalloc(&d.y, (size_t)N));
         SERT_HIP(hipMemcpyAsync(d.y, y_int, N * sizeof(int32_t), hipMemcpyHostToDevice, s));
     } else {
         d.nnz = csr_indptr[N];
+        for (int64_t r = 0; r < N; ++r)
+            d.max_labels_per_row = std::max<int64_t>(d.max_labels_per_row, csr_indptr[r + 1] - csr_indptr[r]);
         SERT_TRY(dmalloc(&d.csr_indptr, (size_t)N + 1));
         SERT_TRY(dmalloc(&d.csr_indices, (size_t)std::max<int64_t>(1, d.nnz)));
         SERT_TRY(dmalloc(&d.csr_data, (size_t)std::max<int64_t>(1, d.nnz)));
@@ -1066,6 +1081,50 @@ const char* sert_timing_name(sert_model*, int i) { return (i >= 0 && i < TG_COUN
 double sert_timing_avg_us(sert_model* m, int i) {
     if (!m || i < 0 || i >= TG_COUNT || m->timing.samples[i] == 0) return 0.0;
     return m->timing.total_us[i] / (double)m->timing.samples[i];
+}
+
+int sert_bench_gemm(int device, int ta, int tb, int epi, int M, int N, int K, int splits, int iters,
+                    double* avg_us) {
+    if (!avg_us || M <= 0 || N <= 0 || K <= 0 || iters <= 0) SERT_FAIL("bad argument");
+    SERT_HIP(hipSetDevice(device));
+    hipStream_t s;
+    SERT_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    if (splits < 1) splits = 1;
+    int kper = (int)round_up(cdiv(K, splits), GK);
+    splits = cdiv(K, kper);
+    const size_t na = (size_t)M * K, nb = (size_t)K * N, nc = (size_t)M * N * splits;
+    float *A = nullptr, *B = nullptr, *C = nullptr, *bias = nullptr;
+    SERT_TRY(dmalloc(&A, na)); SERT_TRY(dmalloc(&B, nb)); SERT_TRY(dmalloc(&C, nc)); SERT_TRY(dmalloc(&bias, (size_t)N));
+    std::vector<float> h(std::max(std::max(na, nb), (size_t)N));
+    uint32_t x = 12345u;
+    auto fill = [&](float* d, size_t n) {
+        for (size_t i = 0; i < n; ++i) { x = x * 1664525u + 1013904223u; h[i] = ((x >> 8) * (1.0f / 8388608.0f)) - 1.0f; }
+        return hipMemcpy(d, h.data(), n * sizeof(float), hipMemcpyHostToDevice);
+    };
+    SERT_HIP(fill(A, na)); SERT_HIP(fill(B, nb)); SERT_HIP(fill(bias, (size_t)N));
+    const int lda = ta ? M : K, ldb = tb ? K : N;
+    auto run = [&]() {
+#define SERT_BG(TA, TB, E) launch_gemm<TA, TB, E>(s, A, B, C, bias, M, N, K, lda, ldb, N, splits, kper, (size_t)M * N)
+        if (!ta && !tb) { if (epi == 2) SERT_BG(false, false, EPI_BIAS_TANH); else if (epi == 1) SERT_BG(false, false, EPI_BIAS); else SERT_BG(false, false, EPI_STORE); }
+        else if (ta && !tb) SERT_BG(true, false, EPI_STORE);
+        else if (!ta && tb) SERT_BG(false, true, EPI_STORE);
+        else SERT_BG(true, true, EPI_STORE);
+#undef SERT_BG
+    };
+    hipEvent_t e0, e1;
+    SERT_HIP(hipEventCreate(&e0)); SERT_HIP(hipEventCreate(&e1));
+    run(); run();
+    SERT_HIP(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) run();
+    SERT_HIP(hipEventRecord(e1, s));
+    SERT_HIP(hipStreamSynchronize(s));
+    float ms = 0.f;
+    SERT_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *avg_us = 1000.0 * ms / iters;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(A); (void)hipFree(B); (void)hipFree(C); (void)hipFree(bias);
+    (void)hipStreamDestroy(s);
+    return 0;
 }
 
 }  // extern "C"

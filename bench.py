@@ -49,28 +49,55 @@ def glorot(rng, shape):
 
 
 def group_work(kind, B, n, s, dw, de, Ve, Vw, z):
-    """Algorithmic bytes / flops per launch group (SURVEY 8(d) per-pair figures
-    x the pairs one step processes; per-step optimiser term 32*P)."""
+    """Algorithmic bytes / flops per timed kernel (SURVEY 8(d) per-pair figures x
+    the pairs one step processes; per-step optimiser term 32 B per parameter).
+    Keys = timing group names of libsert_hip.so (sert_timing_name)."""
     if kind == 'vectorspace':
-        P = Vw * dw + Ve * de + dw * de + de
         return {
-            'gather':    ('hbm', B * (n * s + 4 * n * dw)),
-            'gemm_fwd':  ('mfma', 2.0 * B * dw * de),
-            'loss':      ('hbm', B * (8 + 4 * (1 + z) * de)),
-            'entity_grad': ('hbm', B * (8 * (1 + z) * de)),
-            'gemm_bwd':  ('mfma', 4.0 * B * dw * de),
-            'scatter':   ('hbm', B * (8 * n * dw)),
-            'optimizer': ('hbm', 32.0 * P),
+            'gather':               ('hbm', B * (n * s + 4 * n * dw)),          # vs_gather_mean
+            'gemm_fwd':             ('mfma', 2.0 * B * dw * de),               # gemm_f32_mfma NN+tanh
+            'loss':                 ('hbm', B * (8 + 4 * (1 + z) * de)),       # vs_nce
+            'entity_sort':          ('hbm', B * (1 + z) * 16.0),               # csort_* (keys+values r/w)
+            'entity_grad_reduce':   ('hbm', B * (8 * (1 + z) * de)),           # egrad_chunk_reduce
+            'entity_grad_fixup':    ('hbm', 8.0 * Ve * de),                    # egrad_fixup
+            'gemm_dW':              ('mfma', 2.0 * B * dw * de),               # gemm_f32_mfma TN split-K
+            'splitk_combine':       ('hbm', 4.0 * 1024 * (dw * de + de)),      # reduce_partials
+            'gemm_dX':              ('mfma', 2.0 * B * dw * de),               # gemm_f32_mfma NT
+            'word_grad_segsum':     ('hbm', B * (8 * n * dw)),                 # segsum_rows
+            'optimizer_word_table': ('hbm', 32.0 * Vw * dw),                   # adam_l2 (R_w)
+            'optimizer_other':      ('hbm', 32.0 * (Ve * de + dw * de + de)),  # adam_l2 (R_e, W, b)
         }
-    P = Vw * dw + dw * Ve + Ve
     return {
-        'gather':    ('hbm', B * (n * s + 4 * n * dw)),
-        'gemm_fwd':  ('mfma', 2.0 * B * n * dw * Ve),
-        'loss':      ('hbm', B * (12.0 * n * Ve)),
-        'gemm_bwd':  ('mfma', 4.0 * B * n * dw * Ve),
-        'scatter':   ('hbm', B * (8 * n * dw)),
-        'optimizer': ('hbm', 32.0 * P),
+        'gather':               ('hbm', B * (n * s + 4 * n * dw)),
+        'gemm_fwd':             ('mfma', 2.0 * B * n * dw * Ve),
+        'loss':                 ('hbm', B * (8.0 * n * Ve)),                     # Z read + dZ write
+        'gemm_dW':              ('mfma', 2.0 * B * n * dw * Ve),
+        'gemm_dX':              ('mfma', 2.0 * B * n * dw * Ve),
+        'word_grad_segsum':     ('hbm', B * (8 * n * dw)),
+        'optimizer_word_table': ('hbm', 32.0 * Vw * dw),
+        'optimizer_other':      ('hbm', 32.0 * (dw * Ve + Ve)),
     }
+
+
+KERNEL_OF_GROUP = {
+    'gather': 'vs_gather_mean<unsigned int, 4>', 'gemm_fwd': 'gemm_f32_mfma<false, false, 2, false, true>',
+    'loss': 'vs_nce<2, true>', 'entity_grad_reduce': 'egrad_chunk_reduce<4, 2>',
+    'entity_grad_fixup': 'egrad_fixup<4>', 'gemm_dW': 'gemm_f32_mfma<true, false, 0, true, true>',
+    'splitk_combine': 'reduce_partials', 'gemm_dX': 'gemm_f32_mfma<false, true, 0, false, true>',
+    'word_grad_segsum': 'segsum_rows<32>', 'optimizer_word_table': 'adam_l2<false>',
+    'optimizer_other': 'adam_l2<false>', 'entity_sort': 'csort_scatter',
+}
+PMC_FILE = 'profiles/r01_c_vs_c2_pmc.json'
+
+
+def load_pmc():
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2
+    per the gfx950 correction + WRITE_SIZE; tools/rocpd_pmc.py)."""
+    path = os.path.join(ROOT, PMC_FILE)
+    if not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        return json.load(f)
 
 
 def build_model(kind, models, B_global, n, Vw, Ve, dw, de, z, X, y, w, seed):
@@ -216,8 +243,11 @@ def main():
     X, y, w = synth_data(rng, args.num_batches * Bg, n, Vw, Ve)
     model = build_model(kind, models, Bg, n, Vw, Ve, d, d, z, X, y, w, seed=0)
 
-    dt, timings, last_loss = timed_steps(model, dist, args.num_batches, args.steps, args.warmup)
+    # pass 1 (the number): K untimed steps.  pass 2: the same K steps again with HIP
+    # events around every kernel (serialised, slower) for the per-kernel table.
+    dt, _, last_loss = timed_steps(model, dist, args.num_batches, args.steps, args.warmup, timing=False)
     value = args.steps * Bg / dt
+    dt_instr, timings, _ = timed_steps(model, dist, args.num_batches, args.steps, 2, timing=True)
 
     out = None
     if ctx.rank == 0:
@@ -236,15 +266,20 @@ def main():
                 ach = amount / (us * 1e-6) / 1e12
                 kernels[name] = dict(us=round(us, 2), bound='mfma', achieved=round(ach, 2),
                                      unit='TFLOP/s', frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4))
-        for name in ('allreduce', 'finalize'):
-            if timings.get(name, 0) > 0:
-                kernels[name] = dict(us=round(timings[name], 2))
+        for name, us in timings.items():
+            if us > 0 and name not in kernels:
+                kernels[name] = dict(us=round(us, 2))
+        pmc = load_pmc()
         dom = max((k for k in kernels if 'bound' in kernels[k]), key=lambda k: kernels[k]['us'])
         kd = kernels[dom]
-        roofline = dict(kernel=dom, bound=kd['bound'], achieved=kd['achieved'],
+        roofline = dict(kernel=dom, hip_kernel=KERNEL_OF_GROUP.get(dom), bound=kd['bound'],
+                        achieved=kd['achieved'],
                         peak=HBM_PEAK_GBS if kd['bound'] == 'hbm' else MFMA_F32_PEAK_TFLOPS,
-                        unit=kd['unit'], frac=kd['frac'], traffic=None,
-                        avg_us=kd['us'])
+                        unit=kd['unit'], frac=kd['frac'],
+                        traffic=pmc.get(KERNEL_OF_GROUP.get(dom), {}).get('hbm_bytes') if kind == 'vectorspace' else None,
+                        traffic_source=PMC_FILE if pmc else None, avg_us=kd['us'],
+                        note='achieved = algorithmic bytes (SURVEY 8d) / HIP-event time; tables that fit the '
+                             '256 MB Infinity Cache can exceed the HBM peak')
         out = {
             'metric': 'training_pairs_per_sec', 'value': value, 'unit': 'pairs/s',
             'n_gpus': N, 'steps': args.steps, 'warmup': args.warmup,
@@ -259,6 +294,7 @@ def main():
                 'id_dtype': str(X.dtype), 'lambda': 0.01,
             },
             'roofline': roofline,
+            'ms_per_step_instrumented': 1000.0 * dt_instr / args.steps,
             'kernels': kernels,
             'last_loss': last_loss,
             'device': _capi.device_info(model._engine.cfg.device),
@@ -272,7 +308,8 @@ def main():
         X2, y2, w2 = synth_data(rng2, 4 * Bll, n, Vw, Ve)
         m2 = build_model('loglinear', models, Bll, n, Vw, Ve, d, d, z, X2, y2, w2, seed=1)
         st = max(5, min(20, args.steps))
-        dt2, tm2, _ = timed_steps(m2, dist, 4, st, 3)
+        dt2, _, _ = timed_steps(m2, dist, 4, st, 3, timing=False)
+        _, tm2, _ = timed_steps(m2, dist, 4, st, 1, timing=True)
         work2 = group_work('loglinear', Bll, n, X2.dtype.itemsize, d, d, Ve, Vw, z)
         fl = sum(v for k, (b, v) in work2.items() if b == 'mfma')
         out['loglinear'] = {

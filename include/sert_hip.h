@@ -206,7 +206,10 @@ int sert_comm_destroy(sert_model* m);
 int sert_synchronize(sert_model* m);
 /* Average duration in microseconds of the named kernel group over the steps
  * since the last sert_timing_reset (HIP events on the handle's stream).
- * Enabled with sert_timing_enable(m, 1).  Groups: see sert_timing_names(). */
+ * Enabled with sert_timing_enable(m, 1); while enabled the step runs fully serialised
+ * on one stream (each kernel is measured alone) and every event record drains the
+ * stream, so a timed step is slower than an untimed one: take throughput from
+ * untimed steps.  Groups: sert_timing_count / sert_timing_name. */
 int sert_timing_enable(sert_model* m, int on);
 int sert_timing_reset(sert_model* m);
 int sert_timing_count(sert_model* m);

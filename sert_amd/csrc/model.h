@@ -26,14 +26,19 @@ struct DataSplit {
 
 // Timed kernel groups (HIP events on the model's stream).
 enum TimingGroup {
-    TG_GATHER = 0,    // embedding gather (+ mean-pool)
-    TG_GEMM_FWD,      // projection / logits GEMM
-    TG_LOSS,          // NCE or softmax/window/CE forward+backward
-    TG_EGRAD,         // entity-table gradient: sort + chunk reduce + fix-up (vectorspace)
-    TG_GEMM_BWD,      // dW, dh/dG GEMMs, db
-    TG_SCATTER,       // scatter-add into the word table
+    TG_GATHER = 0,    // vs_gather_mean / ll_gather_rows                      (1 launch)
+    TG_GEMM_FWD,      // gemm_f32_mfma: projection / logits                   (1 launch)
+    TG_LOSS,          // vs_nce / ll_fused_row (or ll_softmax_rows+ll_window)  (1-2 launches)
+    TG_SORT,          // csort_hist + csort_scan_bins + csort_scatter per digit
+    TG_EGRAD,         // egrad_chunk_reduce                                   (1 launch)
+    TG_EFIX,          // egrad_fixup                                          (1 launch)
+    TG_GEMM_DW,       // gemm_f32_mfma<TN, split-K, +column sums>             (1 launch)
+    TG_SPLITK,        // reduce_partials                                      (1 launch)
+    TG_GEMM_DX,       // gemm_f32_mfma<NT>: dh / dG                           (1 launch)
+    TG_SCATTER,       // segsum_rows, one launch per tree level
     TG_ALLREDUCE,     // RCCL gradient exchange
-    TG_OPTIMIZER,     // fused L2 + Adam/Adadelta over all tensors
+    TG_OPT_WORD,      // adam_l2 / adadelta_l2 on the word table R_w          (1 launch)
+    TG_OPTIMIZER,     // the other tensors (R_e, W, b)                        (2-3 launches)
     TG_FINALIZE,      // loss reduction
     TG_COUNT
 };

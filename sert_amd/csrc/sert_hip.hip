@@ -23,9 +23,10 @@
 namespace sert {
 thread_local std::string g_last_error;
 
-static const char* kTimingNames[TG_COUNT] = {"gather",   "gemm_fwd", "loss",      "entity_grad",
-                                             "gemm_bwd", "scatter",  "allreduce", "optimizer",
-                                             "finalize"};
+static const char* kTimingNames[TG_COUNT] = {
+    "gather",        "gemm_fwd", "loss",      "entity_sort",          "entity_grad_reduce",
+    "entity_grad_fixup", "gemm_dW", "splitk_combine", "gemm_dX",      "word_grad_segsum",
+    "allreduce",     "optimizer_word_table",  "optimizer_other",      "finalize"};
 
 // ---- timing ----------------------------------------------------------------
 struct ScopedTimer {
@@ -33,7 +34,8 @@ struct ScopedTimer {
     int g;
     hipStream_t s;
     ScopedTimer(sert_model* m_, int g_, hipStream_t s_ = nullptr) : m(m_), g(g_), s(s_ ? s_ : m_->stream) {
-        if (m->timing.enabled) {
+        // a group bracketed several times in one step spans first start .. last end
+        if (m->timing.enabled && !m->timing.used[g]) {
             (void)hipEventRecord(m->timing.ev[g][0], s);
         }
     }
@@ -313,35 +315,45 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
     {
         // fork: this chain only depends on the NCE kernel and is independent of the
         // GEMMs / word-table reduction below, so it runs on the side stream
-        hipStream_t st = m->stream2;
+        // (timing mode measures every kernel alone: everything stays on the main stream)
+        hipStream_t st = m->timing.enabled ? m->stream : m->stream2;
         SERT_HIP(hipEventRecord(m->ev_fork, m->stream));
         SERT_HIP(hipStreamWaitEvent(st, m->ev_fork, 0));
-        ScopedTimer t(m, TG_EGRAD, st);
         // dR_e: stable sort of the (entity, pair) keys, chunked reduce, carry fix-up
         const int total = B * (c.num_negatives + 1);
         const int V = c.num_entities;
-        SERT_TRY(entity_key_sort(m, total, st));
+        {
+            ScopedTimer t(m, TG_SORT, st);
+            SERT_TRY(entity_key_sort(m, total, st));
+        }
         const int chunks = cdiv(total, kEChunk);
         dim3 cgrid(cdiv(chunks, 16)), fgrid(cdiv(V, 4)), blk(256);
 #define SERT_EG_ARGS m->cand_sorted, m->pair_sorted, m->coef, m->T, total, c.num_negatives + 1, de, \
                      m->g_re, m->ehead, m->etail, m->run_start, m->run_end
-        if (de % 4 == 0) {
-            const int nch = cdiv(de / 4, 16);
-            if (nch <= 1)      hipLaunchKernelGGL((egrad_chunk_reduce<4, 1>), cgrid, blk, 0, st, SERT_EG_ARGS);
-            else if (nch <= 2) hipLaunchKernelGGL((egrad_chunk_reduce<4, 2>), cgrid, blk, 0, st, SERT_EG_ARGS);
-            else if (nch <= 5) hipLaunchKernelGGL((egrad_chunk_reduce<4, 5>), cgrid, blk, 0, st, SERT_EG_ARGS);
-            else               hipLaunchKernelGGL((egrad_chunk_reduce<4, 8>), cgrid, blk, 0, st, SERT_EG_ARGS);
-            hipLaunchKernelGGL((egrad_fixup<4>), fgrid, blk, 0, st, m->run_start, m->run_end, V, de,
-                               m->ehead, m->etail, m->g_re);
-        } else {
-            hipLaunchKernelGGL((egrad_chunk_reduce<1, 4>), cgrid, blk, 0, st, SERT_EG_ARGS);
-            hipLaunchKernelGGL((egrad_fixup<1>), fgrid, blk, 0, st, m->run_start, m->run_end, V, de,
-                               m->ehead, m->etail, m->g_re);
+        {
+            ScopedTimer t(m, TG_EGRAD, st);
+            if (de % 4 == 0) {
+                const int nch = cdiv(de / 4, 16);
+                if (nch <= 1)      hipLaunchKernelGGL((egrad_chunk_reduce<4, 1>), cgrid, blk, 0, st, SERT_EG_ARGS);
+                else if (nch <= 2) hipLaunchKernelGGL((egrad_chunk_reduce<4, 2>), cgrid, blk, 0, st, SERT_EG_ARGS);
+                else if (nch <= 5) hipLaunchKernelGGL((egrad_chunk_reduce<4, 5>), cgrid, blk, 0, st, SERT_EG_ARGS);
+                else               hipLaunchKernelGGL((egrad_chunk_reduce<4, 8>), cgrid, blk, 0, st, SERT_EG_ARGS);
+            } else {
+                hipLaunchKernelGGL((egrad_chunk_reduce<1, 4>), cgrid, blk, 0, st, SERT_EG_ARGS);
+            }
+        }
+        {
+            ScopedTimer t(m, TG_EFIX, st);
+            if (de % 4 == 0)
+                hipLaunchKernelGGL((egrad_fixup<4>), fgrid, blk, 0, st, m->run_start, m->run_end, V, de,
+                                   m->ehead, m->etail, m->g_re);
+            else
+                hipLaunchKernelGGL((egrad_fixup<1>), fgrid, blk, 0, st, m->run_start, m->run_end, V, de,
+                                   m->ehead, m->etail, m->g_re);
         }
 #undef SERT_EG_ARGS
     }
     {
-        ScopedTimer t(m, TG_GEMM_BWD);
         // dW = h^T.da (reduction over the batch: split-K, order-fixed combine);
         // db = sum_i da_i rides along as the column sums of the da operand
         static const int want_splits = [] { const char* e = getenv("SERT_DW_SPLITS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
@@ -350,13 +362,22 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         splits = cdiv(B, kper);
         const size_t mn = (size_t)dw * de;
         const size_t stride = mn + de;
-        launch_gemm<true, false, EPI_STORE, true>(m->stream, m->H, m->DA, m->part, nullptr, dw, de,
-                                                  B, dw, de, de, splits, kper, stride);
-        hipLaunchKernelGGL(reduce_partials, dim3(cdiv(stride, 64)), dim3(256), 0, m->stream, m->part,
-                           splits, stride, stride, m->g_w, mn, m->g_b);
-        // dh = da.W^T
-        launch_gemm<false, true, EPI_STORE>(m->stream, m->DA, m->W, m->DH, nullptr, B, dw, de, de,
-                                            de, dw);
+        {
+            ScopedTimer t(m, TG_GEMM_DW);
+            launch_gemm<true, false, EPI_STORE, true>(m->stream, m->H, m->DA, m->part, nullptr, dw, de,
+                                                      B, dw, de, de, splits, kper, stride);
+        }
+        {
+            ScopedTimer t(m, TG_SPLITK);
+            hipLaunchKernelGGL(reduce_partials, dim3(cdiv(stride, 64)), dim3(256), 0, m->stream, m->part,
+                               splits, stride, stride, m->g_w, mn, m->g_b);
+        }
+        {
+            // dh = da.W^T
+            ScopedTimer t(m, TG_GEMM_DX);
+            launch_gemm<false, true, EPI_STORE>(m->stream, m->DA, m->W, m->DH, nullptr, B, dw, de, de,
+                                                de, dw);
+        }
     }
     {
         ScopedTimer t(m, TG_SCATTER);
@@ -420,7 +441,6 @@ static int ll_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
     const size_t row0 = (size_t)batch_index * B;
     const int64_t rows = (int64_t)B * n;
     {
-        ScopedTimer t(m, TG_GEMM_BWD);
         // dW (d, V) = G^T.dZ, reduction over the B*n tokens; db = column sums of dZ
         const int tiles = cdiv(V, GN) * cdiv(d, GM);
         int splits = std::max(1, std::min(cdiv(rows, GK), cdiv(1024, tiles)));
@@ -428,13 +448,22 @@ static int ll_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         splits = cdiv(rows, kper);
         const size_t mn = (size_t)d * V;
         const size_t stride = mn + V;
-        launch_gemm<true, false, EPI_STORE, true>(m->stream, m->G, m->Z, m->part, nullptr, d, V,
-                                                  (int)rows, d, V, V, splits, kper, stride);
-        hipLaunchKernelGGL(reduce_partials, dim3(cdiv(stride, 64)), dim3(256), 0, m->stream, m->part,
-                           splits, stride, stride, m->g_w, mn, m->g_b);
-        // dG (rows, d) = dZ.W^T
-        launch_gemm<false, true, EPI_STORE>(m->stream, m->Z, m->W, m->DG, nullptr, (int)rows, d, V, V,
-                                            V, d);
+        {
+            ScopedTimer t(m, TG_GEMM_DW);
+            launch_gemm<true, false, EPI_STORE, true>(m->stream, m->G, m->Z, m->part, nullptr, d, V,
+                                                      (int)rows, d, V, V, splits, kper, stride);
+        }
+        {
+            ScopedTimer t(m, TG_SPLITK);
+            hipLaunchKernelGGL(reduce_partials, dim3(cdiv(stride, 64)), dim3(256), 0, m->stream, m->part,
+                               splits, stride, stride, m->g_w, mn, m->g_b);
+        }
+        {
+            // dG (rows, d) = dZ.W^T
+            ScopedTimer t(m, TG_GEMM_DX);
+            launch_gemm<false, true, EPI_STORE>(m->stream, m->Z, m->W, m->DG, nullptr, (int)rows, d, V, V,
+                                                V, d);
+        }
     }
     {
         ScopedTimer t(m, TG_SCATTER);
@@ -465,11 +494,11 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst /* device [3] */) {
     m->step += 1;
     int n_sq = 0;
     {
-        ScopedTimer t(m, TG_OPTIMIZER);
         struct Item { float *p, *g, *s0, *s1; size_t count; bool l2; };
-        // update order of the reference: [R_e, R_w, W, b] (models.py:542-543, :1105)
-        Item items[4] = {{m->re, m->g_re, m->s0_re, m->s1_re, m->n_re, true},
-                         {m->rw, m->g_rw, m->s0_rw, m->s1_rw, m->n_rw, true},
+        // parameters of the reference: [R_e, R_w, W, b] (models.py:542-543, :1105); the
+        // tensors are independent, the big word table simply goes first
+        Item items[4] = {{m->rw, m->g_rw, m->s0_rw, m->s1_rw, m->n_rw, true},
+                         {m->re, m->g_re, m->s0_re, m->s1_re, m->n_re, true},
                          {m->W, m->g_w, m->s0_w, m->s1_w, m->n_w, true},
                          {m->b, m->g_b, m->s0_b, m->s1_b, m->n_b, false}};
         float a_t = 0.f;
@@ -479,6 +508,7 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst /* device [3] */) {
         }
         for (auto& it : items) {
             if (it.count == 0) continue;
+            ScopedTimer t(m, it.p == m->rw ? TG_OPT_WORD : TG_OPTIMIZER);
             const int nb = std::min<int64_t>(kOptBlocks, cdiv(it.count, 256));
             float* sq = m->red_sq + n_sq;
             if (is_vs(m)) {

@@ -39,85 +39,193 @@ __device__ __forceinline__ float key_to_float(uint32_t k) {
     return __uint_as_float(u);
 }
 
-// Top-k of one row of cosine scores, one workgroup (256 threads) per query:
-// 4-pass 8-bit radix select of the k-th largest value, ordered collection
-// (ties at the threshold: lowest entity index first), bitonic sort of the k
-// survivors by (score desc, index asc).  Emits score = (cos + 1)/2
-// (query.py:352-357), computed in fp32.
+// Visit every element of a row with 16-byte loads, 4 independent loads per
+// thread in flight (a 4-byte load per iteration left this kernel latency-bound:
+// 2.8 TB/s with 32 waves per CU).  f(value, index) is called in arbitrary order.
+template <typename F>
+__device__ __forceinline__ void topk_scan_row(const float* __restrict__ row, int V, F f) {
+    const int tid = threadIdx.x;
+    if (((reinterpret_cast<uintptr_t>(row)) & 15) == 0) {
+        const int V4 = V >> 2;
+        const float4* r4 = reinterpret_cast<const float4*>(row);
+        for (int i0 = tid; i0 < V4; i0 += 4 * 256) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 256;
+                if (i < V4) v[u] = r4[i];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 256;
+                if (i < V4) {
+                    f(v[u].x, 4 * i); f(v[u].y, 4 * i + 1); f(v[u].z, 4 * i + 2); f(v[u].w, 4 * i + 3);
+                }
+            }
+        }
+        for (int e = (V4 << 2) + tid; e < V; e += 256) f(row[e], e);
+    } else {
+        for (int e = tid; e < V; e += 256) f(row[e], e);
+    }
+}
+
+constexpr int kTopKCand = 2048;   // LDS capacity for the threshold-bin candidates
+
+// Top-k of one row of cosine scores, one workgroup (256 threads) per query.
+//   pass 1 (1 read)  2048-bin histogram of the top 11 bits of the order-preserving
+//                    key -> the bin holding the k-th best score
+//   pass 2 (1 read)  scores in better bins are winners; the threshold bin's
+//                    elements go to an LDS candidate list
+//   in LDS           bitonic sort of the candidates by (score desc, index asc),
+//                    the best `need` join the winners; final sort of the k winners
+// Two reads of the row instead of six for the plain 4x8-bit radix select, which
+// remains as the fallback when the threshold bin overflows the candidate list
+// (many equal scores).  Ties resolve to the lowest entity index.  Emits
+// score = (cos + 1)/2 (query.py:352-357), computed in fp32.
 __global__ __launch_bounds__(256) void topk_rows(const float* __restrict__ S, int V, int k,
                                                  int32_t* __restrict__ idx_out,
                                                  float* __restrict__ val_out) {
-    __shared__ uint32_t hist[256];
+    __shared__ uint32_t hist[2048];
     __shared__ unsigned long long keys[kTopKMax];
-    __shared__ uint32_t s_prefix, s_krem, s_count, s_ties;
+    __shared__ unsigned long long cand[kTopKCand];
+    __shared__ uint32_t scan_tmp[256];
+    __shared__ uint32_t s_bin, s_need, s_count, s_ncand, s_prefix, s_krem, s_ties;
     __shared__ uint32_t wave_cnt[4];
     const int tid = threadIdx.x;
     const float* row = S + (size_t)blockIdx.x * V;
+    int sort_n = 2;
+    while (sort_n < k) sort_n <<= 1;
 
-    if (tid == 0) { s_prefix = 0; s_krem = (uint32_t)k; }
+    // ---- pass 1: 11-bit histogram ---------------------------------------------
+    for (int b = tid; b < 2048; b += 256) hist[b] = 0;
+    for (int i = tid; i < sort_n; i += 256) keys[i] = ~0ull;
+    if (tid == 0) { s_count = 0; s_ncand = 0; s_bin = 0; s_need = 0; }
     __syncthreads();
-    for (int pass = 3; pass >= 0; --pass) {
-        hist[tid] = 0;
+    topk_scan_row(row, V, [&](float x, int) { atomicAdd(&hist[desc_key(x) >> 21], 1u); });
+    __syncthreads();
+    // locate the bin of the k-th best: 8 consecutive bins per thread + block scan
+    uint32_t local[8], sum = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { local[q] = hist[tid * 8 + q]; sum += local[q]; }
+    scan_tmp[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const uint32_t v = (tid >= off) ? scan_tmp[tid - off] : 0;
         __syncthreads();
-        const uint32_t prefix = s_prefix;
-        const int shift_hi = 8 * (pass + 1);
-        for (int e = tid; e < V; e += 256) {
-            const uint32_t key = desc_key(row[e]);
-            const bool match = (pass == 3) || ((key >> shift_hi) == prefix);
-            if (match) atomicAdd(&hist[(key >> (8 * pass)) & 0xffu], 1u);
-        }
+        scan_tmp[tid] += v;
         __syncthreads();
-        if (tid == 0) {
-            uint32_t krem = s_krem, b = 0;
-            for (; b < 256; ++b) {
-                if (hist[b] >= krem) break;
-                krem -= hist[b];
+    }
+    {
+        uint32_t before = scan_tmp[tid] - sum;          // elements in bins of earlier threads
+        if (before < (uint32_t)k && before + sum >= (uint32_t)k) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (before < (uint32_t)k && before + local[q] >= (uint32_t)k) {
+                    s_bin = tid * 8 + q;
+                    s_need = (uint32_t)k - before;       // how many to take from this bin
+                }
+                before += local[q];
             }
-            s_krem = krem;
-            s_prefix = (prefix << 8) | b;
-        }
-        __syncthreads();
-    }
-    const uint32_t thr = s_prefix;   // key of the k-th best element
-    const uint32_t n_ties = s_krem;  // how many elements with key == thr to take
-    if (tid == 0) { s_count = 0; s_ties = 0; }
-    for (int i = tid; i < kTopKMax; i += 256) keys[i] = ~0ull;
-    __syncthreads();
-    // elements strictly better than the threshold: any order (sorted below)
-    for (int e = tid; e < V; e += 256) {
-        const uint32_t key = desc_key(row[e]);
-        if (key < thr) {
-            const uint32_t pos = atomicAdd(&s_count, 1u);
-            keys[pos] = ((unsigned long long)key << 32) | (uint32_t)e;
         }
     }
     __syncthreads();
-    // ties at the threshold, in index order
-    const uint32_t base = s_count;
-    const int lane = tid & 63, wv = tid >> 6;
-    for (int e0 = 0; e0 < V; e0 += 256) {
-        const int e = e0 + tid;
-        const bool is_tie = (e < V) && (desc_key(row[e]) == thr);
-        const unsigned long long bal = __ballot(is_tie);
-        const uint32_t before_in_wave = __popcll(bal & ((1ull << lane) - 1ull));
-        if (lane == 0) wave_cnt[wv] = __popcll(bal);
+    const uint32_t tbin = s_bin, need = s_need;
+    const bool fits = hist[tbin] <= (uint32_t)kTopKCand;    // workgroup-uniform
+
+    if (fits) {
+        // ---- pass 2: winners + candidates ---------------------------------------
+        topk_scan_row(row, V, [&](float x, int e) {
+            const uint32_t key = desc_key(x);
+            const uint32_t bin = key >> 21;
+            if (bin < tbin) {
+                keys[atomicAdd(&s_count, 1u)] = ((unsigned long long)key << 32) | (uint32_t)e;
+            } else if (bin == tbin) {
+                cand[atomicAdd(&s_ncand, 1u)] = ((unsigned long long)key << 32) | (uint32_t)e;
+            }
+        });
         __syncthreads();
-        uint32_t before = s_ties;
-        for (int q = 0; q < wv; ++q) before += wave_cnt[q];
-        if (is_tie) {
-            const uint32_t t = before + before_in_wave;
-            if (t < n_ties) keys[base + t] = ((unsigned long long)thr << 32) | (uint32_t)e;
+        const int nc = (int)s_ncand;
+        int cn = 2;
+        while (cn < nc) cn <<= 1;
+        for (int i = nc + tid; i < cn; i += 256) cand[i] = ~0ull;
+        __syncthreads();
+        for (int size = 2; size <= cn; size <<= 1) {
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int i = tid; i < cn / 2; i += 256) {
+                    const int lo = 2 * i - (i & (stride - 1));
+                    const int hi = lo + stride;
+                    const bool up = ((lo & size) == 0);
+                    const unsigned long long a = cand[lo], b = cand[hi];
+                    if ((a > b) == up) { cand[lo] = b; cand[hi] = a; }
+                }
+                __syncthreads();
+            }
+        }
+        const uint32_t base = s_count;
+        for (int i = tid; i < (int)need; i += 256) keys[base + i] = cand[i];
+        __syncthreads();
+    } else {
+        // ---- fallback: 4 x 8-bit radix select straight from global memory --------
+        if (tid == 0) { s_prefix = 0; s_krem = (uint32_t)k; }
+        __syncthreads();
+        for (int pass = 3; pass >= 0; --pass) {
+            hist[tid] = 0;
+            __syncthreads();
+            const uint32_t prefix = s_prefix;
+            const int shift_hi = 8 * (pass + 1);
+            topk_scan_row(row, V, [&](float x, int) {
+                const uint32_t key = desc_key(x);
+                const bool match = (pass == 3) || ((key >> shift_hi) == prefix);
+                if (match) atomicAdd(&hist[(key >> (8 * pass)) & 0xffu], 1u);
+            });
+            __syncthreads();
+            if (tid == 0) {
+                uint32_t krem = s_krem, b = 0;
+                for (; b < 256; ++b) {
+                    if (hist[b] >= krem) break;
+                    krem -= hist[b];
+                }
+                s_krem = krem;
+                s_prefix = (prefix << 8) | b;
+            }
+            __syncthreads();
+        }
+        const uint32_t thr = s_prefix;   // key of the k-th best element
+        const uint32_t n_ties = s_krem;  // how many elements with key == thr to take
+        if (tid == 0) { s_count = 0; s_ties = 0; }
+        __syncthreads();
+        topk_scan_row(row, V, [&](float x, int e) {
+            const uint32_t key = desc_key(x);
+            if (key < thr) keys[atomicAdd(&s_count, 1u)] = ((unsigned long long)key << 32) | (uint32_t)e;
+        });
+        __syncthreads();
+        // ties at the threshold, in index order
+        const uint32_t base = s_count;
+        const int lane = tid & 63, wv = tid >> 6;
+        for (int e0 = 0; e0 < V; e0 += 256) {
+            const int e = e0 + tid;
+            const bool is_tie = (e < V) && (desc_key(row[e]) == thr);
+            const unsigned long long bal = __ballot(is_tie);
+            const uint32_t before_in_wave = __popcll(bal & ((1ull << lane) - 1ull));
+            if (lane == 0) wave_cnt[wv] = __popcll(bal);
+            __syncthreads();
+            uint32_t before = s_ties;
+            for (int q = 0; q < wv; ++q) before += wave_cnt[q];
+            if (is_tie) {
+                const uint32_t t = before + before_in_wave;
+                if (t < n_ties) keys[base + t] = ((unsigned long long)thr << 32) | (uint32_t)e;
+            }
+            __syncthreads();
+            if (tid == 0) s_ties += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+            __syncthreads();
+            if (s_ties >= n_ties) break;
         }
         __syncthreads();
-        if (tid == 0) s_ties += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-        __syncthreads();
-        if (s_ties >= n_ties) break;
     }
-    __syncthreads();
-    // bitonic sort of kTopKMax 64-bit keys ascending (= score desc, index asc)
-    for (int size = 2; size <= kTopKMax; size <<= 1) {
+    // ---- final: bitonic sort of the k winners (score desc, index asc) -------------
+    for (int size = 2; size <= sort_n; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int i = tid; i < kTopKMax / 2; i += 256) {
+            for (int i = tid; i < sort_n / 2; i += 256) {
                 const int lo = 2 * i - (i & (stride - 1));
                 const int hi = lo + stride;
                 const bool up = ((lo & size) == 0);

@@ -124,7 +124,10 @@ struct sert_scorer {
     int dim = 0;
     float* E = nullptr;      // (V, dim) L2-normalised entity table
     float* P = nullptr;      // (Q, dim) query projections
-    float* S = nullptr;      // (QT, V) cosine slab of one query tile
+    float* S = nullptr;      // 2 x (QT, V) cosine slabs: query tiles alternate between two
+                             // streams so the GEMM of tile t+1 overlaps the top-k of tile t
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_ready = nullptr, ev_done = nullptr;
     float* val = nullptr;    // (Q, k)
     int32_t* idx = nullptr;  // (Q, k)
     int64_t cap_q = 0, cap_qk = 0, cap_s = 0;

@@ -955,6 +955,9 @@ int sert_scorer_create(int device, const float* entities, int64_t V, int32_t dim
     sc->V = V;
     sc->dim = dim;
     SERT_HIP(hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking));
+    SERT_HIP(hipStreamCreateWithFlags(&sc->stream2, hipStreamNonBlocking));
+    SERT_HIP(hipEventCreateWithFlags(&sc->ev_ready, hipEventDisableTiming));
+    SERT_HIP(hipEventCreateWithFlags(&sc->ev_done, hipEventDisableTiming));
     SERT_TRY(dmalloc(&sc->E, (size_t)V * dim));
     SERT_HIP(hipMemcpyAsync(sc->E, entities, (size_t)V * dim * sizeof(float), hipMemcpyHostToDevice, sc->stream));
     hipLaunchKernelGGL(l2_normalize_rows, dim3(cdiv(V, 4)), dim3(256), 0, sc->stream, sc->E, V, dim);
@@ -967,6 +970,9 @@ int sert_scorer_destroy(sert_scorer* sc) {
     if (!sc) return 0;
     (void)hipSetDevice(sc->device);
     (void)hipFree(sc->E); (void)hipFree(sc->P); (void)hipFree(sc->S); (void)hipFree(sc->val); (void)hipFree(sc->idx);
+    if (sc->ev_ready) (void)hipEventDestroy(sc->ev_ready);
+    if (sc->ev_done) (void)hipEventDestroy(sc->ev_done);
+    if (sc->stream2) (void)hipStreamDestroy(sc->stream2);
     if (sc->stream) (void)hipStreamDestroy(sc->stream);
     delete sc;
     return 0;
@@ -982,8 +988,8 @@ int sert_scorer_topk(sert_scorer* sc, const float* proj, int64_t Q, int32_t k, i
     hipStream_t s = sc->stream;
     const int64_t V = sc->V;
     const int dim = sc->dim;
-    // query tile: bounds the materialised score slab to ~1 GiB
-    const int64_t QT = std::min<int64_t>(Q, std::max<int64_t>(128, ((int64_t)1 << 28) / V / 128 * 128));
+    // query tile: bounds one materialised score slab to ~0.5 GiB (two slabs alternate)
+    const int64_t QT = std::min<int64_t>(Q, std::max<int64_t>(128, ((int64_t)1 << 27) / V / 128 * 128));
     if (sc->cap_q < Q) {
         (void)hipFree(sc->P); (void)hipFree(sc->val); (void)hipFree(sc->idx);
         SERT_TRY(dmalloc(&sc->P, (size_t)Q * dim));
@@ -997,21 +1003,28 @@ int sert_scorer_topk(sert_scorer* sc, const float* proj, int64_t Q, int32_t k, i
         SERT_TRY(dmalloc(&sc->idx, (size_t)Q * k));
         sc->cap_qk = Q * k;
     }
-    if (sc->cap_s < QT * V) {
+    if (sc->cap_s < 2 * QT * V) {
         (void)hipFree(sc->S);
-        SERT_TRY(dmalloc(&sc->S, (size_t)QT * V));
-        sc->cap_s = QT * V;
+        SERT_TRY(dmalloc(&sc->S, (size_t)2 * QT * V));
+        sc->cap_s = 2 * QT * V;
     }
     SERT_HIP(hipMemcpyAsync(sc->P, proj, (size_t)Q * dim * sizeof(float), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(l2_normalize_rows, dim3(cdiv(Q, 4)), dim3(256), 0, s, sc->P, Q, dim);
-    for (int64_t q0 = 0; q0 < Q; q0 += QT) {
+    SERT_HIP(hipEventRecord(sc->ev_ready, s));
+    SERT_HIP(hipStreamWaitEvent(sc->stream2, sc->ev_ready, 0));
+    int t = 0;
+    for (int64_t q0 = 0; q0 < Q; q0 += QT, ++t) {
         const int64_t qn = std::min(QT, Q - q0);
-        // S = P.E^T  (cosines)
-        launch_gemm<false, true, EPI_STORE>(s, sc->P + q0 * dim, sc->E, sc->S, nullptr, (int)qn, (int)V, dim,
+        hipStream_t st = (t & 1) ? sc->stream2 : s;
+        float* S = sc->S + (size_t)(t & 1) * QT * V;
+        // S = P.E^T  (cosines), then per-row selection; tiles alternate streams
+        launch_gemm<false, true, EPI_STORE>(st, sc->P + q0 * dim, sc->E, S, nullptr, (int)qn, (int)V, dim,
                                             dim, dim, (int)V);
-        hipLaunchKernelGGL(topk_rows, dim3((unsigned)qn), dim3(256), 0, s, sc->S, (int)V, k,
+        hipLaunchKernelGGL(topk_rows, dim3((unsigned)qn), dim3(256), 0, st, S, (int)V, k,
                            sc->idx + q0 * k, sc->val + q0 * k);
     }
+    SERT_HIP(hipEventRecord(sc->ev_done, sc->stream2));
+    SERT_HIP(hipStreamWaitEvent(s, sc->ev_done, 0));
     SERT_HIP(hipMemcpyAsync(idx_out, sc->idx, (size_t)Q * k * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     SERT_HIP(hipMemcpyAsync(score_out, sc->val, (size_t)Q * k * sizeof(float), hipMemcpyDeviceToHost, s));
     SERT_HIP(hipStreamSynchronize(s));

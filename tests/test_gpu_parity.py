@@ -163,6 +163,23 @@ def test_score_topk_ties(hip_lib):
         assert val[q][0] == val[q][1]
 
 
+@pytest.mark.parametrize('V', [5000, 9000])
+def test_score_topk_mass_ties(hip_lib, V):
+    """Only 3 distinct entity directions: thousands of exactly equal scores.
+    V=5000 keeps the threshold bin inside the LDS candidate list (fast path),
+    V=9000 overflows it (4-pass fallback).  Either way: lowest index first."""
+    rng = np.random.RandomState(6)
+    dirs = rng.randn(3, 16).astype(np.float32)
+    which = np.arange(V) % 3
+    E = dirs[which]
+    Pj = dirs[[2]] + 0.01 * dirs[[0]]
+    k = 100
+    idx, val = C.score_topk(E, Pj, k)
+    expect = np.nonzero(which == 2)[0][:k]
+    assert np.array_equal(idx[0], expect)
+    assert np.all(val[0] == val[0][0])
+
+
 def test_device_sampler_uniform_and_rank_invariant(hip_lib):
     """The Philox sampler draws iid uniform ids; training with it is finite."""
     B, n, z, Vw, Ve, dw, de = 512, 4, 8, 100, 16, 16, 16

@@ -12,7 +12,7 @@
 
 namespace sert {
 
-constexpr int kOptBlocks = 1024;  // fixed grid => fixed reduction tree => deterministic
+constexpr int kOptBlocks = 2048;  // fixed grid => fixed reduction tree => deterministic
 
 struct AdamArgs {
     float l2k;   // lambda / B
@@ -22,6 +22,21 @@ struct AdamArgs {
 
 // Lasagne 0.1 adam [upstream]:
 //   m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g^2 ; p = p - a_t*m/(sqrt(v)+eps)
+__device__ __forceinline__ void adam_elem(float& p, float& g, float& m, float& v, const AdamArgs& a,
+                                          float omb1, float omb2, float& ss) {
+    const float pv = p;
+    const float gv = g + a.l2k * pv;
+    ss += pv * pv;
+    const float mv = a.b1 * m + omb1 * gv;
+    const float vv = a.b2 * v + omb2 * gv * gv;
+    m = mv;
+    v = vv;
+    p = pv - a.a_t * mv / (sqrtf(vv) + a.eps);
+    g = gv;
+}
+
+// 16-byte accesses (4 streams in, 3-4 out); tensors are 16-byte aligned, the
+// (< 4 element) tail is handled by the first threads of block 0.
 template <bool STORE_G>
 __global__ __launch_bounds__(256) void adam_l2(float* __restrict__ p, float* __restrict__ g,
                                                float* __restrict__ m, float* __restrict__ v,
@@ -30,17 +45,33 @@ __global__ __launch_bounds__(256) void adam_l2(float* __restrict__ p, float* __r
     __shared__ float red[4];
     float ss = 0.f;
     const float omb1 = 1.0f - a.b1, omb2 = 1.0f - a.b2;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count;
-         i += (size_t)gridDim.x * blockDim.x) {
-        const float pv = p[i];
-        const float gv = g[i] + a.l2k * pv;
-        ss += pv * pv;
-        const float mv = a.b1 * m[i] + omb1 * gv;
-        const float vv = a.b2 * v[i] + omb2 * gv * gv;
-        m[i] = mv;
-        v[i] = vv;
-        p[i] = pv - a.a_t * mv / (sqrtf(vv) + a.eps);
-        if (STORE_G) g[i] = gv;
+    const size_t n4 = count >> 2;
+    float4* p4 = reinterpret_cast<float4*>(p);
+    float4* g4 = reinterpret_cast<float4*>(g);
+    float4* m4 = reinterpret_cast<float4*>(m);
+    float4* v4 = reinterpret_cast<float4*>(v);
+    // each workgroup streams ONE contiguous slice (a grid-stride walk at a 4 MB
+    // power-of-two stride keeps all workgroups on the same HBM channels at once)
+    const size_t per = (n4 + gridDim.x - 1) / gridDim.x;
+    const size_t lo = (size_t)blockIdx.x * per;
+    const size_t hi = lo + per < n4 ? lo + per : n4;
+    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
+        adam_elem(pp.x, gg.x, mm.x, vv.x, a, omb1, omb2, ss);
+        adam_elem(pp.y, gg.y, mm.y, vv.y, a, omb1, omb2, ss);
+        adam_elem(pp.z, gg.z, mm.z, vv.z, a, omb1, omb2, ss);
+        adam_elem(pp.w, gg.w, mm.w, vv.w, a, omb1, omb2, ss);
+        p4[i] = pp; m4[i] = mm; v4[i] = vv;
+        if (STORE_G) g4[i] = gg;
+    }
+    if (blockIdx.x == 0) {
+        const size_t i = (n4 << 2) + threadIdx.x;
+        if (i < count) {
+            float pp = p[i], gg = g[i], mm = m[i], vv = v[i];
+            adam_elem(pp, gg, mm, vv, a, omb1, omb2, ss);
+            p[i] = pp; m[i] = mm; v[i] = vv;
+            if (STORE_G) g[i] = gg;
+        }
     }
     const float tot = block_sum_256(ss, red);
     if (threadIdx.x == 0) sumsq_partial[blockIdx.x] = tot;
@@ -53,6 +84,20 @@ struct AdadeltaArgs {
 // Lasagne 0.1 adadelta [upstream]:
 //   a = rho*a + (1-rho)*g^2 ; u = g*sqrt(d+eps)/sqrt(a+eps) ; p = p - lr*u ;
 //   d = rho*d + (1-rho)*u^2
+__device__ __forceinline__ void adadelta_elem(float& p, float& g, float& accu, float& delta,
+                                              const AdadeltaArgs& a, float omr, float& ss) {
+    const float pv = p;
+    const float gv = g + a.l2k * pv;
+    ss += pv * pv;
+    const float av = a.rho * accu + omr * gv * gv;
+    const float dv = delta;
+    const float u = gv * sqrtf(dv + a.eps) / sqrtf(av + a.eps);
+    accu = av;
+    p = pv - a.lr * u;
+    delta = a.rho * dv + omr * u * u;
+    g = gv;
+}
+
 template <bool STORE_G>
 __global__ __launch_bounds__(256) void adadelta_l2(float* __restrict__ p, float* __restrict__ g,
                                                    float* __restrict__ accu,
@@ -62,18 +107,33 @@ __global__ __launch_bounds__(256) void adadelta_l2(float* __restrict__ p, float*
     __shared__ float red[4];
     float ss = 0.f;
     const float omr = 1.0f - a.rho;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count;
-         i += (size_t)gridDim.x * blockDim.x) {
-        const float pv = p[i];
-        const float gv = g[i] + a.l2k * pv;
-        ss += pv * pv;
-        const float av = a.rho * accu[i] + omr * gv * gv;
-        const float dv = delta[i];
-        const float u = gv * sqrtf(dv + a.eps) / sqrtf(av + a.eps);
-        accu[i] = av;
-        p[i] = pv - a.lr * u;
-        delta[i] = a.rho * dv + omr * u * u;
-        if (STORE_G) g[i] = gv;
+    const size_t n4 = count >> 2;
+    float4* p4 = reinterpret_cast<float4*>(p);
+    float4* g4 = reinterpret_cast<float4*>(g);
+    float4* a4 = reinterpret_cast<float4*>(accu);
+    float4* d4 = reinterpret_cast<float4*>(delta);
+    // each workgroup streams ONE contiguous slice (a grid-stride walk at a 4 MB
+    // power-of-two stride keeps all workgroups on the same HBM channels at once)
+    const size_t per = (n4 + gridDim.x - 1) / gridDim.x;
+    const size_t lo = (size_t)blockIdx.x * per;
+    const size_t hi = lo + per < n4 ? lo + per : n4;
+    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        float4 pp = p4[i], gg = g4[i], aa = a4[i], dd = d4[i];
+        adadelta_elem(pp.x, gg.x, aa.x, dd.x, a, omr, ss);
+        adadelta_elem(pp.y, gg.y, aa.y, dd.y, a, omr, ss);
+        adadelta_elem(pp.z, gg.z, aa.z, dd.z, a, omr, ss);
+        adadelta_elem(pp.w, gg.w, aa.w, dd.w, a, omr, ss);
+        p4[i] = pp; a4[i] = aa; d4[i] = dd;
+        if (STORE_G) g4[i] = gg;
+    }
+    if (blockIdx.x == 0) {
+        const size_t i = (n4 << 2) + threadIdx.x;
+        if (i < count) {
+            float pp = p[i], gg = g[i], aa = accu[i], dd = delta[i];
+            adadelta_elem(pp, gg, aa, dd, a, omr, ss);
+            p[i] = pp; accu[i] = aa; delta[i] = dd;
+            if (STORE_G) g[i] = gg;
+        }
     }
     const float tot = block_sum_256(ss, red);
     if (threadIdx.x == 0) sumsq_partial[blockIdx.x] = tot;

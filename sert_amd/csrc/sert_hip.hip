@@ -509,7 +509,7 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst /* device [3] */) {
         for (auto& it : items) {
             if (it.count == 0) continue;
             ScopedTimer t(m, it.p == m->rw ? TG_OPT_WORD : TG_OPTIMIZER);
-            const int nb = std::min<int64_t>(kOptBlocks, cdiv(it.count, 256));
+            const int nb = std::min<int64_t>(kOptBlocks, cdiv(cdiv(it.count, 4), 256));
             float* sq = m->red_sq + n_sq;
             if (is_vs(m)) {
                 AdamArgs a{it.l2 ? l2k : 0.f, a_t, c.beta1, c.beta2, c.eps};
@@ -676,7 +676,7 @@ int sert_create(const sert_config* cfg, sert_model** out) {
         m->part_count = part;
         SERT_TRY(dzalloc(&m->part, part, s));
         SERT_TRY(dzalloc(&m->red_loss, (size_t)kOptBlocks, s));
-        SERT_TRY(dzalloc(&m->red_sq, (size_t)4 * kOptBlocks, s));
+        SERT_TRY(dzalloc(&m->red_sq, (size_t)4 * kOptBlocks, s));  // partials of up to 4 tensors
         SERT_TRY(dzalloc(&m->d_loss, (size_t)4, s));
     }
     SERT_HIP(hipHostMalloc((void**)&m->h_loss, 4 * sizeof(float), hipHostMallocDefault));

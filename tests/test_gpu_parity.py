@@ -191,3 +191,75 @@ def test_device_sampler_uniform_and_rank_invariant(hip_lib):
     l1 = eng.train_batch(0)
     assert np.isfinite(l1)
     eng.close()
+
+
+@pytest.mark.parametrize('dims', [
+    dict(B=1, n=1, z=1, Vw=5, Ve=2, dw=4, de=4),           # smallest legal everything
+    dict(B=3, n=2, z=1, Vw=7, Ve=3, dw=8, de=12),          # B below every tile / group width
+    dict(B=17, n=12, z=31, Vw=300, Ve=5, dw=64, de=64),    # z+1 = 32 candidates per row
+    dict(B=33, n=3, z=2, Vw=256, Ve=300, dw=20, de=36),    # uint8 ids, id 255 used
+])
+def test_vectorspace_edge_shapes(hip_lib, dims):
+    B, n, z = dims['B'], dims['n'], dims['z']
+    p = U.make_vs_problem(41, 2 * B + 1, n, z, dims['Vw'], dims['Ve'], dims['dw'], dims['de'])
+    p['X'][0, 0] = dims['Vw'] - 1
+    eng = U.vs_engine(p, B, n, z, 0.01)
+    eng.upload_dataset(C.SPLIT_TRAIN, p['X'], y_int=p['y'], w=p['w'])   # 1 row of tail ignored
+    ora = O.VectorSpaceOracle(B, n, z, p['Rw'], p['Re'], p['W'], p['b'], 0.01)
+    for s in range(2):
+        sl = slice(s * B, (s + 1) * B)
+        neg = p['rng'].randint(0, dims['Ve'], size=(B, z)).astype(np.int64)
+        ref = ora.train_step(p['X'][sl], p['y'][sl], p['w'][sl], neg)
+        got = eng.train_batch(s, neg)
+        assert abs(got - ref) <= LOSS_TOL * abs(ref)
+    assert U.rel_err(eng.get_tensor(C.T_RW), ora.R_w.ravel()) < PARAM_TOL
+    assert U.rel_err(eng.get_tensor(C.T_RE), ora.R_e.ravel()) < PARAM_TOL
+    with pytest.raises(C.SertError):
+        eng.train_batch(3)            # beyond the data (an incomplete tail batch does not exist)
+    eng.close()
+
+
+def test_error_paths(hip_lib):
+    p = U.make_vs_problem(42, 8, 2, 2, 10, 4, 4, 4)
+    eng = U.vs_engine(p, 4, 2, 2, 0.0)
+    with pytest.raises(C.SertError):
+        eng.train_batch(0)                                   # nothing uploaded
+    bad = p['X'].copy()
+    bad[3, 1] = 10                                           # id == vocab_size
+    with pytest.raises(C.SertError):
+        eng.upload_dataset(C.SPLIT_TRAIN, bad, y_int=p['y'], w=p['w'])
+    with pytest.raises(C.SertError):
+        eng.set_tensor(C.T_RW, np.zeros(3, np.float32))      # wrong element count
+    with pytest.raises(C.SertError):
+        eng.predict_tokens(np.zeros((1, 2), np.uint8))       # loglinear-only entry point
+    eng.close()
+    with pytest.raises(C.SertError):
+        C.score_topk(np.ones((4, 2), np.float32), np.ones((1, 2), np.float32), 5)   # k > V_e
+    with pytest.raises(C.SertError):
+        C.Engine(kind=C.KIND_VECTORSPACE, batch_size=4, global_batch_size=4, window_size=2,
+                 vocab_size=10, num_entities=4, word_dim=4, entity_dim=4, num_negatives=2,
+                 id_bytes=3, device=0)                       # id width must be 1, 2 or 4
+
+
+def test_model_with_empty_validation_and_short_data(hip_lib):
+    """validation set empty -> mean of no batches is nan (as np.mean([]) in the
+    reference); fewer instances than one batch -> zero batches, no crash."""
+    import warnings
+    from sert_amd import models
+    B, n, z, Vw, Ve, d = 16, 3, 2, 50, 6, 8
+    p = U.make_vs_problem(43, B * 2 + 5, n, z, Vw, Ve, d, d)
+    m = models.VectorSpaceLanguageModel(
+        batch_size=B, window_size=n, num_negative_samples=z, representations_init=p['Rw'],
+        entity_representations_init=p['Re'], regularization_lambda=0.01,
+        training_set=(p['X'], p['y'], p['w']),
+        validation_set=(np.zeros((0,), p['X'].dtype), np.zeros((0,), np.int32)))
+    nb, mean = m.train()
+    assert nb == 2 and np.isfinite(mean)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        vm, vs = m.validation_error()
+    assert np.isnan(vm)
+    # non-finite loss -> RuntimeError from the epoch loop (models.py:372-379)
+    m._engine.set_tensor(C.T_W, np.full((d, d), np.nan, np.float32))
+    with pytest.raises(RuntimeError):
+        m.train()

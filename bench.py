@@ -100,6 +100,18 @@ def load_pmc():
         return json.load(f)
 
 
+def pmc_traffic(pmc, hip_kernel, avg_us):
+    """HBM bytes of the profiled launch of `hip_kernel` whose duration is closest to
+    the measured one (the PMC file is keyed 'kernel @grid_size')."""
+    best = None
+    for key, rec in pmc.items():
+        if hip_kernel and key.split(' @')[0].startswith(hip_kernel.split('(')[0]):
+            d = abs(rec.get('avg_us_profiled', 0.0) - avg_us)
+            if best is None or d < best[0]:
+                best = (d, rec.get('hbm_bytes'))
+    return best[1] if best else None
+
+
 def build_model(kind, models, B_global, n, Vw, Ve, dw, de, z, X, y, w, seed):
     np.random.seed(seed)
     rng = np.random.RandomState(seed + 1)
@@ -113,6 +125,12 @@ def build_model(kind, models, B_global, n, Vw, Ve, dw, de, z, X, y, w, seed):
             representations_init=Rw, entity_representations_init=Re,
             regularization_lambda=0.01, training_set=(X, y, w),
             validation_set=(empty_x, empty_y))
+    elif kind == 'vectorspace_softmax':
+        Re = glorot(rng, (Ve, de))
+        m = models.VectorSpaceSoftmaxLanguageModel(
+            batch_size=B_global, window_size=n, representations_init=Rw,
+            entity_representations_init=Re, regularization_lambda=0.01,
+            training_set=(X, y, w), validation_set=(empty_x, empty_y))
     else:
         m = models.LanguageModel(
             batch_size=B_global, window_size=n, representations_init=Rw,
@@ -276,7 +294,7 @@ def main():
                         achieved=kd['achieved'],
                         peak=HBM_PEAK_GBS if kd['bound'] == 'hbm' else MFMA_F32_PEAK_TFLOPS,
                         unit=kd['unit'], frac=kd['frac'],
-                        traffic=pmc.get(KERNEL_OF_GROUP.get(dom), {}).get('hbm_bytes') if kind == 'vectorspace' else None,
+                        traffic=pmc_traffic(pmc, KERNEL_OF_GROUP.get(dom), kd['us']) if kind == 'vectorspace' else None,
                         traffic_source=PMC_FILE if pmc else None, avg_us=kd['us'],
                         note='achieved = algorithmic bytes (SURVEY 8d) / HIP-event time; tables that fit the '
                              '256 MB Infinity Cache can exceed the HBM peak')
@@ -319,6 +337,22 @@ def main():
             'mfma_tflops_whole_step': fl / (dt2 / st) / 1e12,
         }
         del m2
+        # extra: the ADDITIVE full-softmax LSE variant (BASELINE.json configs[1] wording:
+        # "embed gather + MFMA projection + full softmax"), same dims and batch as the headline
+        m3 = build_model('vectorspace_softmax', models, Bl, n, Vw, Ve, d, d, z, X[:4 * Bl], y[:4 * Bl],
+                         w[:4 * Bl], seed=2)
+        dt3, _, _ = timed_steps(m3, dist, 4, st, 3, timing=False)
+        _, tm3, _ = timed_steps(m3, dist, 4, st, 1, timing=True)
+        fl3 = 6.0 * Bl * d * d + 6.0 * Bl * d * Ve
+        out['lse_full_softmax'] = {
+            'workload': 'VectorSpaceSoftmaxLanguageModel (additive, not in the reference): gather + mean-pool + '
+                        'tanh projection + full softmax over V_e=%d, Adam; V_w=%d d=%d window=%d batch=%d' % (
+                            Ve, Vw, d, n, Bl),
+            'value': st * Bl / dt3, 'unit': 'pairs/s', 'ms_per_step': 1000 * dt3 / st,
+            'kernels_us': {k: round(v, 1) for k, v in tm3.items() if v > 0},
+            'mfma_tflops_whole_step': fl3 / (dt3 / st) / 1e12,
+        }
+        del m3
 
     if ctx.rank == 0 and N == 1 and not args.no_query_extra:
         out['query'] = query_bench(_capi, cpu=not args.no_cpu_baseline)

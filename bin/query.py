@@ -101,7 +101,8 @@ def main(argv=None):
         if model_args.type == models.LanguageModel:
             result_callback = scoring.LogLinearCallback(
                 args, model_args, tokens, f_debug_out, ranker_callback)
-        elif model_args.type == models.VectorSpaceLanguageModel:
+        elif model_args.type in (models.VectorSpaceLanguageModel,
+                                 models.VectorSpaceSoftmaxLanguageModel):
             result_callback = scoring.VectorSpaceCallback(
                 entity_representations,
                 args, model_args, tokens, f_debug_out, ranker_callback,

@@ -35,6 +35,8 @@ from sert_amd.utils import argparse_utils, embedding_utils, logging_utils  # noq
 MODELS = {
     'loglinear': models.LanguageModel,
     'vectorspace': models.VectorSpaceLanguageModel,
+    # additive (not in the reference): vectorspace encoder + full softmax over entities
+    'vectorspace_softmax': models.VectorSpaceSoftmaxLanguageModel,
 }
 
 
@@ -186,7 +188,8 @@ def main(argv=None):
 
     if args.type == models.LanguageModel:
         model_options.update(output_layer_size=num_entities)
-    elif args.type == models.VectorSpaceLanguageModel:
+    elif args.type in (models.VectorSpaceLanguageModel,
+                       models.VectorSpaceSoftmaxLanguageModel):
         entity_representations = glorot_uniform(
             (num_entities, args.entity_representation_size))
 

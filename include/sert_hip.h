@@ -33,7 +33,12 @@ typedef struct sert_model sert_model;
 /* model kind: bin/train.py:21-24 */
 enum {
     SERT_KIND_LOGLINEAR = 0,   /* sert.models.LanguageModel            (models.py:804) */
-    SERT_KIND_VECTORSPACE = 1  /* sert.models.VectorSpaceLanguageModel (models.py:1024) */
+    SERT_KIND_VECTORSPACE = 1, /* sert.models.VectorSpaceLanguageModel (models.py:1024) */
+    /* ADDITIVE, not in the reference (BASELINE.json configs[1] wording
+     * "embed gather + MFMA projection + full softmax"): the vectorspace encoder
+     * (gather, mean-pool, tanh projection) scored against ALL entities,
+     * logits = clip(t).R_e^T, clipped softmax cross-entropy, dense L2, Adam. */
+    SERT_KIND_VECTORSPACE_SOFTMAX = 2
 };
 
 /* data split: ModelBase.TRAIN / VALIDATE givens (models.py:482-522) */

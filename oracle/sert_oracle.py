@@ -248,6 +248,74 @@ class VectorSpaceOracle(object):
         return np.tanh(avg @ self.W + self.b).astype(self.dtype)
 
 
+class VectorSpaceSoftmaxOracle(VectorSpaceOracle):
+    """ADDITIVE variant, not in the reference (BASELINE.json
+    configs[1] "embed gather + MFMA projection + full softmax"): the vectorspace
+    encoder of models.py:1044-1068 scored against ALL entities,
+    logits = clip(t) . R_e^T, loss = clipped categorical cross-entropy
+    (clipped_categorical_crossentropy, models.py:289-292), same L2 and Adam.
+    Its only pin is this restatement + finite differences."""
+
+    def __init__(self, batch_size, window_size, R_w, R_e, W, b, regularization_lambda,
+                 dtype=np.float32, adam_kwargs=None):
+        VectorSpaceOracle.__init__(self, batch_size, window_size, 0, R_w, R_e, W, b,
+                                   regularization_lambda, dtype, adam_kwargs)
+
+    def forward(self, X, y):
+        dt = self.dtype
+        T = dt.type
+        lo, hi = clip_bounds(dt)
+        X = np.asarray(X).astype(np.int64)
+        h = (_sum(self.R_w[X], axis=1, dtype=dt) / T(self.n)).astype(dt)
+        a = (h @ self.W + self.b).astype(dt)
+        t = np.tanh(a)
+        p = np.clip(t, -hi, hi)
+        Z = (p @ self.R_e.T).astype(dt)
+        P = softmax_rows(Z)
+        py = P[np.arange(len(y)), np.asarray(y, dtype=np.int64)]
+        loss = -np.log(np.clip(py, lo, hi))
+        return dict(h=h, a=a, t=t, p=p, Z=Z, P=P, py=py, loss=loss.astype(dt))
+
+    def eval_loss(self, X, y):
+        f = self.forward(X, y)
+        return _sum(f['loss'], dtype=self.dtype) / self.dtype.type(len(y))
+
+    def loss_and_grads(self, X, y, w):
+        dt = self.dtype
+        T = dt.type
+        lo, hi = clip_bounds(dt)
+        B = len(y)
+        f = self.forward(X, y)
+        w = np.asarray(w, dtype=dt)
+        loss_train = T(_sum(f['loss'] * w, dtype=dt) / T(B)) + self.regularizer()
+        g = (w / T(B)).astype(dt)
+        inside = ((f['py'] >= lo) & (f['py'] <= hi)).astype(dt)
+        Y = np.zeros_like(f['P'])
+        Y[np.arange(B), np.asarray(y, dtype=np.int64)] = 1
+        dZ = ((g * inside)[:, None] * (f['P'] - Y)).astype(dt)
+        dR_e = (dZ.T @ f['p']).astype(dt)
+        dp = (dZ @ self.R_e).astype(dt)
+        t = f['t']
+        da = (dp * ((t >= -hi) & (t <= hi)).astype(dt) * (T(1) - t * t)).astype(dt)
+        dW = (f['h'].T @ da).astype(dt)
+        db = _sum(da, axis=0, dtype=dt)
+        dh = (da @ self.W.T).astype(dt)
+        dR_w = np.zeros_like(self.R_w)
+        np.add.at(dR_w, np.asarray(X).astype(np.int64).ravel(), np.repeat(dh / T(self.n), self.n, axis=0))
+        if self.lam > 0.0:
+            k = T(self.lam) / T(self.B)
+            dW += k * self.W
+            dR_w += k * self.R_w
+            dR_e += k * self.R_e
+        f.update(dZ=dZ, dp=dp, da=da, dh=dh)
+        return loss_train, [dR_e, dR_w, dW, db], f
+
+    def train_step(self, X, y, w):
+        loss, grads, _ = self.loss_and_grads(X, y, w)
+        self.opt.update(self.params(), grads)
+        return loss
+
+
 # --------------------------------------------------------------------------- #
 # loglinear  (sert/models.py:804-890)
 # --------------------------------------------------------------------------- #

@@ -11,7 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libsert_hip.so')
 
-KIND_LOGLINEAR, KIND_VECTORSPACE = 0, 1
+KIND_LOGLINEAR, KIND_VECTORSPACE, KIND_VECTORSPACE_SOFTMAX = 0, 1, 2
 SPLIT_TRAIN, SPLIT_VALIDATE = 0, 1
 
 T_RW, T_RE, T_W, T_B = 0, 1, 2, 3

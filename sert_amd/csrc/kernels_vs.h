@@ -245,6 +245,60 @@ __global__ __launch_bounds__(256) void vs_nce_scalar(const float* __restrict__ T
     if (lane == 0) rowloss[i] = wi * loss;
 }
 
+// ---- full-softmax variant (SERT_KIND_VECTORSPACE_SOFTMAX; additive) -----------
+// In place on the logits Z (B, V): P = softmax(Z_i);
+//   loss_i = -log clip(P[y_i], eps, 1-eps)      (same clipping as models.py:289-292)
+//   TRAIN: Z_i <- dL/dZ_i = g_i * [eps <= P_y <= 1-eps] * (P - onehot(y_i)),  g_i = w_i / B
+// One wave per row.
+template <bool TRAIN>
+__global__ __launch_bounds__(256) void fs_softmax_ce(float* __restrict__ Z,
+                                                     const int32_t* __restrict__ y,
+                                                     const float* __restrict__ w,
+                                                     float* __restrict__ rowloss, int B, int V,
+                                                     float inv_batch) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= B) return;
+    float* z = Z + (size_t)i * V;
+    float mx = -INFINITY;
+    for (int e = lane; e < V; e += 64) mx = fmaxf(mx, z[e]);
+    mx = wave_max(mx);
+    float sm = 0.f;
+    for (int e = lane; e < V; e += 64) sm += expf(z[e] - mx);
+    sm = wave_sum(sm);
+    const int yi = y[i];
+    const float py = expf(z[yi] - mx) / sm;
+    const float pyc = fminf(fmaxf(py, SERT_CLIP_LO), SERT_CLIP_HI);
+    const float wi = TRAIN ? w[i] : 1.f;
+    if (lane == 0) rowloss[i] = -wi * logf(pyc);
+    if (TRAIN) {
+        const bool inside = (py >= SERT_CLIP_LO) && (py <= SERT_CLIP_HI);
+        const float g = inside ? wi * inv_batch : 0.f;
+        for (int e = lane; e < V; e += 64) {
+            const float p = expf(z[e] - mx) / sm;
+            z[e] = g * (p - (e == yi ? 1.f : 0.f));
+        }
+    }
+}
+
+// da = dp * [|t| <= 1-eps] * (1 - t^2), in place on dp   (Clip.grad + tanh')
+__global__ void vs_tanh_backward(float* __restrict__ DP, const float* __restrict__ T, size_t count) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const float t = T[i];
+        const bool inside = (t >= -SERT_CLIP_HI) && (t <= SERT_CLIP_HI);
+        DP[i] = inside ? DP[i] * (1.0f - t * t) : 0.f;
+    }
+}
+
+// P = clip(T), elementwise (models.py:1065-1068) -- materialised only for the
+// full-softmax variant, whose logits GEMM consumes it
+__global__ void vs_clip(const float* __restrict__ T, float* __restrict__ P, size_t count) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < count;
+         i += (size_t)gridDim.x * blockDim.x)
+        P[i] = fminf(fmaxf(T[i], -SERT_CLIP_HI), SERT_CLIP_HI);
+}
+
 // out = tanh(avg.W + b) is done by the GEMM with the EPI_BIAS_TANH epilogue.
 
 }  // namespace sert

@@ -78,6 +78,7 @@ struct sert_model {
 
     // per-batch activations
     float *H = nullptr, *T = nullptr, *DA = nullptr, *DH = nullptr, *rowloss = nullptr;
+    float* DH2 = nullptr;         // full-softmax variant: p = clip(t)  (B, d_e)
     int32_t* neg = nullptr;       // (B, z) device negatives
     int64_t* neg_stage = nullptr; // (B, z) int64 staging for host-supplied negatives
     // entity-gradient machinery (kernels_egrad.h), all (B*(1+z)) long

@@ -124,7 +124,10 @@ static inline int grid_for(int64_t work_items, int block = 256, int cap = 256 * 
 }
 static inline size_t round_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
 
-static bool is_vs(const sert_model* m) { return m->cfg.kind == SERT_KIND_VECTORSPACE; }
+// vectorspace-shaped parameters (R_e, projection W/b): both the reference's NCE
+// model and the additive full-softmax variant
+static bool is_vs(const sert_model* m) { return m->cfg.kind != SERT_KIND_LOGLINEAR; }
+static bool is_fs(const sert_model* m) { return m->cfg.kind == SERT_KIND_VECTORSPACE_SOFTMAX; }
 
 struct TensorRef {
     float* ptr;
@@ -391,6 +394,90 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
     return 0;
 }
 
+// ---- the full-softmax vectorspace variant (additive) ----------------------------
+template <bool TRAIN>
+static int fs_forward(sert_model* m, const DataSplit& ds, int64_t batch_index) {
+    const auto& c = m->cfg;
+    const int B = c.batch_size, n = c.window_size, dw = c.word_dim, de = c.entity_dim, V = c.num_entities;
+    const size_t row0 = (size_t)batch_index * B;
+    {
+        ScopedTimer t(m, TG_GATHER);
+        SERT_ID_DISPATCH(c.id_bytes, {
+            const IdT* X = (const IdT*)ds.x + row0 * n;
+            if (dw % 4 == 0)
+                hipLaunchKernelGGL((vs_gather_mean<IdT, 4>), dim3(grid_for((int64_t)B * dw / 4, 256, 1 << 20)),
+                                   dim3(256), 0, m->stream, X, m->rw, m->H, B, n, dw);
+            else
+                hipLaunchKernelGGL((vs_gather_mean<IdT, 1>), dim3(grid_for((int64_t)B * dw, 256, 1 << 20)),
+                                   dim3(256), 0, m->stream, X, m->rw, m->H, B, n, dw);
+        });
+    }
+    {
+        ScopedTimer t(m, TG_GEMM_FWD);
+        launch_gemm<false, false, EPI_BIAS_TANH>(m->stream, m->H, m->W, m->T, m->b, B, de, dw, dw, de, de);
+        // p = clip(t) ; logits = p.R_e^T   (B, V)
+        hipLaunchKernelGGL(vs_clip, dim3(grid_for((int64_t)B * de)), dim3(256), 0, m->stream, m->T, m->DH2,
+                           (size_t)B * de);
+        launch_gemm<false, true, EPI_STORE>(m->stream, m->DH2, m->re, m->Z, nullptr, B, V, de, de, de, V);
+    }
+    {
+        ScopedTimer t(m, TG_LOSS);
+        const float inv_batch = 1.0f / (float)c.global_batch_size;
+        hipLaunchKernelGGL((fs_softmax_ce<TRAIN>), dim3(cdiv(B, 4)), dim3(256), 0, m->stream, m->Z,
+                           ds.y + row0, TRAIN ? ds.w + row0 : nullptr, m->rowloss, B, V, inv_batch);
+    }
+    return 0;
+}
+
+static int fs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) {
+    const auto& c = m->cfg;
+    const int B = c.batch_size, n = c.window_size, dw = c.word_dim, de = c.entity_dim, V = c.num_entities;
+    {
+        // dR_e (V, d_e) = dZ^T.p : reduction over the batch, split-K, order-fixed combine
+        ScopedTimer t(m, TG_EGRAD);
+        const int tiles = cdiv(de, GN) * cdiv(V, GM);
+        int splits = std::max(1, std::min(cdiv(B, GK), cdiv(1024, tiles)));
+        int kper = (int)round_up(cdiv(B, splits), GK);
+        splits = cdiv(B, kper);
+        const size_t mn = (size_t)V * de;
+        launch_gemm<true, false, EPI_STORE>(m->stream, m->Z, m->DH2, m->part, nullptr, V, de, B, V, de, de,
+                                            splits, kper, mn);
+        hipLaunchKernelGGL(reduce_partials, dim3(cdiv(mn, 64)), dim3(256), 0, m->stream, m->part, splits, mn,
+                           mn, m->g_re, mn, m->g_re);
+    }
+    {
+        // dp = dZ.R_e (B, d_e) ; da = dp * clip'(t) * tanh'(a)
+        ScopedTimer t(m, TG_GEMM_DX);
+        launch_gemm<false, false, EPI_STORE>(m->stream, m->Z, m->re, m->DA, nullptr, B, de, V, V, de, de);
+        hipLaunchKernelGGL(vs_tanh_backward, dim3(grid_for((int64_t)B * de)), dim3(256), 0, m->stream, m->DA,
+                           m->T, (size_t)B * de);
+    }
+    {
+        static const int want_splits = [] { const char* e = getenv("SERT_DW_SPLITS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
+        int splits = std::min(want_splits, cdiv(B, GK));
+        int kper = (int)round_up(cdiv(B, splits), GK);
+        splits = cdiv(B, kper);
+        const size_t mn = (size_t)dw * de;
+        const size_t stride = mn + de;
+        {
+            ScopedTimer t(m, TG_GEMM_DW);
+            launch_gemm<true, false, EPI_STORE, true>(m->stream, m->H, m->DA, m->part, nullptr, dw, de, B, dw, de,
+                                                      de, splits, kper, stride);
+        }
+        {
+            ScopedTimer t(m, TG_SPLITK);
+            hipLaunchKernelGGL(reduce_partials, dim3(cdiv(stride, 64)), dim3(256), 0, m->stream, m->part, splits,
+                               stride, stride, m->g_w, mn, m->g_b);
+        }
+        launch_gemm<false, true, EPI_STORE>(m->stream, m->DA, m->W, m->DH, nullptr, B, dw, de, de, de, dw);
+    }
+    {
+        ScopedTimer t(m, TG_SCATTER);
+        SERT_TRY(word_grad_segsum(m, ds, batch_index, m->DH, (float)n));
+    }
+    return 0;
+}
+
 // ---- the loglinear step -------------------------------------------------------
 template <bool TRAIN>
 static int ll_forward(sert_model* m, const DataSplit& ds, int64_t batch_index) {
@@ -541,7 +628,10 @@ static int train_step_async(sert_model* m, int64_t batch_index, const int64_t* n
     if (ds.N == 0) SERT_FAIL("no training data uploaded");
     if (batch_index < 0 || (batch_index + 1) * (int64_t)B > ds.N) SERT_FAIL("batch_index out of range");
     SERT_HIP(hipMemsetAsync(m->gflat, 0, m->gflat_alloc * sizeof(float), m->stream));
-    if (is_vs(m)) {
+    if (is_fs(m)) {
+        SERT_TRY(fs_forward<true>(m, ds, batch_index));
+        SERT_TRY(fs_backward(m, ds, batch_index));
+    } else if (is_vs(m)) {
         SERT_TRY(vs_negatives(m, negatives, (uint64_t)m->step * 2));
         SERT_TRY(vs_forward<true>(m, ds, batch_index));
         SERT_TRY(vs_backward(m, ds, batch_index));
@@ -588,13 +678,15 @@ int sert_device_info(int device, char* buf, size_t buflen) {
 int sert_create(const sert_config* cfg, sert_model** out) {
     if (!cfg || !out) SERT_FAIL("null argument");
     if (cfg->struct_size != sizeof(sert_config)) SERT_FAIL("sert_config size mismatch (ABI)");
-    if (cfg->kind != SERT_KIND_LOGLINEAR && cfg->kind != SERT_KIND_VECTORSPACE) SERT_FAIL("bad kind");
+    if (cfg->kind != SERT_KIND_LOGLINEAR && cfg->kind != SERT_KIND_VECTORSPACE &&
+        cfg->kind != SERT_KIND_VECTORSPACE_SOFTMAX)
+        SERT_FAIL("bad kind");
     if (cfg->batch_size <= 0 || cfg->window_size <= 0 || cfg->vocab_size <= 0 ||
         cfg->num_entities <= 0 || cfg->word_dim <= 0)
         SERT_FAIL("sizes must be positive");
     if (cfg->global_batch_size < cfg->batch_size) SERT_FAIL("global_batch_size < batch_size");
     if (cfg->id_bytes != 1 && cfg->id_bytes != 2 && cfg->id_bytes != 4) SERT_FAIL("id_bytes must be 1, 2 or 4");
-    if (cfg->kind == SERT_KIND_VECTORSPACE) {
+    if (cfg->kind != SERT_KIND_LOGLINEAR) {
         if (cfg->entity_dim <= 0 || cfg->entity_dim > 512) SERT_FAIL("entity_dim must be in [1, 512]");
         if (cfg->num_negatives < 0) SERT_FAIL("num_negatives must be >= 0");
     }
@@ -646,6 +738,13 @@ int sert_create(const sert_config* cfg, sert_model** out) {
             SERT_TRY(dzalloc(&m->neg, std::max<size_t>(4, B * c.num_negatives), s));
             SERT_TRY(dzalloc(&m->neg_stage, std::max<size_t>(4, B * c.num_negatives), s));
             part = (size_t)1024 * (dw * de + de);
+            if (c.kind == SERT_KIND_VECTORSPACE_SOFTMAX) {
+                SERT_TRY(dzalloc(&m->Z, B * V, s));       // logits -> dL/dlogits
+                SERT_TRY(dzalloc(&m->DH2, B * de, s));    // p = clip(t)
+                const size_t tiles = (size_t)cdiv(de, GN) * cdiv(V, GM);
+                const size_t sp = std::max<size_t>(1, cdiv(1024, tiles)) + 1;
+                part = std::max(part, sp * V * de);
+            }
             const size_t total = B * (c.num_negatives + 1);
             SERT_TRY(dzalloc(&m->cand, total, s));        SERT_TRY(dzalloc(&m->cand_sorted, total + 1, s));
             SERT_TRY(dzalloc(&m->pair_sorted, total, s));
@@ -702,7 +801,7 @@ int sert_destroy(sert_model* m) {
     if (m->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(m->comm);
     float* bufs[] = {m->rw, m->re, m->W, m->b, m->s0_rw, m->s0_re, m->s0_w, m->s0_b, m->s1_rw,
                      m->s1_re, m->s1_w, m->s1_b, m->gflat, m->H, m->T, m->DA, m->DH, m->rowloss,
-                     m->G, m->Z, m->J, m->DG, m->part, m->wpart, m->red_loss, m->red_sq, m->d_loss,
+                     m->G, m->Z, m->J, m->DG, m->DH2, m->part, m->wpart, m->red_loss, m->red_sq, m->d_loss,
                      m->d_losses};
     for (float* p : bufs) (void)hipFree(p);
     (void)hipFree(m->neg); (void)hipFree(m->neg_stage);
@@ -872,7 +971,9 @@ int sert_eval_batch(sert_model* m, int split, int64_t batch_index, const int64_t
     const int B = m->cfg.batch_size;
     if (m->cfg.inference_only) SERT_FAIL("model was created inference_only");
     if (batch_index < 0 || (batch_index + 1) * (int64_t)B > ds.N) SERT_FAIL("batch_index out of range");
-    if (is_vs(m)) {
+    if (is_fs(m)) {
+        SERT_TRY(fs_forward<false>(m, ds, batch_index));
+    } else if (is_vs(m)) {
         SERT_TRY(vs_negatives(m, negatives, (uint64_t)(m->eval_draws++) * 2 + 1));
         SERT_TRY(vs_forward<false>(m, ds, batch_index));
     } else {

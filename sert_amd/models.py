@@ -657,3 +657,54 @@ class VectorSpaceLanguageModel(VectorSpaceLanguageModelBase):
     def set_dense(self, W, b):
         self._engine.set_tensor(_capi.T_W, W)
         self._engine.set_tensor(_capi.T_B, b)
+
+
+class VectorSpaceSoftmaxLanguageModel(VectorSpaceLanguageModelBase):
+    """ADDITIVE model, not in the reference: the vectorspace
+    encoder (window mean-pool -> tanh projection -> clip) scored against ALL
+    entities -- logits = p . R_e^T, clipped softmax cross-entropy -- instead of
+    NCE against z sampled negatives; same dense L2 and Adam.  This is the
+    "embed gather + MFMA projection + full softmax" workload BASELINE.json names
+    for the LSE config.  predict_fn and get_state() are those of the vectorspace
+    model, so bin/query.py ranks with it unchanged."""
+
+    _STATE_TENSORS = VectorSpaceLanguageModel._STATE_TENSORS
+
+    def __init__(self,
+                 batch_size, window_size,
+                 representations_init,
+                 entity_representations_init,
+                 regularization_lambda,
+                 training_set,
+                 validation_set,
+                 num_negative_samples=None):
+        super(VectorSpaceSoftmaxLanguageModel, self).__init__(
+            batch_size=batch_size,
+            window_size=window_size,
+            num_negative_samples=None,
+            representations_init=representations_init,
+            entity_representations_init=entity_representations_init,
+            regularization_lambda=regularization_lambda,
+            training_set=training_set,
+            validation_set=validation_set)
+
+        self._create_engine(
+            _capi.KIND_VECTORSPACE_SOFTMAX, self.vocabulary_size,
+            self.representation_size, self.num_entities,
+            self.entity_representation_size, 0, 'adam')
+
+        dense_W = _glorot_uniform(
+            (self.representation_size, self.entity_representation_size))
+        dense_W = distributed.broadcast_array(dense_W)
+        self._engine.set_tensor(_capi.T_RW, representations_init)
+        self._engine.set_tensor(_capi.T_RE, entity_representations_init)
+        self._engine.set_tensor(_capi.T_W, dense_W)
+        self._engine.set_tensor(
+            _capi.T_B,
+            np.zeros(self.entity_representation_size, dtype=np.float32))
+
+        self.predict_fn = VectorSpacePredictFn(model=self)
+
+    get_dense_weights = VectorSpaceLanguageModel.get_dense_weights
+    get_dense_bias = VectorSpaceLanguageModel.get_dense_bias
+    set_dense = VectorSpaceLanguageModel.set_dense

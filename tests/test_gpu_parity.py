@@ -263,3 +263,41 @@ def test_model_with_empty_validation_and_short_data(hip_lib):
     m._engine.set_tensor(C.T_W, np.full((d, d), np.nan, np.float32))
     with pytest.raises(RuntimeError):
         m.train()
+
+
+@pytest.mark.parametrize('dims', [
+    dict(B=64, n=5, Vw=500, Ve=37, dw=32, de=48),
+    dict(B=96, n=3, Vw=200, Ve=1000, dw=30, de=68),
+    dict(B=256, n=10, Vw=3000, Ve=1000, dw=128, de=128),     # C2-shaped
+])
+def test_vectorspace_softmax_variant_steps(hip_lib, dims):
+    """Additive full-softmax variant (SERT_KIND_VECTORSPACE_SOFTMAX) vs its oracle."""
+    B, n = dims['B'], dims['n']
+    steps = 3
+    p = U.make_vs_problem(8, B * steps, n, 0, dims['Vw'], dims['Ve'], dims['dw'], dims['de'], zipf=True)
+    eng = C.Engine(kind=C.KIND_VECTORSPACE_SOFTMAX, batch_size=B, global_batch_size=B, window_size=n,
+                   vocab_size=dims['Vw'], num_entities=dims['Ve'], word_dim=dims['dw'],
+                   entity_dim=dims['de'], num_negatives=0, id_bytes=p['X'].dtype.itemsize, device=0,
+                   keep_grads=1, deterministic=1, lambda_=0.01, lr=1e-3, beta1=0.9, beta2=0.999,
+                   eps=1e-8, seed=1)
+    for which, a in ((C.T_RW, p['Rw']), (C.T_RE, p['Re']), (C.T_W, p['W']), (C.T_B, p['b'])):
+        eng.set_tensor(which, a)
+    eng.upload_dataset(C.SPLIT_TRAIN, p['X'], y_int=p['y'], w=p['w'])
+    ora = O.VectorSpaceSoftmaxOracle(B, n, p['Rw'], p['Re'], p['W'], p['b'], 0.01)
+    for s in range(steps):
+        sl = slice(s * B, (s + 1) * B)
+        loss_ref, grads_ref, f = ora.loss_and_grads(p['X'][sl], p['y'][sl], p['w'][sl])
+        ora.opt.update(ora.params(), grads_ref)
+        loss = eng.train_batch(s)
+        assert abs(loss - loss_ref) <= LOSS_TOL * abs(loss_ref), (s, loss, loss_ref)
+        dRe, dRw, dW, db = grads_ref
+        assert U.rel_err(eng.get_tensor(C.T_GRAD_RE), dRe.ravel()) < GRAD_TOL
+        assert U.rel_err(eng.get_tensor(C.T_GRAD_RW), dRw.ravel()) < GRAD_TOL
+        assert U.rel_err(eng.get_tensor(C.T_GRAD_W), dW.ravel()) < GRAD_TOL
+        assert U.rel_err(eng.get_tensor(C.T_GRAD_B), db.ravel()) < GRAD_TOL
+    assert U.rel_err(eng.get_tensor(C.T_RW), ora.R_w.ravel()) < PARAM_TOL
+    assert U.rel_err(eng.get_tensor(C.T_RE), ora.R_e.ravel()) < PARAM_TOL
+    ev = eng.eval_batch(C.SPLIT_TRAIN, 0)
+    ev_ref = ora.eval_loss(p['X'][:B], p['y'][:B])
+    assert abs(ev - ev_ref) <= LOSS_TOL * abs(ev_ref)
+    eng.close()

@@ -131,3 +131,22 @@ def test_theano_sigmoid_thresholds():
     x = np.array([-100, -88.5, 0, 15.5, 100], dtype=np.float32)
     s = O.theano_sigmoid(x)
     assert s[0] == 0 and s[1] == 0 and s[2] == 0.5 and s[3] == 1 and s[4] == 1
+
+
+def test_vectorspace_softmax_variant_gradients():
+    """The additive full-softmax variant: FD check + W=0 known answer (log V_e)."""
+    rng = np.random.RandomState(5)
+    B, n, Vw, Ve, dw, de = 6, 3, 15, 7, 5, 4
+    m = O.VectorSpaceSoftmaxOracle(B, n, O.glorot_uniform(rng, (Vw, dw), np.float64),
+                                   O.glorot_uniform(rng, (Ve, de), np.float64),
+                                   O.glorot_uniform(rng, (dw, de), np.float64), 0.1 * rng.randn(de),
+                                   0.01, np.float64)
+    X = rng.randint(0, Vw, (B, n))
+    y = rng.randint(0, Ve, B)
+    w = rng.uniform(.5, 2, B)
+    _, grads, _ = m.loss_and_grads(X, y, w)
+    num = _fd(m.params(), lambda: m.loss_and_grads(X, y, w)[0])
+    for a, b in zip(grads, num):
+        assert np.abs(a - b).max() <= 1e-6 * max(1e-12, np.abs(b).max())
+    m.R_e[:] = 0
+    assert abs(m.eval_loss(X, y) - np.log(Ve)) < 1e-9

@@ -21,10 +21,13 @@ def short(name):
 
 
 def per_kernel(path, counter):
+    """Keyed by 'kernel @grid': the same kernel launched at different sizes (e.g. the
+    optimiser over a 12.8 M-element table and over a 128-element bias) stays apart."""
     db = sqlite3.connect(path)
-    rows = db.execute("select kernel_name, count(*), avg(value), avg(duration) from counters_collection "
-                      "where counter_name = ? group by kernel_name", (counter,)).fetchall()
-    return {short(r[0]): dict(calls=r[1], kib=r[2], us=r[3] / 1e3) for r in rows}
+    rows = db.execute("select kernel_name, grid_size, count(*), avg(value), avg(duration) from "
+                      "counters_collection where counter_name = ? group by kernel_name, grid_size",
+                      (counter,)).fetchall()
+    return {'%s @%d' % (short(r[0]), r[1]): dict(calls=r[2], kib=r[3], us=r[4] / 1e3) for r in rows}
 
 
 def main(argv):

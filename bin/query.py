@@ -23,128 +23,112 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from sert_amd import inference, models, scoring  # noqa: E402
-from sert_amd.utils import argparse_utils, logging_utils, trec_utils  # noqa: E402
+from sert_amd.utils import argparse_utils as au  # noqa: E402
+from sert_amd.utils import logging_utils, trec_utils  # noqa: E402
+
+VECTORSPACE_TYPES = (models.VectorSpaceLanguageModel, models.VectorSpaceSoftmaxLanguageModel)
 
 
 def build_parser():
-    parser = argparse.ArgumentParser()
+    parser = argparse.ArgumentParser(description=__doc__.split('\n')[0])
     parser.add_argument('--loglevel', type=str, default='INFO')
-
-    parser.add_argument('--meta', type=argparse_utils.existing_file_path, required=True)
-    parser.add_argument('--model', type=argparse_utils.existing_file_path, required=True)
-
-    parser.add_argument('--topics', type=argparse_utils.existing_file_path, nargs='+')
-
-    parser.add_argument('--top', type=argparse_utils.positive_int, default=None)
-
-    parser.add_argument('--run_out', type=argparse_utils.nonexisting_file_path,
-                        required=True)
-
-    # additive
+    parser.add_argument('--meta', type=au.existing_file_path, required=True)
+    parser.add_argument('--model', type=au.existing_file_path, required=True)
+    parser.add_argument('--topics', type=au.existing_file_path, nargs='+')
+    parser.add_argument('--top', type=au.positive_int, default=None)
+    parser.add_argument('--run_out', type=au.nonexisting_file_path, required=True)
     parser.add_argument('--no_batch', action='store_true', default=False)
     parser.add_argument('--device', type=int, default=0)
     return parser
 
 
 def load_model(path):
-    """[args, predict_fn, R_w, (R_e)] (train.py:289-300)."""
+    """Pickle stream of bin/train.py: namespace, predict_fn, R_w[, R_e][, extras]."""
+    objects = []
     with open(path, 'rb') as f:
-        model_args, predict_fn = (pickle.load(f) for _ in range(2))
-
-        word_representations = pickle.load(f)
-
-        try:
-            entity_representations = pickle.load(f)
-        except EOFError:
-            entity_representations = None
-        if isinstance(entity_representations, dict):   # trailing optimiser-state pickle
-            entity_representations = None
+        while len(objects) < 5:
+            try:
+                objects.append(pickle.load(f))
+            except EOFError:
+                break
+    model_args, predict_fn, word_representations = objects[:3]
+    entity_representations = None
+    if len(objects) > 3 and not isinstance(objects[3], dict):   # dict = optimiser-state trailer
+        entity_representations = objects[3]
     return model_args, predict_fn, word_representations, entity_representations
+
+
+def load_meta(path):
+    """Five pickles written by bin/prepare.py:373-376."""
+    with open(path, 'rb') as f:
+        return tuple(pickle.load(f) for _ in range(5))
+
+
+def topic_tokens(text, words):
+    """In-vocabulary token ids of a topic; OOV terms are dropped (query.py:129-137)."""
+    ids = []
+    for term in trec_utils.parse_query(text):
+        entry = words.get(term)
+        if entry is None:
+            logging.debug('Term "%s" is OOV.', term)
+        else:
+            ids.append(entry.id)
+    return ids
 
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
-
     try:
         logging_utils.configure_logging(args)
     except IOError:
         return -1
 
-    model_args, predict_fn, word_representations, entity_representations = \
-        load_model(args.model)
+    model_args, predict_fn, word_representations, entity_representations = load_model(args.model)
+    data_args, words, tokens, entity_indices_inv, _entity_assocs = load_meta(args.meta)
 
-    with open(args.meta, 'rb') as f:
-        (data_args,
-         words, tokens,
-         entity_indices_inv, entity_assocs) = (
-            pickle.load(f) for _ in range(5))
+    handles = [open(name, 'r') for name in args.topics]
+    try:
+        topics = trec_utils.parse_topics(handles)
+    finally:
+        for handle in handles:
+            handle.close()
 
-    topic_f = [open(filename, 'r') for filename in args.topics]
-    topics = trec_utils.parse_topics(topic_f)
-    for f_ in topic_f:
-        f_.close()
+    by_entity = collections.defaultdict(list)   # entity profiling: topics per entity
+    by_topic = collections.defaultdict(list)    # entity finding: entities per topic
 
-    model_name = os.path.basename(args.model)
+    def collect(topic_id, entity_indices, scores):
+        for internal_id, score in zip(entity_indices, scores):
+            entity_id = entity_indices_inv[internal_id]
+            by_entity[entity_id].append((score, topic_id))
+            by_topic[topic_id].append((score, entity_id))
 
-    # Entity profiling / entity finding.
-    topics_per_entity = collections.defaultdict(list)
-    entities_per_topic = collections.defaultdict(list)
-
-    def ranker_callback(topic_id, top_ranked_indices, top_ranked_values):
-        for entity_internal_id, relevance in zip(top_ranked_indices, top_ranked_values):
-            entity_id = entity_indices_inv[entity_internal_id]
-
-            topics_per_entity[entity_id].append((relevance, topic_id))
-            entities_per_topic[topic_id].append((relevance, entity_id))
-
-    with open('{0}_debug'.format(args.run_out), 'w') as f_debug_out:
-        if model_args.type == models.LanguageModel:
-            result_callback = scoring.LogLinearCallback(
-                args, model_args, tokens, f_debug_out, ranker_callback)
-        elif model_args.type in (models.VectorSpaceLanguageModel,
-                                 models.VectorSpaceSoftmaxLanguageModel):
-            result_callback = scoring.VectorSpaceCallback(
-                entity_representations,
-                args, model_args, tokens, f_debug_out, ranker_callback,
-                device=args.device)
+    with open(args.run_out + '_debug', 'w') as debug_out:
+        if model_args.type is models.LanguageModel:
+            callback = scoring.LogLinearCallback(args, model_args, tokens, debug_out, collect)
+        elif model_args.type in VECTORSPACE_TYPES:
+            callback = scoring.VectorSpaceCallback(entity_representations, args, model_args, tokens,
+                                                   debug_out, collect, device=args.device)
         else:
             raise RuntimeError('Unknown model type %s.' % model_args.type)
 
-        batcher = inference.create(
-            predict_fn, word_representations,
-            model_args.batch_size, data_args.window_size, len(words),
-            result_callback, batched=not args.no_batch)
-
+        batcher = inference.create(predict_fn, word_representations, model_args.batch_size,
+                                   data_args.window_size, len(words), callback,
+                                   batched=not args.no_batch)
         logging.info('Batching queries using %s.', batcher)
 
-        for q_id, (topic_id, terms) in enumerate(topics.items()):
-            query_terms = trec_utils.parse_query(terms)
-
-            logging.debug('Query (%d/%d) %s: %s (%s)',
-                          q_id + 1, len(topics), topic_id, query_terms, terms)
-
-            query_tokens = []
-            for term in query_terms:
-                if term not in words:
-                    logging.debug('Term "%s" is OOV.', term)
-                    continue
-
-                query_tokens.append(words[term].id)
-
-            if not query_tokens:
-                logging.warning('Skipping query with terms "%s".', terms)
-                continue
-
-            batcher.submit(query_tokens, topic_id=topic_id)
-
+        for position, (topic_id, text) in enumerate(topics.items(), 1):
+            ids = topic_tokens(text, words)
+            logging.debug('Query (%d/%d) %s: %s', position, len(topics), topic_id, text)
+            if ids:
+                batcher.submit(ids, topic_id=topic_id)
+            else:
+                logging.warning('Skipping query with terms "%s".', text)
         batcher.process()
 
-    with io.open('{0}_ep'.format(args.run_out), 'w', encoding='utf8') as out_ep_run:
-        trec_utils.write_run(model_name, topics_per_entity, out_ep_run)
-
-    with io.open('{0}_ef'.format(args.run_out), 'w', encoding='utf8') as out_ef_run:
-        trec_utils.write_run(model_name, entities_per_topic, out_ef_run)
-
+    run_name = os.path.basename(args.model)
+    for suffix, ranking in (('_ep', by_entity), ('_ef', by_topic)):
+        with io.open(args.run_out + suffix, 'w', encoding='utf8') as out:
+            trec_utils.write_run(run_name, ranking, out)
     logging.info('Saved run to %s.', args.run_out)
 
 

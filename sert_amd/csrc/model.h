@@ -68,8 +68,9 @@ struct sert_model {
     float *s0_rw = nullptr, *s0_re = nullptr, *s0_w = nullptr, *s0_b = nullptr;
     float *s1_rw = nullptr, *s1_re = nullptr, *s1_w = nullptr, *s1_b = nullptr;
 
-    // gradients: ONE flat allocation [g_re | g_rw | g_w | g_b | loss_sum(1) | pad]
-    // so that the data-parallel exchange is a single all-reduce.
+    // gradients: ONE flat allocation [g_rw | g_re | g_w | g_b | loss_sum(1) | pad].
+    // Data-parallel exchange = two all-reduces over it: the word-table slice as soon
+    // as it is complete (overlapping the rest of the backward), then the remainder.
     float* gflat = nullptr;
     size_t gflat_count = 0;
     float *g_re = nullptr, *g_rw = nullptr, *g_w = nullptr, *g_b = nullptr, *g_loss = nullptr;
@@ -114,6 +115,9 @@ struct sert_model {
     // data parallel
     int rank = 0, world = 1;
     void* comm = nullptr;         // ncclComm_t
+    hipStream_t comm_stream = nullptr;          // all collectives are issued here, in one fixed order
+    hipEvent_t ev_rw_ready = nullptr, ev_rest_ready = nullptr, ev_ar_done = nullptr;
+    size_t ar_split = 0;          // gflat[0, ar_split) = word-table gradient
 
     sert::Timing timing;
 };

@@ -226,6 +226,41 @@ static int entity_key_sort(sert_model* m, int total, hipStream_t st) {
     return 0;
 }
 
+// ---- data-parallel gradient exchange ---------------------------------------------
+// Two sum-all-reduces over the flat gradient buffer, both issued on comm_stream in
+// the same order on every rank: (1) the word-table slice, as soon as the segmented
+// reduction has produced it -- it overlaps whatever is left of the backward --
+// (2) the remainder (entity table, dense weights, bias, loss sum) once complete.
+static int allreduce_word_grad(sert_model* m) {
+    if (!m->comm) return 0;
+    if (m->timing.enabled) {   // timing mode: serial, on the main stream
+        ScopedTimer t(m, TG_ALLREDUCE);
+        SERT_NCCL(g_rccl.AllReduce(m->gflat, m->gflat, m->ar_split, /*ncclFloat32*/ 7, /*ncclSum*/ 0,
+                                   m->comm, m->stream));
+        return 0;
+    }
+    SERT_HIP(hipEventRecord(m->ev_rw_ready, m->stream));
+    SERT_HIP(hipStreamWaitEvent(m->comm_stream, m->ev_rw_ready, 0));
+    SERT_NCCL(g_rccl.AllReduce(m->gflat, m->gflat, m->ar_split, 7, 0, m->comm, m->comm_stream));
+    return 0;
+}
+static int allreduce_rest(sert_model* m) {
+    if (!m->comm) return 0;
+    float* rest = m->gflat + m->ar_split;
+    const size_t count = m->gflat_count - m->ar_split;
+    if (m->timing.enabled) {
+        ScopedTimer t(m, TG_ALLREDUCE);
+        SERT_NCCL(g_rccl.AllReduce(rest, rest, count, 7, 0, m->comm, m->stream));
+        return 0;
+    }
+    SERT_HIP(hipEventRecord(m->ev_rest_ready, m->stream));
+    SERT_HIP(hipStreamWaitEvent(m->comm_stream, m->ev_rest_ready, 0));
+    SERT_NCCL(g_rccl.AllReduce(rest, rest, count, 7, 0, m->comm, m->comm_stream));
+    SERT_HIP(hipEventRecord(m->ev_ar_done, m->comm_stream));
+    SERT_HIP(hipStreamWaitEvent(m->stream, m->ev_ar_done, 0));
+    return 0;
+}
+
 // ---- the vectorspace step -----------------------------------------------------
 static int vs_negatives(sert_model* m, const int64_t* negatives, uint64_t stream_pos) {
     const auto& c = m->cfg;
@@ -356,7 +391,21 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         }
 #undef SERT_EG_ARGS
     }
-    {
+    auto word_table_grad = [&]() -> int {
+        {
+            // dh = da.W^T
+            ScopedTimer t(m, TG_GEMM_DX);
+            launch_gemm<false, true, EPI_STORE>(m->stream, m->DA, m->W, m->DH, nullptr, B, dw, de, de,
+                                                de, dw);
+        }
+        {
+            ScopedTimer t(m, TG_SCATTER);
+            // dR_w[X[i,k],:] += dh[i,:] / n
+            SERT_TRY(word_grad_segsum(m, ds, batch_index, m->DH, (float)n));
+        }
+        return allreduce_word_grad(m);
+    };
+    auto dense_grad = [&]() -> int {
         // dW = h^T.da (reduction over the batch: split-K, order-fixed combine);
         // db = sum_i da_i rides along as the column sums of the da operand
         static const int want_splits = [] { const char* e = getenv("SERT_DW_SPLITS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
@@ -375,17 +424,17 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
             hipLaunchKernelGGL(reduce_partials, dim3(cdiv(stride, 64)), dim3(256), 0, m->stream, m->part,
                                splits, stride, stride, m->g_w, mn, m->g_b);
         }
-        {
-            // dh = da.W^T
-            ScopedTimer t(m, TG_GEMM_DX);
-            launch_gemm<false, true, EPI_STORE>(m->stream, m->DA, m->W, m->DH, nullptr, B, dw, de, de,
-                                                de, dw);
-        }
-    }
-    {
-        ScopedTimer t(m, TG_SCATTER);
-        // dR_w[X[i,k],:] += dh[i,:] / n
-        SERT_TRY(word_grad_segsum(m, ds, batch_index, m->DH, (float)n));
+        return 0;
+    };
+    if (m->comm) {
+        // data parallel: the word-table gradient first, so that its all-reduce (the
+        // big one) overlaps dW and the entity chain
+        SERT_TRY(word_table_grad());
+        SERT_TRY(dense_grad());
+    } else {
+        // single GPU: the MFMA-bound dW beside the latency-bound sort of the side stream
+        SERT_TRY(dense_grad());
+        SERT_TRY(word_table_grad());
     }
     // join the entity-gradient chain
     SERT_HIP(hipEventRecord(m->ev_join, m->stream2));
@@ -475,6 +524,7 @@ static int fs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         ScopedTimer t(m, TG_SCATTER);
         SERT_TRY(word_grad_segsum(m, ds, batch_index, m->DH, (float)n));
     }
+    SERT_TRY(allreduce_word_grad(m));
     return 0;
 }
 
@@ -557,6 +607,7 @@ static int ll_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         // dR_w[X[r],:] += dG[r,:]
         SERT_TRY(word_grad_segsum(m, ds, batch_index, m->DG, 1.0f));
     }
+    SERT_TRY(allreduce_word_grad(m));
     (void)row0;
     return 0;
 }
@@ -640,11 +691,7 @@ static int train_step_async(sert_model* m, int64_t batch_index, const int64_t* n
         SERT_TRY(ll_backward(m, ds, batch_index));
     }
     SERT_TRY(reduce_rowloss(m, m->g_loss));
-    if (m->comm) {
-        ScopedTimer t(m, TG_ALLREDUCE);
-        SERT_NCCL(g_rccl.AllReduce(m->gflat, m->gflat, m->gflat_count, /*ncclFloat32*/ 7,
-                                   /*ncclSum*/ 0, m->comm, m->stream));
-    }
+    SERT_TRY(allreduce_rest(m));
     SERT_TRY(optimizer_and_loss(m, loss_dst));
     return 0;
 }
@@ -714,9 +761,10 @@ int sert_create(const sert_config* cfg, sert_model** out) {
         SERT_TRY(dzalloc(&m->s1_rw, m->n_rw, s)); SERT_TRY(dzalloc(&m->s1_re, m->n_re, s));
         SERT_TRY(dzalloc(&m->s1_w, m->n_w, s));   SERT_TRY(dzalloc(&m->s1_b, m->n_b, s));
         // flat gradient buffer, every sub-tensor 16-byte aligned
-        const size_t o_re = 0, o_rw = o_re + round_up(m->n_re, 4), o_w = o_rw + round_up(m->n_rw, 4),
+        const size_t o_rw = 0, o_re = o_rw + round_up(m->n_rw, 4), o_w = o_re + round_up(m->n_re, 4),
                      o_b = o_w + round_up(m->n_w, 4), o_l = o_b + round_up(m->n_b, 4);
         m->gflat_count = o_l + 4;
+        m->ar_split = o_re;
         // tail of the same allocation (zeroed with the gradients every step, not
         // part of the all-reduce): per-entity sorted-run bounds
         m->gflat_alloc = m->gflat_count + (vs ? 2 * round_up(V, 4) : 0);
@@ -798,7 +846,12 @@ int sert_destroy(sert_model* m) {
     if (!m) return 0;
     (void)hipSetDevice(m->cfg.device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
+    if (m->comm_stream) (void)hipStreamSynchronize(m->comm_stream);
     if (m->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(m->comm);
+    if (m->ev_rw_ready) (void)hipEventDestroy(m->ev_rw_ready);
+    if (m->ev_rest_ready) (void)hipEventDestroy(m->ev_rest_ready);
+    if (m->ev_ar_done) (void)hipEventDestroy(m->ev_ar_done);
+    if (m->comm_stream) (void)hipStreamDestroy(m->comm_stream);
     float* bufs[] = {m->rw, m->re, m->W, m->b, m->s0_rw, m->s0_re, m->s0_w, m->s0_b, m->s1_rw,
                      m->s1_re, m->s1_w, m->s1_b, m->gflat, m->H, m->T, m->DA, m->DH, m->rowloss,
                      m->G, m->Z, m->J, m->DG, m->DH2, m->part, m->wpart, m->red_loss, m->red_sq, m->d_loss,
@@ -1190,6 +1243,12 @@ int sert_comm_init(sert_model* m, const char id[SERT_COMM_ID_BYTES], int rank, i
     SERT_NCCL(g_rccl.CommInitRank(&m->comm, world, uid, rank));
     m->rank = rank;
     m->world = world;
+    if (!m->comm_stream) {
+        SERT_HIP(hipStreamCreateWithFlags(&m->comm_stream, hipStreamNonBlocking));
+        SERT_HIP(hipEventCreateWithFlags(&m->ev_rw_ready, hipEventDisableTiming));
+        SERT_HIP(hipEventCreateWithFlags(&m->ev_rest_ready, hipEventDisableTiming));
+        SERT_HIP(hipEventCreateWithFlags(&m->ev_ar_done, hipEventDisableTiming));
+    }
     return 0;
 }
 

@@ -329,3 +329,32 @@ def test_cli_train_then_query(hip_lib, tmp_path, kind):
     res = trec_utils.evaluate_run(run, qrels, k=100)
     assert res['ndcg_cut_100'] > 0.5, res
     assert os.path.exists(str(tmp_path / 'run_ep')) and os.path.exists(str(tmp_path / 'run_debug'))
+
+
+def test_full_pipeline_prepare_train_query(hip_lib, tmp_path):
+    """bin/prepare.py -> bin/train.py -> bin/query.py on a toy TREC corpus: the
+    three stages agree on the file formats and the right entity is found."""
+    from tests.test_prepare_cpu import _corpus
+    _corpus(tmp_path, ndocs=60)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    run = lambda *cmd: subprocess.check_call([sys.executable] + list(cmd), env=env)
+    run(os.path.join(ROOT, 'bin', 'prepare.py'), '--seed', '3', str(tmp_path / 'docs.trectext'),
+        '--assoc_path', str(tmp_path / 'assocs'), '--window_size', '4', '--overlapping',
+        '--vocabulary_min_count', '1', '--validation_set_ratio', '0.1', '--no_instance_weights',
+        '--meta_output', str(tmp_path / 'meta'), '--data_output', str(tmp_path / 'data.npz'),
+        '--loglevel', 'ERROR')
+    run(os.path.join(ROOT, 'bin', 'train.py'), '--data', str(tmp_path / 'data.npz'), '--meta',
+        str(tmp_path / 'meta'), '--type', 'vectorspace', '--iterations', '30', '--batch_size', '64',
+        '--word_representation_size', '16', '--entity_representation_size', '16',
+        '--num_negative_samples', '2', '--one_hot_classes', '--regularization_lambda', '0.0',
+        '--model_output', str(tmp_path / 'model'), '--seed', '1', '--loglevel', 'ERROR')
+    (tmp_path / 'topics').write_text('t0;alpha beta gamma\nt1;kappa lambda sigma\nt2;red green blue\n')
+    last = sorted((f for f in os.listdir(str(tmp_path)) if f.startswith('model_')),
+                  key=lambda f: int(f.split('_')[1].split('.')[0]))[-1]
+    run(os.path.join(ROOT, 'bin', 'query.py'), '--meta', str(tmp_path / 'meta'), '--model',
+        str(tmp_path / last), '--topics', str(tmp_path / 'topics'), '--top', '3', '--run_out',
+        str(tmp_path / 'run'), '--loglevel', 'ERROR')
+    from sert_amd.utils import trec_utils
+    with open(str(tmp_path / 'run_ef')) as f:
+        ranked = {t: [e for _, e in sorted(v, reverse=True)] for t, v in trec_utils.parse_run(f).items()}
+    assert ranked['t0'][0] == 'E0' and ranked['t1'][0] == 'E1' and ranked['t2'][0] == 'E2'

@@ -358,3 +358,42 @@ def test_full_pipeline_prepare_train_query(hip_lib, tmp_path):
     with open(str(tmp_path / 'run_ef')) as f:
         ranked = {t: [e for _, e in sorted(v, reverse=True)] for t, v in trec_utils.parse_run(f).items()}
     assert ranked['t0'][0] == 'E0' and ranked['t1'][0] == 'E1' and ranked['t2'][0] == 'E2'
+
+
+def test_trained_model_ndcg_parity_with_oracle(hip_lib):
+    """north_star: query-time nDCG@100 within +-1e-4 of the CPU path on the same
+    inputs.  Train the SAME vectorspace model (same init, batches, negatives) for
+    40 steps on the GPU and with the oracle, rank 64 queries with each model's own
+    parameters (GPU: device scorer; oracle: fp64 cosine), compare nDCG@100."""
+    B, n, z, Vw, Ve, d = 256, 4, 5, 600, 300, 32
+    steps = 40
+    p = U.make_vs_problem(51, B * 8, n, z, Vw, Ve, d, d)
+    # learnable structure: entity = f(first token)
+    p['y'] = (p['X'][:, 0].astype(np.int64) % Ve).astype(np.int32)
+    eng = U.vs_engine(p, B, n, z, 0.01, lr=0.01)
+    eng.upload_dataset(C.SPLIT_TRAIN, p['X'], y_int=p['y'], w=p['w'])
+    ora = O.VectorSpaceOracle(B, n, z, p['Rw'], p['Re'], p['W'], p['b'], 0.01,
+                              adam_kwargs=dict(lr=0.01))
+    for s in range(steps):
+        j = s % 8
+        sl = slice(j * B, (j + 1) * B)
+        neg = p['rng'].randint(0, Ve, size=(B, z)).astype(np.int64)
+        ref = ora.train_step(p['X'][sl], p['y'][sl], p['w'][sl], neg)
+        got = eng.train_batch(j, neg)
+        assert abs(got - ref) <= 5e-5 * abs(ref), (s, got, ref)
+    Rw_g = eng.get_tensor(C.T_RW, (Vw, d))
+    Re_g = eng.get_tensor(C.T_RE, (Ve, d))
+    assert U.rel_err(Rw_g, ora.R_w) < 1e-3 and U.rel_err(Re_g, ora.R_e) < 1e-3
+    rng = np.random.RandomState(3)
+    queries = [rng.randint(0, Vw, size=rng.randint(1, 6)) for _ in range(64)]
+    avg_g = np.stack([Rw_g[q].mean(axis=0) for q in queries])
+    proj_g = eng.predict_project(avg_g)
+    idx, _ = C.score_topk(Re_g, proj_g, 100)
+    diffs = []
+    for qi, q in enumerate(queries):
+        proj_o = ora.predict(ora.R_w[q].mean(axis=0))
+        order, _ = O.vectorspace_rank(proj_o.astype(np.float64), ora.R_e.astype(np.float64), top=100)
+        rel = set(int(t) % Ve for t in q) | set(order[:3].tolist())
+        diffs.append(abs(O.ndcg_at_k(list(idx[qi]), rel, 100) - O.ndcg_at_k(list(order), rel, 100)))
+    assert max(diffs) <= 1e-4, max(diffs)
+    eng.close()

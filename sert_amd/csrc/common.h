@@ -34,29 +34,39 @@ inline int fail(const char* file, int line, const std::string& msg) {
     } while (0)
 
 // ---- wave-level reductions -------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, kWave);
-    return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, kWave));
-    return v;
-}
-
-// Sum over each aligned group of 16 lanes (one DPP "row"); pure VALU, no LDS
-// traffic.  Every lane of the group receives the total.
+// DPP row operations (pure VALU, ~1 issue each) reduce each 16-lane row, four
+// v_readlane + scalar ops combine the rows: no LDS round trips (the generic
+// __shfl_xor lowers to ds_bpermute, ~50 cycles of dependent latency per step).
+// Every lane of the wave must be active; every lane receives the result.
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
+// sum over each aligned group of 16 lanes (one DPP "row")
 __device__ __forceinline__ float row16_sum(float v) {
     v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]  (xor 1)
     v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]  (xor 2)
     v += dpp_mov<0x124>(v);   // row_ror:4
     v += dpp_mov<0x128>(v);   // row_ror:8
     return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_mov<0xB1>(v));
+    v = fmaxf(v, dpp_mov<0x4E>(v));
+    v = fmaxf(v, dpp_mov<0x124>(v));
+    v = fmaxf(v, dpp_mov<0x128>(v));
+    return v;
+}
+__device__ __forceinline__ float read_lane(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v = row16_sum(v);
+    return (read_lane(v, 0) + read_lane(v, 16)) + (read_lane(v, 32) + read_lane(v, 48));
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = row16_max(v);
+    return fmaxf(fmaxf(read_lane(v, 0), read_lane(v, 16)), fmaxf(read_lane(v, 32), read_lane(v, 48)));
 }
 
 // Block-wide sum for blockDim.x == 256 (4 waves). `red` is >= 4 floats of LDS.

@@ -168,7 +168,8 @@ __device__ __forceinline__ void lstore_cmajor(float (*dst)[GLD], const float4 (&
 // CSB: additionally emit the column sums of op(B) over this split's k range
 // (row tile 0 only) at C[z] + M*N .. +N  -- used for db = sum_i da_i, which
 // rides along with the dW = h^T.da GEMM for free (the da tile is in LDS anyway).
-template <bool TA, bool TB, int EPI, bool CSB, bool VEC>
+// FULL: M and N are multiples of the tile => no guards in the epilogue.
+template <bool TA, bool TB, int EPI, bool CSB, bool VEC, bool FULL>
 __global__ __launch_bounds__(256, SERT_GEMM_WAVES) void gemm_f32_mfma(const GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float As[2][GK][GLD];
     __shared__ __attribute__((aligned(16))) float Bs[2][GK][GLD];
@@ -210,8 +211,21 @@ __global__ __launch_bounds__(256, SERT_GEMM_WAVES) void gemm_f32_mfma(const Gemm
         if (TB) lstore_cmajor(Bs[buf], rb); else lstore_kmajor(Bs[buf], rb);
     };
 
+    // bias of this wave's two column groups, fetched at the START of every tile so
+    // that its latency hides under the MFMAs (loaded in the epilogue it cost ~6 us)
+    float bias_v[2] = {0.f, 0.f};
+    auto load_bias = [&]() {
+        if (EPI != EPI_STORE) {
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) {
+                const int col = n0 + wc * 64 + tn * 32 + li;
+                bias_v[tn] = (col < g.N) ? g.bias[col] : 0.f;
+            }
+        }
+    };
     float4 ra[GNV], rb[GNV];
     decode(item);
+    load_bias();
     gload(m0, n0, kbeg, kend, ra, rb);
     lstore(0, ra, rb);
     __syncthreads();
@@ -284,25 +298,41 @@ __global__ __launch_bounds__(256, SERT_GEMM_WAVES) void gemm_f32_mfma(const Gemm
                 const int mrem = g.M - m0, nrem = g.N - n0;
                 unsigned uld = (unsigned)g.ldc;
                 asm volatile("" : "+s"(uld));   // keep the 64 store offsets out of the main loop's live set
+                // pin the prefetched bias in registers NOW: otherwise every predicated
+                // store block gets its own s_waitcnt vmcnt(0), which (vmcnt counts
+                // stores on CDNA4) serialises the 64 stores behind each other
+                float bv0 = bias_v[0], bv1 = bias_v[1];
+                if (EPI != EPI_STORE) asm volatile("" : "+v"(bv0), "+v"(bv1));
 #pragma unroll
                 for (int tm = 0; tm < 2; ++tm) {
 #pragma unroll
                     for (int tn = 0; tn < 2; ++tn) {
                         const int col = wc * 64 + tn * 32 + li;
                         const int row0 = wr * 64 + tm * 32 + 4 * lh;
-                        const bool cok = col < nrem;
-                        float bv = 0.f;
-                        if (EPI != EPI_STORE && cok) bv = g.bias[n0 + col];
+                        const float bv = tn ? bv1 : bv0;
                         unsigned off = (unsigned)row0 * uld + (unsigned)col;
+                        if (FULL) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int row = row0 + (r & 3) + 8 * (r >> 2);
-                            float v = acc[tm][tn][r];
-                            if (EPI == EPI_BIAS) v = v + bv;
-                            if (EPI == EPI_BIAS_TANH) v = fast_tanh(v + bv);
-                            if (cok && row < mrem) Ct[off] = v;
-                            acc[tm][tn][r] = 0.f;
-                            off += ((r & 3) == 3) ? 5u * uld : uld;
+                            for (int r = 0; r < 16; ++r) {
+                                float v = acc[tm][tn][r];
+                                if (EPI == EPI_BIAS) v = v + bv;
+                                if (EPI == EPI_BIAS_TANH) v = fast_tanh(v + bv);
+                                Ct[off] = v;
+                                acc[tm][tn][r] = 0.f;
+                                off += ((r & 3) == 3) ? 5u * uld : uld;
+                            }
+                        } else {
+                            const bool cok = col < nrem;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int row = row0 + (r & 3) + 8 * (r >> 2);
+                                float v = acc[tm][tn][r];
+                                if (EPI == EPI_BIAS) v = v + bv;
+                                if (EPI == EPI_BIAS_TANH) v = fast_tanh(v + bv);
+                                if (cok && row < mrem) Ct[off] = v;
+                                acc[tm][tn][r] = 0.f;
+                                off += ((r & 3) == 3) ? 5u * uld : uld;
+                            }
                         }
                     }
                 }
@@ -313,6 +343,7 @@ __global__ __launch_bounds__(256, SERT_GEMM_WAVES) void gemm_f32_mfma(const Gemm
         if (!has_next_item) break;
         item = next_item;
         decode(item);
+        load_bias();
     }
 }
 
@@ -341,8 +372,10 @@ inline void launch_gemm(hipStream_t s, const float* A, const float* B, float* C,
         return v > 0 ? v : 256 * SERT_GEMM_WAVES;
     }();
     const int grid = (int)std::min<long long>(total, max_grid);
-    if (vec) hipLaunchKernelGGL((gemm_f32_mfma<TA, TB, EPI, CSB, true>), dim3(grid), dim3(256), 0, s, g);
-    else     hipLaunchKernelGGL((gemm_f32_mfma<TA, TB, EPI, CSB, false>), dim3(grid), dim3(256), 0, s, g);
+    const bool full = (M % GM == 0) && (N % GN == 0);
+    if (vec && full) hipLaunchKernelGGL((gemm_f32_mfma<TA, TB, EPI, CSB, true, true>), dim3(grid), dim3(256), 0, s, g);
+    else if (vec)    hipLaunchKernelGGL((gemm_f32_mfma<TA, TB, EPI, CSB, true, false>), dim3(grid), dim3(256), 0, s, g);
+    else             hipLaunchKernelGGL((gemm_f32_mfma<TA, TB, EPI, CSB, false, false>), dim3(grid), dim3(256), 0, s, g);
 }
 
 // out[i] = sum_s part[s*stride + i] over the split-K partial slabs, in a fixed

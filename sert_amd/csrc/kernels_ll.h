@@ -202,14 +202,17 @@ __global__ __launch_bounds__(256) void ll_fused_row(float* __restrict__ Z,
     for (int k = wv; k < n; k += 4) {
         float* zk = S + (size_t)k * V;
         float tmx = -INFINITY;
+#pragma unroll 8
         for (int e = lane; e < V; e += 64) tmx = fmaxf(tmx, zk[e]);
         tmx = wave_max(tmx);
         float sm = 0.f;
         // __expf = v_exp_f32(x*log2e): rel. error <= ~|x|*6e-8, far inside the 1e-5 loss tolerance;
         // the libm expf expansion made this kernel VALU-bound (12 waves/CU, 2 exps per element)
+#pragma unroll 8
         for (int e = lane; e < V; e += 64) sm += __expf(zk[e] - tmx);
         sm = wave_sum(sm);
         const float lsm = logf(sm);
+#pragma unroll 8
         for (int e = lane; e < V; e += 64) zk[e] = (zk[e] - tmx) - lsm;
     }
     __syncthreads();
@@ -217,6 +220,7 @@ __global__ __launch_bounds__(256) void ll_fused_row(float* __restrict__ Z,
     float mx = -INFINITY;
     for (int e = tid; e < V; e += 256) {
         float a = 0.f;
+#pragma unroll 5
         for (int k = 0; k < n; ++k) a += fminf(fmaxf(S[(size_t)k * V + e], LOGLO), LOGHI);
         Jl[e] = a;
         mx = fmaxf(mx, a);
@@ -272,12 +276,14 @@ __global__ __launch_bounds__(256) void ll_fused_row(float* __restrict__ Z,
     for (int k = wv; k < n; k += 4) {
         const float* lk = S + (size_t)k * V;
         float r = 0.f;
+#pragma unroll 8
         for (int e = lane; e < V; e += 64) {
             const float lp = lk[e];
-            if (lp >= LOGLO && lp <= LOGHI) r += Jl[e];
+            r += (lp >= LOGLO && lp <= LOGHI) ? Jl[e] : 0.f;
         }
         r = wave_sum(r);
         float* out = Zi + (size_t)k * V;
+#pragma unroll 8
         for (int e = lane; e < V; e += 64) {
             const float lp = lk[e];
             const float dj = (lp >= LOGLO && lp <= LOGHI) ? Jl[e] : 0.f;

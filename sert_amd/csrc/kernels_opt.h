@@ -139,6 +139,46 @@ __global__ __launch_bounds__(256) void adadelta_l2(float* __restrict__ p, float*
     if (threadIdx.x == 0) sumsq_partial[blockIdx.x] = tot;
 }
 
+// The small tensors (entity table at small V_e, dense W, bias) in ONE launch: a
+// kernel boundary costs more than updating them.  Block b works on the tensor
+// whose block range contains it; partial sums of squares of non-regularised
+// tensors (the bias) are written as 0.
+struct SmallTensors {
+    float* p[3];
+    float* g[3];
+    float* s0[3];
+    float* s1[3];
+    unsigned long long count[3];
+    int first_block[4];     // block range of tensor i = [first_block[i], first_block[i+1])
+    float l2k[3];           // lambda/B, or 0 for a tensor without L2
+};
+
+template <bool ADAM, bool STORE_G>
+__global__ __launch_bounds__(256) void optimizer_small(SmallTensors t, AdamArgs aa, AdadeltaArgs da,
+                                                       float* __restrict__ sumsq_partial) {
+    __shared__ float red[4];
+    int i = 0;
+    if ((int)blockIdx.x >= t.first_block[1]) i = 1;
+    if ((int)blockIdx.x >= t.first_block[2]) i = 2;
+    const int nb = t.first_block[i + 1] - t.first_block[i];
+    const int b = blockIdx.x - t.first_block[i];
+    float *p = t.p[i], *g = t.g[i], *s0 = t.s0[i], *s1 = t.s1[i];
+    const size_t count = (size_t)t.count[i];
+    aa.l2k = t.l2k[i];
+    da.l2k = t.l2k[i];
+    const float omb1 = 1.0f - aa.b1, omb2 = 1.0f - aa.b2, omr = 1.0f - da.rho;
+    float ss = 0.f;
+    for (size_t k = (size_t)b * 256 + threadIdx.x; k < count; k += (size_t)nb * 256) {
+        float pp = p[k], gg = g[k], a0 = s0[k], a1 = s1[k];
+        if (ADAM) adam_elem(pp, gg, a0, a1, aa, omb1, omb2, ss);
+        else adadelta_elem(pp, gg, a0, a1, da, omr, ss);
+        p[k] = pp; s0[k] = a0; s1[k] = a1;
+        if (STORE_G) g[k] = gg;
+    }
+    const float tot = block_sum_256(ss, red);
+    if (threadIdx.x == 0) sumsq_partial[blockIdx.x] = (t.l2k[i] != 0.f) ? tot : 0.f;
+}
+
 // partial[b] = sum of block b's strided share of in[0..count)
 __global__ __launch_bounds__(256) void sum_partial(const float* __restrict__ in, size_t count,
                                                    float* __restrict__ partial) {
@@ -149,6 +189,22 @@ __global__ __launch_bounds__(256) void sum_partial(const float* __restrict__ in,
         s += in[i];
     const float tot = block_sum_256(s, red);
     if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+// out[0] = sum of n partials (fp64, fixed order): the local loss sum that travels in
+// the flat gradient buffer of a data-parallel step
+__global__ __launch_bounds__(256) void partials_to_scalar(const float* __restrict__ partials, int n,
+                                                          float* __restrict__ out) {
+    __shared__ double red[256];
+    double a = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) a += (double)partials[i];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (float)red[0];
 }
 
 // loss = (sum rowloss)/B + lambda/(2B) * sum of squares of the regularised

@@ -408,7 +408,7 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
     auto dense_grad = [&]() -> int {
         // dW = h^T.da (reduction over the batch: split-K, order-fixed combine);
         // db = sum_i da_i rides along as the column sums of the da operand
-        static const int want_splits = [] { const char* e = getenv("SERT_DW_SPLITS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
+        static const int want_splits = [] { const char* e = getenv("SERT_DW_SPLITS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
         int splits = std::min(want_splits, cdiv(B, GK));
         int kper = (int)round_up(cdiv(B, splits), GK);
         splits = cdiv(B, kper);
@@ -613,59 +613,92 @@ static int ll_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
 }
 
 // ---- shared tail: loss sum, exchange, optimiser, loss ---------------------------
-static int reduce_rowloss(sert_model* m, float* dst_sum /* device, 1 float */) {
+// rowloss (B) -> per-block partials in red_loss; returns their count.  In a
+// data-parallel step the partials are folded into the scalar slot of the flat
+// gradient buffer so that the loss sum rides in the all-reduce.
+static int reduce_rowloss(sert_model* m, int* n_partials) {
     const int B = m->cfg.batch_size;
     const int nb = std::min(kOptBlocks, cdiv(B, 256));
     hipLaunchKernelGGL(sum_partial, dim3(nb), dim3(256), 0, m->stream, m->rowloss, (size_t)B,
                        m->red_loss);
-    // single-block fp64 combine, result (sum, not mean) to dst_sum[0]
-    hipLaunchKernelGGL(finalize_loss, dim3(1), dim3(256), 0, m->stream, m->red_loss, nb,
-                       m->red_loss, 0, 1.0f, 0.0f, m->d_loss);
-    SERT_HIP(hipMemcpyAsync(dst_sum, m->d_loss, sizeof(float), hipMemcpyDeviceToDevice, m->stream));
+    if (m->comm)
+        hipLaunchKernelGGL(partials_to_scalar, dim3(1), dim3(256), 0, m->stream, m->red_loss, nb, m->g_loss);
+    *n_partials = nb;
     return 0;
 }
 
-static int optimizer_and_loss(sert_model* m, float* loss_dst /* device [3] */) {
+static int optimizer_and_loss(sert_model* m, float* loss_dst /* device [3] */, int n_loss_partials) {
     const auto& c = m->cfg;
     const bool keep = c.keep_grads != 0;
     const float l2k = c.lambda_ > 0.f ? c.lambda_ / (float)c.global_batch_size : 0.f;
     m->step += 1;
+    AdamArgs aa{l2k, 0.f, c.beta1, c.beta2, c.eps};
+    AdadeltaArgs da{l2k, c.lr, c.beta1, c.eps};
+    if (is_vs(m)) {
+        const float t = (float)m->step;
+        aa.a_t = c.lr * sqrtf(1.0f - powf(c.beta2, t)) / (1.0f - powf(c.beta1, t));
+    }
     int n_sq = 0;
     {
-        struct Item { float *p, *g, *s0, *s1; size_t count; bool l2; };
-        // parameters of the reference: [R_e, R_w, W, b] (models.py:542-543, :1105); the
-        // tensors are independent, the big word table simply goes first
-        Item items[4] = {{m->rw, m->g_rw, m->s0_rw, m->s1_rw, m->n_rw, true},
-                         {m->re, m->g_re, m->s0_re, m->s1_re, m->n_re, true},
-                         {m->W, m->g_w, m->s0_w, m->s1_w, m->n_w, true},
-                         {m->b, m->g_b, m->s0_b, m->s1_b, m->n_b, false}};
-        float a_t = 0.f;
+        // the word table: one streaming launch
+        ScopedTimer t(m, TG_OPT_WORD);
+        const int nb = std::min<int64_t>(kOptBlocks, cdiv(cdiv(m->n_rw, 4), 256));
+        float* sq = m->red_sq + n_sq;
         if (is_vs(m)) {
-            const float t = (float)m->step;
-            a_t = c.lr * sqrtf(1.0f - powf(c.beta2, t)) / (1.0f - powf(c.beta1, t));
+            if (keep) hipLaunchKernelGGL((adam_l2<true>), dim3(nb), dim3(256), 0, m->stream, m->rw, m->g_rw, m->s0_rw, m->s1_rw, m->n_rw, aa, sq);
+            else      hipLaunchKernelGGL((adam_l2<false>), dim3(nb), dim3(256), 0, m->stream, m->rw, m->g_rw, m->s0_rw, m->s1_rw, m->n_rw, aa, sq);
+        } else {
+            if (keep) hipLaunchKernelGGL((adadelta_l2<true>), dim3(nb), dim3(256), 0, m->stream, m->rw, m->g_rw, m->s0_rw, m->s1_rw, m->n_rw, da, sq);
+            else      hipLaunchKernelGGL((adadelta_l2<false>), dim3(nb), dim3(256), 0, m->stream, m->rw, m->g_rw, m->s0_rw, m->s1_rw, m->n_rw, da, sq);
         }
-        for (auto& it : items) {
-            if (it.count == 0) continue;
-            ScopedTimer t(m, it.p == m->rw ? TG_OPT_WORD : TG_OPTIMIZER);
-            const int nb = std::min<int64_t>(kOptBlocks, cdiv(cdiv(it.count, 4), 256));
+        n_sq += nb;
+    }
+    {
+        // parameters of the reference: [R_e, R_w, W, b] (models.py:542-543, :1105); the
+        // tensors are independent.  A large entity table streams like the word table;
+        // everything small goes into one launch.
+        ScopedTimer t(m, TG_OPTIMIZER);
+        const bool big_re = m->n_re > ((size_t)1 << 22);
+        if (big_re) {
+            const int nb = std::min<int64_t>(kOptBlocks, cdiv(cdiv(m->n_re, 4), 256));
             float* sq = m->red_sq + n_sq;
-            if (is_vs(m)) {
-                AdamArgs a{it.l2 ? l2k : 0.f, a_t, c.beta1, c.beta2, c.eps};
-                if (keep) hipLaunchKernelGGL((adam_l2<true>), dim3(nb), dim3(256), 0, m->stream, it.p, it.g, it.s0, it.s1, it.count, a, sq);
-                else      hipLaunchKernelGGL((adam_l2<false>), dim3(nb), dim3(256), 0, m->stream, it.p, it.g, it.s0, it.s1, it.count, a, sq);
-            } else {
-                AdadeltaArgs a{it.l2 ? l2k : 0.f, c.lr, c.beta1, c.eps};
-                if (keep) hipLaunchKernelGGL((adadelta_l2<true>), dim3(nb), dim3(256), 0, m->stream, it.p, it.g, it.s0, it.s1, it.count, a, sq);
-                else      hipLaunchKernelGGL((adadelta_l2<false>), dim3(nb), dim3(256), 0, m->stream, it.p, it.g, it.s0, it.s1, it.count, a, sq);
-            }
-            if (it.l2) n_sq += nb;  // bias partials are overwritten by the next tensor / ignored
+            if (keep) hipLaunchKernelGGL((adam_l2<true>), dim3(nb), dim3(256), 0, m->stream, m->re, m->g_re, m->s0_re, m->s1_re, m->n_re, aa, sq);
+            else      hipLaunchKernelGGL((adam_l2<false>), dim3(nb), dim3(256), 0, m->stream, m->re, m->g_re, m->s0_re, m->s1_re, m->n_re, aa, sq);
+            n_sq += nb;
         }
+        SmallTensors st;
+        int k = 0, blocks = 0;
+        auto add = [&](float* p, float* g, float* s0, float* s1, size_t count, float l2) {
+            if (count == 0) return;
+            st.p[k] = p; st.g[k] = g; st.s0[k] = s0; st.s1[k] = s1; st.count[k] = count; st.l2k[k] = l2;
+            st.first_block[k] = blocks;
+            blocks += (int)std::min<int64_t>(512, cdiv(count, 256));
+            ++k;
+        };
+        if (!big_re) add(m->re, m->g_re, m->s0_re, m->s1_re, m->n_re, l2k);
+        add(m->W, m->g_w, m->s0_w, m->s1_w, m->n_w, l2k);
+        add(m->b, m->g_b, m->s0_b, m->s1_b, m->n_b, 0.f);
+        for (int i = k; i < 3; ++i) { st.p[i] = st.g[i] = st.s0[i] = st.s1[i] = nullptr; st.count[i] = 0; st.l2k[i] = 0.f; st.first_block[i] = blocks; }
+        st.first_block[3] = blocks;
+        for (int i = k; i <= 3; ++i) st.first_block[i] = blocks;
+        float* sq = m->red_sq + n_sq;
+        if (is_vs(m)) {
+            if (keep) hipLaunchKernelGGL((optimizer_small<true, true>), dim3(blocks), dim3(256), 0, m->stream, st, aa, da, sq);
+            else      hipLaunchKernelGGL((optimizer_small<true, false>), dim3(blocks), dim3(256), 0, m->stream, st, aa, da, sq);
+        } else {
+            if (keep) hipLaunchKernelGGL((optimizer_small<false, true>), dim3(blocks), dim3(256), 0, m->stream, st, aa, da, sq);
+            else      hipLaunchKernelGGL((optimizer_small<false, false>), dim3(blocks), dim3(256), 0, m->stream, st, aa, da, sq);
+        }
+        n_sq += blocks;
     }
     {
         ScopedTimer t(m, TG_FINALIZE);
         const float inv_batch = 1.0f / (float)c.global_batch_size;
         const float reg_scale = c.lambda_ > 0.f ? c.lambda_ / (2.0f * (float)c.global_batch_size) : 0.f;
-        hipLaunchKernelGGL(finalize_loss, dim3(1), dim3(256), 0, m->stream, m->g_loss, 1, m->red_sq,
+        // single GPU: the loss partials directly; data parallel: the all-reduced scalar
+        const float* lp = m->comm ? m->g_loss : m->red_loss;
+        const int nl = m->comm ? 1 : n_loss_partials;
+        hipLaunchKernelGGL(finalize_loss, dim3(1), dim3(256), 0, m->stream, lp, nl, m->red_sq,
                            n_sq, inv_batch, reg_scale, loss_dst);
     }
     return 0;
@@ -690,9 +723,10 @@ static int train_step_async(sert_model* m, int64_t batch_index, const int64_t* n
         SERT_TRY(ll_forward<true>(m, ds, batch_index));
         SERT_TRY(ll_backward(m, ds, batch_index));
     }
-    SERT_TRY(reduce_rowloss(m, m->g_loss));
+    int n_loss_partials = 0;
+    SERT_TRY(reduce_rowloss(m, &n_loss_partials));
     SERT_TRY(allreduce_rest(m));
-    SERT_TRY(optimizer_and_loss(m, loss_dst));
+    SERT_TRY(optimizer_and_loss(m, loss_dst, n_loss_partials));
     return 0;
 }
 

@@ -145,6 +145,11 @@ class ModelBase(ModelInterface):
     #: seed of the device sampler (the reference seeds RandomStreams from the
     #: global np.random, models.py:958-959)
     sampler_seed = None
+    #: additive throughput knob for train(): number of consecutive batches issued
+    #: to the device before their losses are read back.  1 (default) = the
+    #: reference's behaviour (one host synchronisation and finite-check per batch,
+    #: models.py:369-379); k > 1 defers the check by up to k-1 batches.
+    steps_per_sync = 1
 
     def __init__(self, batch_size,
                  training_set, validation_set,
@@ -290,11 +295,43 @@ class ModelBase(ModelInterface):
                      self.training_num_instances,
                      self._number_of_batches(self.training_num_instances))
 
-        num_batches, errors = self._iterate_batches(
-            self.train_fn, self.training_num_instances,
-            report_interval=1000, shuffle=True)
+        if self.steps_per_sync > 1 and self.negative_sampler is None:
+            num_batches, errors = self._iterate_batches_deferred(
+                self.training_num_instances, self.steps_per_sync)
+        else:
+            num_batches, errors = self._iterate_batches(
+                self.train_fn, self.training_num_instances,
+                report_interval=1000, shuffle=True)
 
         return num_batches, np.mean(errors)
+
+    def _iterate_batches_deferred(self, num_instances, chunk):
+        """train() with the loss read-back deferred: same batch order (shuffled
+        with the global np.random), same results, same RuntimeError on a
+        non-finite loss -- raised at the end of the chunk that contains it."""
+        start = time.time()
+        num_batches = self._number_of_batches(num_instances)
+        if num_instances % self.batch_size > 0:
+            logging.warning('\tIgnoring incomplete batch of size %d.',
+                            num_instances % self.batch_size)
+        batch_indices = list(range(num_batches))
+        np.random.shuffle(batch_indices)
+        results = []
+        for lo in range(0, num_batches, chunk):
+            losses = self._engine.train_batches(batch_indices[lo:lo + chunk])
+            for loss in losses:
+                results.append(loss)
+                if not np.isfinite(loss):
+                    raise RuntimeError(
+                        'Encountered NaN or infinity ({error}) '
+                        'during batch iteration '
+                        '(batch {batches_finished}/{num_batches}).'.format(
+                            error=loss, batches_finished=len(results),
+                            num_batches=num_batches))
+        elapsed = max(float(time.time() - start), 1e-9)
+        logging.info('\tProcessed %d batches; %.2f batches per second; '
+                     '0 minutes 0 seconds remaining.', len(results), len(results) / elapsed)
+        return num_batches, results
 
     def train_error(self):
         logging.info('Measuring error on %d training instances (%d batches).',

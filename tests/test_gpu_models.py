@@ -397,3 +397,25 @@ def test_trained_model_ndcg_parity_with_oracle(hip_lib):
         diffs.append(abs(O.ndcg_at_k(list(idx[qi]), rel, 100) - O.ndcg_at_k(list(order), rel, 100)))
     assert max(diffs) <= 1e-4, max(diffs)
     eng.close()
+
+
+def test_deferred_loss_readback_gives_identical_results(hip_lib):
+    """steps_per_sync > 1 (additive): same batch order, same losses, same parameters."""
+    B, n, z, Vw, Ve, d = 64, 3, 4, 200, 20, 16
+    p = U.make_vs_problem(61, B * 7, n, z, Vw, Ve, d, d)
+    outs = []
+    for sps in (1, 4):
+        np.random.seed(5)
+        m = models.VectorSpaceLanguageModel(
+            batch_size=B, window_size=n, num_negative_samples=z, representations_init=p['Rw'],
+            entity_representations_init=p['Re'], regularization_lambda=0.01,
+            training_set=(p['X'], p['y'], p['w']),
+            validation_set=(np.zeros((0, n), p['X'].dtype), np.zeros((0,), np.int32)))
+        m.sampler_seed = 9
+        m.steps_per_sync = sps
+        np.random.seed(7)
+        nb, mean = m.train()
+        outs.append((nb, mean, m.get_representations()[0].copy()))
+    assert outs[0][0] == outs[1][0] == 7
+    assert outs[0][1] == outs[1][1]
+    assert np.array_equal(outs[0][2], outs[1][2])

@@ -243,6 +243,12 @@ def main():
     ap.add_argument('--no-query-extra', action='store_true')
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON record: everything else that writes to
+    # fd 1 (RCCL prints a version banner there at communicator creation) goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     from sert_amd import _build
     _build.build()
     from sert_amd import distributed as dist
@@ -383,7 +389,8 @@ def main():
         out['cpu_baseline'] = None
 
     if ctx.rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + '\n').encode())
     dist.barrier()
     dist.shutdown()
 

@@ -118,6 +118,12 @@ struct sert_model {
     hipStream_t comm_stream = nullptr;          // all collectives are issued here, in one fixed order
     hipEvent_t ev_rw_ready = nullptr, ev_rest_ready = nullptr, ev_ar_done = nullptr;
     size_t ar_split = 0;          // gflat[0, ar_split) = word-table gradient
+    // the word-table exchange is cut into ar_chunks slices so that the optimiser of
+    // slice c runs while slice c+1 is still on the links
+    static constexpr int kMaxArChunks = 16;
+    int ar_chunks = 1;
+    hipEvent_t ev_rw_chunk[kMaxArChunks] = {};
+    bool rw_chunked = false;      // this step's word-table all-reduce was issued in slices
 
     sert::Timing timing;
 };

@@ -20,15 +20,14 @@ import numpy as np
 class Context(object):
     def __init__(self, rank=0, local_rank=0, world_size=1):
         self.rank, self.local_rank, self.world_size = rank, local_rank, world_size
-        self._uid = None
 
     def unique_id(self):
-        """ncclGetUniqueId on rank 0, shipped to everyone through gloo."""
-        if self._uid is None:
-            from sert_amd import _capi
-            uid = _capi.comm_unique_id() if self.rank == 0 else None
-            self._uid = broadcast_object(uid)
-        return self._uid
+        """A fresh ncclGetUniqueId from rank 0, shipped to everyone through gloo.
+        Collective: every rank calls it once per communicator (= per model), in
+        the same order; an id is never reused for a second communicator."""
+        from sert_amd import _capi
+        uid = _capi.comm_unique_id() if self.rank == 0 else None
+        return broadcast_object(uid)
 
 
 _context = Context()

@@ -19,6 +19,7 @@ Differences that are deliberate and additive:
     set to a callable ``batch_index -> (B, z) int64`` (parity runs).
 """
 import logging
+import os
 import time
 
 import numpy as np
@@ -241,7 +242,9 @@ class ModelBase(ModelInterface):
             inference_only=0, lambda_=float(self.regularization_lambda),
             seed=seed, **opt)
 
-        if ctx.world_size > 1:
+        # SERT_FORCE_COMM=1: run the exchange path (RCCL, world of one) on a single
+        # GPU -- for profiling the data-parallel step structure on a 1-GPU box
+        if ctx.world_size > 1 or os.environ.get('SERT_FORCE_COMM') == '1':
             self._engine.comm_init(ctx.unique_id(), ctx.rank, ctx.world_size)
 
         self._upload(_capi.SPLIT_TRAIN, x_train, self.training_set[1],

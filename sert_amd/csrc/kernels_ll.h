@@ -292,4 +292,260 @@ __global__ __launch_bounds__(256) void ll_fused_row(float* __restrict__ Z,
     }
 }
 
+// ---- streaming path for entity vocabularies whose (n, V) slab does not fit LDS ----
+// (BASELINE configs[3]: V_e = 100k.)  Same maths and citations as ll_window /
+// ll_fused_row, organised as passes over Z in which every workgroup owns ONE
+// kLlSeg-element segment of one row, so that B*n*ceil(V/kLlSeg) workgroups stream
+// with 16-byte loads instead of B workgroups walking whole rows element-wise:
+//   ll_s_tokstat   Z -> per (token row, segment) (max, sum exp)          1 read
+//   ll_s_lse       -> log-sum-exp per token row
+//   ll_s_window    Z, lse -> J (B, V) + per (row, segment) softmax partials 1 read
+//   ll_s_rowloss   -> loss, (max J, sum, s) per batch row, label corrections
+//   ll_s_dj        J -> dJ (dense part), ll_s_labfix adds the label entries
+//   ll_s_tokr      Z, dJ -> r_k partials                                  1 read
+//   ll_s_rsum      -> r_k
+//   ll_s_dz        Z, dJ, r -> dZ in place                        1 read, 1 write
+// All reductions are order-fixed (deterministic).
+constexpr int kLlSeg = 4096;
+
+// the 16 elements of (row, segment) owned by this thread: 4 x float4 when the
+// rows are 16-byte aligned (V % 4 == 0), else 16 strided scalars
+template <bool V4>
+__device__ __forceinline__ void seg_load(const float* __restrict__ row, int V, int seg, float (&x)[16],
+                                         float fill) {
+    const int base = seg * kLlSeg;
+    if (V4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = base + (u * 256 + threadIdx.x) * 4;
+            float4 v = make_float4(fill, fill, fill, fill);
+            if (e < V) v = *reinterpret_cast<const float4*>(row + e);
+            x[4 * u] = v.x; x[4 * u + 1] = v.y; x[4 * u + 2] = v.z; x[4 * u + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int e = base + u * 256 + threadIdx.x;
+            x[u] = (e < V) ? row[e] : fill;
+        }
+    }
+}
+template <bool V4>
+__device__ __forceinline__ int seg_index(int seg, int u) {   // element index of x[u]
+    return V4 ? seg * kLlSeg + ((u >> 2) * 256 + threadIdx.x) * 4 + (u & 3)
+              : seg * kLlSeg + u * 256 + threadIdx.x;
+}
+template <bool V4>
+__device__ __forceinline__ void seg_store(float* __restrict__ row, int V, int seg, const float (&x)[16]) {
+    const int base = seg * kLlSeg;
+    if (V4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = base + (u * 256 + threadIdx.x) * 4;
+            if (e < V) *reinterpret_cast<float4*>(row + e) = make_float4(x[4 * u], x[4 * u + 1], x[4 * u + 2], x[4 * u + 3]);
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int e = base + u * 256 + threadIdx.x;
+            if (e < V) row[e] = x[u];
+        }
+    }
+}
+
+template <bool V4>
+__global__ __launch_bounds__(256) void ll_s_tokstat(const float* __restrict__ Z, int V, int nseg,
+                                                    float2* __restrict__ stat) {
+    __shared__ float red[4];
+    const int64_t row = blockIdx.x / nseg;
+    const int seg = (int)(blockIdx.x - row * nseg);
+    float x[16];
+    seg_load<V4>(Z + (size_t)row * V, V, seg, x, -INFINITY);
+    float mx = x[0];
+#pragma unroll
+    for (int u = 1; u < 16; ++u) mx = fmaxf(mx, x[u]);
+    mx = block_max_256(mx, red);
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s += __expf(x[u] - mx);   // exp(-inf) = 0 for the padding
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) stat[blockIdx.x] = make_float2(mx, s);
+}
+
+// out[row] = max + log(sum): merge of the nseg (max, sum) partials of a row, one wave per row
+__global__ __launch_bounds__(256) void ll_s_lse(const float2* __restrict__ stat, int64_t rows, int nseg,
+                                                float* __restrict__ lse) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float2* st = stat + (size_t)r * nseg;
+    float mx = -INFINITY;
+    for (int s = lane; s < nseg; s += 64) mx = fmaxf(mx, st[s].x);
+    mx = wave_max(mx);
+    float sm = 0.f;
+    for (int s = lane; s < nseg; s += 64) sm += st[s].y * __expf(st[s].x - mx);
+    sm = wave_sum(sm);
+    if (lane == 0) lse[r] = mx + logf(sm);
+}
+
+template <bool V4>
+__global__ __launch_bounds__(256) void ll_s_window(const float* __restrict__ Z, const float* __restrict__ lse,
+                                                   int n, int V, int nseg, float* __restrict__ J,
+                                                   float2* __restrict__ jstat) {
+    __shared__ float red[4];
+    const int64_t i = blockIdx.x / nseg;
+    const int seg = (int)(blockIdx.x - i * nseg);
+    const float LOGLO = logf(SERT_CLIP_LO), LOGHI = logf(SERT_CLIP_HI);
+    float acc[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc[u] = 0.f;
+    for (int k = 0; k < n; ++k) {
+        const int64_t row = i * n + k;
+        const float l = lse[row];
+        float x[16];
+        seg_load<V4>(Z + (size_t)row * V, V, seg, x, 0.f);
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc[u] += fminf(fmaxf(x[u] - l, LOGLO), LOGHI);
+    }
+    seg_store<V4>(J + (size_t)i * V, V, seg, acc);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) if (seg_index<V4>(seg, u) < V) mx = fmaxf(mx, acc[u]);
+    mx = block_max_256(mx, red);
+    float se = 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) if (seg_index<V4>(seg, u) < V) se += expf(acc[u] - mx);
+    se = block_sum_256(se, red);
+    if (threadIdx.x == 0) jstat[blockIdx.x] = make_float2(mx, se);
+}
+
+// per batch row: merge the J partials, loss, s = sum_e dQ_e Q_e, and the label
+// entries' Q_e dQ_e (added to dJ by ll_s_labfix once ll_s_dj has written the dense part)
+template <bool TRAIN>
+__global__ __launch_bounds__(256) void ll_s_rowloss(const float* __restrict__ J, const float2* __restrict__ jstat,
+                                                    const int32_t* __restrict__ y_int,
+                                                    const int64_t* __restrict__ indptr,
+                                                    const int32_t* __restrict__ indices,
+                                                    const float* __restrict__ data,
+                                                    const float* __restrict__ w, float* __restrict__ rowloss,
+                                                    float4* __restrict__ rowinfo, float* __restrict__ labfix,
+                                                    int V, int nseg, float inv_batch) {
+    __shared__ float red[4];
+    const int i = blockIdx.x, tid = threadIdx.x;
+    const float2* st = jstat + (size_t)i * nseg;
+    const float* Ji = J + (size_t)i * V;
+    float mx = -INFINITY;
+    for (int s = tid; s < nseg; s += 256) mx = fmaxf(mx, st[s].x);
+    mx = block_max_256(mx, red);
+    float se = 0.f;
+    for (int s = tid; s < nseg; s += 256) se += st[s].y * expf(st[s].x - mx);
+    se = block_sum_256(se, red);
+    const float wi = TRAIN ? w[i] : 1.f;
+    const float g = wi * inv_batch;
+    float loss = 0.f, sdq = 0.f;
+    int64_t l0 = 0, l1 = 1;
+    if (y_int == nullptr) { l0 = indptr[i]; l1 = indptr[i + 1]; }
+    for (int64_t l = l0 + tid; l < l1; l += 256) {
+        const int e = y_int ? y_int[i] : indices[l];
+        const float yv = y_int ? 1.f : data[l];
+        const float q = expf(Ji[e] - mx) / se;
+        const float qc = fminf(fmaxf(q, SERT_CLIP_LO), SERT_CLIP_HI);
+        loss -= yv * logf(qc);
+        if (TRAIN) {
+            const bool inside = (q >= SERT_CLIP_LO) && (q <= SERT_CLIP_HI);
+            const float qdq = q * (inside ? -(g * yv) / qc : 0.f);
+            sdq += qdq;
+            labfix[y_int ? (int64_t)i : l] = qdq;
+        }
+    }
+    loss = block_sum_256(loss, red);
+    if (tid == 0) rowloss[i] = wi * loss;
+    if (!TRAIN) return;
+    sdq = block_sum_256(sdq, red);
+    if (tid == 0) rowinfo[i] = make_float4(mx, se, sdq, 0.f);
+}
+
+// dJ_e = -Q_e s (the dense part of Q_e (dQ_e - s)), in place over J
+template <bool V4>
+__global__ __launch_bounds__(256) void ll_s_dj(float* __restrict__ J, const float4* __restrict__ rowinfo,
+                                               int V, int nseg) {
+    const int64_t i = blockIdx.x / nseg;
+    const int seg = (int)(blockIdx.x - i * nseg);
+    const float4 info = rowinfo[i];
+    float x[16];
+    seg_load<V4>(J + (size_t)i * V, V, seg, x, 0.f);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) x[u] = -(expf(x[u] - info.x) / info.y) * info.z;
+    seg_store<V4>(J + (size_t)i * V, V, seg, x);
+}
+
+__global__ __launch_bounds__(256) void ll_s_labfix(float* __restrict__ J, const int32_t* __restrict__ y_int,
+                                                   const int64_t* __restrict__ indptr,
+                                                   const int32_t* __restrict__ indices,
+                                                   const float* __restrict__ labfix, int V) {
+    const int i = blockIdx.x;
+    int64_t l0 = 0, l1 = 1;
+    if (y_int == nullptr) { l0 = indptr[i]; l1 = indptr[i + 1]; }
+    for (int64_t l = l0 + threadIdx.x; l < l1; l += 256) {
+        const int e = y_int ? y_int[i] : indices[l];
+        J[(size_t)i * V + e] += labfix[y_int ? (int64_t)i : l];
+    }
+}
+
+// r_k partials: sum over the segment of mask_ke dJ_e, mask = eps <= P_ke <= 1-eps
+template <bool V4>
+__global__ __launch_bounds__(256) void ll_s_tokr(const float* __restrict__ Z, const float* __restrict__ lse,
+                                                 const float* __restrict__ dJ, int n, int V, int nseg,
+                                                 float* __restrict__ rpart) {
+    __shared__ float red[4];
+    const int64_t row = blockIdx.x / nseg;
+    const int seg = (int)(blockIdx.x - row * nseg);
+    const int64_t i = row / n;
+    const float LOGLO = logf(SERT_CLIP_LO), LOGHI = logf(SERT_CLIP_HI);
+    const float l = lse[row];
+    float x[16], dj[16];
+    seg_load<V4>(Z + (size_t)row * V, V, seg, x, INFINITY);   // padding: log p = +inf -> masked out
+    seg_load<V4>(dJ + (size_t)i * V, V, seg, dj, 0.f);
+    float r = 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const float lp = x[u] - l;
+        r += (lp >= LOGLO && lp <= LOGHI) ? dj[u] : 0.f;
+    }
+    r = block_sum_256(r, red);
+    if (threadIdx.x == 0) rpart[blockIdx.x] = r;
+}
+
+__global__ __launch_bounds__(256) void ll_s_rsum(const float* __restrict__ rpart, int64_t rows, int nseg,
+                                                 float* __restrict__ r) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float a = 0.f;
+    for (int s = lane; s < nseg; s += 64) a += rpart[(size_t)row * nseg + s];
+    a = wave_sum(a);
+    if (lane == 0) r[row] = a;
+}
+
+// dZ_ke = mask_ke dJ_e - P_ke r_k, in place over Z
+template <bool V4>
+__global__ __launch_bounds__(256) void ll_s_dz(float* __restrict__ Z, const float* __restrict__ lse,
+                                               const float* __restrict__ dJ, const float* __restrict__ r,
+                                               int n, int V, int nseg) {
+    const int64_t row = blockIdx.x / nseg;
+    const int seg = (int)(blockIdx.x - row * nseg);
+    const int64_t i = row / n;
+    const float LOGLO = logf(SERT_CLIP_LO), LOGHI = logf(SERT_CLIP_HI);
+    const float l = lse[row], rk = r[row];
+    float x[16], dj[16];
+    seg_load<V4>(Z + (size_t)row * V, V, seg, x, 0.f);
+    seg_load<V4>(dJ + (size_t)i * V, V, seg, dj, 0.f);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const float lp = x[u] - l;
+        x[u] = ((lp >= LOGLO && lp <= LOGHI) ? dj[u] : 0.f) - __expf(lp) * rk;
+    }
+    seg_store<V4>(Z + (size_t)row * V, V, seg, x);
+}
+
 }  // namespace sert

@@ -18,6 +18,7 @@ struct DataSplit {
     int64_t nnz = 0;
     int64_t max_labels_per_row = 0;
     float* w = nullptr;         // (N,) instance weights (train split)
+    float* labfix = nullptr;    // loglinear streaming loss: per label entry Q_e dQ_e (N or nnz)
     // inverted index word -> rows of every complete batch (train split only)
     int32_t* idx_rows = nullptr;
     int4* idx_items = nullptr;
@@ -100,6 +101,11 @@ struct sert_model {
     size_t wpart_rows = 0;
     float* part = nullptr;        // split-K partials
     size_t part_count = 0;
+    // loglinear streaming loss (kernels_ll.h, ll_s_*): per (row, segment) partials
+    float2* ll_tokstat = nullptr; float* ll_lse = nullptr; float2* ll_jstat = nullptr;
+    float4* ll_rowinfo = nullptr; float* ll_rpart = nullptr; float* ll_r = nullptr;
+    float* skbuf = nullptr;       // split-K partials of the long-K dX GEMMs (grown on demand)
+    size_t skbuf_count = 0;
     float* red_loss = nullptr;    // loss partials [kOptBlocks]
     float* red_sq = nullptr;      // sumsq partials [3 * kOptBlocks]
     float* d_loss = nullptr;      // [3] loss, data term, reg term (device)

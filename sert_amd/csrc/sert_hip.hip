@@ -226,6 +226,35 @@ static int entity_key_sort(sert_model* m, int total, hipStream_t st) {
     return 0;
 }
 
+// C (M,N, contiguous) = op(A).op(B) for a contraction over a LONG K (the entity
+// vocabulary in the dX GEMMs of the full-softmax models) whose output has too few
+// 128x128 tiles to fill 256 CUs: split K so that ~1024 workgroup items exist, then an
+// order-fixed combine (deterministic).
+template <bool TA, bool TB>
+static int gemm_long_k(sert_model* m, hipStream_t s, const float* A, const float* Bm, float* C, int M,
+                       int N, int K, int lda, int ldb) {
+    const int tiles = cdiv(M, GM) * cdiv(N, GN);
+    int splits = 1;
+    if (tiles < 512 && K >= 4096) splits = std::min(cdiv(1024, tiles), K / 1024);
+    if (splits <= 1) {
+        launch_gemm<TA, TB, EPI_STORE>(s, A, Bm, C, nullptr, M, N, K, lda, ldb, N);
+        return 0;
+    }
+    const int kper = (int)round_up(cdiv(K, splits), GK);
+    splits = cdiv(K, kper);
+    const size_t mn = (size_t)M * N;
+    if (mn * splits > m->skbuf_count) {
+        SERT_HIP(hipStreamSynchronize(s));
+        if (m->skbuf) (void)hipFree(m->skbuf);
+        m->skbuf = nullptr;
+        m->skbuf_count = mn * splits;
+        SERT_TRY(dmalloc(&m->skbuf, m->skbuf_count));
+    }
+    launch_gemm<TA, TB, EPI_STORE>(s, A, Bm, m->skbuf, nullptr, M, N, K, lda, ldb, N, splits, kper, mn);
+    hipLaunchKernelGGL(reduce_partials, dim3(cdiv(mn, 64)), dim3(256), 0, s, m->skbuf, splits, mn, mn, C, mn, C);
+    return 0;
+}
+
 // ---- data-parallel gradient exchange ---------------------------------------------
 // Sum-all-reduces over the flat gradient buffer, all issued on comm_stream in the
 // same order on every rank: (1) the word-table part, as soon as the segmented
@@ -511,7 +540,7 @@ static int fs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
     {
         // dp = dZ.R_e (B, d_e) ; da = dp * clip'(t) * tanh'(a)
         ScopedTimer t(m, TG_GEMM_DX);
-        launch_gemm<false, false, EPI_STORE>(m->stream, m->Z, m->re, m->DA, nullptr, B, de, V, V, de, de);
+        SERT_TRY((gemm_long_k<false, false>(m, m->stream, m->Z, m->re, m->DA, B, de, V, V, de)));
         hipLaunchKernelGGL(vs_tanh_backward, dim3(grid_for((int64_t)B * de)), dim3(256), 0, m->stream, m->DA,
                            m->T, (size_t)B * de);
     }
@@ -543,6 +572,34 @@ static int fs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
 }
 
 // ---- the loglinear step -------------------------------------------------------
+// Streaming loss for entity vocabularies beyond the LDS-resident slab (kernels_ll.h).
+template <bool TRAIN, bool V4>
+static int ll_stream_loss(sert_model* m, const DataSplit& ds, size_t row0, const int32_t* y,
+                          const int64_t* indptr, const float* w, float inv_batch) {
+    const auto& c = m->cfg;
+    const int B = c.batch_size, n = c.window_size, V = c.num_entities;
+    const int64_t rows = (int64_t)B * n;
+    const int nseg = cdiv(V, kLlSeg);
+    hipStream_t s = m->stream;
+    if (TRAIN && !ds.labfix) SERT_FAIL("training split has no label scratch");
+    float* labfix = TRAIN ? ds.labfix + (y ? row0 : 0) : nullptr;
+    hipLaunchKernelGGL((ll_s_tokstat<V4>), dim3((unsigned)(rows * nseg)), dim3(256), 0, s, m->Z, V, nseg, m->ll_tokstat);
+    hipLaunchKernelGGL(ll_s_lse, dim3(cdiv(rows, 4)), dim3(256), 0, s, m->ll_tokstat, rows, nseg, m->ll_lse);
+    hipLaunchKernelGGL((ll_s_window<V4>), dim3((unsigned)((int64_t)B * nseg)), dim3(256), 0, s, m->Z, m->ll_lse, n, V,
+                       nseg, m->J, m->ll_jstat);
+    hipLaunchKernelGGL((ll_s_rowloss<TRAIN>), dim3(B), dim3(256), 0, s, m->J, m->ll_jstat, y, indptr,
+                       ds.csr_indices, ds.csr_data, w, m->rowloss, m->ll_rowinfo, labfix, V, nseg, inv_batch);
+    if (!TRAIN) return 0;
+    hipLaunchKernelGGL((ll_s_dj<V4>), dim3((unsigned)((int64_t)B * nseg)), dim3(256), 0, s, m->J, m->ll_rowinfo, V, nseg);
+    hipLaunchKernelGGL(ll_s_labfix, dim3(B), dim3(256), 0, s, m->J, y, indptr, ds.csr_indices, labfix, V);
+    hipLaunchKernelGGL((ll_s_tokr<V4>), dim3((unsigned)(rows * nseg)), dim3(256), 0, s, m->Z, m->ll_lse, m->J, n, V,
+                       nseg, m->ll_rpart);
+    hipLaunchKernelGGL(ll_s_rsum, dim3(cdiv(rows, 4)), dim3(256), 0, s, m->ll_rpart, rows, nseg, m->ll_r);
+    hipLaunchKernelGGL((ll_s_dz<V4>), dim3((unsigned)(rows * nseg)), dim3(256), 0, s, m->Z, m->ll_lse, m->J, m->ll_r, n,
+                       V, nseg);
+    return 0;
+}
+
 template <bool TRAIN>
 static int ll_forward(sert_model* m, const DataSplit& ds, int64_t batch_index) {
     const auto& c = m->cfg;
@@ -576,12 +633,17 @@ static int ll_forward(sert_model* m, const DataSplit& ds, int64_t batch_index) {
         ScopedTimer t(m, TG_LOSS);
         hipLaunchKernelGGL((ll_fused_row<TRAIN>), dim3(B), dim3(256), fused_lds, m->stream, m->Z, y, indptr,
                            ds.csr_indices, ds.csr_data, w, m->rowloss, n, V, inv_batch);
-    } else {
+    } else if (getenv("SERT_LL_ROWWISE")) {
+        // the plain row-per-workgroup kernels (kept as a cross-check of the streaming path)
         ScopedTimer t(m, TG_LOSS);
         hipLaunchKernelGGL(ll_softmax_rows, dim3(cdiv(rows, 4)), dim3(256), 0, m->stream, m->Z, rows,
                            V);
         hipLaunchKernelGGL((ll_window<TRAIN>), dim3(B), dim3(256), 0, m->stream, m->Z, m->J, y,
                            indptr, ds.csr_indices, ds.csr_data, w, m->rowloss, n, V, inv_batch);
+    } else {
+        ScopedTimer t(m, TG_LOSS);
+        if (V % 4 == 0) SERT_TRY((ll_stream_loss<TRAIN, true>(m, ds, row0, y, indptr, w, inv_batch)));
+        else            SERT_TRY((ll_stream_loss<TRAIN, false>(m, ds, row0, y, indptr, w, inv_batch)));
     }
     return 0;
 }
@@ -612,8 +674,7 @@ static int ll_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         {
             // dG (rows, d) = dZ.W^T
             ScopedTimer t(m, TG_GEMM_DX);
-            launch_gemm<false, true, EPI_STORE>(m->stream, m->Z, m->W, m->DG, nullptr, (int)rows, d, V, V,
-                                                V, d);
+            SERT_TRY((gemm_long_k<false, true>(m, m->stream, m->Z, m->W, m->DG, (int)rows, d, V, V, V)));
         }
     }
     {
@@ -876,6 +937,10 @@ int sert_create(const sert_config* cfg, sert_model** out) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
             SERT_TRY(dzalloc(&m->G, B * n * dw, s));  SERT_TRY(dzalloc(&m->Z, B * n * V, s));
             SERT_TRY(dzalloc(&m->J, B * V, s));       SERT_TRY(dzalloc(&m->DG, B * n * dw, s));
+            const size_t nseg = cdiv(V, kLlSeg);
+            SERT_TRY(dzalloc(&m->ll_tokstat, B * n * nseg, s)); SERT_TRY(dzalloc(&m->ll_lse, B * n, s));
+            SERT_TRY(dzalloc(&m->ll_jstat, B * nseg, s));       SERT_TRY(dzalloc(&m->ll_rowinfo, B, s));
+            SERT_TRY(dzalloc(&m->ll_rpart, B * n * nseg, s));   SERT_TRY(dzalloc(&m->ll_r, B * n, s));
             const size_t tiles = (size_t)cdiv(V, GN) * cdiv(dw, GM);
             const size_t splits = std::max<size_t>(1, cdiv(1024, tiles)) + 1;
             part = splits * (dw * V + V);
@@ -897,7 +962,7 @@ int sert_create(const sert_config* cfg, sert_model** out) {
 
 static void free_split(DataSplit& d) {
     (void)hipFree(d.x); (void)hipFree(d.y); (void)hipFree(d.csr_indptr);
-    (void)hipFree(d.csr_indices); (void)hipFree(d.csr_data); (void)hipFree(d.w);
+    (void)hipFree(d.csr_indices); (void)hipFree(d.csr_data); (void)hipFree(d.w); (void)hipFree(d.labfix);
     (void)hipFree(d.idx_rows); (void)hipFree(d.idx_items);
     d = DataSplit();
 }
@@ -916,9 +981,11 @@ int sert_destroy(sert_model* m) {
     if (m->comm_stream) (void)hipStreamDestroy(m->comm_stream);
     float* bufs[] = {m->rw, m->re, m->W, m->b, m->s0_rw, m->s0_re, m->s0_w, m->s0_b, m->s1_rw,
                      m->s1_re, m->s1_w, m->s1_b, m->gflat, m->H, m->T, m->DA, m->DH, m->rowloss,
-                     m->G, m->Z, m->J, m->DG, m->DH2, m->part, m->wpart, m->red_loss, m->red_sq, m->d_loss,
+                     m->G, m->Z, m->J, m->DG, m->DH2, m->part, m->skbuf, m->wpart, m->red_loss, m->red_sq, m->d_loss,
                      m->d_losses};
     for (float* p : bufs) (void)hipFree(p);
+    (void)hipFree(m->ll_tokstat); (void)hipFree(m->ll_lse); (void)hipFree(m->ll_jstat);
+    (void)hipFree(m->ll_rowinfo); (void)hipFree(m->ll_rpart); (void)hipFree(m->ll_r);
     (void)hipFree(m->neg); (void)hipFree(m->neg_stage);
     (void)hipFree(m->cand); (void)hipFree(m->cand_sorted); 
     (void)hipFree(m->pair_sorted); (void)hipFree(m->coef); (void)hipFree(m->ehead);
@@ -1016,6 +1083,8 @@ int sert_upload_dataset(sert_model* m, int split, const void* x, const int32_t* 
             SERT_HIP(hipStreamSynchronize(s));
         }
     }
+    if (split == SERT_SPLIT_TRAIN && !m->cfg.inference_only && !is_vs(m))
+        SERT_TRY(dmalloc(&d.labfix, (size_t)std::max<int64_t>(1, y_int ? N : d.nnz)));
     if (split == SERT_SPLIT_TRAIN && !m->cfg.inference_only) {
         const int B = m->cfg.batch_size, n = m->cfg.window_size;
         const int64_t nb = N / B;

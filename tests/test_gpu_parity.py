@@ -98,7 +98,9 @@ def test_vectorspace_predict(hip_lib):
     dict(B=64, n=5, Vw=10000, Ve=100, d=64),     # C1-shaped
     dict(B=40, n=3, Vw=500, Ve=1000, d=30),
     dict(B=8, n=10, Vw=300, Ve=3500, d=16),       # 154 KB slab: fused kernel
-    dict(B=8, n=12, Vw=300, Ve=4000, d=16),       # > LDS: unfused fallback
+    dict(B=8, n=12, Vw=300, Ve=4000, d=16),       # > LDS: streaming path, one segment
+    dict(B=5, n=5, Vw=300, Ve=12000, d=16),       # streaming path, 3 segments, 16-byte rows
+    dict(B=4, n=4, Vw=200, Ve=9001, d=12),        # streaming path, ragged last segment, scalar rows
 ])
 def test_loglinear_steps(hip_lib, dims, labels):
     B, n = dims['B'], dims['n']

@@ -80,14 +80,14 @@ def group_work(kind, B, n, s, dw, de, Ve, Vw, z):
 
 
 KERNEL_OF_GROUP = {
-    'gather': 'vs_gather_mean<unsigned int, 4>', 'gemm_fwd': 'gemm_f32_mfma<false, false, 2, false, true>',
+    'gather': 'vs_gather_mean<unsigned int, 4>', 'gemm_fwd': 'gemm_f32_mfma<false, false, 2, false, true, true>',
     'loss': 'vs_nce<2, true>', 'entity_grad_reduce': 'egrad_chunk_reduce<4, 2>',
-    'entity_grad_fixup': 'egrad_fixup<4>', 'gemm_dW': 'gemm_f32_mfma<true, false, 0, true, true>',
-    'splitk_combine': 'reduce_partials', 'gemm_dX': 'gemm_f32_mfma<false, true, 0, false, true>',
+    'entity_grad_fixup': 'egrad_fixup<4>', 'gemm_dW': 'gemm_f32_mfma<true, false, 0, true, true, true>',
+    'splitk_combine': 'reduce_partials', 'gemm_dX': 'gemm_f32_mfma<false, true, 0, false, true, true>',
     'word_grad_segsum': 'segsum_rows<32>', 'optimizer_word_table': 'adam_l2<false>',
     'optimizer_other': 'adam_l2<false>', 'entity_sort': 'csort_scatter',
 }
-PMC_FILE = 'profiles/r01_c_vs_c2_pmc.json'
+PMC_FILE = 'profiles/r01_d_vs_c2_pmc.json'
 
 
 def load_pmc():

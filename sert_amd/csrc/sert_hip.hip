@@ -1274,7 +1274,12 @@ int sert_scorer_topk(sert_scorer* sc, const float* proj, int64_t Q, int32_t k, i
     const int64_t V = sc->V;
     const int dim = sc->dim;
     // query tile: bounds one materialised score slab to ~0.5 GiB (two slabs alternate)
-    const int64_t QT = std::min<int64_t>(Q, std::max<int64_t>(128, ((int64_t)1 << 27) / V / 128 * 128));
+    static const int64_t slab_elems = [] {
+        const char* e = getenv("SERT_SCORE_SLAB_MB");   // tuning knob
+        const int64_t mb = e ? atoll(e) : 0;
+        return mb > 0 ? (mb << 20) / 4 : ((int64_t)1 << 27);
+    }();
+    const int64_t QT = std::min<int64_t>(Q, std::max<int64_t>(128, slab_elems / V / 128 * 128));
     if (sc->cap_q < Q) {
         (void)hipFree(sc->P); (void)hipFree(sc->val); (void)hipFree(sc->idx);
         SERT_TRY(dmalloc(&sc->P, (size_t)Q * dim));

@@ -88,6 +88,18 @@ __device__ __forceinline__ float block_max_256(float v, float* red) {
     return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
+// Order-preserving map float -> uint32 such that ascending uint == DESCENDING float.
+__device__ __forceinline__ uint32_t desc_key(float f) {
+    uint32_t u = __float_as_uint(f);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // ascending map
+    return ~u;                                        // flip => descending
+}
+__device__ __forceinline__ float key_to_float(uint32_t k) {
+    uint32_t u = ~k;
+    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    return __uint_as_float(u);
+}
+
 // clip bounds of the reference as fp32 constants: 1e-7 and float32(1 - 1e-7)
 // = 1 - 2^-23 (sert/models.py:200, :290, :900, :1067-1068)
 #define SERT_CLIP_LO 1e-7f

@@ -41,7 +41,14 @@ constexpr int GM = 128, GN = 128, GK = SERT_GK, GLD = 132;
 constexpr int GNV = GK / 8;          // float4 pieces per thread per operand slab
 constexpr int GTPR = 256 / GK;       // threads per k-row in the k-major loader
 
-enum { EPI_STORE = 0, EPI_BIAS = 1, EPI_BIAS_TANH = 2 };
+enum { EPI_STORE = 0, EPI_BIAS = 1, EPI_BIAS_TANH = 2, EPI_FILTER = 3 };
+// EPI_FILTER (query scoring): nothing is stored to C.  The elements of row r that reach
+// the row's threshold (bias[r]) are written, as (order-preserving key, column), to small
+// per-(row, 64-column group) lists: the 32 lanes of a half-wave hold the same row, so the
+// slot of an element is a ballot/popcount prefix -- NO atomics (device-scope atomics run
+// at ~4 G/s on this part: 8 M appends cost more than the whole GEMM).  cand holds
+// `cap` slots per group, cnt (bytes) the group's element count (saturated at 255; a
+// count > cap tells the consumer the group overflowed).  Deterministic layout.
 
 // tanh for the projection epilogue (sert/models.py:1055): ~15 instructions instead
 // of the libm expansion (which, inlined 64x per lane, spilled the accumulators).
@@ -68,6 +75,10 @@ struct GemmArgs {
     int tiles_m, tiles_n;
     size_t c_split_stride;    // C offset between splits
     int vecA, vecB;           // 16-byte loads allowed
+    // EPI_FILTER only
+    unsigned long long* cand;   // [M][2*tiles_n][cap]
+    unsigned char* cnt;         // [M][2*tiles_n], zeroed by the caller
+    int cap;
 };
 
 // --- global -> registers (zero padded) ----------------------------------------
@@ -215,7 +226,7 @@ __global__ __launch_bounds__(256, SERT_GEMM_WAVES) void gemm_f32_mfma(const Gemm
     // that its latency hides under the MFMAs (loaded in the epilogue it cost ~6 us)
     float bias_v[2] = {0.f, 0.f};
     auto load_bias = [&]() {
-        if (EPI != EPI_STORE) {
+        if (EPI == EPI_BIAS || EPI == EPI_BIAS_TANH) {
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn) {
                 const int col = n0 + wc * 64 + tn * 32 + li;
@@ -302,7 +313,7 @@ __global__ __launch_bounds__(256, SERT_GEMM_WAVES) void gemm_f32_mfma(const Gemm
                 // store block gets its own s_waitcnt vmcnt(0), which (vmcnt counts
                 // stores on CDNA4) serialises the 64 stores behind each other
                 float bv0 = bias_v[0], bv1 = bias_v[1];
-                if (EPI != EPI_STORE) asm volatile("" : "+v"(bv0), "+v"(bv1));
+                if (EPI == EPI_BIAS || EPI == EPI_BIAS_TANH) asm volatile("" : "+v"(bv0), "+v"(bv1));
 #pragma unroll
                 for (int tm = 0; tm < 2; ++tm) {
 #pragma unroll
@@ -311,7 +322,61 @@ __global__ __launch_bounds__(256, SERT_GEMM_WAVES) void gemm_f32_mfma(const Gemm
                         const int row0 = wr * 64 + tm * 32 + 4 * lh;
                         const float bv = tn ? bv1 : bv0;
                         unsigned off = (unsigned)row0 * uld + (unsigned)col;
-                        if (FULL) {
+                        if (EPI == EPI_FILTER) {
+                            // handled once per tm (needs both tn values of the lane).  All
+                            // addresses are a workgroup-uniform tile base + a 32-bit lane offset
+                            // built from an opaque stride, so nothing is hoisted out of the
+                            // persistent loop and spilled (cf. the C-store path).
+                            if (tn == 0) {
+                                const int col0 = col, col1 = col + 32;
+                                const bool c0ok = col0 < nrem, c1ok = col1 < nrem;
+                                const unsigned below = (1u << li) - 1u;
+                                unsigned ngr = 2u * (unsigned)g.tiles_n;          // groups per row
+                                unsigned ucap = (unsigned)g.cap;
+                                asm volatile("" : "+s"(ngr), "+s"(ucap));
+                                const size_t gbase = (size_t)m0 * ngr + 2u * (unsigned)(n0 / GN);
+                                unsigned long long* cand_t = g.cand + gbase * ucap;
+                                unsigned char* cnt_t = g.cnt + gbase;
+                                const float* thr_t = g.bias + m0;
+                                float thr[16];
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) {
+                                    const int lrow = row0 + (r & 3) + 8 * (r >> 2);
+                                    thr[r] = (lrow < mrem) ? thr_t[lrow] : INFINITY;
+                                }
+                                unsigned goff = (unsigned)row0 * ngr + (unsigned)wc;   // group of (row, wc)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) {
+                                    const float v0 = acc[tm][0][r], v1 = acc[tm][1][r];
+                                    const bool p0 = c0ok && v0 >= thr[r];
+                                    const bool p1 = c1ok && v1 >= thr[r];
+                                    const unsigned h0 = (unsigned)(__ballot(p0) >> (32 * lh));
+                                    const unsigned h1 = (unsigned)(__ballot(p1) >> (32 * lh));
+                                    if (h0 | h1) {
+                                        const unsigned n0c = __popc(h0);
+                                        if (p0) {
+                                            const unsigned slot = __popc(h0 & below);
+                                            if (slot < ucap)
+                                                cand_t[goff * ucap + slot] =
+                                                    ((unsigned long long)desc_key(v0) << 32) | (unsigned)(n0 + col0);
+                                        }
+                                        if (p1) {
+                                            const unsigned slot = n0c + __popc(h1 & below);
+                                            if (slot < ucap)
+                                                cand_t[goff * ucap + slot] =
+                                                    ((unsigned long long)desc_key(v1) << 32) | (unsigned)(n0 + col1);
+                                        }
+                                        if (li == 0) {
+                                            const unsigned tot = n0c + __popc(h1);
+                                            cnt_t[goff] = (unsigned char)(tot > 255u ? 255u : tot);
+                                        }
+                                    }
+                                    goff += ((r & 3) == 3) ? 5u * ngr : ngr;
+                                }
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) { acc[tm][0][r] = 0.f; acc[tm][1][r] = 0.f; }
+                            }
+                        } else if (FULL) {
 #pragma unroll
                             for (int r = 0; r < 16; ++r) {
                                 float v = acc[tm][tn][r];
@@ -350,9 +415,11 @@ __global__ __launch_bounds__(256, SERT_GEMM_WAVES) void gemm_f32_mfma(const Gemm
 template <bool TA, bool TB, int EPI, bool CSB = false>
 inline void launch_gemm(hipStream_t s, const float* A, const float* B, float* C, const float* bias,
                         int M, int N, int K, int lda, int ldb, int ldc, int splits = 1,
-                        int kper = 0, size_t c_split_stride = 0) {
+                        int kper = 0, size_t c_split_stride = 0, unsigned long long* cand = nullptr,
+                        unsigned char* cnt = nullptr, int cap = 0) {
     if (splits <= 1) { splits = 1; kper = K; }
     GemmArgs g;
+    g.cand = cand; g.cnt = cnt; g.cap = cap;
     g.A = A; g.B = B; g.C = C; g.bias = bias;
     g.M = M; g.N = N; g.K = K;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc;
@@ -372,7 +439,7 @@ inline void launch_gemm(hipStream_t s, const float* A, const float* B, float* C,
         return v > 0 ? v : 256 * SERT_GEMM_WAVES;
     }();
     const int grid = (int)std::min<long long>(total, max_grid);
-    const bool full = (M % GM == 0) && (N % GN == 0);
+    const bool full = (M % GM == 0) && (N % GN == 0) && EPI != EPI_FILTER;
     if (vec && full) hipLaunchKernelGGL((gemm_f32_mfma<TA, TB, EPI, CSB, true, true>), dim3(grid), dim3(256), 0, s, g);
     else if (vec)    hipLaunchKernelGGL((gemm_f32_mfma<TA, TB, EPI, CSB, true, false>), dim3(grid), dim3(256), 0, s, g);
     else             hipLaunchKernelGGL((gemm_f32_mfma<TA, TB, EPI, CSB, false, false>), dim3(grid), dim3(256), 0, s, g);

@@ -27,18 +27,6 @@ __global__ void cos_to_score(float* __restrict__ S, size_t count) {
         S[i] = (S[i] + 1.0f) / 2.0f;
 }
 
-// Order-preserving map float -> uint32 such that ascending uint == DESCENDING float.
-__device__ __forceinline__ uint32_t desc_key(float f) {
-    uint32_t u = __float_as_uint(f);
-    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // ascending map
-    return ~u;                                        // flip => descending
-}
-__device__ __forceinline__ float key_to_float(uint32_t k) {
-    uint32_t u = ~k;
-    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
-    return __uint_as_float(u);
-}
-
 // Visit every element of a row with 16-byte loads, 4 independent loads per
 // thread in flight (a 4-byte load per iteration left this kernel latency-bound:
 // 2.8 TB/s with 32 waves per CU).  f(value, index) is called in arbitrary order.
@@ -82,9 +70,12 @@ constexpr int kTopKCand = 2048;   // LDS capacity for the threshold-bin candidat
 // remains as the fallback when the threshold bin overflows the candidate list
 // (many equal scores).  Ties resolve to the lowest entity index.  Emits
 // score = (cos + 1)/2 (query.py:352-357), computed in fp32.
+// thr_out (optional): instead of the (index, score) lists, only the RAW cosine of the
+// k-th best element is written per row (the sampled threshold of the fused path).
 __global__ __launch_bounds__(256) void topk_rows(const float* __restrict__ S, int V, int k,
                                                  int32_t* __restrict__ idx_out,
-                                                 float* __restrict__ val_out) {
+                                                 float* __restrict__ val_out,
+                                                 float* __restrict__ thr_out = nullptr) {
     __shared__ uint32_t hist[2048];
     __shared__ unsigned long long keys[kTopKMax];
     __shared__ unsigned long long cand[kTopKCand];
@@ -235,11 +226,119 @@ __global__ __launch_bounds__(256) void topk_rows(const float* __restrict__ S, in
             __syncthreads();
         }
     }
+    if (thr_out) {
+        if (tid == 0) thr_out[blockIdx.x] = key_to_float((uint32_t)(keys[k - 1] >> 32));
+        return;
+    }
     for (int i = tid; i < k; i += 256) {
         const unsigned long long kv = keys[i];
         idx_out[(size_t)blockIdx.x * k + i] = (int32_t)(uint32_t)kv;
         const float cosv = key_to_float((uint32_t)(kv >> 32));
         val_out[(size_t)blockIdx.x * k + i] = (cosv + 1.0f) / 2.0f;
+    }
+}
+
+// ---- fused path: GEMM with a filtering epilogue (gemm.h, EPI_FILTER) ---------------
+// For large entity tables the (Q, V) score matrix is never materialised:
+//   1. cosines against every kScoreStride-th entity (a 1/16 GEMM) and, per query, the
+//      r-th best of that sample = a threshold that about r*16 entities will reach;
+//   2. the full GEMM writes the elements that reach their row's threshold into small
+//      per-(row, 64-entity group) lists (about a thousand of V per row, no atomics);
+//   3. topk_from_groups gathers and sorts each row's lists (score desc, index asc) and
+//      emits the k best.
+// A row with an overflowed group, fewer than k or more than kCandCap candidates (a
+// threshold that the sample misjudged: heavy ties, adversarial entity order) is flagged
+// and recomputed by the materialising path, so the result is exact in every case.
+constexpr int kScoreStride = 16;
+constexpr int kCandCap = 4096;
+
+// One workgroup per query: gather the row's per-group lists (EPI_FILTER layout) into
+// LDS, sort (score desc, index asc), emit the k best.  Rows with an overflowed group,
+// fewer than k candidates or more than kCandCap are flagged for the materialising path.
+__global__ __launch_bounds__(256) void topk_from_groups(const unsigned long long* __restrict__ cand,
+                                                        const unsigned char* __restrict__ gcnt, int ngroups,
+                                                        int gcap, int k, int32_t* __restrict__ idx_out,
+                                                        float* __restrict__ val_out, int q_base,
+                                                        int* __restrict__ nflag, int* __restrict__ flag_list) {
+    __shared__ unsigned long long keys[kCandCap];
+    __shared__ unsigned scan[256];
+    __shared__ unsigned s_bad;
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const unsigned char* gc = gcnt + (size_t)q * ngroups;
+    // contiguous chunk of groups per thread -> exclusive offsets by a block scan
+    const int per = (ngroups + 255) / 256;
+    const int g0 = tid * per, g1 = min(ngroups, g0 + per);
+    unsigned mine = 0;
+    bool bad = false;
+    for (int g = g0; g < g1; ++g) {
+        const unsigned c = gc[g];
+        bad |= c > (unsigned)gcap;
+        mine += c;
+    }
+    if (tid == 0) s_bad = 0;
+    scan[tid] = mine;
+    __syncthreads();
+    if (bad) s_bad = 1;
+    for (int off = 1; off < 256; off <<= 1) {
+        const unsigned v = (tid >= off) ? scan[tid - off] : 0;
+        __syncthreads();
+        scan[tid] += v;
+        __syncthreads();
+    }
+    const unsigned total = scan[255];
+    if (s_bad || total < (unsigned)k || total > (unsigned)kCandCap) {     // workgroup-uniform
+        if (tid == 0) flag_list[atomicAdd(nflag, 1)] = q_base + q;
+        return;
+    }
+    unsigned pos = scan[tid] - mine;
+    for (int g = g0; g < g1; ++g) {
+        const unsigned c = gc[g];
+        const unsigned long long* src = cand + ((size_t)q * ngroups + g) * gcap;
+        for (unsigned j = 0; j < c; ++j) keys[pos + j] = src[j];
+        pos += c;
+    }
+    int sort_n = 2;
+    while (sort_n < (int)total) sort_n <<= 1;
+    for (int i = (int)total + tid; i < sort_n; i += 256) keys[i] = ~0ull;
+    __syncthreads();
+    for (int size = 2; size <= sort_n; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = tid; i < sort_n / 2; i += 256) {
+                const int lo = 2 * i - (i & (stride - 1));
+                const int hi = lo + stride;
+                const bool up = ((lo & size) == 0);
+                const unsigned long long a = keys[lo], b = keys[hi];
+                if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < k; i += 256) {
+        const unsigned long long kv = keys[i];
+        idx_out[(size_t)q * k + i] = (int32_t)(uint32_t)kv;
+        val_out[(size_t)q * k + i] = (key_to_float((uint32_t)(kv >> 32)) + 1.0f) / 2.0f;
+    }
+}
+
+// dst[i,:] = src[list[i],:]
+__global__ void gather_rows_f32(const float* __restrict__ src, const int* __restrict__ list, int rows,
+                                int d, float* __restrict__ dst) {
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < (size_t)rows * d;
+         t += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = t / d;
+        dst[t] = src[(size_t)list[r] * d + (t - r * d)];
+    }
+}
+// (idx, val)[list[i],:] = (idx_c, val_c)[i,:]
+__global__ void scatter_topk_rows(const int32_t* __restrict__ idx_c, const float* __restrict__ val_c,
+                                  const int* __restrict__ list, int rows, int k,
+                                  int32_t* __restrict__ idx, float* __restrict__ val) {
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < (size_t)rows * k;
+         t += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = t / k;
+        const size_t o = (size_t)list[r] * k + (t - r * k);
+        idx[o] = idx_c[t];
+        val[o] = val_c[t];
     }
 }
 

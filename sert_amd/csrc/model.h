@@ -148,4 +148,10 @@ struct sert_scorer {
     float* val = nullptr;    // (Q, k)
     int32_t* idx = nullptr;  // (Q, k)
     int64_t cap_q = 0, cap_qk = 0, cap_s = 0;
+    // fused path (GEMM with filtering epilogue): sample cosines, thresholds, candidate lists
+    float* Ss = nullptr; float* thr = nullptr;
+    unsigned long long* cand = nullptr; unsigned char* cnt = nullptr;
+    int* nflag = nullptr; int* flag_list = nullptr;
+    float* Pc = nullptr; int32_t* idx_c = nullptr; float* val_c = nullptr;
+    int64_t cap_ss = 0, cap_ft = 0, cap_cand = 0, cap_flag = 0, cap_c = 0, cap_ck = 0;
 };

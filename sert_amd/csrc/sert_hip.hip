@@ -1255,11 +1255,137 @@ int sert_scorer_destroy(sert_scorer* sc) {
     if (!sc) return 0;
     (void)hipSetDevice(sc->device);
     (void)hipFree(sc->E); (void)hipFree(sc->P); (void)hipFree(sc->S); (void)hipFree(sc->val); (void)hipFree(sc->idx);
+    (void)hipFree(sc->Ss); (void)hipFree(sc->thr); (void)hipFree(sc->cand); (void)hipFree(sc->cnt);
+    (void)hipFree(sc->nflag); (void)hipFree(sc->flag_list); (void)hipFree(sc->Pc); (void)hipFree(sc->idx_c);
+    (void)hipFree(sc->val_c);
     if (sc->ev_ready) (void)hipEventDestroy(sc->ev_ready);
     if (sc->ev_done) (void)hipEventDestroy(sc->ev_done);
     if (sc->stream2) (void)hipStreamDestroy(sc->stream2);
     if (sc->stream) (void)hipStreamDestroy(sc->stream);
     delete sc;
+    return 0;
+}
+
+// Materialising path: (QT, V) cosine slabs + per-row selection, for a device-resident
+// block of normalised projections.  Query tiles alternate between two streams; on return
+// everything is ordered on sc->stream.
+static int scorer_topk_materialised(sert_scorer* sc, const float* P, int64_t Q, int k, int32_t* idx,
+                                    float* val) {
+    hipStream_t s = sc->stream;
+    const int64_t V = sc->V;
+    const int dim = sc->dim;
+    static const int64_t slab_elems = [] {
+        const char* e = getenv("SERT_SCORE_SLAB_MB");   // tuning knob
+        const int64_t mb = e ? atoll(e) : 0;
+        return mb > 0 ? (mb << 20) / 4 : ((int64_t)1 << 27);
+    }();
+    // query tile: bounds one materialised score slab to ~0.5 GiB (two slabs alternate)
+    const int64_t QT = std::min<int64_t>(Q, std::max<int64_t>(128, slab_elems / V / 128 * 128));
+    if (sc->cap_s < 2 * QT * V) {
+        SERT_HIP(hipStreamSynchronize(s));
+        (void)hipFree(sc->S);
+        sc->S = nullptr; sc->cap_s = 0;
+        SERT_TRY(dmalloc(&sc->S, (size_t)2 * QT * V));
+        sc->cap_s = 2 * QT * V;
+    }
+    SERT_HIP(hipEventRecord(sc->ev_ready, s));
+    SERT_HIP(hipStreamWaitEvent(sc->stream2, sc->ev_ready, 0));
+    int t = 0;
+    for (int64_t q0 = 0; q0 < Q; q0 += QT, ++t) {
+        const int64_t qn = std::min(QT, Q - q0);
+        hipStream_t st = (t & 1) ? sc->stream2 : s;
+        float* S = sc->S + (size_t)(t & 1) * QT * V;
+        // S = P.E^T  (cosines), then per-row selection
+        launch_gemm<false, true, EPI_STORE>(st, P + q0 * dim, sc->E, S, nullptr, (int)qn, (int)V, dim,
+                                            dim, dim, (int)V);
+        hipLaunchKernelGGL(topk_rows, dim3((unsigned)qn), dim3(256), 0, st, S, (int)V, k, idx + q0 * k,
+                           val + q0 * k, (float*)nullptr);
+    }
+    SERT_HIP(hipEventRecord(sc->ev_done, sc->stream2));
+    SERT_HIP(hipStreamWaitEvent(s, sc->ev_done, 0));
+    return 0;
+}
+
+// Fused path (kernels_score.h): sampled thresholds, GEMM with a filtering epilogue,
+// selection from the candidate lists; flagged rows are redone by the materialising path.
+static int scorer_topk_fused(sert_scorer* sc, int64_t Q, int k, int rs) {
+    hipStream_t s = sc->stream;
+    const int64_t V = sc->V;
+    const int dim = sc->dim;
+    const int64_t Vs = cdiv(V, kScoreStride);
+    const int64_t QT = std::min<int64_t>(Q, 4096);
+    if (sc->cap_ss < QT * Vs) {
+        (void)hipFree(sc->Ss); sc->Ss = nullptr; sc->cap_ss = 0;
+        SERT_TRY(dmalloc(&sc->Ss, (size_t)(QT * Vs)));
+        sc->cap_ss = QT * Vs;
+    }
+    // per-(row, 64-entity group) candidate lists: 8 slots for ~0.5 expected entries per
+    // group (k <= 128), 16 beyond
+    const int ngroups = 2 * cdiv((int)V, GN);
+    const int gcap = k <= 128 ? 8 : 16;
+    if (sc->cap_ft < QT) {
+        (void)hipFree(sc->thr); sc->thr = nullptr; sc->cap_ft = 0;
+        SERT_TRY(dmalloc(&sc->thr, (size_t)QT));
+        sc->cap_ft = QT;
+    }
+    if (sc->cap_cand < QT * ngroups * gcap) {
+        (void)hipFree(sc->cand); (void)hipFree(sc->cnt);
+        sc->cand = nullptr; sc->cnt = nullptr; sc->cap_cand = 0;
+        SERT_TRY(dmalloc(&sc->cand, (size_t)QT * ngroups * gcap));
+        SERT_TRY(dmalloc(&sc->cnt, (size_t)QT * ngroups * 16 / 8));   // sized for either gcap
+        sc->cap_cand = QT * ngroups * gcap;
+    }
+    if (sc->cap_flag < Q) {
+        (void)hipFree(sc->flag_list); (void)hipFree(sc->nflag);
+        sc->flag_list = nullptr; sc->nflag = nullptr; sc->cap_flag = 0;
+        SERT_TRY(dmalloc(&sc->flag_list, (size_t)Q));
+        SERT_TRY(dmalloc(&sc->nflag, (size_t)1));
+        sc->cap_flag = Q;
+    }
+    SERT_HIP(hipMemsetAsync(sc->nflag, 0, sizeof(int), s));
+    for (int64_t q0 = 0; q0 < Q; q0 += QT) {
+        const int64_t qn = std::min(QT, Q - q0);
+        const float* P = sc->P + q0 * dim;
+        SERT_HIP(hipMemsetAsync(sc->cnt, 0, (size_t)qn * ngroups, s));
+        // 1. cosines against every kScoreStride-th entity; threshold = rs-th best of the sample
+        launch_gemm<false, true, EPI_STORE>(s, P, sc->E, sc->Ss, nullptr, (int)qn, (int)Vs, dim, dim,
+                                            dim * kScoreStride, (int)Vs);
+        hipLaunchKernelGGL(topk_rows, dim3((unsigned)qn), dim3(256), 0, s, sc->Ss, (int)Vs, rs,
+                           (int32_t*)nullptr, (float*)nullptr, sc->thr);
+        // 2. full GEMM, filtering epilogue
+        launch_gemm<false, true, EPI_FILTER>(s, P, sc->E, nullptr, sc->thr, (int)qn, (int)V, dim, dim, dim,
+                                             (int)V, 1, 0, 0, sc->cand, sc->cnt, gcap);
+        // 3. selection from the candidate lists
+        hipLaunchKernelGGL(topk_from_groups, dim3((unsigned)qn), dim3(256), 0, s, sc->cand, sc->cnt,
+                           ngroups, gcap, k, sc->idx + q0 * k, sc->val + q0 * k, (int)q0, sc->nflag,
+                           sc->flag_list);
+    }
+    int nf = 0;
+    SERT_HIP(hipMemcpyAsync(&nf, sc->nflag, sizeof(int), hipMemcpyDeviceToHost, s));
+    SERT_HIP(hipStreamSynchronize(s));
+    if (nf == 0) return 0;
+    // rows the sample misjudged: recompute exactly (ascending order, for reproducibility)
+    std::vector<int> list((size_t)nf);
+    SERT_HIP(hipMemcpy(list.data(), sc->flag_list, (size_t)nf * sizeof(int), hipMemcpyDeviceToHost));
+    std::sort(list.begin(), list.end());
+    SERT_HIP(hipMemcpyAsync(sc->flag_list, list.data(), (size_t)nf * sizeof(int), hipMemcpyHostToDevice, s));
+    if (sc->cap_c < nf) {
+        (void)hipFree(sc->Pc); sc->Pc = nullptr; sc->cap_c = 0;
+        SERT_TRY(dmalloc(&sc->Pc, (size_t)nf * dim));
+        sc->cap_c = nf;
+    }
+    if (sc->cap_ck < (int64_t)nf * k) {
+        (void)hipFree(sc->idx_c); (void)hipFree(sc->val_c);
+        sc->idx_c = nullptr; sc->val_c = nullptr; sc->cap_ck = 0;
+        SERT_TRY(dmalloc(&sc->idx_c, (size_t)nf * k));
+        SERT_TRY(dmalloc(&sc->val_c, (size_t)nf * k));
+        sc->cap_ck = (int64_t)nf * k;
+    }
+    hipLaunchKernelGGL(gather_rows_f32, dim3(grid_for((int64_t)nf * dim)), dim3(256), 0, s, sc->P,
+                       sc->flag_list, nf, dim, sc->Pc);
+    SERT_TRY(scorer_topk_materialised(sc, sc->Pc, nf, k, sc->idx_c, sc->val_c));
+    hipLaunchKernelGGL(scatter_topk_rows, dim3(grid_for((int64_t)nf * k)), dim3(256), 0, s, sc->idx_c,
+                       sc->val_c, sc->flag_list, nf, k, sc->idx, sc->val);
     return 0;
 }
 
@@ -1273,48 +1399,31 @@ int sert_scorer_topk(sert_scorer* sc, const float* proj, int64_t Q, int32_t k, i
     hipStream_t s = sc->stream;
     const int64_t V = sc->V;
     const int dim = sc->dim;
-    // query tile: bounds one materialised score slab to ~0.5 GiB (two slabs alternate)
-    static const int64_t slab_elems = [] {
-        const char* e = getenv("SERT_SCORE_SLAB_MB");   // tuning knob
-        const int64_t mb = e ? atoll(e) : 0;
-        return mb > 0 ? (mb << 20) / 4 : ((int64_t)1 << 27);
-    }();
-    const int64_t QT = std::min<int64_t>(Q, std::max<int64_t>(128, slab_elems / V / 128 * 128));
     if (sc->cap_q < Q) {
         (void)hipFree(sc->P); (void)hipFree(sc->val); (void)hipFree(sc->idx);
+        sc->P = nullptr; sc->val = nullptr; sc->idx = nullptr;
+        sc->cap_q = 0; sc->cap_qk = 0;
         SERT_TRY(dmalloc(&sc->P, (size_t)Q * dim));
         sc->cap_q = Q;
-        sc->cap_qk = 0;
-        sc->val = nullptr; sc->idx = nullptr;
     }
     if (sc->cap_qk < Q * k) {
         (void)hipFree(sc->val); (void)hipFree(sc->idx);
+        sc->val = nullptr; sc->idx = nullptr; sc->cap_qk = 0;
         SERT_TRY(dmalloc(&sc->val, (size_t)Q * k));
         SERT_TRY(dmalloc(&sc->idx, (size_t)Q * k));
         sc->cap_qk = Q * k;
     }
-    if (sc->cap_s < 2 * QT * V) {
-        (void)hipFree(sc->S);
-        SERT_TRY(dmalloc(&sc->S, (size_t)2 * QT * V));
-        sc->cap_s = 2 * QT * V;
-    }
     SERT_HIP(hipMemcpyAsync(sc->P, proj, (size_t)Q * dim * sizeof(float), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(l2_normalize_rows, dim3(cdiv(Q, 4)), dim3(256), 0, s, sc->P, Q, dim);
-    SERT_HIP(hipEventRecord(sc->ev_ready, s));
-    SERT_HIP(hipStreamWaitEvent(sc->stream2, sc->ev_ready, 0));
-    int t = 0;
-    for (int64_t q0 = 0; q0 < Q; q0 += QT, ++t) {
-        const int64_t qn = std::min(QT, Q - q0);
-        hipStream_t st = (t & 1) ? sc->stream2 : s;
-        float* S = sc->S + (size_t)(t & 1) * QT * V;
-        // S = P.E^T  (cosines), then per-row selection; tiles alternate streams
-        launch_gemm<false, true, EPI_STORE>(st, sc->P + q0 * dim, sc->E, S, nullptr, (int)qn, (int)V, dim,
-                                            dim, dim, (int)V);
-        hipLaunchKernelGGL(topk_rows, dim3((unsigned)qn), dim3(256), 0, st, S, (int)V, k,
-                           sc->idx + q0 * k, sc->val + q0 * k);
-    }
-    SERT_HIP(hipEventRecord(sc->ev_done, sc->stream2));
-    SERT_HIP(hipStreamWaitEvent(s, sc->ev_done, 0));
+    // fused path for large entity tables: the sample must be big enough for a stable
+    // threshold: rank rs among the V/16 sampled entities, i.e. an expected 2k+400 (std ~
+    // sqrt(rs)*16) candidates of V -- at k=100: 608 +- 99, >= k at 5 sigma, <= 1024 at 4
+    const int rs = cdiv(2 * k + 400, kScoreStride);
+    static const bool never_fuse = getenv("SERT_SCORE_MATERIALISE") != nullptr;   // cross-check knob
+    const bool fused = !never_fuse && V >= 32768 && dim % 4 == 0 && rs <= kTopKMax &&
+                       cdiv(V, kScoreStride) >= 8 * (int64_t)rs;
+    if (fused) SERT_TRY(scorer_topk_fused(sc, Q, k, rs));
+    else       SERT_TRY(scorer_topk_materialised(sc, sc->P, Q, k, sc->idx, sc->val));
     SERT_HIP(hipMemcpyAsync(idx_out, sc->idx, (size_t)Q * k * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     SERT_HIP(hipMemcpyAsync(score_out, sc->val, (size_t)Q * k * sizeof(float), hipMemcpyDeviceToHost, s));
     SERT_HIP(hipStreamSynchronize(s));

@@ -4,6 +4,10 @@ Tolerances (stated, fp32): per-step loss rel 1e-5; activations rel 1e-5;
 gradients rel 1e-4 (fp32 reassociation in atomics / MFMA / split-K);
 parameters after k steps rel 1e-4.
 """
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 
@@ -180,6 +184,75 @@ def test_score_topk_mass_ties(hip_lib, V):
     expect = np.nonzero(which == 2)[0][:k]
     assert np.array_equal(idx[0], expect)
     assert np.all(val[0] == val[0][0])
+
+
+def _check_topk_against_oracle(E, Pj, idx, val, k):
+    E64, P64 = E.astype(np.float64), Pj.astype(np.float64)
+    for q in range(Pj.shape[0]):
+        order, sc = O.vectorspace_rank(P64[q], E64, top=k)
+        full = None
+        for r in np.nonzero(idx[q] != order)[0]:
+            # identical ranking except where the fp64 score gap is below 1e-6
+            if full is None:
+                full = O.vectorspace_scores(P64[q], E64)
+            assert abs(full[idx[q][r]] - sc[r]) < 1e-6
+        assert np.abs(val[q] - sc).max() < 1e-6
+        assert len(set(idx[q].tolist())) == k
+
+
+@pytest.mark.parametrize('V,d,Q,k', [(40000, 16, 37, 10), (65536, 32, 130, 100), (50001, 64, 9, 1000)])
+def test_score_topk_fused_filter_path(hip_lib, V, d, Q, k):
+    """V >= 32768: sampled thresholds + GEMM with a filtering epilogue + selection from
+    the candidate lists (the score matrix is never materialised); same contract."""
+    rng = np.random.RandomState(11)
+    E = rng.randn(V, d).astype(np.float32)
+    Pj = np.tanh(rng.randn(Q, d)).astype(np.float32)
+    idx, val = C.score_topk(E, Pj, k)
+    _check_topk_against_oracle(E, Pj, idx, val, k)
+
+
+def test_score_topk_fused_path_adversarial_rows(hip_lib):
+    """Rows whose sampled threshold is useless are recomputed exactly:
+    (a) a query aligned with thousands of identical entities (every sampled and
+        unsampled copy ties: the candidate list overflows);
+    (b) the best entities all sit at indices the stride-16 sample never sees
+        (too few candidates would be impossible only by luck -- the flag catches it);
+    (c) ordinary queries in the same call keep the fused result."""
+    rng = np.random.RandomState(12)
+    V, d, k = 40000, 16, 50
+    E = rng.randn(V, d).astype(np.float32)
+    hot = rng.randn(d).astype(np.float32)
+    E[5000:15000] = hot                               # (a) 10 000 exact duplicates
+    spike = rng.randn(d).astype(np.float32)
+    off_sample = np.arange(20001, 20001 + 16 * 60, 16)   # (b) indices = 1 mod 16
+    E[off_sample] = spike + 0.01 * rng.randn(len(off_sample), d).astype(np.float32)
+    Pj = np.stack([hot, spike] + [np.tanh(rng.randn(d)).astype(np.float32) for _ in range(6)]).astype(np.float32)
+    idx, val = C.score_topk(E, Pj, k)
+    assert np.array_equal(idx[0], np.arange(5000, 5000 + k))       # ties -> lowest index first
+    assert np.all(val[0] == val[0][0])
+    assert set(idx[1].tolist()) <= set(off_sample.tolist())
+    _check_topk_against_oracle(E, Pj[1:], idx[1:], val[1:], k)
+
+
+def test_score_topk_fused_equals_materialised(hip_lib, monkeypatch):
+    """The two scoring paths return identical indices and bit-identical scores."""
+    rng = np.random.RandomState(13)
+    V, d, Q, k = 70000, 32, 300, 100
+    E = rng.randn(V, d).astype(np.float32)
+    Pj = np.tanh(rng.randn(Q, d)).astype(np.float32)
+    idx_f, val_f = C.score_topk(E, Pj, k)
+    code = ("import numpy as np, sys; sys.path.insert(0, %r); from sert_amd import _capi as C;"
+            "rng = np.random.RandomState(13); E = rng.randn(%d, %d).astype(np.float32);"
+            "Pj = np.tanh(rng.randn(%d, %d)).astype(np.float32); idx, val = C.score_topk(E, Pj, %d);"
+            "np.savez(sys.argv[1], idx=idx, val=val)" % (U.ROOT, V, d, Q, d, k))
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, 'm.npz')
+        env = dict(os.environ, SERT_SCORE_MATERIALISE='1')
+        subprocess.run([sys.executable, '-c', code, out], check=True, env=env)
+        ref = np.load(out)
+        assert np.array_equal(idx_f, ref['idx'])
+        assert np.array_equal(val_f, ref['val'])
 
 
 def test_device_sampler_uniform_and_rank_invariant(hip_lib):

@@ -1,5 +1,9 @@
 """Shared helpers for the parity tests (oracle = checker, HIP engine = subject)."""
+import os
+
 import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from oracle import sert_oracle as O
 from sert_amd import _capi as C

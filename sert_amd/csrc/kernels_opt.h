@@ -37,11 +37,15 @@ __device__ __forceinline__ void adam_elem(float& p, float& g, float& m, float& v
 
 // 16-byte accesses (4 streams in, 3-4 out); tensors are 16-byte aligned, the
 // (< 4 element) tail is handled by the first threads of block 0.
+// touched/row_len (optional, word table without memset): the gradient of a row whose
+// flag is 0 is zero and is not read (row_len % 4 == 0, count < 2^32).
 template <bool STORE_G>
 __global__ __launch_bounds__(256) void adam_l2(float* __restrict__ p, float* __restrict__ g,
                                                float* __restrict__ m, float* __restrict__ v,
                                                size_t count, AdamArgs a,
-                                               float* __restrict__ sumsq_partial) {
+                                               float* __restrict__ sumsq_partial,
+                                               const unsigned char* __restrict__ touched = nullptr,
+                                               unsigned row_len = 1) {
     __shared__ float red[4];
     float ss = 0.f;
     const float omb1 = 1.0f - a.b1, omb2 = 1.0f - a.b2;
@@ -56,7 +60,9 @@ __global__ __launch_bounds__(256) void adam_l2(float* __restrict__ p, float* __r
     const size_t lo = (size_t)blockIdx.x * per;
     const size_t hi = lo + per < n4 ? lo + per : n4;
     for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
+        float4 pp = p4[i], mm = m4[i], vv = v4[i];
+        float4 gg = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!touched || touched[((unsigned)i << 2) / row_len]) gg = g4[i];
         adam_elem(pp.x, gg.x, mm.x, vv.x, a, omb1, omb2, ss);
         adam_elem(pp.y, gg.y, mm.y, vv.y, a, omb1, omb2, ss);
         adam_elem(pp.z, gg.z, mm.z, vv.z, a, omb1, omb2, ss);
@@ -103,7 +109,9 @@ __global__ __launch_bounds__(256) void adadelta_l2(float* __restrict__ p, float*
                                                    float* __restrict__ accu,
                                                    float* __restrict__ delta, size_t count,
                                                    AdadeltaArgs a,
-                                                   float* __restrict__ sumsq_partial) {
+                                                   float* __restrict__ sumsq_partial,
+                                                   const unsigned char* __restrict__ touched = nullptr,
+                                                   unsigned row_len = 1) {
     __shared__ float red[4];
     float ss = 0.f;
     const float omr = 1.0f - a.rho;
@@ -118,7 +126,9 @@ __global__ __launch_bounds__(256) void adadelta_l2(float* __restrict__ p, float*
     const size_t lo = (size_t)blockIdx.x * per;
     const size_t hi = lo + per < n4 ? lo + per : n4;
     for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        float4 pp = p4[i], gg = g4[i], aa = a4[i], dd = d4[i];
+        float4 pp = p4[i], aa = a4[i], dd = d4[i];
+        float4 gg = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!touched || touched[((unsigned)i << 2) / row_len]) gg = g4[i];
         adadelta_elem(pp.x, gg.x, aa.x, dd.x, a, omr, ss);
         adadelta_elem(pp.y, gg.y, aa.y, dd.y, a, omr, ss);
         adadelta_elem(pp.z, gg.z, aa.z, dd.z, a, omr, ss);

@@ -10,18 +10,23 @@ namespace sert {
 //       dst <  0 : partial[-(dst+1), :] = acc        (next level's input)
 // row(e) = rows ? rows[e] : e.  LPI lanes cooperate on one item (LPI = 32 when
 // d/4 <= 32 so a wave carries two items), each lane owns float4 column chunks.
+// touched (optional): touched[dst] = 1 for every final row written -- the optimiser
+// then treats unflagged rows as zero gradient, so the table needs no memset and the
+// zeros are never read back.
 template <int LPI>
 __global__ __launch_bounds__(256) void segsum_rows(const float* __restrict__ src,
                                                    const int32_t* __restrict__ rows,
                                                    const int4* __restrict__ items, int nitems,
                                                    float* __restrict__ final_dst,
                                                    float* __restrict__ partial_dst, int d,
-                                                   float divisor) {
+                                                   float divisor,
+                                                   unsigned char* __restrict__ touched) {
     constexpr int IPB = 256 / LPI;  // items per block
     const int sub = threadIdx.x / LPI, l = threadIdx.x % LPI;
     const int item = blockIdx.x * IPB + sub;
     if (item >= nitems) return;
     const int4 it = items[item];
+    if (touched && l == 0 && it.z >= 0) touched[it.z] = 1;
     const int chunks = d >> 2;
     for (int c = l; c < chunks; c += LPI) {
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -59,11 +64,13 @@ __global__ __launch_bounds__(256) void segsum_rows_scalar(const float* __restric
                                                           const int4* __restrict__ items,
                                                           int nitems, float* __restrict__ final_dst,
                                                           float* __restrict__ partial_dst, int d,
-                                                          float divisor) {
+                                                          float divisor,
+                                                          unsigned char* __restrict__ touched) {
     const int lane = threadIdx.x & 63;
     const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (item >= nitems) return;
     const int4 it = items[item];
+    if (touched && lane == 0 && it.z >= 0) touched[it.z] = 1;
     for (int c = lane; c < d; c += 64) {
         float a = 0.f;
         for (int e = it.x; e < it.y; ++e) {

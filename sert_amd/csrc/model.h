@@ -59,7 +59,8 @@ struct sert_model {
     sert_config cfg;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // side stream: the entity-gradient chain runs beside the GEMMs
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr;
+    hipStream_t stream3 = nullptr;   // dW + split-K combine, beside dX/segsum and the entity chain
 
     // shapes
     size_t n_rw = 0, n_re = 0, n_w = 0, n_b = 0;
@@ -104,6 +105,10 @@ struct sert_model {
     // loglinear streaming loss (kernels_ll.h, ll_s_*): per (row, segment) partials
     float2* ll_tokstat = nullptr; float* ll_lse = nullptr; float2* ll_jstat = nullptr;
     float4* ll_rowinfo = nullptr; float* ll_rpart = nullptr; float* ll_r = nullptr;
+    // touched-row flags of the word table for this step (single GPU): the word-gradient
+    // table is then neither zeroed nor read where no token of the batch points
+    unsigned char* rw_touched = nullptr;
+    bool use_touched = false;
     float* skbuf = nullptr;       // split-K partials of the long-K dX GEMMs (grown on demand)
     size_t skbuf_count = 0;
     float* red_loss = nullptr;    // loss partials [kOptBlocks]

@@ -177,6 +177,7 @@ static int word_grad_segsum(sert_model* m, const DataSplit& ds, int64_t batch_in
     const int d = m->cfg.word_dim;
     if ((size_t)batch_index >= ds.idx_batches.size()) SERT_FAIL("batch has no word index");
     const BatchIndex& bx = ds.idx_batches[(size_t)batch_index];
+    unsigned char* touched = m->use_touched ? m->rw_touched : nullptr;
     for (int l = 0; l < bx.nlevels; ++l) {
         const int nitems = bx.item_cnt[l];
         if (nitems == 0) continue;
@@ -187,13 +188,13 @@ static int word_grad_segsum(sert_model* m, const DataSplit& ds, int64_t batch_in
         if (d % 4 == 0) {
             if (d / 4 <= 32)
                 hipLaunchKernelGGL((segsum_rows<32>), dim3(cdiv(nitems, 8)), dim3(256), 0, m->stream,
-                                   in, rows, items, nitems, m->g_rw, pout, d, divisor);
+                                   in, rows, items, nitems, m->g_rw, pout, d, divisor, touched);
             else
                 hipLaunchKernelGGL((segsum_rows<64>), dim3(cdiv(nitems, 4)), dim3(256), 0, m->stream,
-                                   in, rows, items, nitems, m->g_rw, pout, d, divisor);
+                                   in, rows, items, nitems, m->g_rw, pout, d, divisor, touched);
         } else {
             hipLaunchKernelGGL(segsum_rows_scalar, dim3(cdiv(nitems, 4)), dim3(256), 0, m->stream, in,
-                               rows, items, nitems, m->g_rw, pout, d, divisor);
+                               rows, items, nitems, m->g_rw, pout, d, divisor, touched);
         }
     }
     return 0;
@@ -450,7 +451,11 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
     };
     auto dense_grad = [&]() -> int {
         // dW = h^T.da (reduction over the batch: split-K, order-fixed combine);
-        // db = sum_i da_i rides along as the column sums of the da operand
+        // db = sum_i da_i rides along as the column sums of the da operand.
+        // Third stream: dW and dh are both 512-workgroup launches (2 waves per SIMD, too
+        // few to hide their own latencies) -- side by side they fill each other's bubbles.
+        hipStream_t sd = m->timing.enabled ? m->stream : m->stream3;
+        if (sd != m->stream) SERT_HIP(hipStreamWaitEvent(sd, m->ev_fork, 0));
         static const int want_splits = [] { const char* e = getenv("SERT_DW_SPLITS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
         int splits = std::min(want_splits, cdiv(B, GK));
         int kper = (int)round_up(cdiv(B, splits), GK);
@@ -459,14 +464,15 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         const size_t stride = mn + de;
         {
             ScopedTimer t(m, TG_GEMM_DW);
-            launch_gemm<true, false, EPI_STORE, true>(m->stream, m->H, m->DA, m->part, nullptr, dw, de,
+            launch_gemm<true, false, EPI_STORE, true>(sd, m->H, m->DA, m->part, nullptr, dw, de,
                                                       B, dw, de, de, splits, kper, stride);
         }
         {
             ScopedTimer t(m, TG_SPLITK);
-            hipLaunchKernelGGL(reduce_partials, dim3(cdiv(stride, 64)), dim3(256), 0, m->stream, m->part,
+            hipLaunchKernelGGL(reduce_partials, dim3(cdiv(stride, 64)), dim3(256), 0, sd, m->part,
                                splits, stride, stride, m->g_w, mn, m->g_b);
         }
+        if (sd != m->stream) SERT_HIP(hipEventRecord(m->ev_join3, sd));
         return 0;
     };
     if (m->comm) {
@@ -479,9 +485,10 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         SERT_TRY(dense_grad());
         SERT_TRY(word_table_grad());
     }
-    // join the entity-gradient chain
+    // join the entity-gradient chain and the dense gradients
     SERT_HIP(hipEventRecord(m->ev_join, m->stream2));
     SERT_HIP(hipStreamWaitEvent(m->stream, m->ev_join, 0));
+    if (!m->timing.enabled) SERT_HIP(hipStreamWaitEvent(m->stream, m->ev_join3, 0));
     (void)row0;
     return 0;
 }
@@ -729,12 +736,14 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst /* device [3] */, i
             const int nb = (int)std::min<int64_t>(std::max(1, kOptBlocks / nchunks), cdiv(cdiv(cnt, 4), 256));
             float* sq = m->red_sq + n_sq;
             float *p = m->rw + lo, *g = m->g_rw + lo, *s0 = m->s0_rw + lo, *s1 = m->s1_rw + lo;
+            const unsigned char* tf = m->use_touched ? m->rw_touched : nullptr;   // (never with slices)
+            const unsigned rl = (unsigned)c.word_dim;
             if (is_vs(m)) {
-                if (keep) hipLaunchKernelGGL((adam_l2<true>), dim3(nb), dim3(256), 0, m->stream, p, g, s0, s1, cnt, aa, sq);
-                else      hipLaunchKernelGGL((adam_l2<false>), dim3(nb), dim3(256), 0, m->stream, p, g, s0, s1, cnt, aa, sq);
+                if (keep) hipLaunchKernelGGL((adam_l2<true>), dim3(nb), dim3(256), 0, m->stream, p, g, s0, s1, cnt, aa, sq, tf, rl);
+                else      hipLaunchKernelGGL((adam_l2<false>), dim3(nb), dim3(256), 0, m->stream, p, g, s0, s1, cnt, aa, sq, tf, rl);
             } else {
-                if (keep) hipLaunchKernelGGL((adadelta_l2<true>), dim3(nb), dim3(256), 0, m->stream, p, g, s0, s1, cnt, da, sq);
-                else      hipLaunchKernelGGL((adadelta_l2<false>), dim3(nb), dim3(256), 0, m->stream, p, g, s0, s1, cnt, da, sq);
+                if (keep) hipLaunchKernelGGL((adadelta_l2<true>), dim3(nb), dim3(256), 0, m->stream, p, g, s0, s1, cnt, da, sq, tf, rl);
+                else      hipLaunchKernelGGL((adadelta_l2<false>), dim3(nb), dim3(256), 0, m->stream, p, g, s0, s1, cnt, da, sq, tf, rl);
             }
             n_sq += nb;
         }
@@ -749,8 +758,8 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst /* device [3] */, i
         if (big_re) {
             const int nb = std::min<int64_t>(kOptBlocks, cdiv(cdiv(m->n_re, 4), 256));
             float* sq = m->red_sq + n_sq;
-            if (keep) hipLaunchKernelGGL((adam_l2<true>), dim3(nb), dim3(256), 0, m->stream, m->re, m->g_re, m->s0_re, m->s1_re, m->n_re, aa, sq);
-            else      hipLaunchKernelGGL((adam_l2<false>), dim3(nb), dim3(256), 0, m->stream, m->re, m->g_re, m->s0_re, m->s1_re, m->n_re, aa, sq);
+            if (keep) hipLaunchKernelGGL((adam_l2<true>), dim3(nb), dim3(256), 0, m->stream, m->re, m->g_re, m->s0_re, m->s1_re, m->n_re, aa, sq, (const unsigned char*)nullptr, 1u);
+            else      hipLaunchKernelGGL((adam_l2<false>), dim3(nb), dim3(256), 0, m->stream, m->re, m->g_re, m->s0_re, m->s1_re, m->n_re, aa, sq, (const unsigned char*)nullptr, 1u);
             n_sq += nb;
         }
         SmallTensors st;
@@ -798,7 +807,18 @@ static int train_step_async(sert_model* m, int64_t batch_index, const int64_t* n
     if (m->cfg.inference_only) SERT_FAIL("model was created inference_only");
     if (ds.N == 0) SERT_FAIL("no training data uploaded");
     if (batch_index < 0 || (batch_index + 1) * (int64_t)B > ds.N) SERT_FAIL("batch_index out of range");
-    SERT_HIP(hipMemsetAsync(m->gflat, 0, m->gflat_alloc * sizeof(float), m->stream));
+    // Single GPU: the word-gradient table is not zeroed -- the segmented reduction flags
+    // the rows it writes and the optimiser takes every other row's gradient as zero.
+    // (Data parallel: the all-reduce needs the dense table; keep_grads: so does the caller.)
+    static const bool no_touched = getenv("SERT_NO_TOUCHED") != nullptr;   // cross-check knob
+    m->use_touched = !no_touched && !m->comm && !m->cfg.keep_grads && m->cfg.word_dim % 4 == 0 &&
+                     m->n_rw < ((size_t)1 << 32) && m->rw_touched != nullptr;
+    if (m->use_touched) {
+        SERT_HIP(hipMemsetAsync(m->gflat + m->ar_split, 0, (m->gflat_alloc - m->ar_split) * sizeof(float), m->stream));
+        SERT_HIP(hipMemsetAsync(m->rw_touched, 0, (size_t)m->cfg.vocab_size, m->stream));
+    } else {
+        SERT_HIP(hipMemsetAsync(m->gflat, 0, m->gflat_alloc * sizeof(float), m->stream));
+    }
     if (is_fs(m)) {
         SERT_TRY(fs_forward<true>(m, ds, batch_index));
         SERT_TRY(fs_backward(m, ds, batch_index));
@@ -864,6 +884,8 @@ int sert_create(const sert_config* cfg, sert_model** out) {
     const auto& c = m->cfg;
     SERT_HIP(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
     SERT_HIP(hipStreamCreateWithFlags(&m->stream2, hipStreamNonBlocking));
+    SERT_HIP(hipStreamCreateWithFlags(&m->stream3, hipStreamNonBlocking));
+    SERT_HIP(hipEventCreateWithFlags(&m->ev_join3, hipEventDisableTiming));
     SERT_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
     SERT_HIP(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
     const size_t B = c.batch_size, n = c.window_size, dw = c.word_dim, V = c.num_entities;
@@ -946,6 +968,7 @@ int sert_create(const sert_config* cfg, sert_model** out) {
             part = splits * (dw * V + V);
         }
         m->part_count = part;
+        SERT_TRY(dzalloc(&m->rw_touched, (size_t)c.vocab_size, s));
         SERT_TRY(dzalloc(&m->part, part, s));
         SERT_TRY(dzalloc(&m->red_loss, (size_t)kOptBlocks, s));
         SERT_TRY(dzalloc(&m->red_sq, (size_t)4 * kOptBlocks, s));  // partials of up to 4 tensors
@@ -986,6 +1009,7 @@ int sert_destroy(sert_model* m) {
     for (float* p : bufs) (void)hipFree(p);
     (void)hipFree(m->ll_tokstat); (void)hipFree(m->ll_lse); (void)hipFree(m->ll_jstat);
     (void)hipFree(m->ll_rowinfo); (void)hipFree(m->ll_rpart); (void)hipFree(m->ll_r);
+    (void)hipFree(m->rw_touched);
     (void)hipFree(m->neg); (void)hipFree(m->neg_stage);
     (void)hipFree(m->cand); (void)hipFree(m->cand_sorted); 
     (void)hipFree(m->pair_sorted); (void)hipFree(m->coef); (void)hipFree(m->ehead);
@@ -999,6 +1023,8 @@ int sert_destroy(sert_model* m) {
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     if (m->ev_join) (void)hipEventDestroy(m->ev_join);
     if (m->stream2) (void)hipStreamDestroy(m->stream2);
+    if (m->ev_join3) (void)hipEventDestroy(m->ev_join3);
+    if (m->stream3) (void)hipStreamDestroy(m->stream3);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
     return 0;

@@ -376,3 +376,26 @@ def test_vectorspace_softmax_variant_steps(hip_lib, dims):
     ev_ref = ora.eval_loss(p['X'][:B], p['y'][:B])
     assert abs(ev - ev_ref) <= LOSS_TOL * abs(ev_ref)
     eng.close()
+
+
+@pytest.mark.parametrize('dw', [16, 10])
+def test_untouched_word_rows_need_no_memset(hip_lib, dw):
+    """keep_grads=0 (the product setting): the word-gradient table is neither zeroed nor
+    read where no token of the batch points; the optimiser still applies the L2 / moment
+    decay to those rows.  Must equal the keep_grads=1 run (dense, zeroed table) bit for
+    bit.  dw=10 (not a multiple of 4) keeps the dense path in both runs."""
+    B, n, z, Vw, Ve, de = 32, 3, 4, 5000, 12, 16      # 96 tokens per batch over 5000 words
+    p = U.make_vs_problem(41, B * 4, n, z, Vw, Ve, dw, de)
+    neg = p['rng'].randint(0, Ve, (B, z)).astype(np.int64)
+    outs = []
+    for keep in (1, 0):
+        eng = U.vs_engine(p, B, n, z, 0.05, keep_grads=keep)
+        eng.upload_dataset(C.SPLIT_TRAIN, p['X'], y_int=p['y'], w=p['w'])
+        losses = [eng.train_batch(s % 4, neg) for s in range(6)]
+        outs.append((losses, eng.get_tensor(C.T_RW).copy(), eng.get_tensor(C.T_RE).copy()))
+        eng.close()
+    assert outs[0][0] == outs[1][0]
+    assert np.array_equal(outs[0][1], outs[1][1])
+    assert np.array_equal(outs[0][2], outs[1][2])
+    # and the untouched rows did move (L2 + Adam on a zero data gradient)
+    assert not np.array_equal(outs[1][1].reshape(Vw, dw)[-50:], p['Rw'][-50:])

@@ -225,7 +225,9 @@ __global__ __launch_bounds__(256) void finalize_loss(const float* __restrict__ l
                                                      int n_loss,
                                                      const float* __restrict__ sq_partials,
                                                      int n_sq, float inv_batch, float reg_scale,
-                                                     float* __restrict__ out) {
+                                                     float* __restrict__ out,
+                                                     unsigned* __restrict__ host_flag = nullptr,
+                                                     unsigned seq = 0) {
     __shared__ double red[256];
     double a = 0.0;
     for (int i = threadIdx.x; i < n_loss; i += 256) a += (double)loss_partials[i];
@@ -251,6 +253,9 @@ __global__ __launch_bounds__(256) void finalize_loss(const float* __restrict__ l
         out[0] = data + reg;
         out[1] = data;
         out[2] = reg;
+        // out may be pinned host memory: publish the step's sequence number after the
+        // values (system-scope release) -- the host spins on it instead of a stream sync
+        if (host_flag) __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 

@@ -61,6 +61,16 @@ struct sert_model {
     hipStream_t stream2 = nullptr;   // side stream: the entity-gradient chain runs beside the GEMMs
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join3 = nullptr;
     hipStream_t stream3 = nullptr;   // dW + split-K combine, beside dX/segsum and the entity chain
+    // step prologue (zeroing, negative sampling) and the small-tensor optimiser run on
+    // stream2 beside the main chain; these events order them
+    hipEvent_t ev_step_done = nullptr, ev_neg = nullptr, ev_opt_fork = nullptr, ev_small = nullptr;
+    int n_loss_partials = 0;
+    // SERT_STREAMS: 1 = everything on the main stream (0.423 ms/step at C2), 2 = + the entity
+    // chain, the step prologue and the small-tensor optimiser on a side stream (0.396),
+    // 3 = + dW on a third (0.403: every cross-queue dependency costs 15-25 us of idle GPU)
+    int nstreams = 2;
+    unsigned loss_seq = 0;        // sequence number the final kernel publishes beside the loss
+    float* h_loss_dev = nullptr;  // device address of the pinned h_loss block
 
     // shapes
     size_t n_rw = 0, n_re = 0, n_w = 0, n_b = 0;

@@ -150,7 +150,10 @@ def timed_steps(model, dist, num_batches, steps, warmup, timing=True):
     t0 = time.perf_counter()
     last = 0.0
     for i in range(steps):
+        # as ModelInterface._iterate_batches does: announce the batch that follows
+        eng.hint_next_batch((warmup + i + 1) % num_batches if i + 1 < steps else None)
         last = model.train_fn((warmup + i) % num_batches)
+    eng.hint_next_batch(None)
     eng.synchronize()
     dist.barrier()
     dt = time.perf_counter() - t0

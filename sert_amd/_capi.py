@@ -26,7 +26,8 @@ COMM_ID_BYTES = 128
 EXPORTS = [
     'sert_create', 'sert_destroy', 'sert_last_error', 'sert_device_info', 'sert_device_count',
     'sert_set_tensor', 'sert_get_tensor', 'sert_tensor_size', 'sert_set_step', 'sert_get_step',
-    'sert_upload_dataset', 'sert_train_batch', 'sert_train_batches', 'sert_eval_batch',
+    'sert_upload_dataset', 'sert_train_batch', 'sert_hint_next_batch', 'sert_train_batches',
+    'sert_eval_batch',
     'sert_predict_project', 'sert_predict_tokens', 'sert_score_topk',
     'sert_scorer_create', 'sert_scorer_destroy', 'sert_scorer_topk', 'sert_scorer_scores',
     'sert_comm_unique_id', 'sert_comm_init', 'sert_comm_destroy',
@@ -96,6 +97,7 @@ def load():
     lib.sert_upload_dataset.argtypes = [vp, ctypes.c_int, fp, fp, fp, fp, fp, fp, i64]
     lib.sert_train_batch.argtypes = [vp, i64, fp, ctypes.POINTER(ctypes.c_float)]
     lib.sert_train_batches.argtypes = [vp, fp, i64, fp]
+    lib.sert_hint_next_batch.argtypes = [vp, i64]
     lib.sert_eval_batch.argtypes = [vp, ctypes.c_int, i64, fp, ctypes.POINTER(ctypes.c_float)]
     lib.sert_predict_project.argtypes = [vp, fp, i64, fp]
     lib.sert_predict_tokens.argtypes = [vp, fp, i64, fp]
@@ -232,6 +234,12 @@ class Engine(object):
         check(self._lib.sert_train_batch(self._h, int(batch_index), _addr(negatives),
                                          ctypes.byref(loss)))
         return np.float32(loss.value)
+
+    def hint_next_batch(self, next_batch_index):
+        """The batch that will be trained after the next train_batch call (or None):
+        its parameter-only forward part is enqueued before that call waits for its loss."""
+        check(self._lib.sert_hint_next_batch(
+            self._h, -1 if next_batch_index is None else int(next_batch_index)))
 
     def train_batches(self, batch_indices):
         idx = np.ascontiguousarray(batch_indices, dtype=np.int64)

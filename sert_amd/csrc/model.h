@@ -69,6 +69,8 @@ struct sert_model {
     // chain, the step prologue and the small-tensor optimiser on a side stream (0.396),
     // 3 = + dW on a third (0.403: every cross-queue dependency costs 15-25 us of idle GPU)
     int nstreams = 2;
+    int64_t hint_next = -1;        // sert_hint_next_batch
+    int64_t projected_batch = -1;  // training batch whose forward projection already sits in H/T
     unsigned loss_seq = 0;        // sequence number the final kernel publishes beside the loss
     float* h_loss_dev = nullptr;  // device address of the pinned h_loss block
 

@@ -850,7 +850,10 @@ static int train_step_async(sert_model* m, int64_t batch_index, const int64_t* n
     hipStream_t pre = side_pre ? m->stream2 : m->stream;
     // the main stream's first kernels go out BEFORE the prologue's host calls: the GPU
     // starts on gather + projection while the host is still enqueueing
-    if (is_vs(m) && !is_fs(m)) SERT_TRY(vs_project(m, ds, batch_index));
+    if (is_vs(m) && !is_fs(m)) {
+        if (m->projected_batch != batch_index) SERT_TRY(vs_project(m, ds, batch_index));
+        m->projected_batch = -1;
+    }
     // (the previous step's optimiser and loss kernels read what the prologue overwrites)
     if (side_pre) SERT_HIP(hipStreamWaitEvent(pre, m->ev_step_done, 0));
     if (m->use_touched) {
@@ -1095,6 +1098,7 @@ size_t sert_tensor_size(sert_model* m, int which) {
 }
 
 int sert_set_tensor(sert_model* m, int which, const float* host, size_t count) {
+    if (m) m->projected_batch = -1;
     if (!m || !host) SERT_FAIL("null argument");
     SERT_HIP(hipSetDevice(m->cfg.device));
     TensorRef t = tensor_ref(m, which);
@@ -1127,6 +1131,8 @@ int sert_upload_dataset(sert_model* m, int split, const void* x, const int32_t* 
                         const int64_t* csr_indptr, const int32_t* csr_indices,
                         const float* csr_data, const float* w, int64_t N) {
     if (!m) SERT_FAIL("null model");
+    m->projected_batch = -1;
+    m->hint_next = -1;
     if (split != SERT_SPLIT_TRAIN && split != SERT_SPLIT_VALIDATE) SERT_FAIL("bad split");
     if (N < 0) SERT_FAIL("negative instance count");
     if (N > 0 && !x) SERT_FAIL("x is null");
@@ -1201,9 +1207,22 @@ int sert_train_batch(sert_model* m, int64_t batch_index, const int64_t* negative
     if (!m) SERT_FAIL("null model");
     SERT_HIP(hipSetDevice(m->cfg.device));
     static const bool no_spin = getenv("SERT_NO_SPIN") != nullptr;   // cross-check knob
+    // sert_hint_next_batch: the next batch's parameter-only forward part goes out behind
+    // this step, before the host starts waiting for this step's loss
+    const int64_t hint = m->hint_next;
+    m->hint_next = -1;
+    auto prefetch_next = [&]() -> int {
+        const DataSplit& ds = m->split[SERT_SPLIT_TRAIN];
+        if (hint < 0 || m->timing.enabled || !is_vs(m) || is_fs(m)) return 0;
+        if ((hint + 1) * (int64_t)m->cfg.batch_size > ds.N) return 0;
+        SERT_TRY(vs_project(m, ds, hint));
+        m->projected_batch = hint;
+        return 0;
+    };
     if (m->timing.enabled || no_spin) {
         SERT_TRY(train_step_async(m, batch_index, negatives, m->d_loss));
         SERT_HIP(hipMemcpyAsync(m->h_loss, m->d_loss, 3 * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+        SERT_TRY(prefetch_next());
         SERT_HIP(hipStreamSynchronize(m->stream));
         timing_collect(m);
         if (loss_out) *loss_out = m->h_loss[0];
@@ -1215,6 +1234,7 @@ int sert_train_batch(sert_model* m, int64_t batch_index, const int64_t* negative
     // (sert/models.py:369-379): 0.412 -> 0.396 ms/step at C2.  Everything the step did is
     // stream-ordered before that kernel, so the parameters are final when the number appears.
     SERT_TRY(train_step_async(m, batch_index, negatives, m->h_loss_dev, true));
+    SERT_TRY(prefetch_next());
     const unsigned want = m->loss_seq;
     volatile unsigned* flag = reinterpret_cast<volatile unsigned*>(m->h_loss + 4);
     for (unsigned spins = 1; *flag != want; ++spins) {
@@ -1232,8 +1252,15 @@ int sert_train_batch(sert_model* m, int64_t batch_index, const int64_t* negative
     return 0;
 }
 
+int sert_hint_next_batch(sert_model* m, int64_t next_batch_index) {
+    if (!m) SERT_FAIL("null model");
+    m->hint_next = next_batch_index;
+    return 0;
+}
+
 int sert_train_batches(sert_model* m, const int64_t* batch_indices, int64_t count, float* losses_out) {
     if (!m || !batch_indices || count < 0) SERT_FAIL("bad argument");
+    m->hint_next = -1;
     SERT_HIP(hipSetDevice(m->cfg.device));
     if (count == 0) return 0;
     if (m->d_losses_cap < count) {
@@ -1264,6 +1291,7 @@ int sert_train_batches(sert_model* m, const int64_t* batch_indices, int64_t coun
 
 int sert_eval_batch(sert_model* m, int split, int64_t batch_index, const int64_t* negatives, float* loss_out) {
     if (!m) SERT_FAIL("null model");
+    m->projected_batch = -1;   // evaluation reuses the activation buffers
     if (split != SERT_SPLIT_TRAIN && split != SERT_SPLIT_VALIDATE) SERT_FAIL("bad split");
     SERT_HIP(hipSetDevice(m->cfg.device));
     const DataSplit& ds = m->split[split];

@@ -75,7 +75,16 @@ class ModelInterface(object):
 
             np.random.shuffle(batch_indices)
 
-        for batch_idx in batch_indices:
+        # The order is known up front: while training, tell the engine which batch
+        # follows, so that it can enqueue that batch's parameter-only forward part
+        # before the host starts waiting for the current loss (no effect on results).
+        hint = getattr(getattr(self, '_engine', None), 'hint_next_batch', None) \
+            if fn == getattr(self, 'train_fn', None) else None
+
+        for position, batch_idx in enumerate(batch_indices):
+            if hint is not None:
+                hint(batch_indices[position + 1]
+                     if position + 1 < len(batch_indices) else None)
             results.append(fn(batch_idx))
 
             if not np.all(np.isfinite(results[-1])):

@@ -399,3 +399,33 @@ def test_untouched_word_rows_need_no_memset(hip_lib, dw):
     assert np.array_equal(outs[0][2], outs[1][2])
     # and the untouched rows did move (L2 + Adam on a zero data gradient)
     assert not np.array_equal(outs[1][1].reshape(Vw, dw)[-50:], p['Rw'][-50:])
+
+
+def test_next_batch_hint_changes_nothing_but_the_schedule(hip_lib):
+    """sert_hint_next_batch: the speculative forward projection of the announced batch
+    must not change any result -- with correct hints, with a WRONG hint (another batch
+    is trained next), and with an evaluation in between (which reuses the buffers)."""
+    B, n, z, Vw, Ve, dw, de = 64, 3, 4, 300, 12, 16, 16
+    p = U.make_vs_problem(51, B * 5, n, z, Vw, Ve, dw, de)
+    neg = p['rng'].randint(0, Ve, (B, z)).astype(np.int64)
+    order = [3, 0, 4, 1, 2, 0]
+    outs = []
+    for mode in ('none', 'right', 'wrong'):
+        eng = U.vs_engine(p, B, n, z, 0.01, keep_grads=0)
+        eng.upload_dataset(C.SPLIT_TRAIN, p['X'], y_int=p['y'], w=p['w'])
+        losses = []
+        for pos, b in enumerate(order):
+            nxt = order[pos + 1] if pos + 1 < len(order) else None
+            if mode == 'right':
+                eng.hint_next_batch(nxt)
+            elif mode == 'wrong':
+                eng.hint_next_batch((b + 2) % 5)
+            losses.append(eng.train_batch(b, neg))
+            if pos == 2:
+                losses.append(eng.eval_batch(C.SPLIT_TRAIN, 1, neg))
+        outs.append((losses, eng.get_tensor(C.T_RW).copy(), eng.get_tensor(C.T_W).copy()))
+        eng.close()
+    for other in outs[1:]:
+        assert outs[0][0] == other[0]
+        assert np.array_equal(outs[0][1], other[1])
+        assert np.array_equal(outs[0][2], other[2])

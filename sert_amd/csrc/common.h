@@ -79,6 +79,31 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
     __syncthreads();
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
+// NW-wave workgroup variants (red: NW floats of LDS)
+template <int NW>
+__device__ __forceinline__ float block_sum_n(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float a = red[0];
+#pragma unroll
+    for (int i = 1; i < NW; ++i) a += red[i];
+    return a;
+}
+template <int NW>
+__device__ __forceinline__ float block_max_n(float v, float* red) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float a = red[0];
+#pragma unroll
+    for (int i = 1; i < NW; ++i) a = fmaxf(a, red[i]);
+    return a;
+}
 __device__ __forceinline__ float block_max_256(float v, float* red) {
     v = wave_max(v);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;

@@ -157,8 +157,8 @@ __global__ __launch_bounds__(256) void ll_window(float* __restrict__ P, float* _
 // when n*V floats (+V) fit the 160 KB LDS (C1 / C2 shapes); same maths, same
 // citations as the two kernels above.
 //   dynamic LDS: S[n*V] | J[V]
-template <bool TRAIN>
-__global__ __launch_bounds__(256) void ll_fused_row(float* __restrict__ Z,
+template <bool TRAIN, int NT>
+__global__ __launch_bounds__(NT) void ll_fused_row(float* __restrict__ Z,
                                                     const int32_t* __restrict__ y_int,
                                                     const int64_t* __restrict__ indptr,
                                                     const int32_t* __restrict__ indices,
@@ -167,7 +167,8 @@ __global__ __launch_bounds__(256) void ll_fused_row(float* __restrict__ Z,
                                                     float* __restrict__ rowloss, int n, int V,
                                                     float inv_batch) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    __shared__ float red[4];
+    constexpr int NW = NT / 64;
+    __shared__ float red[NW];
     float* S = lds;                       // (n, V) logits -> log-probabilities
     float* Jl = lds + (size_t)n * V;      // (V) window log-product -> dJ
     const int i = blockIdx.x;
@@ -178,28 +179,28 @@ __global__ __launch_bounds__(256) void ll_fused_row(float* __restrict__ Z,
     // 1. slab -> LDS: batches of 8 independent 16-byte loads per thread in flight
     //    (a load->ds_write chain per iteration would expose the full HBM latency)
     if ((total & 3) == 0) {
-        for (int t0 = tid * 4; t0 < total; t0 += 8 * 1024) {
+        for (int t0 = tid * 4; t0 < total; t0 += 8 * 4 * NT) {
             float4 v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int t = t0 + u * 1024;
+                const int t = t0 + u * 4 * NT;
                 v[u] = (t < total) ? *reinterpret_cast<const float4*>(Zi + t) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int t = t0 + u * 1024;
+                const int t = t0 + u * 4 * NT;
                 if (t < total) *reinterpret_cast<float4*>(S + t) = v[u];
             }
         }
     } else {
-        for (int t = tid; t < total; t += 256) S[t] = Zi[t];
+        for (int t = tid; t < total; t += NT) S[t] = Zi[t];
     }
     __syncthreads();
     // 2. per-token log-softmax (one wave per token)       models.py:841
     //    kept in the LOG domain: log P = (z - max) - log(sum exp), so the window
     //    log-product needs no per-element logf and clip(P) is a clamp of log P
     const float LOGLO = logf(SERT_CLIP_LO), LOGHI = logf(SERT_CLIP_HI);
-    for (int k = wv; k < n; k += 4) {
+    for (int k = wv; k < n; k += NW) {
         float* zk = S + (size_t)k * V;
         float tmx = -INFINITY;
 #pragma unroll 8
@@ -218,24 +219,24 @@ __global__ __launch_bounds__(256) void ll_fused_row(float* __restrict__ Z,
     __syncthreads();
     // 3. window log-product J_e = sum_k log clip(P_ke) and its softmax   models.py:200-210
     float mx = -INFINITY;
-    for (int e = tid; e < V; e += 256) {
+    for (int e = tid; e < V; e += NT) {
         float a = 0.f;
 #pragma unroll 5
         for (int k = 0; k < n; ++k) a += fminf(fmaxf(S[(size_t)k * V + e], LOGLO), LOGHI);
         Jl[e] = a;
         mx = fmaxf(mx, a);
     }
-    mx = block_max_256(mx, red);
+    mx = block_max_n<NW>(mx, red);
     float se = 0.f;
-    for (int e = tid; e < V; e += 256) se += expf(Jl[e] - mx);
-    se = block_sum_256(se, red);
+    for (int e = tid; e < V; e += NT) se += expf(Jl[e] - mx);
+    se = block_sum_n<NW>(se, red);
     // 4. loss and s = sum_e dQ_e Q_e over the label entries  models.py:289-292
     const float wi = TRAIN ? w[i] : 1.f;
     const float g = wi * inv_batch;
     float loss = 0.f, sdq = 0.f;
     int64_t l0 = 0, l1 = 1;
     if (y_int == nullptr) { l0 = indptr[i]; l1 = indptr[i + 1]; }
-    for (int64_t l = l0 + tid; l < l1; l += 256) {
+    for (int64_t l = l0 + tid; l < l1; l += NT) {
         const int e = y_int ? y_int[i] : indices[l];
         const float yv = y_int ? 1.f : data[l];
         const float q = expf(Jl[e] - mx) / se;
@@ -246,17 +247,17 @@ __global__ __launch_bounds__(256) void ll_fused_row(float* __restrict__ Z,
             sdq += (inside ? -(g * yv) / qc : 0.f) * q;
         }
     }
-    loss = block_sum_256(loss, red);
+    loss = block_sum_n<NW>(loss, red);
     if (tid == 0) rowloss[i] = wi * loss;
     if (!TRAIN) return;
-    sdq = block_sum_256(sdq, red);
+    sdq = block_sum_n<NW>(sdq, red);
     // 5. dJ_e = Q_e (dQ_e - s): label entries first need the un-overwritten J
     //    -> keep their (e, Q_e dQ_e) in registers, write the dense part, then add
     float fix_val[4];
     int fix_e[4];
     int nfix = 0;
     bool overflow = false;
-    for (int64_t l = l0 + tid; l < l1; l += 256) {
+    for (int64_t l = l0 + tid; l < l1; l += NT) {
         const int e = y_int ? y_int[i] : indices[l];
         const float yv = y_int ? 1.f : data[l];
         const float q = expf(Jl[e] - mx) / se;
@@ -267,13 +268,13 @@ __global__ __launch_bounds__(256) void ll_fused_row(float* __restrict__ Z,
     }
     (void)overflow;   // > 1024 labels on one instance is outside this kernel's contract (host checks)
     __syncthreads();
-    for (int e = tid; e < V; e += 256) Jl[e] = -(expf(Jl[e] - mx) / se) * sdq;
+    for (int e = tid; e < V; e += NT) Jl[e] = -(expf(Jl[e] - mx) / se) * sdq;
     __syncthreads();
     for (int f = 0; f < nfix; ++f) Jl[fix_e[f]] += fix_val[f];
     __syncthreads();
     // 6. per token: dZ_k = P_k (dP_k - <dP_k, P_k>) with dP = dJ*mask/P, i.e.
     //    dZ_ke = mask_ke dJ_e - P_ke r_k,  r_k = sum_e mask_ke dJ_e;  straight to HBM
-    for (int k = wv; k < n; k += 4) {
+    for (int k = wv; k < n; k += NW) {
         const float* lk = S + (size_t)k * V;
         float r = 0.f;
 #pragma unroll 8

@@ -654,7 +654,9 @@ static int ll_forward(sert_model* m, const DataSplit& ds, int64_t batch_index) {
     // fused path: the row's (n, V) slab lives in LDS; CSR rows with > 1024 labels fall back
     if (fused_lds <= 150 * 1024 && ds.max_labels_per_row <= 1024) {
         ScopedTimer t(m, TG_LOSS);
-        hipLaunchKernelGGL((ll_fused_row<TRAIN>), dim3(B), dim3(256), fused_lds, m->stream, m->Z, y, indptr,
+        // 512 threads per row: 302 us at 256 (too few waves to hide the slab load), 228 at
+        // 512, 320 at 640 (one wave per token, but only two workgroups fit a CU)
+        hipLaunchKernelGGL((ll_fused_row<TRAIN, 512>), dim3(B), dim3(512), fused_lds, m->stream, m->Z, y, indptr,
                            ds.csr_indices, ds.csr_data, w, m->rowloss, n, V, inv_batch);
     } else if (getenv("SERT_LL_ROWWISE")) {
         // the plain row-per-workgroup kernels (kept as a cross-check of the streaming path)
@@ -1005,10 +1007,11 @@ int sert_create(const sert_config* cfg, sert_model** out) {
             }
         } else {
             // the fused loss kernel may ask for more than the default 64 KB of dynamic LDS
-            SERT_HIP(hipFuncSetAttribute((const void*)ll_fused_row<true>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-            SERT_HIP(hipFuncSetAttribute((const void*)ll_fused_row<false>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+#define SERT_LL_ATTR(NT)                                                                                  \
+    SERT_HIP(hipFuncSetAttribute((const void*)ll_fused_row<true, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); \
+    SERT_HIP(hipFuncSetAttribute((const void*)ll_fused_row<false, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))
+            SERT_LL_ATTR(512);
+#undef SERT_LL_ATTR
             SERT_TRY(dzalloc(&m->G, B * n * dw, s));  SERT_TRY(dzalloc(&m->Z, B * n * V, s));
             SERT_TRY(dzalloc(&m->J, B * V, s));       SERT_TRY(dzalloc(&m->DG, B * n * dw, s));
             const size_t nseg = cdiv(V, kLlSeg);

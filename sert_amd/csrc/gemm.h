@@ -85,14 +85,19 @@ struct GemmArgs {
 // VEC = true : every 4-float piece is 16-byte aligned and either fully inside or
 //              fully outside the matrix (leading dims, extents and pointers are
 //              multiples of 4 floats) -> branch-free: one float4 load from a
-//              clamped address, zeroed by select when outside.
+//              clamped (always valid) address; bit j of `mask` says whether piece j
+//              is inside.  The zeroing happens in lstore_*, AFTER the MFMAs of the
+//              current slab: touching the loaded value here (even a multiply by
+//              the mask) makes the compiler wait for the load on the spot, which
+//              turns the prefetch into a synchronous load (73 % -> MFMA busy).
 // VEC = false: scalar guarded loads (odd sizes; small problems only).
 //
 // Source stored [k][c], contiguous along c (the tile's M or N axis).
 // `base` = src + k0*ld + c0 is workgroup-uniform; lane offsets are 32-bit.
 template <bool VEC>
 __device__ __forceinline__ void gload_kmajor(const float* __restrict__ base, int ld, int krem,
-                                             int crem, float4 (&r)[GNV]) {
+                                             int crem, float4 (&r)[GNV], unsigned& mask) {
+    mask = 0xffffffffu;
     const int t = threadIdx.x;
     const int kr = t / GTPR;
     const int cq = (t % GTPR) * 4;
@@ -102,12 +107,9 @@ __device__ __forceinline__ void gload_kmajor(const float* __restrict__ base, int
     for (int j = 0; j < GNV; ++j) {
         const int c = cq + j * (GTPR * 4);
         if (VEC) {
-            // unconditional load from a clamped (always valid) offset, zeroed by a
-            // multiply: a select would make hipcc branch around every load
             const bool ok = kok && (c < crem);
-            const float okf = ok ? 1.f : 0.f;
-            const float4 v = *reinterpret_cast<const float4*>(base + (ok ? roff + (unsigned)c : 0u));
-            r[j] = make_float4(v.x * okf, v.y * okf, v.z * okf, v.w * okf);
+            if (!ok) mask &= ~(1u << j);
+            r[j] = *reinterpret_cast<const float4*>(base + (ok ? roff + (unsigned)c : 0u));
         } else {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (kok) {
@@ -120,18 +122,23 @@ __device__ __forceinline__ void gload_kmajor(const float* __restrict__ base, int
         }
     }
 }
-__device__ __forceinline__ void lstore_kmajor(float (*dst)[GLD], const float4 (&r)[GNV]) {
+__device__ __forceinline__ void lstore_kmajor(float (*dst)[GLD], const float4 (&r)[GNV], unsigned mask) {
     const int t = threadIdx.x;
     const int kr = t / GTPR, cq = (t % GTPR) * 4;
 #pragma unroll
-    for (int j = 0; j < GNV; ++j) *reinterpret_cast<float4*>(&dst[kr][cq + j * (GTPR * 4)]) = r[j];
+    for (int j = 0; j < GNV; ++j) {
+        const bool ok = (mask >> j) & 1u;
+        *reinterpret_cast<float4*>(&dst[kr][cq + j * (GTPR * 4)]) =
+            make_float4(ok ? r[j].x : 0.f, ok ? r[j].y : 0.f, ok ? r[j].z : 0.f, ok ? r[j].w : 0.f);
+    }
 }
 
 // Source stored [c][k], contiguous along k: transposed on the way into LDS.
 // `base` = src + c0*ld + k0 is workgroup-uniform.
 template <bool VEC>
 __device__ __forceinline__ void gload_cmajor(const float* __restrict__ base, int ld, int krem,
-                                             int crem, float4 (&r)[GNV]) {
+                                             int crem, float4 (&r)[GNV], unsigned& mask) {
+    mask = 0xffffffffu;
     const int t = threadIdx.x;
     const int c = t >> 1;
     const int kh = (t & 1) * (GK / 2);
@@ -142,9 +149,8 @@ __device__ __forceinline__ void gload_cmajor(const float* __restrict__ base, int
         const int k = kh + j * 4;
         if (VEC) {
             const bool ok = cok && (k < krem);
-            const float okf = ok ? 1.f : 0.f;
-            const float4 v = *reinterpret_cast<const float4*>(base + (ok ? roff + (unsigned)k : 0u));
-            r[j] = make_float4(v.x * okf, v.y * okf, v.z * okf, v.w * okf);
+            if (!ok) mask &= ~(1u << j);
+            r[j] = *reinterpret_cast<const float4*>(base + (ok ? roff + (unsigned)k : 0u));
         } else {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (cok) {
@@ -157,16 +163,17 @@ __device__ __forceinline__ void gload_cmajor(const float* __restrict__ base, int
         }
     }
 }
-__device__ __forceinline__ void lstore_cmajor(float (*dst)[GLD], const float4 (&r)[GNV]) {
+__device__ __forceinline__ void lstore_cmajor(float (*dst)[GLD], const float4 (&r)[GNV], unsigned mask) {
     const int t = threadIdx.x;
     const int c = t >> 1, kh = (t & 1) * (GK / 2);
 #pragma unroll
     for (int j = 0; j < GNV; ++j) {
         const int kl = kh + j * 4;
-        dst[kl + 0][c] = r[j].x;
-        dst[kl + 1][c] = r[j].y;
-        dst[kl + 2][c] = r[j].z;
-        dst[kl + 3][c] = r[j].w;
+        const bool ok = (mask >> j) & 1u;
+        dst[kl + 0][c] = ok ? r[j].x : 0.f;
+        dst[kl + 1][c] = ok ? r[j].y : 0.f;
+        dst[kl + 2][c] = ok ? r[j].z : 0.f;
+        dst[kl + 3][c] = ok ? r[j].w : 0.f;
     }
 }
 
@@ -205,6 +212,7 @@ __global__ __launch_bounds__(256, SERT_GEMM_WAVES) void gemm_f32_mfma(const Gemm
         kbeg = z * g.kper;
         kend = min(g.K, kbeg + g.kper);
     };
+    unsigned mka = 0xffffffffu, mkb = 0xffffffffu;   // inside-masks of the staged pieces
     auto gload = [&](int mm0, int nn0, int k0, int ke, float4 (&ra)[GNV], float4 (&rb)[GNV]) {
         // tile base pointers are workgroup-uniform (SGPRs); per-lane offsets 32-bit.
         // The leading dimensions are made opaque here so that the lane offsets are
@@ -212,14 +220,14 @@ __global__ __launch_bounds__(256, SERT_GEMM_WAVES) void gemm_f32_mfma(const Gemm
         // of the persistent loop and spilled (64-bit addresses x 16 loads).
         int lda_ = g.lda, ldb_ = g.ldb;
         asm volatile("" : "+s"(lda_), "+s"(ldb_));
-        if (TA) gload_kmajor<VEC>(g.A + (size_t)k0 * lda_ + mm0, lda_, ke - k0, g.M - mm0, ra);
-        else    gload_cmajor<VEC>(g.A + (size_t)mm0 * lda_ + k0, lda_, ke - k0, g.M - mm0, ra);
-        if (TB) gload_cmajor<VEC>(g.B + (size_t)nn0 * ldb_ + k0, ldb_, ke - k0, g.N - nn0, rb);
-        else    gload_kmajor<VEC>(g.B + (size_t)k0 * ldb_ + nn0, ldb_, ke - k0, g.N - nn0, rb);
+        if (TA) gload_kmajor<VEC>(g.A + (size_t)k0 * lda_ + mm0, lda_, ke - k0, g.M - mm0, ra, mka);
+        else    gload_cmajor<VEC>(g.A + (size_t)mm0 * lda_ + k0, lda_, ke - k0, g.M - mm0, ra, mka);
+        if (TB) gload_cmajor<VEC>(g.B + (size_t)nn0 * ldb_ + k0, ldb_, ke - k0, g.N - nn0, rb, mkb);
+        else    gload_kmajor<VEC>(g.B + (size_t)k0 * ldb_ + nn0, ldb_, ke - k0, g.N - nn0, rb, mkb);
     };
     auto lstore = [&](int buf, const float4 (&ra)[GNV], const float4 (&rb)[GNV]) {
-        if (TA) lstore_kmajor(As[buf], ra); else lstore_cmajor(As[buf], ra);
-        if (TB) lstore_cmajor(Bs[buf], rb); else lstore_kmajor(Bs[buf], rb);
+        if (TA) lstore_kmajor(As[buf], ra, mka); else lstore_cmajor(As[buf], ra, mka);
+        if (TB) lstore_cmajor(Bs[buf], rb, mkb); else lstore_kmajor(Bs[buf], rb, mkb);
     };
 
     // bias of this wave's two column groups, fetched at the START of every tile so
@@ -279,7 +287,11 @@ __global__ __launch_bounds__(256, SERT_GEMM_WAVES) void gemm_f32_mfma(const Gemm
             }
 #pragma unroll
             for (int kk = 0; kk < GK; kk += 2) {
+#ifdef SERT_GEMM_EXP_NOLDS
+                const int k = lh;          // EXPERIMENT (wrong results): one fragment set per slab
+#else
                 const int k = kk + lh;
+#endif
                 const float a0 = As[buf][k][wr * 64 + li];
                 const float a1 = As[buf][k][wr * 64 + 32 + li];
                 const float b0 = Bs[buf][k][wc * 64 + li];

@@ -87,7 +87,7 @@ KERNEL_OF_GROUP = {
     'word_grad_segsum': 'segsum_rows<32>', 'optimizer_word_table': 'adam_l2<false>',
     'optimizer_other': 'adam_l2<false>', 'entity_sort': 'csort_scatter',
 }
-PMC_FILE = 'profiles/r01_d_vs_c2_pmc.json'
+PMC_FILE = 'profiles/r01_e_vs_c2_pmc.json'
 
 
 def load_pmc():
@@ -314,6 +314,15 @@ def main():
                 kernels[name] = dict(us=round(us, 2))
         pmc = load_pmc()
         dom = max((k for k in kernels if 'bound' in kernels[k]), key=lambda k: kernels[k]['us'])
+        # three launches tie at C2 (entity/word gradient reductions and the word-table
+        # optimiser, ~59 us each): among kernels within 3 % of the longest, report the one
+        # that streams the most real HBM bytes (the PMC file) -- the reductions gather
+        # cache-resident rows, their algorithmic rate is not an HBM rate
+        ties = [k for k in kernels if 'bound' in kernels[k] and kernels[k]['us'] >= 0.97 * kernels[dom]['us']]
+        if len(ties) > 1 and pmc:
+            hbm_of = lambda k: (pmc_traffic(pmc, KERNEL_OF_GROUP.get(k), kernels[k]['us']) or 0.0)
+            # prefer the kernel whose PMC bytes are closest to (not far above) its algorithmic bytes
+            dom = min(ties, key=lambda k: abs(1.0 - hbm_of(k) / max(1.0, work[k][1])))
         kd = kernels[dom]
         roofline = dict(kernel=dom, hip_kernel=KERNEL_OF_GROUP.get(dom), bound=kd['bound'],
                         achieved=kd['achieved'],

@@ -425,3 +425,48 @@ def test_deferred_loss_readback_gives_identical_results(hip_lib):
     assert outs[0][0] == outs[1][0] == 7
     assert outs[0][1] == outs[1][1]
     assert np.array_equal(outs[0][2], outs[1][2])
+
+
+def test_full_size_known_answers(hip_lib):
+    """Size-independent properties at BASELINE.json's full sizes.
+    C2 vectorspace: W = 0, b = 0  =>  every score is 0, loss = (1+z) log 2 exactly
+    (+ the L2 term, checked through lambda = 0), whatever the tokens and negatives.
+    C2-dims loglinear: W = 0, b = 0  =>  uniform distributions, loss = log V_e.
+    C4-sized entity vocabulary (streaming loss path): the same, loss = log 100000;
+    and a one-hot bias makes the loss of the matching label ~ 0."""
+    rng = np.random.RandomState(3)
+    # --- C2, vectorspace ------------------------------------------------------
+    B, n, z, Vw, Ve, d = 65536, 10, 10, 100000, 1000, 128
+    X = rng.randint(0, Vw, size=(B, n)).astype(np.uint32)
+    p = dict(Rw=O.glorot_uniform(rng, (Vw, d)), Re=O.glorot_uniform(rng, (Ve, d)),
+             W=np.zeros((d, d), np.float32), b=np.zeros(d, np.float32), X=X)
+    eng = U.vs_engine(p, B, n, z, 0.0, keep_grads=0, seed=1)
+    eng.upload_dataset(C.SPLIT_TRAIN, X, y_int=rng.randint(0, Ve, B).astype(np.int32),
+                       w=np.ones(B, np.float32))
+    assert abs(eng.train_batch(0) - (1 + z) * np.log(2)) < 2e-5
+    eng.close()
+    # --- C2 dims, loglinear (fused LDS path), B = 8192 -------------------------
+    B = 8192
+    X = rng.randint(0, Vw, size=(B, n)).astype(np.uint32)
+    y = rng.randint(0, Ve, B).astype(np.int32)
+    q = dict(Rw=O.glorot_uniform(rng, (Vw, d)), W=np.zeros((d, Ve), np.float32),
+             b=np.zeros(Ve, np.float32), X=X)
+    eng = U.ll_engine(q, B, n, 0.0)
+    eng.upload_dataset(C.SPLIT_TRAIN, X, y_int=y, w=np.ones(B, np.float32))
+    assert abs(eng.eval_batch(C.SPLIT_TRAIN, 0) - np.log(Ve)) < 1e-4
+    assert abs(eng.train_batch(0) - np.log(Ve)) < 1e-4
+    eng.close()
+    # --- V_e = 100k: streaming loss path ---------------------------------------
+    B, Ve, d, Vw = 64, 100000, 32, 5000
+    X = rng.randint(0, Vw, size=(B, n)).astype(np.uint16)
+    y = np.full(B, 77777, np.int32)
+    q = dict(Rw=O.glorot_uniform(rng, (Vw, d)), W=np.zeros((d, Ve), np.float32),
+             b=np.zeros(Ve, np.float32), X=X)
+    eng = U.ll_engine(q, B, n, 0.0)
+    eng.upload_dataset(C.SPLIT_TRAIN, X, y_int=y, w=np.ones(B, np.float32))
+    assert abs(eng.eval_batch(C.SPLIT_TRAIN, 0) - np.log(Ve)) < 2e-4
+    bias = np.zeros(Ve, np.float32)
+    bias[77777] = 40.0                      # every token's distribution ~ one-hot on the label
+    eng.set_tensor(C.T_B, bias)
+    assert eng.eval_batch(C.SPLIT_TRAIN, 0) < 1e-3
+    eng.close()

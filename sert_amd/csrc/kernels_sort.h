@@ -4,7 +4,7 @@
 // back to a ~20-launch merge sort at this size (145 us measured with rocPRIM);
 // this is 3 launches per digit.
 //
-//   csort_hist      per 2048-key tile: digit histogram (LDS int atomics: the
+//   csort_hist      per tile (256 x kSortKpt keys): digit histogram (LDS int atomics: the
 //                   COUNTS are order-independent)        -> hist[bin][tile]
 //   csort_scan_bins per bin: exclusive scan over tiles   -> hist (in place), bin_total
 //   csort_scatter   per tile: exclusive scan of bin totals (LDS), per-wave
@@ -16,7 +16,11 @@
 
 namespace sert {
 
-constexpr int kSortTile = 2048;      // keys per workgroup (256 threads x 8)
+#ifndef SERT_SORT_KPT
+#define SERT_SORT_KPT 8   /* measured at C2: 2 -> 57 us, 4 -> 44, 8 -> 39, 16 -> 38 (per-tile overhead vs chip fill) */
+#endif
+constexpr int kSortKpt = SERT_SORT_KPT;           // keys per thread
+constexpr int kSortTile = 256 * kSortKpt;        // keys per workgroup
 constexpr int kSortMaxBits = 11;
 constexpr int kSortMaxBins = 1 << kSortMaxBits;
 
@@ -29,7 +33,7 @@ __global__ __launch_bounds__(256) void csort_hist(const int32_t* __restrict__ ke
     __syncthreads();
     const int base = tile * kSortTile;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
+    for (int r = 0; r < kSortKpt; ++r) {
         const int i = base + r * 256 + threadIdx.x;
         if (i < n) atomicAdd(&h[(keys[i] >> shift) & (nbins - 1)], 1);
     }
@@ -102,11 +106,11 @@ __global__ __launch_bounds__(256) void csort_scatter(const int32_t* __restrict__
         run += local[q];
     }
 
-    // phase A: per-wave histograms over the wave's 512-key segment
-    const int seg = tile * kSortTile + w * 512;
-    int32_t key[8];
+    // phase A: per-wave histograms over the wave's (64 x kSortKpt)-key segment
+    const int seg = tile * kSortTile + w * (64 * kSortKpt);
+    int32_t key[kSortKpt];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
+    for (int r = 0; r < kSortKpt; ++r) {
         const int i = seg + r * 64 + lane;
         key[r] = (i < n) ? keys_in[i] : 0;
         if (i < n) atomicAdd(&wh[w][(key[r] >> shift) & (nbins - 1)], 1);
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(256) void csort_scatter(const int32_t* __restrict__
     volatile int32_t* mine = wh[w];
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
+    for (int r = 0; r < kSortKpt; ++r) {
         const int i = seg + r * 64 + lane;
         const bool active = i < n;
         const int d = (key[r] >> shift) & (nbins - 1);

@@ -214,6 +214,14 @@ int sert_score_topk(int device, const float* entities, int64_t num_entities, int
 int sert_comm_unique_id(char id[SERT_COMM_ID_BYTES]);
 /* ncclCommInitRank on this handle's device/stream. */
 int sert_comm_init(sert_model* m, const char id[SERT_COMM_ID_BYTES], int rank, int world);
+/* Host-mediated exchange: every gradient/loss all-reduce becomes device -> pinned host
+ * -> fn (in-place SUM over ranks of host_buf[count]; returns 0 on success) -> device,
+ * synchronously.  A verification transport, not a fast path: it lets several ranks
+ * share ONE GPU (RCCL refuses duplicate devices), so the data-parallel step -- row
+ * sharding, global 1/B scaling, rank-invariant negatives, L2 applied once, loss
+ * reduction -- can be checked against a single-process run on a 1-GPU box. */
+typedef int (*sert_allreduce_fn)(void* user, float* host_buf, size_t count);
+int sert_comm_init_host(sert_model* m, int rank, int world, sert_allreduce_fn fn, void* user);
 int sert_comm_destroy(sert_model* m);
 
 /* ---- diagnostics -------------------------------------------------------- */

@@ -30,10 +30,15 @@ EXPORTS = [
     'sert_eval_batch',
     'sert_predict_project', 'sert_predict_tokens', 'sert_score_topk',
     'sert_scorer_create', 'sert_scorer_destroy', 'sert_scorer_topk', 'sert_scorer_scores',
-    'sert_comm_unique_id', 'sert_comm_init', 'sert_comm_destroy',
+    'sert_comm_unique_id', 'sert_comm_init', 'sert_comm_init_host', 'sert_comm_destroy',
     'sert_synchronize', 'sert_timing_enable', 'sert_timing_reset', 'sert_timing_count',
     'sert_timing_name', 'sert_timing_avg_us', 'sert_bench_gemm',
 ]
+
+
+# int (*sert_allreduce_fn)(void* user, float* host_buf, size_t count)
+ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float),
+                                ctypes.c_size_t)
 
 
 class SertConfig(ctypes.Structure):
@@ -109,6 +114,7 @@ def load():
     lib.sert_comm_unique_id.argtypes = [ctypes.c_char_p]
     lib.sert_comm_init.argtypes = [vp, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
     lib.sert_comm_destroy.argtypes = [vp]
+    lib.sert_comm_init_host.argtypes = [vp, ctypes.c_int, ctypes.c_int, ALLREDUCE_FN, vp]
     lib.sert_synchronize.argtypes = [vp]
     lib.sert_timing_enable.argtypes = [vp, ctypes.c_int]
     lib.sert_timing_reset.argtypes = [vp]
@@ -274,6 +280,20 @@ class Engine(object):
     def comm_init(self, unique_id, rank, world):
         assert len(unique_id) == COMM_ID_BYTES
         check(self._lib.sert_comm_init(self._h, unique_id, rank, world))
+
+    def comm_init_host(self, rank, world, allreduce):
+        """Host-mediated exchange (verification transport, sert_comm_init_host):
+        ``allreduce(array)`` sums a float32 numpy array over the ranks IN PLACE."""
+        def trampoline(_user, buf, count):
+            try:
+                allreduce(np.ctypeslib.as_array(buf, shape=(count,)))
+                return 0
+            except Exception:  # noqa: BLE001 - reported through the C error path
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._host_allreduce = ALLREDUCE_FN(trampoline)   # keep the thunk alive
+        check(self._lib.sert_comm_init_host(self._h, rank, world, self._host_allreduce, None))
 
     # diagnostics
     def synchronize(self):

@@ -138,6 +138,11 @@ struct sert_model {
     // data parallel
     int rank = 0, world = 1;
     void* comm = nullptr;         // ncclComm_t
+    // host-mediated exchange (sert_comm_init_host): verification transport
+    int (*host_ar)(void*, float*, size_t) = nullptr;
+    void* host_ar_user = nullptr;
+    float* host_ar_buf = nullptr;   // pinned staging
+    size_t host_ar_cap = 0;
     hipStream_t comm_stream = nullptr;          // all collectives are issued here, in one fixed order
     hipEvent_t ev_rw_ready = nullptr, ev_rest_ready = nullptr, ev_ar_done = nullptr;
     size_t ar_split = 0;          // gflat[0, ar_split) = word-table gradient

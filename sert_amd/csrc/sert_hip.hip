@@ -263,13 +263,33 @@ static int gemm_long_k(sert_model* m, hipStream_t s, const float* A, const float
 // reduction has produced it, in ar_chunks slices -- it overlaps whatever is left of
 // the backward, and the optimiser of slice c overlaps the exchange of slice c+1 --
 // (2) the remainder (entity table, dense weights, bias, loss sum) once complete.
+static inline bool is_dp(const sert_model* m) { return m->comm != nullptr || m->host_ar != nullptr; }
+
+// device -> pinned host -> callback (sum over ranks) -> device, synchronously on `st`
+static int host_allreduce(sert_model* m, float* dev, size_t count, hipStream_t st) {
+    if (count == 0) return 0;
+    if (m->host_ar_cap < count) {
+        if (m->host_ar_buf) (void)hipHostFree(m->host_ar_buf);
+        m->host_ar_buf = nullptr; m->host_ar_cap = 0;
+        SERT_HIP(hipHostMalloc((void**)&m->host_ar_buf, count * sizeof(float), hipHostMallocDefault));
+        m->host_ar_cap = count;
+    }
+    SERT_HIP(hipMemcpyAsync(m->host_ar_buf, dev, count * sizeof(float), hipMemcpyDeviceToHost, st));
+    SERT_HIP(hipStreamSynchronize(st));
+    if (m->host_ar(m->host_ar_user, m->host_ar_buf, count) != 0) SERT_FAIL("host all-reduce callback failed");
+    SERT_HIP(hipMemcpyAsync(dev, m->host_ar_buf, count * sizeof(float), hipMemcpyHostToDevice, st));
+    SERT_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+
 static inline size_t word_chunk_lo(const sert_model* m, int c) {
     if (c >= m->ar_chunks) return m->n_rw;
     return ((m->n_rw * (size_t)c) / (size_t)m->ar_chunks) & ~(size_t)3;   // 16-byte aligned slices
 }
 static int allreduce_word_grad(sert_model* m) {
-    if (!m->comm) return 0;
+    if (!is_dp(m)) return 0;
     m->rw_chunked = false;
+    if (m->host_ar) return host_allreduce(m, m->gflat, m->ar_split, m->stream);
     if (m->timing.enabled) {   // timing mode: serial, on the main stream
         ScopedTimer t(m, TG_ALLREDUCE);
         SERT_NCCL(g_rccl.AllReduce(m->gflat, m->gflat, m->ar_split, /*ncclFloat32*/ 7, /*ncclSum*/ 0,
@@ -290,9 +310,10 @@ static int allreduce_word_grad(sert_model* m) {
     return 0;
 }
 static int allreduce_rest(sert_model* m) {
-    if (!m->comm) return 0;
+    if (!is_dp(m)) return 0;
     float* rest = m->gflat + m->ar_split;
     const size_t count = m->gflat_count - m->ar_split;
+    if (m->host_ar) return host_allreduce(m, rest, count, m->stream);
     if (m->timing.enabled) {
         ScopedTimer t(m, TG_ALLREDUCE);
         SERT_NCCL(g_rccl.AllReduce(rest, rest, count, 7, 0, m->comm, m->stream));
@@ -489,7 +510,7 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         if (sd != m->stream) SERT_HIP(hipEventRecord(m->ev_join3, sd));
         return 0;
     };
-    if (m->comm) {
+    if (is_dp(m)) {
         // data parallel: the word-table gradient first, so that its all-reduce (the
         // big one) overlaps dW and the entity chain
         SERT_TRY(word_table_grad());
@@ -720,7 +741,7 @@ static int reduce_rowloss(sert_model* m, hipStream_t st) {
     const int B = m->cfg.batch_size;
     const int nb = std::min(kOptBlocks, cdiv(B, 256));
     hipLaunchKernelGGL(sum_partial, dim3(nb), dim3(256), 0, st, m->rowloss, (size_t)B, m->red_loss);
-    if (m->comm)
+    if (is_dp(m))
         hipLaunchKernelGGL(partials_to_scalar, dim3(1), dim3(256), 0, st, m->red_loss, nb, m->g_loss);
     m->n_loss_partials = nb;
     return 0;
@@ -744,7 +765,7 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
     const bool exchanged = m->comm && !m->timing.enabled;
     // single GPU: the small tensors are updated on the side stream WHILE the word table
     // streams on the main one (independent tensors; every gradient is complete here)
-    const bool side_small = !m->comm && !m->timing.enabled && m->nstreams >= 2;
+    const bool side_small = !is_dp(m) && !m->timing.enabled && m->nstreams >= 2;
     hipStream_t ss = side_small ? m->stream2 : m->stream;
     if (side_small) {
         SERT_HIP(hipEventRecord(m->ev_opt_fork, m->stream));
@@ -824,8 +845,8 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
         const float inv_batch = 1.0f / (float)c.global_batch_size;
         const float reg_scale = c.lambda_ > 0.f ? c.lambda_ / (2.0f * (float)c.global_batch_size) : 0.f;
         // single GPU: the loss partials directly; data parallel: the all-reduced scalar
-        const float* lp = m->comm ? m->g_loss : m->red_loss;
-        const int nl = m->comm ? 1 : n_loss_partials;
+        const float* lp = is_dp(m) ? m->g_loss : m->red_loss;
+        const int nl = is_dp(m) ? 1 : n_loss_partials;
         unsigned* flag = publish ? reinterpret_cast<unsigned*>(loss_dst + 4) : nullptr;
         hipLaunchKernelGGL(finalize_loss, dim3(1), dim3(256), 0, m->stream, lp, nl, m->red_sq,
                            n_sq, inv_batch, reg_scale, loss_dst, flag, publish ? ++m->loss_seq : 0u);
@@ -844,7 +865,7 @@ static int train_step_async(sert_model* m, int64_t batch_index, const int64_t* n
     // the rows it writes and the optimiser takes every other row's gradient as zero.
     // (Data parallel: the all-reduce needs the dense table; keep_grads: so does the caller.)
     static const bool no_touched = getenv("SERT_NO_TOUCHED") != nullptr;   // cross-check knob
-    m->use_touched = !no_touched && !m->comm && !m->cfg.keep_grads && m->cfg.word_dim % 4 == 0 &&
+    m->use_touched = !no_touched && !is_dp(m) && !m->cfg.keep_grads && m->cfg.word_dim % 4 == 0 &&
                      m->n_rw < ((size_t)1 << 32) && m->rw_touched != nullptr;
     // Prologue (zeroing, negative sampling): nothing before the loss kernel needs it, so
     // for the vectorspace step it runs on the side stream beside gather + projection.
@@ -883,6 +904,7 @@ static int train_step_async(sert_model* m, int64_t batch_index, const int64_t* n
     }
     SERT_TRY(allreduce_rest(m));
     SERT_TRY(optimizer_and_loss(m, loss_dst, publish));
+    SERT_HIP(hipGetLastError());   // a rejected launch (bad configuration) surfaces here, not as a hang
     SERT_HIP(hipEventRecord(m->ev_step_done, m->stream));
     return 0;
 }
@@ -1079,6 +1101,7 @@ int sert_destroy(sert_model* m) {
     (void)hipFree(m->etail); (void)hipFree(m->sort_hist); (void)hipFree(m->sort_bin_total);
     (void)hipFree(m->sort_k_tmp); (void)hipFree(m->sort_v_tmp);
     if (m->h_loss) (void)hipHostFree(m->h_loss);
+    if (m->host_ar_buf) (void)hipHostFree(m->host_ar_buf);
     free_split(m->split[0]); free_split(m->split[1]);
     if (m->timing.created)
         for (int g = 0; g < TG_COUNT; ++g)
@@ -1318,11 +1341,12 @@ int sert_eval_batch(sert_model* m, int split, int64_t batch_index, const int64_t
     SERT_HIP(hipMemcpyAsync(m->h_loss, m->d_loss, 3 * sizeof(float), hipMemcpyDeviceToHost, m->stream));
     SERT_HIP(hipStreamSynchronize(m->stream));
     float v = m->h_loss[0];
-    if (m->comm) {
+    if (is_dp(m)) {
         // eval loss of the global batch = mean of the per-rank means (equal shares)
         float* tmp = m->d_loss + 3;
         SERT_HIP(hipMemcpyAsync(tmp, m->d_loss, sizeof(float), hipMemcpyDeviceToDevice, m->stream));
-        SERT_NCCL(g_rccl.AllReduce(tmp, tmp, 1, 7, 0, m->comm, m->stream));
+        if (m->host_ar) SERT_TRY(host_allreduce(m, tmp, 1, m->stream));
+        else            SERT_NCCL(g_rccl.AllReduce(tmp, tmp, 1, 7, 0, m->comm, m->stream));
         SERT_HIP(hipMemcpyAsync(m->h_loss, tmp, sizeof(float), hipMemcpyDeviceToHost, m->stream));
         SERT_HIP(hipStreamSynchronize(m->stream));
         v = m->h_loss[0] / (float)m->world;
@@ -1571,6 +1595,7 @@ int sert_scorer_topk(sert_scorer* sc, const float* proj, int64_t Q, int32_t k, i
                        cdiv(V, kScoreStride) >= 8 * (int64_t)rs;
     if (fused) SERT_TRY(scorer_topk_fused(sc, Q, k, rs));
     else       SERT_TRY(scorer_topk_materialised(sc, sc->P, Q, k, sc->idx, sc->val));
+    SERT_HIP(hipGetLastError());
     SERT_HIP(hipMemcpyAsync(idx_out, sc->idx, (size_t)Q * k * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     SERT_HIP(hipMemcpyAsync(score_out, sc->val, (size_t)Q * k * sizeof(float), hipMemcpyDeviceToHost, s));
     SERT_HIP(hipStreamSynchronize(s));
@@ -1653,7 +1678,27 @@ int sert_comm_init(sert_model* m, const char id[SERT_COMM_ID_BYTES], int rank, i
     return 0;
 }
 
+int sert_comm_init_host(sert_model* m, int rank, int world, sert_allreduce_fn fn, void* user) {
+    if (!m || !fn) SERT_FAIL("null argument");
+    if (world < 1 || rank < 0 || rank >= world) SERT_FAIL("bad rank/world");
+    if ((int64_t)m->cfg.batch_size * world != m->cfg.global_batch_size)
+        SERT_FAIL("global_batch_size must equal batch_size * world");
+    if (m->comm) SERT_FAIL("an RCCL communicator is already attached");
+    m->host_ar = fn;
+    m->host_ar_user = user;
+    m->rank = rank;
+    m->world = world;
+    m->projected_batch = -1;
+    return 0;
+}
+
 int sert_comm_destroy(sert_model* m) {
+    if (m && m->host_ar) {
+        m->host_ar = nullptr;
+        m->host_ar_user = nullptr;
+        m->rank = 0;
+        m->world = 1;
+    }
     if (m && m->comm) {
         SERT_NCCL(g_rccl.CommDestroy(m->comm));
         m->comm = nullptr;

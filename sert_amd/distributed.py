@@ -96,6 +96,17 @@ def broadcast_array(a, src=0):
     return t.numpy()
 
 
+def host_allreduce(array):
+    """In-place sum of a float32 numpy array over the ranks through gloo -- the callback
+    of the host-mediated exchange (SERT_COMM=host: several ranks on one GPU, for
+    verification; RCCL refuses duplicate devices)."""
+    if _context.world_size <= 1:
+        return
+    import torch
+    t = torch.from_numpy(array)
+    _dist().all_reduce(t)
+
+
 def barrier():
     if _context.world_size > 1:
         _dist().barrier()

@@ -253,7 +253,12 @@ class ModelBase(ModelInterface):
 
         # SERT_FORCE_COMM=1: run the exchange path (RCCL, world of one) on a single
         # GPU -- for profiling the data-parallel step structure on a 1-GPU box
-        if ctx.world_size > 1 or os.environ.get('SERT_FORCE_COMM') == '1':
+        if ctx.world_size > 1 and os.environ.get('SERT_COMM') == 'host':
+            # verification transport: the exchange goes through pinned host memory and
+            # gloo, so that several ranks can share one GPU (tests on a 1-GPU box)
+            self._engine.comm_init_host(ctx.rank, ctx.world_size,
+                                        distributed.host_allreduce)
+        elif ctx.world_size > 1 or os.environ.get('SERT_FORCE_COMM') == '1':
             self._engine.comm_init(ctx.unique_id(), ctx.rank, ctx.world_size)
 
         self._upload(_capi.SPLIT_TRAIN, x_train, self.training_set[1],

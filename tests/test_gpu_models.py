@@ -470,3 +470,31 @@ def test_full_size_known_answers(hip_lib):
     eng.set_tensor(C.T_B, bias)
     assert eng.eval_batch(C.SPLIT_TRAIN, 0) < 1e-3
     eng.close()
+
+
+@pytest.mark.parametrize('kind', ['vectorspace', 'loglinear'])
+def test_two_ranks_on_one_gpu_match_single_process(hip_lib, tmp_path, kind):
+    """The data-parallel step with TWO real ranks (torch.distributed.run, one process each)
+    on the one GPU of the test box, through the host-mediated exchange (RCCL refuses
+    duplicate devices): row sharding, global 1/B scaling, rank-invariant negatives, L2
+    applied once, the loss and eval-loss reductions -- against the same code run
+    single-process.  Tolerance: fp32 reassociation of the cross-rank sums."""
+    import socket
+    from tests import dp_worker
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / 'dp.npz')
+    env = dict(os.environ, SERT_COMM='host', OMP_NUM_THREADS='1')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                    '--master-addr', '127.0.0.1', '--master-port', str(port),
+                    os.path.join(U.ROOT, 'tests', 'dp_worker.py'), kind, out],
+                   check=True, env=env, cwd=U.ROOT, timeout=600)
+    two = np.load(out)
+    one = dp_worker.run(kind)
+    for key in ('epoch1', 'epoch2', 'train_error', 'validation_error'):
+        assert abs(float(two[key]) - float(one[key])) <= 2e-5 * abs(float(one[key])), key
+    for key in [k for k in one if k not in ('epoch1', 'epoch2', 'train_error', 'validation_error')]:
+        assert U.rel_err(two[key], one[key]) < 2e-5, key

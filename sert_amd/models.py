@@ -228,6 +228,8 @@ class ModelBase(ModelInterface):
             x_val = x_val.astype(x_train.dtype)
 
         device = self.device
+        if device is None and os.environ.get('SERT_DEVICE'):
+            device = int(os.environ['SERT_DEVICE'])   # e.g. several ranks on one GPU (tests)
         if device is None:
             device = ctx.local_rank if ctx.world_size > 1 else 0
 

@@ -64,6 +64,8 @@ struct sert_model {
     // step prologue (zeroing, negative sampling) and the small-tensor optimiser run on
     // stream2 beside the main chain; these events order them
     hipEvent_t ev_step_done = nullptr, ev_neg = nullptr, ev_opt_fork = nullptr, ev_small = nullptr;
+    hipEvent_t ev_dense = nullptr;   // dW, db and the loss partials are complete (main stream)
+    bool lazy_join = false;          // this step: the main stream never waits for the entity chain
     int n_loss_partials = 0;
     // SERT_STREAMS: 1 = everything on the main stream (0.423 ms/step at C2), 2 = + the entity
     // chain, the step prologue and the small-tensor optimiser on a side stream (0.396),

@@ -429,3 +429,40 @@ def test_next_batch_hint_changes_nothing_but_the_schedule(hip_lib):
         assert outs[0][0] == other[0]
         assert np.array_equal(outs[0][1], other[1])
         assert np.array_equal(outs[0][2], other[2])
+
+
+@pytest.mark.parametrize('kind', ['vectorspace', 'loglinear'])
+def test_parameters_after_100_steps(hip_lib, kind):
+    """SURVEY 8(d) tolerance: parameters after 100 optimiser steps within rel. 1e-4 of the
+    oracle (fresh negatives every step for vectorspace; 4 batches cycled)."""
+    steps, B, n = 100, 64, 4
+    if kind == 'vectorspace':
+        z, Vw, Ve, dw, de = 5, 300, 25, 32, 32
+        p = U.make_vs_problem(71, B * 4, n, z, Vw, Ve, dw, de)
+        eng = U.vs_engine(p, B, n, z, 0.01, keep_grads=0)
+        eng.upload_dataset(C.SPLIT_TRAIN, p['X'], y_int=p['y'], w=p['w'])
+        ora = O.VectorSpaceOracle(B, n, z, p['Rw'], p['Re'], p['W'], p['b'], 0.01)
+        for s in range(steps):
+            j = s % 4
+            sl = slice(j * B, (j + 1) * B)
+            neg = p['rng'].randint(0, Ve, (B, z)).astype(np.int64)
+            ref = ora.train_step(p['X'][sl], p['y'][sl], p['w'][sl], neg)
+            loss = eng.train_batch(j, neg)
+            assert abs(loss - ref) <= 2e-5 * abs(ref), (s, loss, ref)
+        pairs = [(C.T_RW, ora.R_w), (C.T_RE, ora.R_e), (C.T_W, ora.W), (C.T_B, ora.b)]
+    else:
+        Vw, Ve, d = 300, 40, 24
+        p = U.make_ll_problem(72, B * 4, n, Vw, Ve, d, 'csr')
+        eng = U.ll_engine(p, B, n, 0.01, keep_grads=0)
+        eng.upload_dataset(C.SPLIT_TRAIN, p['X'], csr=p['y'], w=p['w'])
+        ora = O.LogLinearOracle(B, n, p['Rw'], p['W'], p['b'], 0.01)
+        for s in range(steps):
+            j = s % 4
+            sl = slice(j * B, (j + 1) * B)
+            ref = ora.train_step(p['X'][sl], p['ydense'][sl], p['w'][sl])
+            loss = eng.train_batch(j)
+            assert abs(loss - ref) <= 2e-5 * abs(ref), (s, loss, ref)
+        pairs = [(C.T_RW, ora.R_w), (C.T_W, ora.W), (C.T_B, ora.b)]
+    for which, ref in pairs:
+        assert U.rel_err(eng.get_tensor(which), np.asarray(ref).ravel()) < 1e-4, which
+    eng.close()

@@ -157,8 +157,14 @@ __global__ __launch_bounds__(256) void ll_window(float* __restrict__ P, float* _
 // when n*V floats (+V) fit the 160 KB LDS (C1 / C2 shapes); same maths, same
 // citations as the two kernels above.
 //   dynamic LDS: S[n*V] | J[V]
+// slot (optional, with Zu): token (i, k) reads its logits from Zu[slot[i*n + k], :] -- the
+// table of logit rows computed ONCE per distinct word of the batch -- and dL/dZ of every
+// token still goes to Z[(i*n + k), :] (summed per word afterwards).  slot == nullptr: the
+// logits are read from Z itself and overwritten in place.
 template <bool TRAIN, int NT>
 __global__ __launch_bounds__(NT) void ll_fused_row(float* __restrict__ Z,
+                                                    const float* __restrict__ Zu,
+                                                    const int32_t* __restrict__ slot,
                                                     const int32_t* __restrict__ y_int,
                                                     const int64_t* __restrict__ indptr,
                                                     const int32_t* __restrict__ indices,
@@ -178,7 +184,39 @@ __global__ __launch_bounds__(NT) void ll_fused_row(float* __restrict__ Z,
 
     // 1. slab -> LDS: batches of 8 independent 16-byte loads per thread in flight
     //    (a load->ds_write chain per iteration would expose the full HBM latency)
-    if ((total & 3) == 0) {
+    if (slot != nullptr && (V & 3) == 0 && n <= V) {
+        // per token: the row of its word in the distinct-word table.  The n slots go to LDS
+        // first (the J area is free until phase 3), then all threads stream the n rows as one
+        // flat sequence of 16-byte pieces, 8 loads in flight each.
+        int* s_slot = reinterpret_cast<int*>(Jl);
+        if (tid < n) s_slot[tid] = slot[(size_t)i * n + tid];
+        __syncthreads();
+        const int V4 = V >> 2, total4 = n * V4;
+        const float inv_v4 = 1.0f / (float)V4;
+        for (int q0 = tid; q0 < total4; q0 += 8 * NT) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int q = q0 + u * NT;
+                if (q < total4) {
+                    int k = (int)((float)q * inv_v4);          // q / V4, fixed up below
+                    k -= (k * V4 > q);
+                    k += ((k + 1) * V4 <= q);
+                    v[u] = reinterpret_cast<const float4*>(Zu + (size_t)s_slot[k] * V)[q - k * V4];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int q = q0 + u * NT;
+                if (q < total4) *reinterpret_cast<float4*>(S + 4 * q) = v[u];
+            }
+        }
+    } else if (slot != nullptr) {
+        for (int t = tid; t < total; t += NT) {
+            const int k = t / V;
+            S[t] = Zu[(size_t)slot[(size_t)i * n + k] * V + (t - k * V)];
+        }
+    } else if ((total & 3) == 0) {
         for (int t0 = tid * 4; t0 < total; t0 += 8 * 4 * NT) {
             float4 v[8];
 #pragma unroll
@@ -290,6 +328,23 @@ __global__ __launch_bounds__(NT) void ll_fused_row(float* __restrict__ Z,
             const float dj = (lp >= LOGLO && lp <= LOGHI) ? Jl[e] : 0.f;
             out[e] = dj - __expf(lp) * r;
         }
+    }
+}
+
+// dst[ids[u], :] = src[u, :] (the word-table gradient rows of the batch's distinct words);
+// touched (optional): touched[ids[u]] = 1.
+__global__ __launch_bounds__(256) void ll_scatter_rows(const float* __restrict__ src,
+                                                       const int32_t* __restrict__ ids, int64_t rows,
+                                                       int d, float* __restrict__ dst,
+                                                       unsigned char* __restrict__ touched) {
+    const int64_t total = rows * d;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t u = t / d;
+        const int c = (int)(t - u * d);
+        const size_t w = (size_t)ids[u];
+        dst[w * d + c] = src[t];
+        if (touched && c == 0) touched[w] = 1;
     }
 }
 

@@ -10,10 +10,12 @@ namespace sert {
 //       dst <  0 : partial[-(dst+1), :] = acc        (next level's input)
 // row(e) = rows ? rows[e] : e.  LPI lanes cooperate on one item (LPI = 32 when
 // d/4 <= 32 so a wave carries two items), each lane owns float4 column chunks.
+// DST_SLOT: final rows go to final[item.slot, :] (the word's rank among the batch's
+// distinct words) instead of final[item.dst, :] -- loglinear per-distinct-word sums.
 // touched (optional): touched[dst] = 1 for every final row written -- the optimiser
 // then treats unflagged rows as zero gradient, so the table needs no memset and the
 // zeros are never read back.
-template <int LPI>
+template <int LPI, bool DST_SLOT = false>
 __global__ __launch_bounds__(256) void segsum_rows(const float* __restrict__ src,
                                                    const int32_t* __restrict__ rows,
                                                    const int4* __restrict__ items, int nitems,
@@ -28,7 +30,9 @@ __global__ __launch_bounds__(256) void segsum_rows(const float* __restrict__ src
     const int4 it = items[item];
     if (touched && l == 0 && it.z >= 0) touched[it.z] = 1;
     const int chunks = d >> 2;
-    for (int c = l; c < chunks; c += LPI) {
+    // gridDim.y > 1: wide rows (d/4 > LPI) are cut into gridDim.y column groups, one
+    // workgroup row each -- more, shorter chains instead of one wave walking the whole row
+    for (int c = blockIdx.y * LPI + l; c < chunks; c += LPI * gridDim.y) {
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
         int e = it.x;
         for (; e + 4 <= it.y; e += 4) {
@@ -51,7 +55,7 @@ __global__ __launch_bounds__(256) void segsum_rows(const float* __restrict__ src
         }
         if (it.z >= 0) {
             a.x /= divisor; a.y /= divisor; a.z /= divisor; a.w /= divisor;
-            *reinterpret_cast<float4*>(final_dst + (size_t)it.z * d + 4 * c) = a;
+            *reinterpret_cast<float4*>(final_dst + (size_t)(DST_SLOT ? it.w : it.z) * d + 4 * c) = a;
         } else {
             *reinterpret_cast<float4*>(partial_dst + (size_t)(-(it.z + 1)) * d + 4 * c) = a;
         }
@@ -59,6 +63,7 @@ __global__ __launch_bounds__(256) void segsum_rows(const float* __restrict__ src
 }
 
 // Scalar variant for d % 4 != 0: one wave per item, lanes stride over columns.
+template <bool DST_SLOT = false>
 __global__ __launch_bounds__(256) void segsum_rows_scalar(const float* __restrict__ src,
                                                           const int32_t* __restrict__ rows,
                                                           const int4* __restrict__ items,
@@ -77,7 +82,7 @@ __global__ __launch_bounds__(256) void segsum_rows_scalar(const float* __restric
             const int r = rows ? rows[e] : e;
             a += src[(size_t)r * d + c];
         }
-        if (it.z >= 0) final_dst[(size_t)it.z * d + c] = a / divisor;
+        if (it.z >= 0) final_dst[(size_t)(DST_SLOT ? it.w : it.z) * d + c] = a / divisor;
         else partial_dst[(size_t)(-(it.z + 1)) * d + c] = a;
     }
 }

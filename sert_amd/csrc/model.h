@@ -22,6 +22,8 @@ struct DataSplit {
     // inverted index word -> rows of every complete batch (train split only)
     int32_t* idx_rows = nullptr;
     int4* idx_items = nullptr;
+    int32_t* idx_uwords = nullptr;   // loglinear: distinct words of every batch (sorted)
+    int32_t* idx_slots = nullptr;    // loglinear: per token position, rank of its word among them
     std::vector<BatchIndex> idx_batches;
 };
 
@@ -123,6 +125,14 @@ struct sert_model {
     // table is then neither zeroed nor read where no token of the batch points
     unsigned char* rw_touched = nullptr;
     bool use_touched = false;
+    // loglinear, logits per DISTINCT word of the batch (duplicate tokens share a row):
+    float* Zu = nullptr;          // (U, V_e) logits
+    float* dZu = nullptr;         // (U, V_e) per-word sums of dL/dZ
+    size_t zu_rows = 0;
+    float* zpart = nullptr;       // V_e-wide partial rows of the per-word sum tree
+    size_t zpart_rows = 0;
+    bool ll_dedup = false;        // this step ran on the distinct-word table
+    int ll_U = 0;
     float* skbuf = nullptr;       // split-K partials of the long-K dX GEMMs (grown on demand)
     size_t skbuf_count = 0;
     float* red_loss = nullptr;    // loss partials [kOptBlocks]

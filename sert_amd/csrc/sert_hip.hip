@@ -194,9 +194,32 @@ static int word_grad_segsum(sert_model* m, const DataSplit& ds, int64_t batch_in
                 hipLaunchKernelGGL((segsum_rows<64>), dim3(cdiv(nitems, 4)), dim3(256), 0, m->stream,
                                    in, rows, items, nitems, m->g_rw, pout, d, divisor, touched);
         } else {
-            hipLaunchKernelGGL(segsum_rows_scalar, dim3(cdiv(nitems, 4)), dim3(256), 0, m->stream, in,
+            hipLaunchKernelGGL((segsum_rows_scalar<false>), dim3(cdiv(nitems, 4)), dim3(256), 0, m->stream, in,
                                rows, items, nitems, m->g_rw, pout, d, divisor, touched);
         }
+    }
+    return 0;
+}
+
+// Loglinear on the distinct-word table: dZu[slot(word), :] = sum of dL/dZ over the word's
+// occurrences in the batch -- the same order-fixed tree as the word gradient, over
+// V_e-wide rows, destination = the word's rank among the batch's distinct words.
+static int dz_word_sums(sert_model* m, const DataSplit& ds, int64_t batch_index) {
+    const int V = m->cfg.num_entities;
+    const BatchIndex& bx = ds.idx_batches[(size_t)batch_index];
+    for (int l = 0; l < bx.nlevels; ++l) {
+        const int nitems = bx.item_cnt[l];
+        if (nitems == 0) continue;
+        const float* in = (l == 0) ? m->Z : m->zpart + (size_t)bx.part_off[l - 1] * V;
+        const int32_t* rows = (l == 0) ? ds.idx_rows + bx.rows_off : nullptr;
+        const int4* items = ds.idx_items + bx.item_off[l];
+        float* pout = m->zpart + (size_t)bx.part_off[l] * V;
+        if (V % 4 == 0)
+            hipLaunchKernelGGL((segsum_rows<64, true>), dim3(cdiv(nitems, 4), cdiv(V / 4, 64)), dim3(256), 0,
+                               m->stream, in, rows, items, nitems, m->dZu, pout, V, 1.0f, (unsigned char*)nullptr);
+        else
+            hipLaunchKernelGGL((segsum_rows_scalar<true>), dim3(cdiv(nitems, 4)), dim3(256), 0, m->stream, in,
+                               rows, items, nitems, m->dZu, pout, V, 1.0f, (unsigned char*)nullptr);
     }
     return 0;
 }
@@ -238,6 +261,7 @@ static int gemm_long_k(sert_model* m, hipStream_t s, const float* A, const float
     const int tiles = cdiv(M, GM) * cdiv(N, GN);
     int splits = 1;
     if (tiles < 512 && K >= 4096) splits = std::min(cdiv(1024, tiles), K / 1024);
+    else if (tiles < 256 && K >= 512) splits = std::min(cdiv(1024, tiles), K / 128);   // few tiles, medium K
     if (splits <= 1) {
         launch_gemm<TA, TB, EPI_STORE>(s, A, Bm, C, nullptr, M, N, K, lda, ldb, N);
         return 0;
@@ -658,35 +682,58 @@ static int ll_forward(sert_model* m, const DataSplit& ds, int64_t batch_index) {
     const int B = c.batch_size, n = c.window_size, d = c.word_dim, V = c.num_entities;
     const size_t row0 = (size_t)batch_index * B;
     const int64_t rows = (int64_t)B * n;
+    const size_t fused_lds = ((size_t)n * V + V) * sizeof(float);
+    const bool fused = fused_lds <= 150 * 1024 && ds.max_labels_per_row <= 1024;
+    // Duplicate tokens share their logit row (Z[r,:] = R_w[X[r],:].W + b depends on the word
+    // only): in a training step the gather and all three GEMMs run on the batch's DISTINCT
+    // words (Zipfian batches: a third of the tokens), the loss kernel reads the table through
+    // the per-token slot, and dL/dZ is summed per word before the backward GEMMs.
+    static const bool no_dedup = getenv("SERT_LL_NODEDUP") != nullptr;   // cross-check knob
+    m->ll_dedup = TRAIN && fused && !no_dedup && ds.idx_slots != nullptr &&
+                  (size_t)batch_index < ds.idx_batches.size();
+    const BatchIndex* bx = m->ll_dedup ? &ds.idx_batches[(size_t)batch_index] : nullptr;
+    m->ll_U = bx ? bx->num_distinct : 0;
+    const int64_t grows = m->ll_dedup ? m->ll_U : rows;          // rows of the gathered operand
     {
         ScopedTimer t(m, TG_GATHER);
-        SERT_ID_DISPATCH(c.id_bytes, {
-            const IdT* X = (const IdT*)ds.x + row0 * n;
+        if (m->ll_dedup) {
+            const uint32_t* U = reinterpret_cast<const uint32_t*>(ds.idx_uwords + bx->uw_off);
             if (d % 4 == 0)
-                hipLaunchKernelGGL((ll_gather_rows<IdT, 4>), dim3(grid_for(rows * d / 4, 256, 1 << 20)),
-                                   dim3(256), 0, m->stream, X, m->rw, m->G, rows, d);
+                hipLaunchKernelGGL((ll_gather_rows<uint32_t, 4>), dim3(grid_for(grows * d / 4, 256, 1 << 20)),
+                                   dim3(256), 0, m->stream, U, m->rw, m->G, grows, d);
             else
-                hipLaunchKernelGGL((ll_gather_rows<IdT, 1>), dim3(grid_for(rows * d, 256, 1 << 20)),
-                                   dim3(256), 0, m->stream, X, m->rw, m->G, rows, d);
-        });
+                hipLaunchKernelGGL((ll_gather_rows<uint32_t, 1>), dim3(grid_for(grows * d, 256, 1 << 20)),
+                                   dim3(256), 0, m->stream, U, m->rw, m->G, grows, d);
+        } else {
+            SERT_ID_DISPATCH(c.id_bytes, {
+                const IdT* X = (const IdT*)ds.x + row0 * n;
+                if (d % 4 == 0)
+                    hipLaunchKernelGGL((ll_gather_rows<IdT, 4>), dim3(grid_for(rows * d / 4, 256, 1 << 20)),
+                                       dim3(256), 0, m->stream, X, m->rw, m->G, rows, d);
+                else
+                    hipLaunchKernelGGL((ll_gather_rows<IdT, 1>), dim3(grid_for(rows * d, 256, 1 << 20)),
+                                       dim3(256), 0, m->stream, X, m->rw, m->G, rows, d);
+            });
+        }
     }
     {
         ScopedTimer t(m, TG_GEMM_FWD);
-        launch_gemm<false, false, EPI_BIAS>(m->stream, m->G, m->W, m->Z, m->b, (int)rows, V, d, d, V,
-                                            V);
+        launch_gemm<false, false, EPI_BIAS>(m->stream, m->G, m->W, m->ll_dedup ? m->Zu : m->Z, m->b, (int)grows,
+                                            V, d, d, V, V);
     }
     const float inv_batch = 1.0f / (float)c.global_batch_size;
     const int32_t* y = ds.y ? ds.y + row0 : nullptr;
     const int64_t* indptr = ds.csr_indptr ? ds.csr_indptr + row0 : nullptr;
     const float* w = TRAIN ? ds.w + row0 : nullptr;
-    const size_t fused_lds = ((size_t)n * V + V) * sizeof(float);
     // fused path: the row's (n, V) slab lives in LDS; CSR rows with > 1024 labels fall back
-    if (fused_lds <= 150 * 1024 && ds.max_labels_per_row <= 1024) {
+    if (fused) {
         ScopedTimer t(m, TG_LOSS);
+        const int32_t* slot = m->ll_dedup ? ds.idx_slots + (size_t)batch_index * rows : nullptr;
         // 512 threads per row: 302 us at 256 (too few waves to hide the slab load), 228 at
         // 512, 320 at 640 (one wave per token, but only two workgroups fit a CU)
-        hipLaunchKernelGGL((ll_fused_row<TRAIN, 512>), dim3(B), dim3(512), fused_lds, m->stream, m->Z, y, indptr,
-                           ds.csr_indices, ds.csr_data, w, m->rowloss, n, V, inv_batch);
+        hipLaunchKernelGGL((ll_fused_row<TRAIN, 512>), dim3(B), dim3(512), fused_lds, m->stream, m->Z,
+                           (const float*)m->Zu, slot, y, indptr, ds.csr_indices, ds.csr_data, w, m->rowloss, n,
+                           V, inv_batch);
     } else if (getenv("SERT_LL_ROWWISE")) {
         // the plain row-per-workgroup kernels (kept as a cross-check of the streaming path)
         ScopedTimer t(m, TG_LOSS);
@@ -706,9 +753,17 @@ static int ll_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
     const auto& c = m->cfg;
     const int B = c.batch_size, n = c.window_size, d = c.word_dim, V = c.num_entities;
     const size_t row0 = (size_t)batch_index * B;
-    const int64_t rows = (int64_t)B * n;
+    int64_t rows = (int64_t)B * n;          // rows of the dZ operand of the two GEMMs
+    const float* dZ = m->Z;
+    if (m->ll_dedup) {
+        // per-word sums of dL/dZ (the backward of "duplicate tokens share a logit row")
+        ScopedTimer t(m, TG_EGRAD);
+        SERT_TRY(dz_word_sums(m, ds, batch_index));
+        dZ = m->dZu;
+        rows = m->ll_U;
+    }
     {
-        // dW (d, V) = G^T.dZ, reduction over the B*n tokens; db = column sums of dZ
+        // dW (d, V) = G^T.dZ, reduction over the tokens (distinct words); db = column sums of dZ
         const int tiles = cdiv(V, GN) * cdiv(d, GM);
         int splits = std::max(1, std::min(cdiv(rows, GK), cdiv(1024, tiles)));
         int kper = (int)round_up(cdiv(rows, splits), GK);
@@ -717,7 +772,7 @@ static int ll_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         const size_t stride = mn + V;
         {
             ScopedTimer t(m, TG_GEMM_DW);
-            launch_gemm<true, false, EPI_STORE, true>(m->stream, m->G, m->Z, m->part, nullptr, d, V,
+            launch_gemm<true, false, EPI_STORE, true>(m->stream, m->G, dZ, m->part, nullptr, d, V,
                                                       (int)rows, d, V, V, splits, kper, stride);
         }
         {
@@ -728,13 +783,21 @@ static int ll_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         {
             // dG (rows, d) = dZ.W^T
             ScopedTimer t(m, TG_GEMM_DX);
-            SERT_TRY((gemm_long_k<false, true>(m, m->stream, m->Z, m->W, m->DG, (int)rows, d, V, V, V)));
+            SERT_TRY((gemm_long_k<false, true>(m, m->stream, dZ, m->W, m->DG, (int)rows, d, V, V, V)));
         }
     }
     {
         ScopedTimer t(m, TG_SCATTER);
-        // dR_w[X[r],:] += dG[r,:]
-        SERT_TRY(word_grad_segsum(m, ds, batch_index, m->DG, 1.0f));
+        if (m->ll_dedup) {
+            // dG already holds one row per distinct word: dR_w[word_u, :] = dG[u, :]
+            const BatchIndex& bx = ds.idx_batches[(size_t)batch_index];
+            hipLaunchKernelGGL(ll_scatter_rows, dim3(grid_for(rows * d)), dim3(256), 0, m->stream, m->DG,
+                               ds.idx_uwords + bx.uw_off, rows, d, m->g_rw,
+                               m->use_touched ? m->rw_touched : (unsigned char*)nullptr);
+        } else {
+            // dR_w[X[r],:] += dG[r,:]
+            SERT_TRY(word_grad_segsum(m, ds, batch_index, m->DG, 1.0f));
+        }
     }
     SERT_TRY(allreduce_word_grad(m));
     (void)row0;
@@ -1084,6 +1147,8 @@ static void free_split(DataSplit& d) {
     (void)hipFree(d.x); (void)hipFree(d.y); (void)hipFree(d.csr_indptr);
     (void)hipFree(d.csr_indices); (void)hipFree(d.csr_data); (void)hipFree(d.w); (void)hipFree(d.labfix);
     (void)hipFree(d.idx_rows); (void)hipFree(d.idx_items);
+    (void)hipFree(d.idx_uwords); (void)hipFree(d.idx_slots);
+    d.idx_uwords = nullptr; d.idx_slots = nullptr;
     d = DataSplit();
 }
 
@@ -1107,6 +1172,7 @@ int sert_destroy(sert_model* m) {
     (void)hipFree(m->ll_tokstat); (void)hipFree(m->ll_lse); (void)hipFree(m->ll_jstat);
     (void)hipFree(m->ll_rowinfo); (void)hipFree(m->ll_rpart); (void)hipFree(m->ll_r);
     (void)hipFree(m->rw_touched);
+    (void)hipFree(m->Zu); (void)hipFree(m->dZu); (void)hipFree(m->zpart);
     (void)hipFree(m->neg); (void)hipFree(m->neg_stage);
     (void)hipFree(m->cand); (void)hipFree(m->cand_sorted); 
     (void)hipFree(m->pair_sorted); (void)hipFree(m->coef); (void)hipFree(m->ehead);
@@ -1221,8 +1287,30 @@ int sert_upload_dataset(sert_model* m, int split, const void* x, const int32_t* 
         const bool row_is_pos = !is_vs(m);
         bool ids_ok = true;
         SERT_ID_DISPATCH(m->cfg.id_bytes,
-                         ids_ok = build_word_index<IdT>((const IdT*)x, nb, B, n, m->cfg.vocab_size, row_is_pos, wi));
+                         ids_ok = build_word_index<IdT>((const IdT*)x, nb, B, n, m->cfg.vocab_size, row_is_pos, wi,
+                                                        /*want_slots=*/!is_vs(m)));
         if (!ids_ok) SERT_FAIL("token id >= vocab_size in x");
+        if (!is_vs(m) && !wi.slots.empty()) {
+            const size_t V = (size_t)m->cfg.num_entities;
+            SERT_TRY(dmalloc(&d.idx_uwords, std::max<size_t>(1, wi.uwords.size())));
+            SERT_TRY(dmalloc(&d.idx_slots, wi.slots.size()));
+            SERT_HIP(hipMemcpyAsync(d.idx_uwords, wi.uwords.data(), wi.uwords.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+            SERT_HIP(hipMemcpyAsync(d.idx_slots, wi.slots.data(), wi.slots.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+            SERT_HIP(hipStreamSynchronize(s));
+            if ((size_t)wi.max_distinct > m->zu_rows) {
+                (void)hipFree(m->Zu); (void)hipFree(m->dZu);
+                m->Zu = nullptr; m->dZu = nullptr;
+                m->zu_rows = (size_t)wi.max_distinct;
+                SERT_TRY(dmalloc(&m->Zu, m->zu_rows * V));
+                SERT_TRY(dmalloc(&m->dZu, m->zu_rows * V));
+            }
+            if ((size_t)wi.max_part_rows + 1 > m->zpart_rows) {
+                (void)hipFree(m->zpart);
+                m->zpart = nullptr;
+                m->zpart_rows = (size_t)wi.max_part_rows + 1;
+                SERT_TRY(dmalloc(&m->zpart, m->zpart_rows * V));
+            }
+        }
         if (!wi.rows.empty()) {
             SERT_TRY(dmalloc(&d.idx_rows, wi.rows.size()));
             SERT_HIP(hipMemcpyAsync(d.idx_rows, wi.rows.data(), wi.rows.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));

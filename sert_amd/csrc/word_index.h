@@ -26,7 +26,7 @@ struct SegItem {       // 16 bytes, read as int4 on the device
     int32_t end;       // one past the last entry
     int32_t dst;       // >= 0: destination row in the gradient table (final)
                        // <  0: partial row -(dst+1) of this level's output space
-    int32_t pad;
+    int32_t slot;      // final items: rank of the word among the batch's distinct words
 };
 
 struct BatchIndex {
@@ -36,6 +36,8 @@ struct BatchIndex {
     int32_t item_cnt[kSegMaxLevels] = {};
     int64_t part_off[kSegMaxLevels] = {}; // partial-row offset of level l's OUTPUT space
     int64_t part_rows = 0;                // total partial rows of this batch
+    int64_t uw_off = 0;                   // offset of this batch's distinct words in uwords[]
+    int32_t num_distinct = 0;             // U: distinct words of the batch
 };
 
 struct WordIndex {
@@ -43,16 +45,23 @@ struct WordIndex {
     std::vector<SegItem> items;           // all batches, all levels
     std::vector<BatchIndex> batches;
     int64_t max_part_rows = 0;
+    // distinct words per batch (sorted) and, per token position, the rank of its word
+    // among them: a gathered row is then computed ONCE per distinct word (loglinear)
+    std::vector<int32_t> uwords;          // all batches
+    std::vector<int32_t> slots;           // all batches, B*n per batch (want_slots only)
+    int32_t max_distinct = 0;
 };
 
 // ids: (num_batches*B*n) token ids of the complete batches, IdT wide.
 // row_of_pos: entry value = pos / n (vectorspace: row of dh) or pos (loglinear: row of dG).
 template <typename IdT>
 bool build_word_index(const IdT* ids, int64_t num_batches, int B, int n, int vocab,
-                      bool row_is_pos, WordIndex& out) {
+                      bool row_is_pos, WordIndex& out, bool want_slots = false) {
     const int64_t T = (int64_t)B * n;
     out.rows.resize((size_t)(num_batches * T));
     out.batches.resize((size_t)num_batches);
+    if (want_slots) out.slots.resize((size_t)(num_batches * T));
+    std::vector<int32_t> slot_of((size_t)(want_slots ? vocab : 0), 0);
     std::vector<int32_t> count((size_t)vocab + 1, 0);
     std::vector<int32_t> touched;
     touched.reserve((size_t)std::min<int64_t>(T, vocab));
@@ -70,6 +79,15 @@ bool build_word_index(const IdT* ids, int64_t num_batches, int B, int n, int voc
             if (count[wid]++ == 0) touched.push_back(wid);
         }
         std::sort(touched.begin(), touched.end());
+        bx.uw_off = (int64_t)out.uwords.size();
+        bx.num_distinct = (int32_t)touched.size();
+        out.max_distinct = std::max(out.max_distinct, bx.num_distinct);
+        if (want_slots) {
+            out.uwords.insert(out.uwords.end(), touched.begin(), touched.end());
+            for (size_t t = 0; t < touched.size(); ++t) slot_of[(size_t)touched[t]] = (int32_t)t;
+            int32_t* sl = out.slots.data() + bi * T;
+            for (int64_t p = 0; p < T; ++p) sl[p] = slot_of[(size_t)x[p]];
+        }
         // exclusive offsets, stored back into count[] as write cursors
         start.resize(touched.size() + 1);
         int32_t acc = 0;
@@ -88,9 +106,9 @@ bool build_word_index(const IdT* ids, int64_t num_batches, int B, int n, int voc
         for (int32_t wid : touched) count[wid] = 0;
 
         // level 0 items
-        struct Seg { int32_t begin, end, word; };
+        struct Seg { int32_t begin, end, word, slot; };
         std::vector<Seg> segs(touched.size());
-        for (size_t t = 0; t < touched.size(); ++t) segs[t] = {start[t], start[t + 1], touched[t]};
+        for (size_t t = 0; t < touched.size(); ++t) segs[t] = {start[t], start[t + 1], touched[t], (int32_t)t};
         int level = 0;
         int64_t part_base = 0;
         while (!segs.empty() && level < kSegMaxLevels) {
@@ -101,7 +119,7 @@ bool build_word_index(const IdT* ids, int64_t num_batches, int B, int n, int voc
             for (const Seg& s : segs) {
                 const int32_t len = s.end - s.begin;
                 if (len <= kSegChunk || level == kSegMaxLevels - 1) {
-                    out.items.push_back({s.begin, s.end, s.word, 0});
+                    out.items.push_back({s.begin, s.end, s.word, s.slot});
                 } else {
                     const int32_t first = nparts;
                     for (int32_t b = s.begin; b < s.end; b += kSegChunk) {
@@ -109,7 +127,7 @@ bool build_word_index(const IdT* ids, int64_t num_batches, int B, int n, int voc
                         out.items.push_back({b, e, -(nparts + 1), 0});
                         ++nparts;
                     }
-                    next.push_back({first, nparts, s.word});
+                    next.push_back({first, nparts, s.word, s.slot});
                 }
             }
             bx.item_cnt[level] = (int32_t)((int64_t)out.items.size() - bx.item_off[level]);

@@ -157,9 +157,10 @@ __global__ __launch_bounds__(256) void ll_window(float* __restrict__ P, float* _
 // when n*V floats (+V) fit the 160 KB LDS (C1 / C2 shapes); same maths, same
 // citations as the two kernels above.
 //   dynamic LDS: S[n*V] | J[V]
-// slot (optional, with Zu): token (i, k) reads its logits from Zu[slot[i*n + k], :] -- the
-// table of logit rows computed ONCE per distinct word of the batch -- and dL/dZ of every
-// token still goes to Z[(i*n + k), :] (summed per word afterwards).  slot == nullptr: the
+// slot (optional, with Zu): token (i, k) reads its LOG-PROBABILITIES from Zu[slot[i*n + k], :]
+// -- the table computed ONCE per distinct word of the batch (logits GEMM +
+// ll_logsoftmax_rows) -- and dL/dZ of every token still goes to Z[(i*n + k), :] (summed
+// per word afterwards).  slot == nullptr: the
 // logits are read from Z itself and overwritten in place.
 template <bool TRAIN, int NT>
 __global__ __launch_bounds__(NT) void ll_fused_row(float* __restrict__ Z,
@@ -238,23 +239,27 @@ __global__ __launch_bounds__(NT) void ll_fused_row(float* __restrict__ Z,
     //    kept in the LOG domain: log P = (z - max) - log(sum exp), so the window
     //    log-product needs no per-element logf and clip(P) is a clamp of log P
     const float LOGLO = logf(SERT_CLIP_LO), LOGHI = logf(SERT_CLIP_HI);
-    for (int k = wv; k < n; k += NW) {
-        float* zk = S + (size_t)k * V;
-        float tmx = -INFINITY;
+    // (with a slot table the rows of Zu already hold log P: ll_logsoftmax_rows ran once per
+    //  distinct word)
+    if (slot == nullptr) {
+        for (int k = wv; k < n; k += NW) {
+            float* zk = S + (size_t)k * V;
+            float tmx = -INFINITY;
 #pragma unroll 8
-        for (int e = lane; e < V; e += 64) tmx = fmaxf(tmx, zk[e]);
-        tmx = wave_max(tmx);
-        float sm = 0.f;
-        // __expf = v_exp_f32(x*log2e): rel. error <= ~|x|*6e-8, far inside the 1e-5 loss tolerance;
-        // the libm expf expansion made this kernel VALU-bound (12 waves/CU, 2 exps per element)
+            for (int e = lane; e < V; e += 64) tmx = fmaxf(tmx, zk[e]);
+            tmx = wave_max(tmx);
+            float sm = 0.f;
+            // __expf = v_exp_f32(x*log2e): rel. error <= ~|x|*6e-8, far inside the 1e-5 loss tolerance;
+            // the libm expf expansion made this kernel VALU-bound (12 waves/CU, 2 exps per element)
 #pragma unroll 8
-        for (int e = lane; e < V; e += 64) sm += __expf(zk[e] - tmx);
-        sm = wave_sum(sm);
-        const float lsm = logf(sm);
+            for (int e = lane; e < V; e += 64) sm += __expf(zk[e] - tmx);
+            sm = wave_sum(sm);
+            const float lsm = logf(sm);
 #pragma unroll 8
-        for (int e = lane; e < V; e += 64) zk[e] = (zk[e] - tmx) - lsm;
+            for (int e = lane; e < V; e += 64) zk[e] = (zk[e] - tmx) - lsm;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     // 3. window log-product J_e = sum_k log clip(P_ke) and its softmax   models.py:200-210
     float mx = -INFINITY;
     for (int e = tid; e < V; e += NT) {
@@ -329,6 +334,27 @@ __global__ __launch_bounds__(NT) void ll_fused_row(float* __restrict__ Z,
             out[e] = dj - __expf(lp) * r;
         }
     }
+}
+
+// In-place row log-softmax, log P = (z - max) - log(sum exp(z - max)), one wave per row --
+// the per-token phase of ll_fused_row, hoisted to run ONCE per distinct word when the step
+// works on the distinct-word logit table (same formula, same __expf).
+__global__ __launch_bounds__(256) void ll_logsoftmax_rows(float* __restrict__ Z, int64_t rows, int V) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    float* z = Z + (size_t)r * V;
+    float mx = -INFINITY;
+#pragma unroll 4
+    for (int e = lane; e < V; e += 64) mx = fmaxf(mx, z[e]);
+    mx = wave_max(mx);
+    float sm = 0.f;
+#pragma unroll 4
+    for (int e = lane; e < V; e += 64) sm += __expf(z[e] - mx);
+    sm = wave_sum(sm);
+    const float lsm = logf(sm);
+#pragma unroll 4
+    for (int e = lane; e < V; e += 64) z[e] = (z[e] - mx) - lsm;
 }
 
 // dst[ids[u], :] = src[u, :] (the word-table gradient rows of the batch's distinct words);

@@ -729,6 +729,8 @@ static int ll_forward(sert_model* m, const DataSplit& ds, int64_t batch_index) {
     if (fused) {
         ScopedTimer t(m, TG_LOSS);
         const int32_t* slot = m->ll_dedup ? ds.idx_slots + (size_t)batch_index * rows : nullptr;
+        if (m->ll_dedup)   // the per-token log-softmax, once per distinct word
+            hipLaunchKernelGGL(ll_logsoftmax_rows, dim3(cdiv(grows, 4)), dim3(256), 0, m->stream, m->Zu, grows, V);
         // 512 threads per row: 302 us at 256 (too few waves to hide the slab load), 228 at
         // 512, 320 at 640 (one wave per token, but only two workgroups fit a CU)
         hipLaunchKernelGGL((ll_fused_row<TRAIN, 512>), dim3(B), dim3(512), fused_lds, m->stream, m->Z,

@@ -473,7 +473,8 @@ __global__ __launch_bounds__(256) void ll_s_lse(const float2* __restrict__ stat,
 template <bool V4>
 __global__ __launch_bounds__(256) void ll_s_window(const float* __restrict__ Z, const float* __restrict__ lse,
                                                    int n, int V, int nseg, float* __restrict__ J,
-                                                   float2* __restrict__ jstat) {
+                                                   float2* __restrict__ jstat,
+                                                   const int32_t* __restrict__ slot) {
     __shared__ float red[4];
     const int64_t i = blockIdx.x / nseg;
     const int seg = (int)(blockIdx.x - i * nseg);
@@ -482,7 +483,8 @@ __global__ __launch_bounds__(256) void ll_s_window(const float* __restrict__ Z, 
 #pragma unroll
     for (int u = 0; u < 16; ++u) acc[u] = 0.f;
     for (int k = 0; k < n; ++k) {
-        const int64_t row = i * n + k;
+        // slot: Z and lse are the distinct-word tables, row = rank of the token's word
+        const int64_t row = slot ? (int64_t)slot[i * n + k] : i * n + k;
         const float l = lse[row];
         float x[16];
         seg_load<V4>(Z + (size_t)row * V, V, seg, x, 0.f);
@@ -578,15 +580,17 @@ __global__ __launch_bounds__(256) void ll_s_labfix(float* __restrict__ J, const 
 template <bool V4>
 __global__ __launch_bounds__(256) void ll_s_tokr(const float* __restrict__ Z, const float* __restrict__ lse,
                                                  const float* __restrict__ dJ, int n, int V, int nseg,
-                                                 float* __restrict__ rpart) {
+                                                 float* __restrict__ rpart,
+                                                 const int32_t* __restrict__ slot) {
     __shared__ float red[4];
     const int64_t row = blockIdx.x / nseg;
     const int seg = (int)(blockIdx.x - row * nseg);
     const int64_t i = row / n;
     const float LOGLO = logf(SERT_CLIP_LO), LOGHI = logf(SERT_CLIP_HI);
-    const float l = lse[row];
+    const int64_t srow = slot ? (int64_t)slot[row] : row;   // distinct-word tables
+    const float l = lse[srow];
     float x[16], dj[16];
-    seg_load<V4>(Z + (size_t)row * V, V, seg, x, INFINITY);   // padding: log p = +inf -> masked out
+    seg_load<V4>(Z + (size_t)srow * V, V, seg, x, INFINITY);   // padding: log p = +inf -> masked out
     seg_load<V4>(dJ + (size_t)i * V, V, seg, dj, 0.f);
     float r = 0.f;
 #pragma unroll
@@ -613,14 +617,17 @@ __global__ __launch_bounds__(256) void ll_s_rsum(const float* __restrict__ rpart
 template <bool V4>
 __global__ __launch_bounds__(256) void ll_s_dz(float* __restrict__ Z, const float* __restrict__ lse,
                                                const float* __restrict__ dJ, const float* __restrict__ r,
-                                               int n, int V, int nseg) {
+                                               int n, int V, int nseg, const float* __restrict__ Zu,
+                                               const int32_t* __restrict__ slot) {
     const int64_t row = blockIdx.x / nseg;
     const int seg = (int)(blockIdx.x - row * nseg);
     const int64_t i = row / n;
     const float LOGLO = logf(SERT_CLIP_LO), LOGHI = logf(SERT_CLIP_HI);
-    const float l = lse[row], rk = r[row];
+    // slot: logits and lse come from the distinct-word tables, dZ still goes to Z[row]
+    const int64_t srow = slot ? (int64_t)slot[row] : row;
+    const float l = lse[srow], rk = r[row];
     float x[16], dj[16];
-    seg_load<V4>(Z + (size_t)row * V, V, seg, x, 0.f);
+    seg_load<V4>((slot ? Zu : Z) + (size_t)srow * V, V, seg, x, 0.f);
     seg_load<V4>(dJ + (size_t)i * V, V, seg, dj, 0.f);
 #pragma unroll
     for (int u = 0; u < 16; ++u) {

@@ -651,7 +651,7 @@ static int fs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
 // Streaming loss for entity vocabularies beyond the LDS-resident slab (kernels_ll.h).
 template <bool TRAIN, bool V4>
 static int ll_stream_loss(sert_model* m, const DataSplit& ds, size_t row0, const int32_t* y,
-                          const int64_t* indptr, const float* w, float inv_batch) {
+                          const int64_t* indptr, const float* w, float inv_batch, const int32_t* slot) {
     const auto& c = m->cfg;
     const int B = c.batch_size, n = c.window_size, V = c.num_entities;
     const int64_t rows = (int64_t)B * n;
@@ -659,20 +659,24 @@ static int ll_stream_loss(sert_model* m, const DataSplit& ds, size_t row0, const
     hipStream_t s = m->stream;
     if (TRAIN && !ds.labfix) SERT_FAIL("training split has no label scratch");
     float* labfix = TRAIN ? ds.labfix + (y ? row0 : 0) : nullptr;
-    hipLaunchKernelGGL((ll_s_tokstat<V4>), dim3((unsigned)(rows * nseg)), dim3(256), 0, s, m->Z, V, nseg, m->ll_tokstat);
-    hipLaunchKernelGGL(ll_s_lse, dim3(cdiv(rows, 4)), dim3(256), 0, s, m->ll_tokstat, rows, nseg, m->ll_lse);
-    hipLaunchKernelGGL((ll_s_window<V4>), dim3((unsigned)((int64_t)B * nseg)), dim3(256), 0, s, m->Z, m->ll_lse, n, V,
-                       nseg, m->J, m->ll_jstat);
+    // slot: the logits live in the distinct-word table Zu (U rows); the per-token log-sum-exp
+    // is then a per-WORD quantity, and dL/dZ of every token goes to Z
+    const float* logits = slot ? m->Zu : m->Z;
+    const int64_t lrows = slot ? m->ll_U : rows;
+    hipLaunchKernelGGL((ll_s_tokstat<V4>), dim3((unsigned)(lrows * nseg)), dim3(256), 0, s, logits, V, nseg, m->ll_tokstat);
+    hipLaunchKernelGGL(ll_s_lse, dim3(cdiv(lrows, 4)), dim3(256), 0, s, m->ll_tokstat, lrows, nseg, m->ll_lse);
+    hipLaunchKernelGGL((ll_s_window<V4>), dim3((unsigned)((int64_t)B * nseg)), dim3(256), 0, s, logits, m->ll_lse, n, V,
+                       nseg, m->J, m->ll_jstat, slot);
     hipLaunchKernelGGL((ll_s_rowloss<TRAIN>), dim3(B), dim3(256), 0, s, m->J, m->ll_jstat, y, indptr,
                        ds.csr_indices, ds.csr_data, w, m->rowloss, m->ll_rowinfo, labfix, V, nseg, inv_batch);
     if (!TRAIN) return 0;
     hipLaunchKernelGGL((ll_s_dj<V4>), dim3((unsigned)((int64_t)B * nseg)), dim3(256), 0, s, m->J, m->ll_rowinfo, V, nseg);
     hipLaunchKernelGGL(ll_s_labfix, dim3(B), dim3(256), 0, s, m->J, y, indptr, ds.csr_indices, labfix, V);
-    hipLaunchKernelGGL((ll_s_tokr<V4>), dim3((unsigned)(rows * nseg)), dim3(256), 0, s, m->Z, m->ll_lse, m->J, n, V,
-                       nseg, m->ll_rpart);
+    hipLaunchKernelGGL((ll_s_tokr<V4>), dim3((unsigned)(rows * nseg)), dim3(256), 0, s, logits, m->ll_lse, m->J, n, V,
+                       nseg, m->ll_rpart, slot);
     hipLaunchKernelGGL(ll_s_rsum, dim3(cdiv(rows, 4)), dim3(256), 0, s, m->ll_rpart, rows, nseg, m->ll_r);
     hipLaunchKernelGGL((ll_s_dz<V4>), dim3((unsigned)(rows * nseg)), dim3(256), 0, s, m->Z, m->ll_lse, m->J, m->ll_r, n,
-                       V, nseg);
+                       V, nseg, (const float*)m->Zu, slot);
     return 0;
 }
 
@@ -689,7 +693,8 @@ static int ll_forward(sert_model* m, const DataSplit& ds, int64_t batch_index) {
     // words (Zipfian batches: a third of the tokens), the loss kernel reads the table through
     // the per-token slot, and dL/dZ is summed per word before the backward GEMMs.
     static const bool no_dedup = getenv("SERT_LL_NODEDUP") != nullptr;   // cross-check knob
-    m->ll_dedup = TRAIN && fused && !no_dedup && ds.idx_slots != nullptr &&
+    static const bool rowwise = getenv("SERT_LL_ROWWISE") != nullptr;
+    m->ll_dedup = TRAIN && (fused || !rowwise) && !no_dedup && ds.idx_slots != nullptr &&
                   (size_t)batch_index < ds.idx_batches.size();
     const BatchIndex* bx = m->ll_dedup ? &ds.idx_batches[(size_t)batch_index] : nullptr;
     m->ll_U = bx ? bx->num_distinct : 0;
@@ -725,10 +730,10 @@ static int ll_forward(sert_model* m, const DataSplit& ds, int64_t batch_index) {
     const int32_t* y = ds.y ? ds.y + row0 : nullptr;
     const int64_t* indptr = ds.csr_indptr ? ds.csr_indptr + row0 : nullptr;
     const float* w = TRAIN ? ds.w + row0 : nullptr;
+    const int32_t* slot = m->ll_dedup ? ds.idx_slots + (size_t)batch_index * rows : nullptr;
     // fused path: the row's (n, V) slab lives in LDS; CSR rows with > 1024 labels fall back
     if (fused) {
         ScopedTimer t(m, TG_LOSS);
-        const int32_t* slot = m->ll_dedup ? ds.idx_slots + (size_t)batch_index * rows : nullptr;
         if (m->ll_dedup)   // the per-token log-softmax, once per distinct word
             hipLaunchKernelGGL(ll_logsoftmax_rows, dim3(cdiv(grows, 4)), dim3(256), 0, m->stream, m->Zu, grows, V);
         // 512 threads per row: 302 us at 256 (too few waves to hide the slab load), 228 at
@@ -736,7 +741,7 @@ static int ll_forward(sert_model* m, const DataSplit& ds, int64_t batch_index) {
         hipLaunchKernelGGL((ll_fused_row<TRAIN, 512>), dim3(B), dim3(512), fused_lds, m->stream, m->Z,
                            (const float*)m->Zu, slot, y, indptr, ds.csr_indices, ds.csr_data, w, m->rowloss, n,
                            V, inv_batch);
-    } else if (getenv("SERT_LL_ROWWISE")) {
+    } else if (rowwise) {
         // the plain row-per-workgroup kernels (kept as a cross-check of the streaming path)
         ScopedTimer t(m, TG_LOSS);
         hipLaunchKernelGGL(ll_softmax_rows, dim3(cdiv(rows, 4)), dim3(256), 0, m->stream, m->Z, rows,
@@ -745,8 +750,8 @@ static int ll_forward(sert_model* m, const DataSplit& ds, int64_t batch_index) {
                            indptr, ds.csr_indices, ds.csr_data, w, m->rowloss, n, V, inv_batch);
     } else {
         ScopedTimer t(m, TG_LOSS);
-        if (V % 4 == 0) SERT_TRY((ll_stream_loss<TRAIN, true>(m, ds, row0, y, indptr, w, inv_batch)));
-        else            SERT_TRY((ll_stream_loss<TRAIN, false>(m, ds, row0, y, indptr, w, inv_batch)));
+        if (V % 4 == 0) SERT_TRY((ll_stream_loss<TRAIN, true>(m, ds, row0, y, indptr, w, inv_batch, slot)));
+        else            SERT_TRY((ll_stream_loss<TRAIN, false>(m, ds, row0, y, indptr, w, inv_batch, slot)));
     }
     return 0;
 }

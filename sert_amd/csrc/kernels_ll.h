@@ -159,8 +159,12 @@ __global__ __launch_bounds__(256) void ll_window(float* __restrict__ P, float* _
 //   dynamic LDS: S[n*V] | J[V]
 // slot (optional, with Zu): token (i, k) reads its LOG-PROBABILITIES from Zu[slot[i*n + k], :]
 // -- the table computed ONCE per distinct word of the batch (logits GEMM +
-// ll_logsoftmax_rows) -- and dL/dZ of every token still goes to Z[(i*n + k), :] (summed
-// per word afterwards).  slot == nullptr: the
+// ll_logsoftmax_rows).  The backward then stops one level earlier: since P and the clip
+// mask of a token depend on its WORD only,
+//     sum over the occurrences (i,k) of word u of  dZ_ke = mask_ue dJ_ie - P_ue r_ik
+//   = mask_ue (sum_occ dJ_ie) - P_ue (sum_occ r_ik),
+// so the kernel emits dJ_i (V floats per batch row, into Z[i*V ..]) and the n scalars r_ik
+// instead of n rows of dL/dZ: 1/n of the bytes.  ll_dzu_combine finishes per word.  slot == nullptr: the
 // logits are read from Z itself and overwritten in place.
 template <bool TRAIN, int NT>
 __global__ __launch_bounds__(NT) void ll_fused_row(float* __restrict__ Z,
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(NT) void ll_fused_row(float* __restrict__ Z,
                                                     const float* __restrict__ data,
                                                     const float* __restrict__ w,
                                                     float* __restrict__ rowloss, int n, int V,
-                                                    float inv_batch) {
+                                                    float inv_batch, float* __restrict__ r_out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NW = NT / 64;
     __shared__ float red[NW];
@@ -317,6 +321,23 @@ __global__ __launch_bounds__(NT) void ll_fused_row(float* __restrict__ Z,
     __syncthreads();
     // 6. per token: dZ_k = P_k (dP_k - <dP_k, P_k>) with dP = dJ*mask/P, i.e.
     //    dZ_ke = mask_ke dJ_e - P_ke r_k,  r_k = sum_e mask_ke dJ_e;  straight to HBM
+    if (slot != nullptr) {
+        // distinct-word mode: emit dJ_i and the r_k; the per-word combination follows
+        float* dj_out = Z + (size_t)i * V;
+        for (int e = tid; e < V; e += NT) dj_out[e] = Jl[e];
+        for (int k = wv; k < n; k += NW) {
+            const float* lk = S + (size_t)k * V;
+            float r = 0.f;
+#pragma unroll 8
+            for (int e = lane; e < V; e += 64) {
+                const float lp = lk[e];
+                r += (lp >= LOGLO && lp <= LOGHI) ? Jl[e] : 0.f;
+            }
+            r = wave_sum(r);
+            if (lane == 0) r_out[(size_t)i * n + k] = r;
+        }
+        return;
+    }
     for (int k = wv; k < n; k += NW) {
         const float* lk = S + (size_t)k * V;
         float r = 0.f;
@@ -333,6 +354,21 @@ __global__ __launch_bounds__(NT) void ll_fused_row(float* __restrict__ Z,
             const float dj = (lp >= LOGLO && lp <= LOGHI) ? Jl[e] : 0.f;
             out[e] = dj - __expf(lp) * r;
         }
+    }
+}
+
+// dZu[u, e] = mask_ue DJsum[u, e] - P_ue Rsum[u]   (in place over DJsum; logp = the word's
+// log-probability row, mask = eps <= P <= 1-eps)
+__global__ __launch_bounds__(256) void ll_dzu_combine(float* __restrict__ dZu, const float* __restrict__ logp,
+                                                      const float* __restrict__ rsum, int64_t rows, int V) {
+    const float LOGLO = logf(SERT_CLIP_LO), LOGHI = logf(SERT_CLIP_HI);
+    const int64_t total = rows * V;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t u = t / V;
+        const float lp = logp[t];
+        const float dj = (lp >= LOGLO && lp <= LOGHI) ? dZu[t] : 0.f;
+        dZu[t] = dj - __expf(lp) * rsum[u];
     }
 }
 

@@ -224,6 +224,48 @@ static int dz_word_sums(sert_model* m, const DataSplit& ds, int64_t batch_index)
     return 0;
 }
 
+// Same result from 1/n of the bytes (kernels_ll.h, ll_fused_row): per word, the sum of the
+// dJ rows of the batch rows it occurs in and the sum of its r_ik, then
+// dZu = mask dJsum - P rsum.  Both sums ride the word's occurrence tree (rows = positions,
+// source row of the V_e-wide sum = position / n).
+static int dzu_from_dj(sert_model* m, const DataSplit& ds, int64_t batch_index) {
+    const int V = m->cfg.num_entities, n = m->cfg.window_size;
+    const BatchIndex& bx = ds.idx_batches[(size_t)batch_index];
+    // the scalars first: the V_e-wide pass applies them when it stores a word's final row
+    for (int l = 0; l < bx.nlevels; ++l) {
+        const int nitems = bx.item_cnt[l];
+        if (nitems == 0) continue;
+        const int32_t* rows = (l == 0) ? ds.idx_rows + bx.rows_off : nullptr;
+        const int4* items = ds.idx_items + bx.item_off[l];
+        const float* in = (l == 0) ? m->ll_r : m->ll_rpart + (size_t)bx.part_off[l - 1];
+        float* pout = m->ll_rpart + (size_t)bx.part_off[l];
+        hipLaunchKernelGGL((segsum_rows_scalar<true>), dim3(cdiv(nitems, 4)), dim3(256), 0, m->stream, in,
+                           rows, items, nitems, m->ll_rsum, pout, 1, 1.0f, (unsigned char*)nullptr, 1);
+    }
+    for (int l = 0; l < bx.nlevels; ++l) {
+        const int nitems = bx.item_cnt[l];
+        if (nitems == 0) continue;
+        const int32_t* rows = (l == 0) ? ds.idx_rows + bx.rows_off : nullptr;
+        const int4* items = ds.idx_items + bx.item_off[l];
+        const float* in = (l == 0) ? m->J : m->zpart + (size_t)bx.part_off[l - 1] * V;
+        float* pout = m->zpart + (size_t)bx.part_off[l] * V;
+        if (V % 4 == 0) {
+            hipLaunchKernelGGL((segsum_rows<64, true, true>), dim3(cdiv(nitems, 4), cdiv(V / 4, 64)), dim3(256), 0,
+                               m->stream, in, rows, items, nitems, m->dZu, pout, V, 1.0f,
+                               (unsigned char*)nullptr, l == 0 ? n : 1, (const float*)m->Zu,
+                               (const float*)m->ll_rsum);
+        } else {
+            hipLaunchKernelGGL((segsum_rows_scalar<true>), dim3(cdiv(nitems, 4)), dim3(256), 0, m->stream, in,
+                               rows, items, nitems, m->dZu, pout, V, 1.0f, (unsigned char*)nullptr,
+                               l == 0 ? n : 1);
+        }
+    }
+    if (V % 4 != 0)   // (odd V_e: separate finishing pass)
+        hipLaunchKernelGGL(ll_dzu_combine, dim3(grid_for((int64_t)m->ll_U * V)), dim3(256), 0, m->stream, m->dZu,
+                           (const float*)m->Zu, (const float*)m->ll_rsum, (int64_t)m->ll_U, V);
+    return 0;
+}
+
 // Stable sort of the (entity id, pair index) keys of this step: cand -> cand_sorted,
 // iota -> pair_sorted (kernels_sort.h), LSD over ceil(bits/11) digits.
 static int entity_key_sort(sert_model* m, int total, hipStream_t st) {
@@ -698,6 +740,7 @@ static int ll_forward(sert_model* m, const DataSplit& ds, int64_t batch_index) {
                   (size_t)batch_index < ds.idx_batches.size();
     const BatchIndex* bx = m->ll_dedup ? &ds.idx_batches[(size_t)batch_index] : nullptr;
     m->ll_U = bx ? bx->num_distinct : 0;
+    m->ll_dj_level = false;
     const int64_t grows = m->ll_dedup ? m->ll_U : rows;          // rows of the gathered operand
     {
         ScopedTimer t(m, TG_GATHER);
@@ -738,9 +781,11 @@ static int ll_forward(sert_model* m, const DataSplit& ds, int64_t batch_index) {
             hipLaunchKernelGGL(ll_logsoftmax_rows, dim3(cdiv(grows, 4)), dim3(256), 0, m->stream, m->Zu, grows, V);
         // 512 threads per row: 302 us at 256 (too few waves to hide the slab load), 228 at
         // 512, 320 at 640 (one wave per token, but only two workgroups fit a CU)
-        hipLaunchKernelGGL((ll_fused_row<TRAIN, 512>), dim3(B), dim3(512), fused_lds, m->stream, m->Z,
-                           (const float*)m->Zu, slot, y, indptr, ds.csr_indices, ds.csr_data, w, m->rowloss, n,
-                           V, inv_batch);
+        // (distinct-word mode: the kernel writes dJ_i into J and r_ik into ll_r instead of dL/dZ)
+        m->ll_dj_level = m->ll_dedup;
+        hipLaunchKernelGGL((ll_fused_row<TRAIN, 512>), dim3(B), dim3(512), fused_lds, m->stream,
+                           m->ll_dedup ? m->J : m->Z, (const float*)m->Zu, slot, y, indptr, ds.csr_indices,
+                           ds.csr_data, w, m->rowloss, n, V, inv_batch, m->ll_r);
     } else if (rowwise) {
         // the plain row-per-workgroup kernels (kept as a cross-check of the streaming path)
         ScopedTimer t(m, TG_LOSS);
@@ -765,7 +810,8 @@ static int ll_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
     if (m->ll_dedup) {
         // per-word sums of dL/dZ (the backward of "duplicate tokens share a logit row")
         ScopedTimer t(m, TG_EGRAD);
-        SERT_TRY(dz_word_sums(m, ds, batch_index));
+        if (m->ll_dj_level) SERT_TRY(dzu_from_dj(m, ds, batch_index));
+        else                SERT_TRY(dz_word_sums(m, ds, batch_index));
         dZ = m->dZu;
         rows = m->ll_U;
     }
@@ -1122,6 +1168,7 @@ int sert_create(const sert_config* cfg, sert_model** out) {
             SERT_TRY(dzalloc(&m->ll_tokstat, B * n * nseg, s)); SERT_TRY(dzalloc(&m->ll_lse, B * n, s));
             SERT_TRY(dzalloc(&m->ll_jstat, B * nseg, s));       SERT_TRY(dzalloc(&m->ll_rowinfo, B, s));
             SERT_TRY(dzalloc(&m->ll_rpart, B * n * nseg, s));   SERT_TRY(dzalloc(&m->ll_r, B * n, s));
+            SERT_TRY(dzalloc(&m->ll_rsum, B * n, s));
             const size_t tiles = (size_t)cdiv(V, GN) * cdiv(dw, GM);
             const size_t splits = std::max<size_t>(1, cdiv(1024, tiles)) + 1;
             part = splits * (dw * V + V);
@@ -1177,7 +1224,7 @@ int sert_destroy(sert_model* m) {
                      m->d_losses};
     for (float* p : bufs) (void)hipFree(p);
     (void)hipFree(m->ll_tokstat); (void)hipFree(m->ll_lse); (void)hipFree(m->ll_jstat);
-    (void)hipFree(m->ll_rowinfo); (void)hipFree(m->ll_rpart); (void)hipFree(m->ll_r);
+    (void)hipFree(m->ll_rowinfo); (void)hipFree(m->ll_rpart); (void)hipFree(m->ll_r); (void)hipFree(m->ll_rsum);
     (void)hipFree(m->rw_touched);
     (void)hipFree(m->Zu); (void)hipFree(m->dZu); (void)hipFree(m->zpart);
     (void)hipFree(m->neg); (void)hipFree(m->neg_stage);

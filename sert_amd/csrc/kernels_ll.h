@@ -585,6 +585,17 @@ __global__ __launch_bounds__(256) void ll_s_rowloss(const float* __restrict__ J,
     if (tid == 0) rowinfo[i] = make_float4(mx, se, sdq, 0.f);
 }
 
+// Z[row, :] -= lse[row]  (logits -> log-probabilities, per (row, segment) workgroup)
+__global__ __launch_bounds__(256) void ll_s_logp_rows(float* __restrict__ Z, const float* __restrict__ lse,
+                                                      int V, int nseg) {
+    const int64_t row = blockIdx.x / nseg;
+    const int seg = (int)(blockIdx.x - row * nseg);
+    const float l = lse[row];
+    float* z = Z + (size_t)row * V;
+    const int e0 = seg * kLlSeg;
+    for (int e = e0 + threadIdx.x; e < min(V, e0 + kLlSeg); e += 256) z[e] -= l;
+}
+
 // dJ_e = -Q_e s (the dense part of Q_e (dQ_e - s)), in place over J
 template <bool V4>
 __global__ __launch_bounds__(256) void ll_s_dj(float* __restrict__ J, const float4* __restrict__ rowinfo,

@@ -717,6 +717,14 @@ static int ll_stream_loss(sert_model* m, const DataSplit& ds, size_t row0, const
     hipLaunchKernelGGL((ll_s_tokr<V4>), dim3((unsigned)(rows * nseg)), dim3(256), 0, s, logits, m->ll_lse, m->J, n, V,
                        nseg, m->ll_rpart, slot);
     hipLaunchKernelGGL(ll_s_rsum, dim3(cdiv(rows, 4)), dim3(256), 0, s, m->ll_rpart, rows, nseg, m->ll_r);
+    if (slot) {
+        // distinct-word mode: stop here -- dJ (in J) and r_ik are all the per-word backward
+        // needs (dzu_from_dj); the per-token dL/dZ pass and its 2 x B*n*V_e floats are skipped.
+        // The word rows must hold LOG-probabilities for the finishing transform:
+        hipLaunchKernelGGL(ll_s_logp_rows, dim3((unsigned)(lrows * nseg)), dim3(256), 0, s, m->Zu, m->ll_lse, V, nseg);
+        m->ll_dj_level = true;
+        return 0;
+    }
     hipLaunchKernelGGL((ll_s_dz<V4>), dim3((unsigned)(rows * nseg)), dim3(256), 0, s, m->Z, m->ll_lse, m->J, m->ll_r, n,
                        V, nseg, (const float*)m->Zu, slot);
     return 0;

@@ -24,6 +24,7 @@ struct DataSplit {
     int4* idx_items = nullptr;
     int32_t* idx_uwords = nullptr;   // loglinear: distinct words of every batch (sorted)
     int32_t* idx_slots = nullptr;    // loglinear: per token position, rank of its word among them
+    int32_t* idx_rows_div = nullptr; // loglinear: idx_rows / n (batch row of every level-0 entry)
     std::vector<BatchIndex> idx_batches;
 };
 

@@ -229,7 +229,7 @@ static int dz_word_sums(sert_model* m, const DataSplit& ds, int64_t batch_index)
 // dZu = mask dJsum - P rsum.  Both sums ride the word's occurrence tree (rows = positions,
 // source row of the V_e-wide sum = position / n).
 static int dzu_from_dj(sert_model* m, const DataSplit& ds, int64_t batch_index) {
-    const int V = m->cfg.num_entities, n = m->cfg.window_size;
+    const int V = m->cfg.num_entities;
     const BatchIndex& bx = ds.idx_batches[(size_t)batch_index];
     // the scalars first: the V_e-wide pass applies them when it stores a word's final row
     for (int l = 0; l < bx.nlevels; ++l) {
@@ -245,19 +245,18 @@ static int dzu_from_dj(sert_model* m, const DataSplit& ds, int64_t batch_index) 
     for (int l = 0; l < bx.nlevels; ++l) {
         const int nitems = bx.item_cnt[l];
         if (nitems == 0) continue;
-        const int32_t* rows = (l == 0) ? ds.idx_rows + bx.rows_off : nullptr;
+        const int32_t* rows = (l == 0) ? ds.idx_rows_div + bx.rows_off : nullptr;   // batch row of the entry
         const int4* items = ds.idx_items + bx.item_off[l];
         const float* in = (l == 0) ? m->J : m->zpart + (size_t)bx.part_off[l - 1] * V;
         float* pout = m->zpart + (size_t)bx.part_off[l] * V;
         if (V % 4 == 0) {
             hipLaunchKernelGGL((segsum_rows<64, true, true>), dim3(cdiv(nitems, 4), cdiv(V / 4, 64)), dim3(256), 0,
                                m->stream, in, rows, items, nitems, m->dZu, pout, V, 1.0f,
-                               (unsigned char*)nullptr, l == 0 ? n : 1, (const float*)m->Zu,
+                               (unsigned char*)nullptr, 1, (const float*)m->Zu,
                                (const float*)m->ll_rsum);
         } else {
             hipLaunchKernelGGL((segsum_rows_scalar<true>), dim3(cdiv(nitems, 4)), dim3(256), 0, m->stream, in,
-                               rows, items, nitems, m->dZu, pout, V, 1.0f, (unsigned char*)nullptr,
-                               l == 0 ? n : 1);
+                               rows, items, nitems, m->dZu, pout, V, 1.0f, (unsigned char*)nullptr, 1);
         }
     }
     if (V % 4 != 0)   // (odd V_e: separate finishing pass)
@@ -1209,8 +1208,8 @@ static void free_split(DataSplit& d) {
     (void)hipFree(d.x); (void)hipFree(d.y); (void)hipFree(d.csr_indptr);
     (void)hipFree(d.csr_indices); (void)hipFree(d.csr_data); (void)hipFree(d.w); (void)hipFree(d.labfix);
     (void)hipFree(d.idx_rows); (void)hipFree(d.idx_items);
-    (void)hipFree(d.idx_uwords); (void)hipFree(d.idx_slots);
-    d.idx_uwords = nullptr; d.idx_slots = nullptr;
+    (void)hipFree(d.idx_uwords); (void)hipFree(d.idx_slots); (void)hipFree(d.idx_rows_div);
+    d.idx_uwords = nullptr; d.idx_slots = nullptr; d.idx_rows_div = nullptr;
     d = DataSplit();
 }
 
@@ -1358,6 +1357,8 @@ int sert_upload_dataset(sert_model* m, int split, const void* x, const int32_t* 
             SERT_TRY(dmalloc(&d.idx_slots, wi.slots.size()));
             SERT_HIP(hipMemcpyAsync(d.idx_uwords, wi.uwords.data(), wi.uwords.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
             SERT_HIP(hipMemcpyAsync(d.idx_slots, wi.slots.data(), wi.slots.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+            SERT_TRY(dmalloc(&d.idx_rows_div, wi.rows_div.size()));
+            SERT_HIP(hipMemcpyAsync(d.idx_rows_div, wi.rows_div.data(), wi.rows_div.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
             SERT_HIP(hipStreamSynchronize(s));
             if ((size_t)wi.max_distinct > m->zu_rows) {
                 (void)hipFree(m->Zu); (void)hipFree(m->dZu);

@@ -49,6 +49,7 @@ struct WordIndex {
     // among them: a gathered row is then computed ONCE per distinct word (loglinear)
     std::vector<int32_t> uwords;          // all batches
     std::vector<int32_t> slots;           // all batches, B*n per batch (want_slots only)
+    std::vector<int32_t> rows_div;        // rows[] / n: the batch row of every level-0 entry (want_slots only)
     int32_t max_distinct = 0;
 };
 
@@ -104,6 +105,11 @@ bool build_word_index(const IdT* ids, int64_t num_batches, int B, int n, int voc
             rows[count[wid]++] = (int32_t)(row_is_pos ? p : p / n);
         }
         for (int32_t wid : touched) count[wid] = 0;
+        if (want_slots) {
+            if (out.rows_div.size() != out.rows.size()) out.rows_div.resize(out.rows.size());
+            int32_t* rd = out.rows_div.data() + bx.rows_off;
+            for (int64_t e = 0; e < T; ++e) rd[e] = rows[e] / n;
+        }
 
         // level 0 items
         struct Seg { int32_t begin, end, word, slot; };

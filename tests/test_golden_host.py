@@ -251,3 +251,37 @@ def test_oracle_vectorspace_rank_matches_reference(gold, tag, top):
         for r in np.nonzero(order != idx)[0]:
             assert abs(full[idx[r]] - sc[r]) < 1e-6      # only near-ties may swap
         assert np.abs(sc - val).max() < 1e-6
+
+
+def test_epoch_loop_announces_the_following_batch():
+    """_iterate_batches tells the engine which batch follows (sert_hint_next_batch) when it
+    drives train_fn -- and only then; order and results are those of the reference loop."""
+    from sert_amd import models
+
+    class FakeEngine(object):
+        def __init__(self):
+            self.hints, self.trained = [], []
+
+        def hint_next_batch(self, j):
+            self.hints.append(j)
+
+    class M(models.ModelInterface):
+        def __init__(self):
+            self.batch_size = 4
+            self._engine = FakeEngine()
+
+        def train_fn(self, j):
+            self._engine.trained.append(j)
+            return np.float32(j)
+
+        def test_fn(self, j):
+            return np.float32(-j)
+
+    m = M()
+    np.random.seed(3)
+    nb, res = m._iterate_batches(m.train_fn, 4 * 5 + 2, shuffle=True)
+    assert nb == 5 and [int(r) for r in res] == m._engine.trained
+    assert m._engine.hints == m._engine.trained[1:] + [None]
+    m._engine.hints = []
+    m._iterate_batches(m.test_fn, 4 * 5)
+    assert m._engine.hints == []

@@ -1069,6 +1069,8 @@ int sert_device_info(int device, char* buf, size_t buflen) {
                     p.totalGlobalMem / (1024.0 * 1024.0 * 1024.0), p.sharedMemPerBlock / 1024);
 }
 
+static int create_resources(sert_model* m);
+
 int sert_create(const sert_config* cfg, sert_model** out) {
     if (!cfg || !out) SERT_FAIL("null argument");
     if (cfg->struct_size != sizeof(sert_config)) SERT_FAIL("sert_config size mismatch (ABI)");
@@ -1087,6 +1089,20 @@ int sert_create(const sert_config* cfg, sert_model** out) {
     SERT_HIP(hipSetDevice(cfg->device));
     sert_model* m = new sert_model();
     m->cfg = *cfg;
+    // everything below may fail half-way (out of memory, ...): the partially built model is
+    // torn down by sert_destroy, which tolerates null members
+    const int rc = create_resources(m);
+    if (rc != 0) {
+        const std::string why = g_last_error;   // sert_destroy must not clobber the message
+        sert_destroy(m);
+        g_last_error = why;
+        return rc;
+    }
+    *out = m;
+    return 0;
+}
+
+static int create_resources(sert_model* m) {
     const auto& c = m->cfg;
     SERT_HIP(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
     SERT_HIP(hipStreamCreateWithFlags(&m->stream2, hipStreamNonBlocking));
@@ -1200,7 +1216,6 @@ int sert_create(const sert_config* cfg, sert_model** out) {
         for (int k = 0; k < 2; ++k) SERT_HIP(hipEventCreate(&m->timing.ev[g][k]));
     m->timing.created = true;
     SERT_HIP(hipStreamSynchronize(s));
-    *out = m;
     return 0;
 }
 

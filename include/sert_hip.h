@@ -54,7 +54,9 @@ enum {
      *                               Adam v / Adadelta delta = STATE1 */
     SERT_T_STATE0_RW = 4, SERT_T_STATE0_RE = 5, SERT_T_STATE0_W = 6, SERT_T_STATE0_B = 7,
     SERT_T_STATE1_RW = 8, SERT_T_STATE1_RE = 9, SERT_T_STATE1_W = 10, SERT_T_STATE1_B = 11,
-    /* last-step gradients (data term + L2 term), only kept when cfg.keep_grads */
+    /* last-step gradients (data term + L2 term) and activations: readable only from a
+     * model created with cfg.keep_grads (sert_get_tensor fails otherwise: without it these
+     * buffers are scratch) */
     SERT_T_GRAD_RW = 12, SERT_T_GRAD_RE = 13, SERT_T_GRAD_W = 14, SERT_T_GRAD_B = 15,
     /* last-step activations (debug / parity): */
     SERT_T_ACT_H = 16,   /* VS mean-pooled window (B, d_w)      models.py:226  */

@@ -1295,6 +1295,11 @@ int sert_get_tensor(sert_model* m, int which, float* host, size_t count) {
     TensorRef t = tensor_ref(m, which);
     if (!t.ptr || t.count == 0) SERT_FAIL("tensor not present for this model kind");
     if (t.count != count) SERT_FAIL("element count mismatch");
+    // Without keep_grads the gradient buffers are scratch: the word table is neither zeroed
+    // nor fully written, the L2 term is never stored, and the activation buffers may already
+    // hold the NEXT batch (sert_hint_next_batch).  Refuse instead of returning something stale.
+    if (which >= SERT_T_GRAD_RW && which <= SERT_T_ACT_ROWLOSS && !m->cfg.keep_grads)
+        SERT_FAIL("gradients and activations are only readable from a model created with keep_grads = 1");
     SERT_HIP(hipMemcpyAsync(host, t.ptr, count * sizeof(float), hipMemcpyDeviceToHost, m->stream));
     SERT_HIP(hipStreamSynchronize(m->stream));
     return 0;
@@ -1417,7 +1422,8 @@ int sert_train_batch(sert_model* m, int64_t batch_index, const int64_t* negative
     m->hint_next = -1;
     auto prefetch_next = [&]() -> int {
         const DataSplit& ds = m->split[SERT_SPLIT_TRAIN];
-        if (hint < 0 || m->timing.enabled || !is_vs(m) || is_fs(m)) return 0;
+        // (keep_grads: the caller may read this batch's activations after the call)
+        if (hint < 0 || m->timing.enabled || !is_vs(m) || is_fs(m) || m->cfg.keep_grads) return 0;
         if ((hint + 1) * (int64_t)m->cfg.batch_size > ds.N) return 0;
         SERT_TRY(vs_project(m, ds, hint));
         m->projected_batch = hint;

@@ -466,3 +466,16 @@ def test_parameters_after_100_steps(hip_lib, kind):
     for which, ref in pairs:
         assert U.rel_err(eng.get_tensor(which), np.asarray(ref).ravel()) < 1e-4, which
     eng.close()
+
+
+def test_scratch_buffers_are_not_readable_without_keep_grads(hip_lib):
+    B, n, z = 16, 2, 2
+    p = U.make_vs_problem(81, B, n, z, 30, 6, 8, 8)
+    eng = U.vs_engine(p, B, n, z, 0.0, keep_grads=0)
+    eng.upload_dataset(C.SPLIT_TRAIN, p['X'], y_int=p['y'], w=p['w'])
+    eng.train_batch(0)
+    for which in (C.T_GRAD_RW, C.T_GRAD_W, C.T_ACT_H):
+        with pytest.raises(C.SertError):
+            eng.get_tensor(which)
+    assert np.all(np.isfinite(eng.get_tensor(C.T_RW)))
+    eng.close()

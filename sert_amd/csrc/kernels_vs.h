@@ -249,8 +249,11 @@ __global__ __launch_bounds__(256) void vs_nce_scalar(const float* __restrict__ T
 // In place on the logits Z (B, V): P = softmax(Z_i);
 //   loss_i = -log clip(P[y_i], eps, 1-eps)      (same clipping as models.py:289-292)
 //   TRAIN: Z_i <- dL/dZ_i = g_i * [eps <= P_y <= 1-eps] * (P - onehot(y_i)),  g_i = w_i / B
-// One wave per row.
-template <bool TRAIN>
+// One wave per row.  EPL > 0: the row (V <= 64*EPL) stays in registers -- one read of Z,
+// one write of dZ (the 3-pass form below re-reads the row from cache twice and pays two
+// libm expf per element: 206 us at C2 against a 105 us traffic floor).  __expf as in
+// kernels_ll.h (rel. error ~|x|*6e-8, far inside the 1e-5 loss tolerance).
+template <bool TRAIN, int EPL>
 __global__ __launch_bounds__(256) void fs_softmax_ce(float* __restrict__ Z,
                                                      const int32_t* __restrict__ y,
                                                      const float* __restrict__ w,
@@ -260,22 +263,57 @@ __global__ __launch_bounds__(256) void fs_softmax_ce(float* __restrict__ Z,
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= B) return;
     float* z = Z + (size_t)i * V;
+    const int yi = y[i];
+    const float wi = TRAIN ? w[i] : 1.f;
+    if (EPL > 0) {
+        float x[EPL > 0 ? EPL : 1];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < EPL; ++u) {
+            const int e = lane + 64 * u;
+            x[u] = (e < V) ? z[e] : -INFINITY;
+            mx = fmaxf(mx, x[u]);
+        }
+        mx = wave_max(mx);
+        float sm = 0.f;
+#pragma unroll
+        for (int u = 0; u < EPL; ++u) {
+            x[u] = __expf(x[u] - mx);          // exp(-inf) = 0 for the padding
+            sm += x[u];
+        }
+        sm = wave_sum(sm);
+        // the label's probability: held by lane yi % 64, element yi / 64
+        float pyl = 0.f;
+#pragma unroll
+        for (int u = 0; u < EPL; ++u) pyl = (lane + 64 * u == yi) ? x[u] : pyl;
+        const float py = wave_sum(pyl) / sm;
+        const float pyc = fminf(fmaxf(py, SERT_CLIP_LO), SERT_CLIP_HI);
+        if (lane == 0) rowloss[i] = -wi * logf(pyc);
+        if (TRAIN) {
+            const bool inside = (py >= SERT_CLIP_LO) && (py <= SERT_CLIP_HI);
+            const float g = inside ? wi * inv_batch : 0.f;
+#pragma unroll
+            for (int u = 0; u < EPL; ++u) {
+                const int e = lane + 64 * u;
+                if (e < V) z[e] = g * (x[u] / sm - (e == yi ? 1.f : 0.f));
+            }
+        }
+        return;
+    }
     float mx = -INFINITY;
     for (int e = lane; e < V; e += 64) mx = fmaxf(mx, z[e]);
     mx = wave_max(mx);
     float sm = 0.f;
-    for (int e = lane; e < V; e += 64) sm += expf(z[e] - mx);
+    for (int e = lane; e < V; e += 64) sm += __expf(z[e] - mx);
     sm = wave_sum(sm);
-    const int yi = y[i];
-    const float py = expf(z[yi] - mx) / sm;
+    const float py = __expf(z[yi] - mx) / sm;
     const float pyc = fminf(fmaxf(py, SERT_CLIP_LO), SERT_CLIP_HI);
-    const float wi = TRAIN ? w[i] : 1.f;
     if (lane == 0) rowloss[i] = -wi * logf(pyc);
     if (TRAIN) {
         const bool inside = (py >= SERT_CLIP_LO) && (py <= SERT_CLIP_HI);
         const float g = inside ? wi * inv_batch : 0.f;
         for (int e = lane; e < V; e += 64) {
-            const float p = expf(z[e] - mx) / sm;
+            const float p = __expf(z[e] - mx) / sm;
             z[e] = g * (p - (e == yi ? 1.f : 0.f));
         }
     }

@@ -632,8 +632,14 @@ static int fs_forward(sert_model* m, const DataSplit& ds, int64_t batch_index) {
     {
         ScopedTimer t(m, TG_LOSS);
         const float inv_batch = 1.0f / (float)c.global_batch_size;
-        hipLaunchKernelGGL((fs_softmax_ce<TRAIN>), dim3(cdiv(B, 4)), dim3(256), 0, m->stream, m->Z,
-                           ds.y + row0, TRAIN ? ds.w + row0 : nullptr, m->rowloss, B, V, inv_batch);
+        // rows up to 2048 entities stay in registers (one read, one write)
+#define SERT_FS_CE(EPL)                                                                                   \
+    hipLaunchKernelGGL((fs_softmax_ce<TRAIN, EPL>), dim3(cdiv(B, 4)), dim3(256), 0, m->stream, m->Z, \
+                       ds.y + row0, TRAIN ? ds.w + row0 : nullptr, m->rowloss, B, V, inv_batch)
+        if (V <= 64 * 16)      SERT_FS_CE(16);
+        else if (V <= 64 * 32) SERT_FS_CE(32);
+        else                   SERT_FS_CE(0);
+#undef SERT_FS_CE
     }
     return 0;
 }

@@ -498,3 +498,38 @@ def test_two_ranks_on_one_gpu_match_single_process(hip_lib, tmp_path, kind):
         assert abs(float(two[key]) - float(one[key])) <= 2e-5 * abs(float(one[key])), key
     for key in [k for k in one if k not in ('epoch1', 'epoch2', 'train_error', 'validation_error')]:
         assert U.rel_err(two[key], one[key]) < 2e-5, key
+
+
+def test_loglinear_distinct_word_path_is_deterministic_and_matches_per_token_path(hip_lib, tmp_path):
+    """C2-dims loglinear (B=2048 to keep it quick): the distinct-word path is bit-reproducible
+    run to run, and agrees with the per-token path (SERT_LL_NODEDUP=1, separate process) to
+    fp32 reassociation."""
+    B, n, Vw, Ve, d = 2048, 10, 100000, 1000, 128
+    code = '''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from oracle import sert_oracle as O
+from sert_amd import _capi as C
+from tests import util as U
+rng = np.random.RandomState(0)
+B, n, Vw, Ve, d = %d, %d, %d, %d, %d
+ranks = np.minimum(rng.zipf(1.1, size=(2 * B, n)) - 1, Vw - 1)
+X = rng.permutation(Vw).astype(np.uint32)[ranks]
+y = (X[:, 0] %% Ve).astype(np.int32)
+p = dict(Rw=O.glorot_uniform(rng, (Vw, d)), W=O.glorot_uniform(rng, (d, Ve)), b=np.zeros(Ve, np.float32), X=X)
+eng = U.ll_engine(p, B, n, 0.01, keep_grads=0)
+eng.upload_dataset(C.SPLIT_TRAIN, X, y_int=y, w=np.ones(2 * B, np.float32))
+losses = [eng.train_batch(s %% 2) for s in range(6)]
+np.savez(sys.argv[1], losses=np.array(losses), Rw=eng.get_tensor(C.T_RW), W=eng.get_tensor(C.T_W))
+''' % (U.ROOT, B, n, Vw, Ve, d)
+    outs = []
+    for tag, extra in (('a', {}), ('b', {}), ('c', {'SERT_LL_NODEDUP': '1'})):
+        out = str(tmp_path / (tag + '.npz'))
+        subprocess.run([sys.executable, '-c', code, out], check=True, env=dict(os.environ, **extra), cwd=U.ROOT)
+        outs.append(np.load(out))
+    assert np.array_equal(outs[0]['losses'], outs[1]['losses'])
+    assert np.array_equal(outs[0]['Rw'], outs[1]['Rw']) and np.array_equal(outs[0]['W'], outs[1]['W'])
+    assert np.allclose(outs[0]['losses'], outs[2]['losses'], rtol=2e-5)
+    assert U.rel_err(outs[0]['W'], outs[2]['W']) < 1e-4
+    assert U.rel_err(outs[0]['Rw'], outs[2]['Rw']) < 1e-4
+    assert outs[0]['losses'][-1] < outs[0]['losses'][0]

@@ -59,8 +59,20 @@ __device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uin
         k1 += 0xBB67AE85u;
     }
 }
+// zero_f / zero_b (optional): the step's other prologue work rides along -- zero `nzf4`
+// float4 of small gradient buffers and `nzb16` 16-byte words of row flags -- so that a
+// training step needs ONE prologue launch on the main stream instead of two memsets and
+// a sampler on a side stream plus a cross-queue wait (7-11 us of idle GPU).
 __global__ void vs_sample_negatives(int32_t* __restrict__ neg, int64_t count, int64_t global_offset,
-                                    uint32_t num_entities, uint64_t seed, uint64_t step) {
+                                    uint32_t num_entities, uint64_t seed, uint64_t step,
+                                    float4* __restrict__ zero_f = nullptr, size_t nzf4 = 0,
+                                    uint4* __restrict__ zero_b = nullptr, size_t nzb16 = 0) {
+    {
+        const size_t t0 = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+        const size_t stride = (size_t)gridDim.x * blockDim.x;
+        for (size_t i = t0; i < nzf4; i += stride) zero_f[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (size_t i = t0; i < nzb16; i += stride) zero_b[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
     // one thread owns one Philox counter = 4 consecutive GLOBAL sample indices
     const int64_t q_first = global_offset >> 2;
     const int64_t q_last = (global_offset + count - 1) >> 2;

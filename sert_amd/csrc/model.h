@@ -68,6 +68,7 @@ struct sert_model {
     // stream2 beside the main chain; these events order them
     hipEvent_t ev_step_done = nullptr, ev_neg = nullptr, ev_opt_fork = nullptr, ev_small = nullptr;
     hipEvent_t ev_dense = nullptr;   // dW, db and the loss partials are complete (main stream)
+    bool step_done_pending = false;  // the previous step ended without recording ev_step_done
     bool lazy_join = false;          // this step: the main stream never waits for the entity chain
     int n_loss_partials = 0;
     // SERT_STREAMS: 1 = everything on the main stream (0.423 ms/step at C2), 2 = + the entity
@@ -125,6 +126,7 @@ struct sert_model {
     // touched-row flags of the word table for this step (single GPU): the word-gradient
     // table is then neither zeroed nor read where no token of the batch points
     unsigned char* rw_touched = nullptr;
+    size_t rw_touched_alloc = 0;   // bytes, multiple of 16
     bool use_touched = false;
     // loglinear, logits per DISTINCT word of the batch (duplicate tokens share a row):
     float* Zu = nullptr;          // (U, V_e) logits

@@ -1010,28 +1010,48 @@ static int train_step_async(sert_model* m, int64_t batch_index, const int64_t* n
     // for the vectorspace step it runs on the side stream beside gather + projection.
     m->lazy_join = false;
     const bool side_pre = is_vs(m) && !is_fs(m) && !m->timing.enabled && m->nstreams >= 2;
-    hipStream_t pre = side_pre ? m->stream2 : m->stream;
+    // One fused prologue launch on the MAIN stream (sampler + zeroing of the small gradient
+    // buffers and the row flags) when nothing big has to be zeroed and the device draws the
+    // negatives: no side-stream prologue, no cross-queue wait in front of the loss kernel.
+    const bool fused_pre = side_pre && m->use_touched && negatives == nullptr && m->cfg.num_negatives > 0 &&
+                           (m->gflat_alloc - m->ar_split) % 4 == 0 && m->rw_touched_alloc % 16 == 0;
+    hipStream_t pre = (side_pre && !fused_pre) ? m->stream2 : m->stream;
+    if (pre != m->stream && m->step_done_pending) {
+        // a side-stream prologue must follow the previous step, which (fused prologue) did not
+        // mark its end: nothing of this step is on the main stream yet, so mark it now
+        SERT_HIP(hipEventRecord(m->ev_step_done, m->stream));
+        m->step_done_pending = false;
+    }
     // the main stream's first kernels go out BEFORE the prologue's host calls: the GPU
     // starts on gather + projection while the host is still enqueueing
     if (is_vs(m) && !is_fs(m)) {
         if (m->projected_batch != batch_index) SERT_TRY(vs_project(m, ds, batch_index));
         m->projected_batch = -1;
     }
+    if (fused_pre) {
+        const int64_t count = (int64_t)m->cfg.batch_size * m->cfg.num_negatives;
+        hipLaunchKernelGGL(vs_sample_negatives, dim3(grid_for((count + 3) / 4)), dim3(256), 0, m->stream, m->neg,
+                           count, (int64_t)m->rank * count, (uint32_t)m->cfg.num_entities, m->cfg.seed,
+                           (uint64_t)m->step * 2, reinterpret_cast<float4*>(m->gflat + m->ar_split),
+                           (m->gflat_alloc - m->ar_split) / 4, reinterpret_cast<uint4*>(m->rw_touched),
+                           m->rw_touched_alloc / 16);
+    } else {
     // (the previous step's optimiser and loss kernels read what the prologue overwrites)
-    if (side_pre) SERT_HIP(hipStreamWaitEvent(pre, m->ev_step_done, 0));
+    if (pre != m->stream) SERT_HIP(hipStreamWaitEvent(pre, m->ev_step_done, 0));
     if (m->use_touched) {
         SERT_HIP(hipMemsetAsync(m->gflat + m->ar_split, 0, (m->gflat_alloc - m->ar_split) * sizeof(float), pre));
         SERT_HIP(hipMemsetAsync(m->rw_touched, 0, (size_t)m->cfg.vocab_size, pre));
     } else {
         SERT_HIP(hipMemsetAsync(m->gflat, 0, m->gflat_alloc * sizeof(float), pre));
     }
+    }
     if (is_fs(m)) {
         SERT_TRY(fs_forward<true>(m, ds, batch_index));
         SERT_TRY(fs_backward(m, ds, batch_index));
         SERT_TRY(reduce_rowloss(m, m->stream));
     } else if (is_vs(m)) {
-        SERT_TRY(vs_negatives(m, negatives, (uint64_t)m->step * 2, pre));
-        if (side_pre) {
+        if (!fused_pre) SERT_TRY(vs_negatives(m, negatives, (uint64_t)m->step * 2, pre));
+        if (pre != m->stream) {
             SERT_HIP(hipEventRecord(m->ev_neg, pre));
             SERT_HIP(hipStreamWaitEvent(m->stream, m->ev_neg, 0));
         }
@@ -1045,7 +1065,9 @@ static int train_step_async(sert_model* m, int64_t batch_index, const int64_t* n
     SERT_TRY(allreduce_rest(m));
     SERT_TRY(optimizer_and_loss(m, loss_dst, publish));
     SERT_HIP(hipGetLastError());   // a rejected launch (bad configuration) surfaces here, not as a hang
-    SERT_HIP(hipEventRecord(m->ev_step_done, m->stream));
+    // (an event record stalls its queue for ~6 us: steps with the fused prologue skip it)
+    if (fused_pre) m->step_done_pending = true;
+    else { SERT_HIP(hipEventRecord(m->ev_step_done, m->stream)); m->step_done_pending = false; }
     return 0;
 }
 
@@ -1203,7 +1225,8 @@ static int create_resources(sert_model* m) {
             part = splits * (dw * V + V);
         }
         m->part_count = part;
-        SERT_TRY(dzalloc(&m->rw_touched, (size_t)c.vocab_size, s));
+        m->rw_touched_alloc = round_up((size_t)c.vocab_size, 16);
+        SERT_TRY(dzalloc(&m->rw_touched, m->rw_touched_alloc, s));
         SERT_TRY(dzalloc(&m->part, part, s));
         SERT_TRY(dzalloc(&m->red_loss, (size_t)kOptBlocks, s));
         SERT_TRY(dzalloc(&m->red_sq, (size_t)4 * kOptBlocks, s));  // partials of up to 4 tensors

@@ -151,15 +151,18 @@ int sert_upload_dataset(sert_model* m, int split, const void* x, const int32_t* 
 int sert_train_batch(sert_model* m, int64_t batch_index, const int64_t* negatives,
                      float* loss_out);
 
-/* Additive.  Announces the batch the NEXT-BUT-ONE call will train: the next
- * sert_train_batch then enqueues that batch's parameter-only forward part (gather,
- * mean-pool, projection; vectorspace) behind its own step BEFORE it waits for its
- * loss, so the device does not idle through the host round trip of the reference's
- * per-batch loop (sert/models.py:369-379: train_fn, isfinite check, next train_fn).
- * The speculative work touches activations only -- a step that raises on a
- * non-finite loss leaves the model exactly as without the hint -- and is dropped
- * by any intervening call that changes parameters, data or activations.
- * next_batch_index < 0 clears the hint. */
+/* Additive.  Announces the batch the call AFTER the next sert_train_batch will train.
+ * The next sert_train_batch then lets that batch run ahead of the host: behind its own
+ * step, and BEFORE it waits for its own loss, it enqueues the announced batch's forward
+ * and backward (single GPU, device-drawn negatives; data parallel: the parameter-only
+ * forward projection) -- everything that depends on parameters, data and the step
+ * counter only and writes activations and gradient scratch only -- so the device does not
+ * idle through the host round trip of the reference's per-batch loop
+ * (sert/models.py:369-379: train_fn, isfinite check, next train_fn).  The announced step's
+ * UPDATE (optimiser, loss) is never issued ahead: a step that raises on a non-finite loss
+ * leaves the model exactly as without the hint.  A following call that does not match
+ * (another batch, explicit negatives, an evaluation, new parameters or data) simply
+ * recomputes.  next_batch_index < 0 clears the hint. */
 int sert_hint_next_batch(sert_model* m, int64_t next_batch_index);
 
 /* Same, for `count` batches back to back with no host synchronisation in

@@ -67,6 +67,7 @@ struct sert_model {
     // step prologue (zeroing, negative sampling) and the small-tensor optimiser run on
     // stream2 beside the main chain; these events order them
     hipEvent_t ev_step_done = nullptr, ev_neg = nullptr, ev_opt_fork = nullptr, ev_small = nullptr;
+    hipEvent_t ev_loss = nullptr;    // the step's loss has been copied out
     hipEvent_t ev_dense = nullptr;   // dW, db and the loss partials are complete (main stream)
     bool step_done_pending = false;  // the previous step ended without recording ev_step_done
     bool lazy_join = false;          // this step: the main stream never waits for the entity chain
@@ -77,6 +78,9 @@ struct sert_model {
     int nstreams = 2;
     int64_t hint_next = -1;        // sert_hint_next_batch
     int64_t projected_batch = -1;  // training batch whose forward projection already sits in H/T
+    // hinted single-GPU steps go further: the whole forward + backward runs ahead
+    int64_t spec_fb_batch = -1;    // forward + backward of this batch already ran (gradients ready) ...
+    int64_t spec_fb_step = -1;     // ... as optimiser step spec_fb_step
     unsigned loss_seq = 0;        // sequence number the final kernel publishes beside the loss
     float* h_loss_dev = nullptr;  // device address of the pinned h_loss block
 

@@ -129,6 +129,11 @@ static inline size_t round_up(size_t a, size_t b) { return (a + b - 1) / b * b; 
 // model and the additive full-softmax variant
 static bool is_vs(const sert_model* m) { return m->cfg.kind != SERT_KIND_LOGLINEAR; }
 static bool is_fs(const sert_model* m) { return m->cfg.kind == SERT_KIND_VECTORSPACE_SOFTMAX; }
+// drop whatever a previous training call ran ahead for the next one (sert_hint_next_batch)
+static void invalidate_speculation(sert_model* m) {
+    m->projected_batch = -1;
+    m->spec_fb_batch = -1;
+}
 
 struct TensorRef {
     float* ptr;
@@ -993,19 +998,36 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
     return 0;
 }
 
-static int train_step_async(sert_model* m, int64_t batch_index, const int64_t* negatives,
-                            float* loss_dst, bool publish = false) {
-    const DataSplit& ds = m->split[SERT_SPLIT_TRAIN];
-    const int B = m->cfg.batch_size;
-    if (m->cfg.inference_only) SERT_FAIL("model was created inference_only");
-    if (ds.N == 0) SERT_FAIL("no training data uploaded");
-    if (batch_index < 0 || (batch_index + 1) * (int64_t)B > ds.N) SERT_FAIL("batch_index out of range");
+static bool fused_prologue_applies_with(const sert_model* m, bool touched) {
+    return is_vs(m) && !is_fs(m) && !m->timing.enabled && m->nstreams >= 2 && touched &&
+           m->cfg.num_negatives > 0 && (m->gflat_alloc - m->ar_split) % 4 == 0 && m->rw_touched_alloc % 16 == 0;
+}
+static bool fused_prologue_applies(const sert_model* m) { return fused_prologue_applies_with(m, m->use_touched); }
+// sampler of optimiser step m->step + zeroing of the small gradient buffers and row flags
+static void launch_fused_prologue(sert_model* m) {
+    const int64_t count = (int64_t)m->cfg.batch_size * m->cfg.num_negatives;
+    hipLaunchKernelGGL(vs_sample_negatives, dim3(grid_for((count + 3) / 4)), dim3(256), 0, m->stream, m->neg,
+                       count, (int64_t)m->rank * count, (uint32_t)m->cfg.num_entities, m->cfg.seed,
+                       (uint64_t)m->step * 2, reinterpret_cast<float4*>(m->gflat + m->ar_split),
+                       (m->gflat_alloc - m->ar_split) / 4, reinterpret_cast<uint4*>(m->rw_touched),
+                       m->rw_touched_alloc / 16);
+}
+
+static bool use_touched_now(const sert_model* m) {
+    static const bool no_touched = getenv("SERT_NO_TOUCHED") != nullptr;   // cross-check knob
+    return !no_touched && !is_dp(m) && !m->cfg.keep_grads && m->cfg.word_dim % 4 == 0 &&
+           m->n_rw < ((size_t)1 << 32) && m->rw_touched != nullptr;
+}
+
+// Everything of a training step that does NOT change the model: forward, loss, backward into
+// the gradient scratch (all of it a function of parameters, data and step counter only).
+// `fused_pre_out`: whether the step took the fused main-stream prologue.
+static int step_forward_backward(sert_model* m, const DataSplit& ds, int64_t batch_index,
+                                 const int64_t* negatives, bool* fused_pre_out) {
     // Single GPU: the word-gradient table is not zeroed -- the segmented reduction flags
     // the rows it writes and the optimiser takes every other row's gradient as zero.
     // (Data parallel: the all-reduce needs the dense table; keep_grads: so does the caller.)
-    static const bool no_touched = getenv("SERT_NO_TOUCHED") != nullptr;   // cross-check knob
-    m->use_touched = !no_touched && !is_dp(m) && !m->cfg.keep_grads && m->cfg.word_dim % 4 == 0 &&
-                     m->n_rw < ((size_t)1 << 32) && m->rw_touched != nullptr;
+    m->use_touched = use_touched_now(m);
     // Prologue (zeroing, negative sampling): nothing before the loss kernel needs it, so
     // for the vectorspace step it runs on the side stream beside gather + projection.
     m->lazy_join = false;
@@ -1013,8 +1035,8 @@ static int train_step_async(sert_model* m, int64_t batch_index, const int64_t* n
     // One fused prologue launch on the MAIN stream (sampler + zeroing of the small gradient
     // buffers and the row flags) when nothing big has to be zeroed and the device draws the
     // negatives: no side-stream prologue, no cross-queue wait in front of the loss kernel.
-    const bool fused_pre = side_pre && m->use_touched && negatives == nullptr && m->cfg.num_negatives > 0 &&
-                           (m->gflat_alloc - m->ar_split) % 4 == 0 && m->rw_touched_alloc % 16 == 0;
+    const bool fused_pre = side_pre && negatives == nullptr && fused_prologue_applies(m);
+    *fused_pre_out = fused_pre;
     hipStream_t pre = (side_pre && !fused_pre) ? m->stream2 : m->stream;
     if (pre != m->stream && m->step_done_pending) {
         // a side-stream prologue must follow the previous step, which (fused prologue) did not
@@ -1029,21 +1051,16 @@ static int train_step_async(sert_model* m, int64_t batch_index, const int64_t* n
         m->projected_batch = -1;
     }
     if (fused_pre) {
-        const int64_t count = (int64_t)m->cfg.batch_size * m->cfg.num_negatives;
-        hipLaunchKernelGGL(vs_sample_negatives, dim3(grid_for((count + 3) / 4)), dim3(256), 0, m->stream, m->neg,
-                           count, (int64_t)m->rank * count, (uint32_t)m->cfg.num_entities, m->cfg.seed,
-                           (uint64_t)m->step * 2, reinterpret_cast<float4*>(m->gflat + m->ar_split),
-                           (m->gflat_alloc - m->ar_split) / 4, reinterpret_cast<uint4*>(m->rw_touched),
-                           m->rw_touched_alloc / 16);
+        launch_fused_prologue(m);
     } else {
-    // (the previous step's optimiser and loss kernels read what the prologue overwrites)
-    if (pre != m->stream) SERT_HIP(hipStreamWaitEvent(pre, m->ev_step_done, 0));
-    if (m->use_touched) {
-        SERT_HIP(hipMemsetAsync(m->gflat + m->ar_split, 0, (m->gflat_alloc - m->ar_split) * sizeof(float), pre));
-        SERT_HIP(hipMemsetAsync(m->rw_touched, 0, (size_t)m->cfg.vocab_size, pre));
-    } else {
-        SERT_HIP(hipMemsetAsync(m->gflat, 0, m->gflat_alloc * sizeof(float), pre));
-    }
+        // (the previous step's optimiser and loss kernels read what the prologue overwrites)
+        if (pre != m->stream) SERT_HIP(hipStreamWaitEvent(pre, m->ev_step_done, 0));
+        if (m->use_touched) {
+            SERT_HIP(hipMemsetAsync(m->gflat + m->ar_split, 0, (m->gflat_alloc - m->ar_split) * sizeof(float), pre));
+            SERT_HIP(hipMemsetAsync(m->rw_touched, 0, (size_t)m->cfg.vocab_size, pre));
+        } else {
+            SERT_HIP(hipMemsetAsync(m->gflat, 0, m->gflat_alloc * sizeof(float), pre));
+        }
     }
     if (is_fs(m)) {
         SERT_TRY(fs_forward<true>(m, ds, batch_index));
@@ -1062,6 +1079,31 @@ static int train_step_async(sert_model* m, int64_t batch_index, const int64_t* n
         SERT_TRY(ll_backward(m, ds, batch_index));
         SERT_TRY(reduce_rowloss(m, m->stream));
     }
+    return 0;
+}
+
+// May the forward + backward of a hinted next batch run ahead of the host (before the loss
+// of the current step has been read)?  Single GPU, product settings, device sampler only:
+// there it touches nothing but activations and gradient scratch, and the data-parallel
+// exchange (a collective) is never issued speculatively.
+static bool can_speculate_step(const sert_model* m) {
+    return is_vs(m) && !is_fs(m) && !is_dp(m) && !m->timing.enabled && !m->cfg.keep_grads &&
+           use_touched_now(m) && fused_prologue_applies_with(m, true);
+}
+
+static int train_step_async(sert_model* m, int64_t batch_index, const int64_t* negatives,
+                            float* loss_dst, bool publish = false) {
+    const DataSplit& ds = m->split[SERT_SPLIT_TRAIN];
+    const int B = m->cfg.batch_size;
+    if (m->cfg.inference_only) SERT_FAIL("model was created inference_only");
+    if (ds.N == 0) SERT_FAIL("no training data uploaded");
+    if (batch_index < 0 || (batch_index + 1) * (int64_t)B > ds.N) SERT_FAIL("batch_index out of range");
+    // what the previous call already ran ahead for this step (sert_hint_next_batch)
+    const bool have_fb = negatives == nullptr && m->spec_fb_batch == batch_index && m->spec_fb_step == m->step &&
+                         can_speculate_step(m);
+    bool fused_pre = true;   // (a speculated step always took the fused prologue)
+    m->spec_fb_batch = -1;
+    if (!have_fb) SERT_TRY(step_forward_backward(m, ds, batch_index, negatives, &fused_pre));
     SERT_TRY(allreduce_rest(m));
     SERT_TRY(optimizer_and_loss(m, loss_dst, publish));
     SERT_HIP(hipGetLastError());   // a rejected launch (bad configuration) surfaces here, not as a hang
@@ -1140,6 +1182,7 @@ static int create_resources(sert_model* m) {
     SERT_HIP(hipEventCreateWithFlags(&m->ev_neg, hipEventDisableTiming));
     SERT_HIP(hipEventCreateWithFlags(&m->ev_opt_fork, hipEventDisableTiming));
     SERT_HIP(hipEventCreateWithFlags(&m->ev_dense, hipEventDisableTiming));
+    SERT_HIP(hipEventCreateWithFlags(&m->ev_loss, hipEventDisableTiming));
     SERT_HIP(hipEventCreateWithFlags(&m->ev_small, hipEventDisableTiming));
     SERT_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
     SERT_HIP(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
@@ -1293,7 +1336,7 @@ int sert_destroy(sert_model* m) {
     if (m->ev_join) (void)hipEventDestroy(m->ev_join);
     if (m->stream2) (void)hipStreamDestroy(m->stream2);
     if (m->ev_join3) (void)hipEventDestroy(m->ev_join3);
-    for (hipEvent_t e : {m->ev_step_done, m->ev_neg, m->ev_opt_fork, m->ev_small, m->ev_dense})
+    for (hipEvent_t e : {m->ev_step_done, m->ev_neg, m->ev_opt_fork, m->ev_small, m->ev_dense, m->ev_loss})
         if (e) (void)hipEventDestroy(e);
     if (m->stream3) (void)hipStreamDestroy(m->stream3);
     if (m->stream) (void)hipStreamDestroy(m->stream);
@@ -1307,7 +1350,7 @@ size_t sert_tensor_size(sert_model* m, int which) {
 }
 
 int sert_set_tensor(sert_model* m, int which, const float* host, size_t count) {
-    if (m) m->projected_batch = -1;
+    if (m) invalidate_speculation(m);
     if (!m || !host) SERT_FAIL("null argument");
     SERT_HIP(hipSetDevice(m->cfg.device));
     TensorRef t = tensor_ref(m, which);
@@ -1337,6 +1380,7 @@ int sert_get_tensor(sert_model* m, int which, float* host, size_t count) {
 int sert_set_step(sert_model* m, int64_t t) {
     if (!m || t < 0) SERT_FAIL("bad argument");
     m->step = t;
+    invalidate_speculation(m);
     return 0;
 }
 int64_t sert_get_step(sert_model* m) { return m ? m->step : -1; }
@@ -1345,7 +1389,7 @@ int sert_upload_dataset(sert_model* m, int split, const void* x, const int32_t* 
                         const int64_t* csr_indptr, const int32_t* csr_indices,
                         const float* csr_data, const float* w, int64_t N) {
     if (!m) SERT_FAIL("null model");
-    m->projected_batch = -1;
+    invalidate_speculation(m);
     m->hint_next = -1;
     if (split != SERT_SPLIT_TRAIN && split != SERT_SPLIT_VALIDATE) SERT_FAIL("bad split");
     if (N < 0) SERT_FAIL("negative instance count");
@@ -1454,15 +1498,27 @@ int sert_train_batch(sert_model* m, int64_t batch_index, const int64_t* negative
         // (keep_grads: the caller may read this batch's activations after the call)
         if (hint < 0 || m->timing.enabled || !is_vs(m) || is_fs(m) || m->cfg.keep_grads) return 0;
         if ((hint + 1) * (int64_t)m->cfg.batch_size > ds.N) return 0;
-        SERT_TRY(vs_project(m, ds, hint));
-        m->projected_batch = hint;
+        if (can_speculate_step(m)) {
+            // the whole forward + backward of the announced batch runs ahead: it depends on the
+            // parameters (final: this step's update is already in the stream), the data and the
+            // step counter only, and writes activations / gradient scratch only.  The UPDATE of
+            // that step is not issued before the host has seen this step's loss.
+            bool fused = false;
+            SERT_TRY(step_forward_backward(m, ds, hint, nullptr, &fused));
+            m->spec_fb_batch = hint;
+            m->spec_fb_step = m->step;
+        } else {
+            SERT_TRY(vs_project(m, ds, hint));   // data parallel: the parameter-only part
+            m->projected_batch = hint;
+        }
         return 0;
     };
     if (m->timing.enabled || no_spin) {
         SERT_TRY(train_step_async(m, batch_index, negatives, m->d_loss));
         SERT_HIP(hipMemcpyAsync(m->h_loss, m->d_loss, 3 * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+        SERT_HIP(hipEventRecord(m->ev_loss, m->stream));
         SERT_TRY(prefetch_next());
-        SERT_HIP(hipStreamSynchronize(m->stream));
+        SERT_HIP(hipEventSynchronize(m->ev_loss));   // (not the stream: the next batch may be running ahead)
         timing_collect(m);
         if (loss_out) *loss_out = m->h_loss[0];
         return 0;
@@ -1530,7 +1586,7 @@ int sert_train_batches(sert_model* m, const int64_t* batch_indices, int64_t coun
 
 int sert_eval_batch(sert_model* m, int split, int64_t batch_index, const int64_t* negatives, float* loss_out) {
     if (!m) SERT_FAIL("null model");
-    m->projected_batch = -1;   // evaluation reuses the activation buffers
+    invalidate_speculation(m);   // evaluation reuses the activation buffers and the negatives
     if (split != SERT_SPLIT_TRAIN && split != SERT_SPLIT_VALIDATE) SERT_FAIL("bad split");
     SERT_HIP(hipSetDevice(m->cfg.device));
     const DataSplit& ds = m->split[split];
@@ -1868,6 +1924,7 @@ int sert_comm_init(sert_model* m, const char id[SERT_COMM_ID_BYTES], int rank, i
         SERT_FAIL("global_batch_size must equal batch_size * world");
     SERT_TRY(rccl_load());
     SERT_HIP(hipSetDevice(m->cfg.device));
+    invalidate_speculation(m);
     UniqueId uid;
     memcpy(uid.internal, id, SERT_COMM_ID_BYTES);
     SERT_NCCL(g_rccl.CommInitRank(&m->comm, world, uid, rank));
@@ -1901,7 +1958,7 @@ int sert_comm_init_host(sert_model* m, int rank, int world, sert_allreduce_fn fn
     m->host_ar_user = user;
     m->rank = rank;
     m->world = world;
-    m->projected_batch = -1;
+    invalidate_speculation(m);
     return 0;
 }
 

@@ -1036,8 +1036,8 @@ static int step_forward_backward(sert_model* m, const DataSplit& ds, int64_t bat
     // buffers and the row flags) when nothing big has to be zeroed and the device draws the
     // negatives: no side-stream prologue, no cross-queue wait in front of the loss kernel.
     const bool fused_pre = side_pre && negatives == nullptr && fused_prologue_applies(m);
-    *fused_pre_out = fused_pre;
     hipStream_t pre = (side_pre && !fused_pre) ? m->stream2 : m->stream;
+    *fused_pre_out = (pre == m->stream);   // no side-stream prologue: no end-of-step event needed
     if (pre != m->stream && m->step_done_pending) {
         // a side-stream prologue must follow the previous step, which (fused prologue) did not
         // mark its end: nothing of this step is on the main stream yet, so mark it now
@@ -1087,8 +1087,9 @@ static int step_forward_backward(sert_model* m, const DataSplit& ds, int64_t bat
 // there it touches nothing but activations and gradient scratch, and the data-parallel
 // exchange (a collective) is never issued speculatively.
 static bool can_speculate_step(const sert_model* m) {
-    return is_vs(m) && !is_fs(m) && !is_dp(m) && !m->timing.enabled && !m->cfg.keep_grads &&
-           use_touched_now(m) && fused_prologue_applies_with(m, true);
+    if (is_dp(m) || m->timing.enabled || m->cfg.keep_grads) return false;
+    if (is_vs(m) && !is_fs(m)) return use_touched_now(m) && fused_prologue_applies_with(m, true);
+    return true;   // loglinear / full-softmax: the whole step lives on the main stream
 }
 
 static int train_step_async(sert_model* m, int64_t batch_index, const int64_t* negatives,
@@ -1101,7 +1102,7 @@ static int train_step_async(sert_model* m, int64_t batch_index, const int64_t* n
     // what the previous call already ran ahead for this step (sert_hint_next_batch)
     const bool have_fb = negatives == nullptr && m->spec_fb_batch == batch_index && m->spec_fb_step == m->step &&
                          can_speculate_step(m);
-    bool fused_pre = true;   // (a speculated step always took the fused prologue)
+    bool fused_pre = true;   // (a speculated step always ran its prologue on the main stream)
     m->spec_fb_batch = -1;
     if (!have_fb) SERT_TRY(step_forward_backward(m, ds, batch_index, negatives, &fused_pre));
     SERT_TRY(allreduce_rest(m));
@@ -1496,7 +1497,7 @@ int sert_train_batch(sert_model* m, int64_t batch_index, const int64_t* negative
     auto prefetch_next = [&]() -> int {
         const DataSplit& ds = m->split[SERT_SPLIT_TRAIN];
         // (keep_grads: the caller may read this batch's activations after the call)
-        if (hint < 0 || m->timing.enabled || !is_vs(m) || is_fs(m) || m->cfg.keep_grads) return 0;
+        if (hint < 0 || m->timing.enabled || m->cfg.keep_grads) return 0;
         if ((hint + 1) * (int64_t)m->cfg.batch_size > ds.N) return 0;
         if (can_speculate_step(m)) {
             // the whole forward + backward of the announced batch runs ahead: it depends on the
@@ -1507,7 +1508,7 @@ int sert_train_batch(sert_model* m, int64_t batch_index, const int64_t* negative
             SERT_TRY(step_forward_backward(m, ds, hint, nullptr, &fused));
             m->spec_fb_batch = hint;
             m->spec_fb_step = m->step;
-        } else {
+        } else if (is_vs(m) && !is_fs(m)) {
             SERT_TRY(vs_project(m, ds, hint));   // data parallel: the parameter-only part
             m->projected_batch = hint;
         }

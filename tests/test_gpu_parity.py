@@ -401,17 +401,24 @@ def test_untouched_word_rows_need_no_memset(hip_lib, dw):
     assert not np.array_equal(outs[1][1].reshape(Vw, dw)[-50:], p['Rw'][-50:])
 
 
-def test_next_batch_hint_changes_nothing_but_the_schedule(hip_lib):
-    """sert_hint_next_batch: the speculative forward projection of the announced batch
-    must not change any result -- with correct hints, with a WRONG hint (another batch
-    is trained next), and with an evaluation in between (which reuses the buffers)."""
+@pytest.mark.parametrize('kind', ['vectorspace', 'loglinear'])
+def test_next_batch_hint_changes_nothing_but_the_schedule(hip_lib, kind):
+    """sert_hint_next_batch: the announced batch's forward + backward runs ahead of the host;
+    it must not change any result -- with correct hints, with a WRONG hint (another batch is
+    trained next), and with an evaluation in between (which reuses the buffers)."""
     B, n, z, Vw, Ve, dw, de = 64, 3, 4, 300, 12, 16, 16
-    p = U.make_vs_problem(51, B * 5, n, z, Vw, Ve, dw, de)
-    neg = p['rng'].randint(0, Ve, (B, z)).astype(np.int64)
+    if kind == 'vectorspace':
+        p = U.make_vs_problem(51, B * 5, n, z, Vw, Ve, dw, de)
+        neg = p['rng'].randint(0, Ve, (B, z)).astype(np.int64)
+    else:
+        p = U.make_ll_problem(51, B * 5, n, Vw, Ve, dw, 'int')
     order = [3, 0, 4, 1, 2, 0]
     outs = []
     for mode in ('none', 'right', 'wrong'):
-        eng = U.vs_engine(p, B, n, z, 0.01, keep_grads=0)
+        if kind == 'vectorspace':
+            eng = U.vs_engine(p, B, n, z, 0.01, keep_grads=0)
+        else:
+            eng = U.ll_engine(p, B, n, 0.01, keep_grads=0)
         eng.upload_dataset(C.SPLIT_TRAIN, p['X'], y_int=p['y'], w=p['w'])
         losses = []
         for pos, b in enumerate(order):
@@ -420,9 +427,11 @@ def test_next_batch_hint_changes_nothing_but_the_schedule(hip_lib):
                 eng.hint_next_batch(nxt)
             elif mode == 'wrong':
                 eng.hint_next_batch((b + 2) % 5)
-            losses.append(eng.train_batch(b, neg))
+            # vectorspace: device-drawn negatives (explicit ones switch the run-ahead off)
+            losses.append(eng.train_batch(b))
             if pos == 2:
-                losses.append(eng.eval_batch(C.SPLIT_TRAIN, 1, neg))
+                losses.append(eng.eval_batch(C.SPLIT_TRAIN, 1, neg) if kind == 'vectorspace'
+                              else eng.eval_batch(C.SPLIT_TRAIN, 1))
         outs.append((losses, eng.get_tensor(C.T_RW).copy(), eng.get_tensor(C.T_W).copy()))
         eng.close()
     for other in outs[1:]:

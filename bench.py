@@ -84,10 +84,10 @@ KERNEL_OF_GROUP = {
     'loss': 'vs_nce<2, true>', 'entity_grad_reduce': 'egrad_chunk_reduce<4, 2>',
     'entity_grad_fixup': 'egrad_fixup<4>', 'gemm_dW': 'gemm_f32_mfma<true, false, 0, true, true, true>',
     'splitk_combine': 'reduce_partials', 'gemm_dX': 'gemm_f32_mfma<false, true, 0, false, true, true>',
-    'word_grad_segsum': 'segsum_rows<32>', 'optimizer_word_table': 'adam_l2<false>',
+    'word_grad_segsum': 'segsum_rows<32, false, false>', 'optimizer_word_table': 'adam_l2<false>',
     'optimizer_other': 'adam_l2<false>', 'entity_sort': 'csort_scatter',
 }
-PMC_FILE = 'profiles/r01_f_vs_c2_pmc.json'
+PMC_FILE = 'profiles/r01_g_vs_c2_pmc.json'
 
 
 def load_pmc():
@@ -319,10 +319,11 @@ def main():
         pmc = load_pmc()
         dom = max((k for k in kernels if 'bound' in kernels[k]), key=lambda k: kernels[k]['us'])
         # three launches tie at C2 (entity/word gradient reductions and the word-table
-        # optimiser, ~59 us each): among kernels within 3 % of the longest, report the one
+        # optimiser, 59-61 us each, order varying run to run): among kernels within 5 % of the
+        # longest, report the one
         # that streams the most real HBM bytes (the PMC file) -- the reductions gather
         # cache-resident rows, their algorithmic rate is not an HBM rate
-        ties = [k for k in kernels if 'bound' in kernels[k] and kernels[k]['us'] >= 0.97 * kernels[dom]['us']]
+        ties = [k for k in kernels if 'bound' in kernels[k] and kernels[k]['us'] >= 0.95 * kernels[dom]['us']]
         if len(ties) > 1 and pmc:
             hbm_of = lambda k: (pmc_traffic(pmc, KERNEL_OF_GROUP.get(k), kernels[k]['us']) or 0.0)
             # prefer the kernel whose PMC bytes are closest to (not far above) its algorithmic bytes

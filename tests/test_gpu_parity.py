@@ -488,3 +488,38 @@ def test_scratch_buffers_are_not_readable_without_keep_grads(hip_lib):
             eng.get_tensor(which)
     assert np.all(np.isfinite(eng.get_tensor(C.T_RW)))
     eng.close()
+
+
+@pytest.mark.parametrize('dims', [
+    dict(B=16, n=4, Vw=120, Ve=200, d=16),        # fused LDS path
+    dict(B=4, n=4, Vw=120, Ve=9004, d=12),        # streaming path
+])
+@pytest.mark.parametrize('keep', [1, 0])
+def test_loglinear_with_saturated_probabilities(hip_lib, dims, keep):
+    """Large logits: many token probabilities fall below eps = 1e-7 (and one sits above
+    1 - eps), so the clip masks of models.py:200 are exercised in the loss AND in the
+    backward (mask_ke in dZ = mask dJ - P r).  keep=1: the per-token path with gradient
+    checks; keep=0: the distinct-word path, parameters after 3 steps."""
+    B, n = dims['B'], dims['n']
+    p = U.make_ll_problem(91, B * 3, n, dims['Vw'], dims['Ve'], dims['d'], 'int')
+    p['W'] = (p['W'] * 40.0).astype(np.float32)          # logits of magnitude ~10-30
+    p['b'] = (p['b'] * 30.0).astype(np.float32)
+    eng = U.ll_engine(p, B, n, 0.01, keep_grads=keep)
+    eng.upload_dataset(C.SPLIT_TRAIN, p['X'], y_int=p['y'], w=p['w'])
+    ora = O.LogLinearOracle(B, n, p['Rw'], p['W'], p['b'], 0.01)
+    _, Pref = ora.token_distributions(p['X'][:B])
+    assert (Pref < 1e-7).mean() > 0.05                    # the masks really are active
+    for s in range(3):
+        sl = slice(s * B, (s + 1) * B)
+        loss_ref, grads_ref, _ = ora.loss_and_grads(p['X'][sl], p['ydense'][sl], p['w'][sl])
+        ora.opt.update(ora.params(), grads_ref)
+        loss = eng.train_batch(s)
+        assert abs(loss - loss_ref) <= 2e-5 * abs(loss_ref), (s, loss, loss_ref)
+        if keep:
+            dRw, dW, db = grads_ref
+            assert U.rel_err(eng.get_tensor(C.T_GRAD_W), dW.ravel()) < GRAD_TOL
+            assert U.rel_err(eng.get_tensor(C.T_GRAD_B), db.ravel()) < GRAD_TOL
+            assert U.rel_err(eng.get_tensor(C.T_GRAD_RW), dRw.ravel()) < GRAD_TOL
+    assert U.rel_err(eng.get_tensor(C.T_W), ora.W.ravel()) < PARAM_TOL
+    assert U.rel_err(eng.get_tensor(C.T_RW), ora.R_w.ravel()) < PARAM_TOL
+    eng.close()

@@ -357,6 +357,106 @@ __global__ __launch_bounds__(NT) void ll_fused_row(float* __restrict__ Z,
     }
 }
 
+// Distinct-word mode without the LDS slab: the n log-probability rows of batch row i are
+// read straight from the (cache-resident) per-word table, coalesced along e -- one pass.
+//   J_e = sum_k clamp(logp_ke), Q = softmax(J), loss, dJ_e = Q_e (dQ_e - s)     as above
+//   r_k = sum_e mask_ke dJ_e = (sum_e dJ_e) when no element of token k is clipped -- the
+//         common case, detected in the same pass; only clipped tokens re-read their row.
+// Emits dJ_i (into dJ_out[i*V ..]) and r_ik.  LDS: J[V] | slots[n].  TRAIN only.
+template <int NT>
+__global__ __launch_bounds__(NT) void ll_row_from_table(const float* __restrict__ Zu,
+                                                        const int32_t* __restrict__ slot,
+                                                        const int32_t* __restrict__ y_int,
+                                                        const int64_t* __restrict__ indptr,
+                                                        const int32_t* __restrict__ indices,
+                                                        const float* __restrict__ data,
+                                                        const float* __restrict__ w,
+                                                        float* __restrict__ rowloss, int n, int V,
+                                                        float inv_batch, float* __restrict__ dJ_out,
+                                                        float* __restrict__ r_out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NW = NT / 64;
+    __shared__ float red[NW];
+    __shared__ unsigned long long s_oob;      // bit k: token k has a clipped probability (n <= 64)
+    float* Jl = lds;
+    int* s_slot = reinterpret_cast<int*>(lds + V);
+    const int i = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float LOGLO = logf(SERT_CLIP_LO), LOGHI = logf(SERT_CLIP_HI);
+    if (tid < n) s_slot[tid] = slot[(size_t)i * n + tid];
+    if (tid == 0) s_oob = 0ull;
+    __syncthreads();
+    // 1. J and its max; clipped-token bits
+    float mx = -INFINITY;
+    unsigned long long oob = 0ull;
+    for (int e = tid; e < V; e += NT) {
+        float a = 0.f;
+        for (int k = 0; k < n; ++k) {
+            const float lp = Zu[(size_t)s_slot[k] * V + e];
+            if (!(lp >= LOGLO && lp <= LOGHI)) oob |= 1ull << k;
+            a += fminf(fmaxf(lp, LOGLO), LOGHI);
+        }
+        Jl[e] = a;
+        mx = fmaxf(mx, a);
+    }
+    if (oob) atomicOr(&s_oob, oob);           // (an OR: order-independent)
+    mx = block_max_n<NW>(mx, red);
+    float se = 0.f;
+    for (int e = tid; e < V; e += NT) se += expf(Jl[e] - mx);
+    se = block_sum_n<NW>(se, red);
+    // 2. loss and s = sum_e dQ_e Q_e over the label entries  models.py:289-292
+    const float wi = w[i];
+    const float g = wi * inv_batch;
+    float loss = 0.f, sdq = 0.f;
+    int64_t l0 = 0, l1 = 1;
+    if (y_int == nullptr) { l0 = indptr[i]; l1 = indptr[i + 1]; }
+    float fix_val[4];
+    int fix_e[4];
+    int nfix = 0;
+    for (int64_t l = l0 + tid; l < l1; l += NT) {
+        const int e = y_int ? y_int[i] : indices[l];
+        const float yv = y_int ? 1.f : data[l];
+        const float q = expf(Jl[e] - mx) / se;
+        const float qc = fminf(fmaxf(q, SERT_CLIP_LO), SERT_CLIP_HI);
+        loss -= yv * logf(qc);
+        const bool inside = (q >= SERT_CLIP_LO) && (q <= SERT_CLIP_HI);
+        const float qdq = q * (inside ? -(g * yv) / qc : 0.f);
+        sdq += qdq;
+        if (nfix < 4) { fix_e[nfix] = e; fix_val[nfix] = qdq; ++nfix; }
+    }
+    loss = block_sum_n<NW>(loss, red);
+    if (tid == 0) rowloss[i] = wi * loss;
+    sdq = block_sum_n<NW>(sdq, red);
+    // 3. dJ_e = Q_e (dQ_e - s): dense part, then the label entries
+    for (int e = tid; e < V; e += NT) Jl[e] = -(expf(Jl[e] - mx) / se) * sdq;
+    __syncthreads();
+    for (int f = 0; f < nfix; ++f) Jl[fix_e[f]] += fix_val[f];
+    __syncthreads();
+    float tot = 0.f;
+    float* dj_out = dJ_out + (size_t)i * V;
+    for (int e = tid; e < V; e += NT) {
+        const float dj = Jl[e];
+        dj_out[e] = dj;
+        tot += dj;
+    }
+    tot = block_sum_n<NW>(tot, red);
+    // 4. r_k
+    const unsigned long long any = s_oob;
+    for (int k = wv; k < n; k += NW) {
+        float r = tot;
+        if ((any >> k) & 1ull) {               // clipped token: the masked sum, from its row
+            const float* lk = Zu + (size_t)s_slot[k] * V;
+            r = 0.f;
+            for (int e = lane; e < V; e += 64) {
+                const float lp = lk[e];
+                r += (lp >= LOGLO && lp <= LOGHI) ? Jl[e] : 0.f;
+            }
+            r = wave_sum(r);
+        }
+        if (lane == 0) r_out[(size_t)i * n + k] = r;
+    }
+}
+
 // dZu[u, e] = mask_ue DJsum[u, e] - P_ue Rsum[u]   (in place over DJsum; logp = the word's
 // log-probability row, mask = eps <= P <= 1-eps)
 __global__ __launch_bounds__(256) void ll_dzu_combine(float* __restrict__ dZu, const float* __restrict__ logp,

@@ -801,9 +801,18 @@ static int ll_forward(sert_model* m, const DataSplit& ds, int64_t batch_index) {
         // 512, 320 at 640 (one wave per token, but only two workgroups fit a CU)
         // (distinct-word mode: the kernel writes dJ_i into J and r_ik into ll_r instead of dL/dZ)
         m->ll_dj_level = m->ll_dedup;
-        hipLaunchKernelGGL((ll_fused_row<TRAIN, 512>), dim3(B), dim3(512), fused_lds, m->stream,
-                           m->ll_dedup ? m->J : m->Z, (const float*)m->Zu, slot, y, indptr, ds.csr_indices,
-                           ds.csr_data, w, m->rowloss, n, V, inv_batch, m->ll_r);
+        static const bool slab = getenv("SERT_LL_SLAB") != nullptr;   // cross-check knob
+        if (TRAIN && m->ll_dedup && n <= 64 && !slab) {
+            // distinct-word mode: no LDS slab, the n table rows are read once, coalesced along e
+            const size_t lds = ((size_t)V + n) * sizeof(float);
+            hipLaunchKernelGGL((ll_row_from_table<512>), dim3(B), dim3(512), lds, m->stream, (const float*)m->Zu,
+                               slot, y, indptr, ds.csr_indices, ds.csr_data, w, m->rowloss, n, V, inv_batch,
+                               m->J, m->ll_r);
+        } else {
+            hipLaunchKernelGGL((ll_fused_row<TRAIN, 512>), dim3(B), dim3(512), fused_lds, m->stream,
+                               m->ll_dedup ? m->J : m->Z, (const float*)m->Zu, slot, y, indptr, ds.csr_indices,
+                               ds.csr_data, w, m->rowloss, n, V, inv_batch, m->ll_r);
+        }
     } else if (rowwise) {
         // the plain row-per-workgroup kernels (kept as a cross-check of the streaming path)
         ScopedTimer t(m, TG_LOSS);
@@ -1256,6 +1265,7 @@ static int create_resources(sert_model* m) {
     SERT_HIP(hipFuncSetAttribute((const void*)ll_fused_row<true, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); \
     SERT_HIP(hipFuncSetAttribute((const void*)ll_fused_row<false, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))
             SERT_LL_ATTR(512);
+            SERT_HIP(hipFuncSetAttribute((const void*)ll_row_from_table<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
 #undef SERT_LL_ATTR
             SERT_TRY(dzalloc(&m->G, B * n * dw, s));  SERT_TRY(dzalloc(&m->Z, B * n * V, s));
             SERT_TRY(dzalloc(&m->J, B * V, s));       SERT_TRY(dzalloc(&m->DG, B * n * dw, s));

@@ -1315,6 +1315,8 @@ int sert_destroy(sert_model* m) {
     if (!m) return 0;
     (void)hipSetDevice(m->cfg.device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
+    if (m->stream2) (void)hipStreamSynchronize(m->stream2);   // (work that ran ahead of the host)
+    if (m->stream3) (void)hipStreamSynchronize(m->stream3);
     if (m->comm_stream) (void)hipStreamSynchronize(m->comm_stream);
     if (m->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(m->comm);
     if (m->ev_rw_ready) (void)hipEventDestroy(m->ev_rw_ready);
@@ -1993,6 +1995,8 @@ int sert_synchronize(sert_model* m) {
     if (!m) SERT_FAIL("null model");
     SERT_HIP(hipSetDevice(m->cfg.device));
     SERT_HIP(hipStreamSynchronize(m->stream));
+    SERT_HIP(hipStreamSynchronize(m->stream2));
+    SERT_HIP(hipStreamSynchronize(m->stream3));
     return 0;
 }
 

@@ -130,9 +130,19 @@ static inline size_t round_up(size_t a, size_t b) { return (a + b - 1) / b * b; 
 static bool is_vs(const sert_model* m) { return m->cfg.kind != SERT_KIND_LOGLINEAR; }
 static bool is_fs(const sert_model* m) { return m->cfg.kind == SERT_KIND_VECTORSPACE_SOFTMAX; }
 // drop whatever a previous training call ran ahead for the next one (sert_hint_next_batch)
-static void invalidate_speculation(sert_model* m) {
-    m->projected_batch = -1;
+static void discard_run_ahead(sert_model* m) {
+    if (m->spec_fb_batch >= 0 && m->stream2 && m->ev_join) {
+        // a discarded run-ahead may still be busy on the side stream (its entity chain is only
+        // joined by the update that will now never come): order the main stream behind it
+        // before anything reuses the buffers it reads and writes
+        (void)hipEventRecord(m->ev_join, m->stream2);
+        (void)hipStreamWaitEvent(m->stream, m->ev_join, 0);
+    }
     m->spec_fb_batch = -1;
+}
+static void invalidate_speculation(sert_model* m) {
+    discard_run_ahead(m);
+    m->projected_batch = -1;
 }
 
 struct TensorRef {
@@ -1112,7 +1122,8 @@ static int train_step_async(sert_model* m, int64_t batch_index, const int64_t* n
     const bool have_fb = negatives == nullptr && m->spec_fb_batch == batch_index && m->spec_fb_step == m->step &&
                          can_speculate_step(m);
     bool fused_pre = true;   // (a speculated step always ran its prologue on the main stream)
-    m->spec_fb_batch = -1;
+    if (have_fb) m->spec_fb_batch = -1;     // consumed
+    else discard_run_ahead(m);              // a run-ahead for something else: discard it cleanly
     if (!have_fb) SERT_TRY(step_forward_backward(m, ds, batch_index, negatives, &fused_pre));
     SERT_TRY(allreduce_rest(m));
     SERT_TRY(optimizer_and_loss(m, loss_dst, publish));

@@ -40,6 +40,14 @@ __global__ __launch_bounds__(256) void segsum_rows(const float* __restrict__ src
     // workgroup row each -- more, shorter chains instead of one wave walking the whole row
     for (int c = blockIdx.y * LPI + l; c < chunks; c += LPI * gridDim.y) {
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        // LL_FINAL: the word's log-probabilities and r sum do not depend on the row sums --
+        // fetch them now, in the shadow of the row loads, not after them
+        float4 lp_pre = make_float4(0.f, 0.f, 0.f, 0.f);
+        float rs_pre = 0.f;
+        if (LL_FINAL && it.z >= 0) {
+            lp_pre = *reinterpret_cast<const float4*>(logp + (size_t)it.w * d + 4 * c);
+            rs_pre = rsum[it.w];
+        }
         int e = it.x;
         for (; e + 4 <= it.y; e += 4) {
             int r0, r1, r2, r3;
@@ -63,8 +71,8 @@ __global__ __launch_bounds__(256) void segsum_rows(const float* __restrict__ src
         if (it.z >= 0 && LL_FINAL) {
             const float LOGLO = logf(SERT_CLIP_LO), LOGHI = logf(SERT_CLIP_HI);
             const size_t o = (size_t)it.w * d + 4 * c;
-            const float4 lp = *reinterpret_cast<const float4*>(logp + o);
-            const float rs = rsum[it.w];
+            const float4 lp = lp_pre;
+            const float rs = rs_pre;
             a.x = ((lp.x >= LOGLO && lp.x <= LOGHI) ? a.x : 0.f) - __expf(lp.x) * rs;
             a.y = ((lp.y >= LOGLO && lp.y <= LOGHI) ? a.y : 0.f) - __expf(lp.y) * rs;
             a.z = ((lp.z >= LOGLO && lp.z <= LOGHI) ? a.z : 0.f) - __expf(lp.z) * rs;

@@ -238,6 +238,81 @@ __global__ __launch_bounds__(256) void topk_rows(const float* __restrict__ S, in
     }
 }
 
+// thr_out[row] = the k-th largest value of the row (raw cosine), nothing else: 4 x 8-bit
+// radix select straight from (cache-resident) global memory, 1 KB of LDS -- the sampled
+// threshold of the fused path does not need topk_rows' candidate lists and sorts.
+__global__ __launch_bounds__(256) void kth_largest_rows(const float* __restrict__ S, int V, int k,
+                                                        float* __restrict__ thr_out) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t scan_tmp[256];
+    __shared__ uint32_t s_prefix, s_krem;
+    const int tid = threadIdx.x;
+    const float* row = S + (size_t)blockIdx.x * V;
+    if (tid == 0) { s_prefix = 0; s_krem = (uint32_t)k; }
+    for (int pass = 3; pass >= 0; --pass) {
+        hist[tid] = 0;
+        __syncthreads();
+        const uint32_t prefix = s_prefix;
+        const int shift_hi = 8 * (pass + 1);
+        topk_scan_row(row, V, [&](float x, int) {
+            const uint32_t key = desc_key(x);
+            const bool match = (pass == 3) || ((key >> shift_hi) == prefix);
+            if (match) atomicAdd(&hist[(key >> (8 * pass)) & 0xffu], 1u);
+        });
+        __syncthreads();
+        // inclusive scan of the 256 bins; the bin whose cumulative count first reaches krem
+        const uint32_t mine = hist[tid];
+        scan_tmp[tid] = mine;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            const uint32_t v = (tid >= off) ? scan_tmp[tid - off] : 0;
+            __syncthreads();
+            scan_tmp[tid] += v;
+            __syncthreads();
+        }
+        const uint32_t krem = s_krem;
+        const uint32_t incl = scan_tmp[tid], excl = incl - mine;
+        __syncthreads();
+        if (excl < krem && incl >= krem) {        // exactly one thread
+            s_krem = krem - excl;
+            s_prefix = (prefix << 8) | (uint32_t)tid;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) thr_out[blockIdx.x] = key_to_float(s_prefix);
+}
+
+// thr_out[row] ~ the k-th largest value of the row, k <= 64: the k-th largest of the 256
+// per-thread maxima.  The top k of a few thousand values almost surely sit in k different
+// threads' strided subsets, so this lands within a few ranks of the exact answer -- good enough for
+// the fused path, whose threshold only steers the candidate COUNT (the count checks and the
+// exact fallback keep the result exact whatever the threshold).  One read of the row, one
+// 256-key bitonic sort; the exact radix select above pays four passes of LDS atomics that pile
+// onto a handful of bins (cosines share their leading key bits).
+__global__ __launch_bounds__(256) void approx_kth_rows(const float* __restrict__ S, int V, int k,
+                                                       float* __restrict__ thr_out) {
+    __shared__ uint32_t keys[256];
+    const int tid = threadIdx.x;
+    const float* row = S + (size_t)blockIdx.x * V;
+    uint32_t best = 0xffffffffu;                       // desc_key: smaller = larger score
+    topk_scan_row(row, V, [&](float x, int) { best = min(best, desc_key(x)); });
+    keys[tid] = best;
+    __syncthreads();
+    for (int size = 2; size <= 256; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            if (tid < 128) {
+                const int lo = 2 * tid - (tid & (stride - 1));
+                const int hi = lo + stride;
+                const bool up = ((lo & size) == 0);
+                const uint32_t a = keys[lo], b = keys[hi];
+                if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) thr_out[blockIdx.x] = key_to_float(keys[k - 1]);
+}
+
 // ---- fused path: GEMM with a filtering epilogue (gemm.h, EPI_FILTER) ---------------
 // For large entity tables the (Q, V) score matrix is never materialised:
 //   1. cosines against every kScoreStride-th entity (a 1/16 GEMM) and, per query, the
@@ -250,7 +325,7 @@ __global__ __launch_bounds__(256) void topk_rows(const float* __restrict__ S, in
 // threshold that the sample misjudged: heavy ties, adversarial entity order) is flagged
 // and recomputed by the materialising path, so the result is exact in every case.
 constexpr int kScoreStride = 16;
-constexpr int kCandCap = 4096;
+constexpr int kCandCap = 4096;   // upper bound of the per-row candidate capacity (dynamic LDS, `ccap`)
 
 // One workgroup per query: gather the row's per-group lists (EPI_FILTER layout) into
 // LDS, sort (score desc, index asc), emit the k best.  Rows with an overflowed group,
@@ -259,8 +334,11 @@ __global__ __launch_bounds__(256) void topk_from_groups(const unsigned long long
                                                         const unsigned char* __restrict__ gcnt, int ngroups,
                                                         int gcap, int k, int32_t* __restrict__ idx_out,
                                                         float* __restrict__ val_out, int q_base,
-                                                        int* __restrict__ nflag, int* __restrict__ flag_list) {
-    __shared__ unsigned long long keys[kCandCap];
+                                                        int* __restrict__ nflag, int* __restrict__ flag_list,
+                                                        int ccap) {
+    // ccap (a power of two <= kCandCap) keys of dynamic LDS: sized by the host for the expected
+    // candidate count, so that 8 workgroups fit a CU instead of the 4 a 32 KB array allows
+    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
     __shared__ unsigned scan[256];
     __shared__ unsigned s_bad;
     const int q = blockIdx.x, tid = threadIdx.x;
@@ -286,7 +364,7 @@ __global__ __launch_bounds__(256) void topk_from_groups(const unsigned long long
         __syncthreads();
     }
     const unsigned total = scan[255];
-    if (s_bad || total < (unsigned)k || total > (unsigned)kCandCap) {     // workgroup-uniform
+    if (s_bad || total < (unsigned)k || total > (unsigned)ccap) {     // workgroup-uniform
         if (tid == 0) flag_list[atomicAdd(nflag, 1)] = q_base + q;
         return;
     }

@@ -1814,15 +1814,20 @@ static int scorer_topk_fused(sert_scorer* sc, int64_t Q, int k, int rs) {
         // 1. cosines against every kScoreStride-th entity; threshold = rs-th best of the sample
         launch_gemm<false, true, EPI_STORE>(s, P, sc->E, sc->Ss, nullptr, (int)qn, (int)Vs, dim, dim,
                                             dim * kScoreStride, (int)Vs);
-        hipLaunchKernelGGL(topk_rows, dim3((unsigned)qn), dim3(256), 0, s, sc->Ss, (int)Vs, rs,
-                           (int32_t*)nullptr, (float*)nullptr, sc->thr);
+        if (rs <= 64 && Vs >= 2048)
+            hipLaunchKernelGGL(approx_kth_rows, dim3((unsigned)qn), dim3(256), 0, s, sc->Ss, (int)Vs, rs, sc->thr);
+        else
+            hipLaunchKernelGGL(kth_largest_rows, dim3((unsigned)qn), dim3(256), 0, s, sc->Ss, (int)Vs, rs, sc->thr);
         // 2. full GEMM, filtering epilogue
         launch_gemm<false, true, EPI_FILTER>(s, P, sc->E, nullptr, sc->thr, (int)qn, (int)V, dim, dim, dim,
                                              (int)V, 1, 0, 0, sc->cand, sc->cnt, gcap);
         // 3. selection from the candidate lists
-        hipLaunchKernelGGL(topk_from_groups, dim3((unsigned)qn), dim3(256), 0, s, sc->cand, sc->cnt,
-                           ngroups, gcap, k, sc->idx + q0 * k, sc->val + q0 * k, (int)q0, sc->nflag,
-                           sc->flag_list);
+        // candidate capacity: expected 2k+400, sigma ~ 16 sqrt(rs): the next power of two above +6 sigma
+        int ccap = 1024;
+        while (ccap < 2 * k + 400 + 6 * 16 * (int)ceilf(sqrtf((float)rs)) && ccap < kCandCap) ccap <<= 1;
+        hipLaunchKernelGGL(topk_from_groups, dim3((unsigned)qn), dim3(256), (size_t)ccap * sizeof(unsigned long long), s,
+                           sc->cand, sc->cnt, ngroups, gcap, k, sc->idx + q0 * k, sc->val + q0 * k, (int)q0,
+                           sc->nflag, sc->flag_list, ccap);
     }
     int nf = 0;
     SERT_HIP(hipMemcpyAsync(&nf, sc->nflag, sizeof(int), hipMemcpyDeviceToHost, s));

@@ -60,12 +60,44 @@ def import_reference():
         return mod
     train = load(os.path.join(REF, 'bin', 'train.py'), 'ref_train')
     query = load(os.path.join(REF, 'bin', 'query.py'), 'ref_query')
+    # bin/prepare.py: nltk and the pre-0.18 sklearn.cross_validation module are absent too
+    for name in ['nltk', 'nltk.corpus', 'sklearn.cross_validation']:
+        sys.modules[name] = mock.MagicMock()
+    global prepare_mod
+    prepare_mod = load(os.path.join(REF, 'bin', 'prepare.py'), 'ref_prepare')
     return inference, math_utils, models, train, query
+
+
+prepare_mod = None
 
 
 def main():
     inference, math_utils, models, train, query = import_reference()
     arrays, meta = {}, {}
+
+    # ---- f1: instances_and_labels_to_arrays (prepare.py:543-599) ---------------
+    rng = np.random.RandomState(17)
+    ents = ['E%02d' % i for i in range(7)]
+    class_mapping = {e: i for i, e in enumerate(sorted(ents, reverse=True))}   # not the identity
+    cases = []
+    for ci, (N, n, shuffle, seed) in enumerate([(23, 4, False, 0), (40, 3, True, 11), (1, 5, True, 2)]):
+        instances = []
+        for i in range(N):
+            k = rng.randint(1, 4)
+            lab = {ents[j]: float(m) for j, m in zip(rng.choice(7, k, replace=False),
+                                                     rng.randint(1, 4, k))}
+            instances.append(('D%d' % rng.randint(0, 9), tuple(int(t) for t in rng.randint(0, 300, n)), lab))
+        given = [(d, list(w), dict(l)) for d, w, l in instances]
+        np.random.seed(seed)
+        x, y = prepare_mod.instances_and_labels_to_arrays(list(instances), n, class_mapping, np.uint16, shuffle)
+        y = y.tocsr()
+        y.sort_indices()
+        cases.append(dict(window_size=n, shuffle=shuffle, seed=seed, instances=given,
+                          class_mapping=class_mapping, x=x.tolist(), x_dtype=str(x.dtype),
+                          y_indptr=y.indptr.tolist(), y_indices=y.indices.tolist(),
+                          y_data=[float(v) for v in y.data], y_shape=list(y.shape)))
+    meta['instances_to_arrays'] = cases
+    meta['candidate_centric_label'] = prepare_mod._candidate_centric_label(['E03', 'E01'])
 
     # ---- a1: _iterate_batches (models.py:351-399) ---------------------------
     cases = []

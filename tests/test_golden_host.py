@@ -285,3 +285,27 @@ def test_epoch_loop_announces_the_following_batch():
     m._engine.hints = []
     m._iterate_batches(m.test_fn, 4 * 5)
     assert m._engine.hints == []
+
+
+def test_instances_to_arrays_matches_reference():
+    """bin/prepare.py:543-599 (instances_and_labels_to_arrays), run from the real reference
+    by tests/golden/make_golden.py: dense id matrix, CSR label matrix through a non-identity
+    class mapping, np.random shuffle order under a seed."""
+    import scipy.sparse as sp
+    from sert_amd import prepare as prep
+    with open(os.path.join(HERE, 'golden', 'reference_vectors.json')) as f:
+        meta = json.load(f)
+    assert len(meta['instances_to_arrays']) == 3
+    for case in meta['instances_to_arrays']:
+        instances = [(d, tuple(w), dict(l)) for d, w, l in case['instances']]
+        np.random.seed(case['seed'])
+        x, y = prep.to_arrays(instances, case['window_size'], case['class_mapping'],
+                              np.dtype(case['x_dtype']), case['shuffle'])
+        assert x.dtype == np.dtype(case['x_dtype'])
+        assert x.tolist() == case['x']
+        y = sp.csr_matrix(y)
+        y.sort_indices()
+        assert list(y.shape) == case['y_shape']
+        assert y.indptr.tolist() == case['y_indptr']
+        assert y.indices.tolist() == case['y_indices']
+        assert [float(v) for v in y.data] == case['y_data']

@@ -523,3 +523,65 @@ def test_loglinear_with_saturated_probabilities(hip_lib, dims, keep):
     assert U.rel_err(eng.get_tensor(C.T_W), ora.W.ravel()) < PARAM_TOL
     assert U.rel_err(eng.get_tensor(C.T_RW), ora.R_w.ravel()) < PARAM_TOL
     eng.close()
+
+
+@pytest.mark.parametrize('kind', ['vectorspace', 'loglinear'])
+def test_run_ahead_randomised_differential(hip_lib, kind):
+    """Random interleavings of training steps (with right, wrong or no announcements),
+    evaluations, parameter writes/reads and multi-step calls: an engine that is told what comes
+    next must return exactly what an engine that is never told anything returns."""
+    B, n, z, Vw, Ve, d = 32, 3, 4, 150, 10, 16
+    nb = 6
+    if kind == 'vectorspace':
+        p = U.make_vs_problem(97, B * nb, n, z, Vw, Ve, d, d)
+        mk = lambda: U.vs_engine(p, B, n, z, 0.02, keep_grads=0, seed=5)
+    else:
+        p = U.make_ll_problem(97, B * nb, n, Vw, Ve, d, 'int')
+        mk = lambda: U.ll_engine(p, B, n, 0.02, keep_grads=0)
+    rng = np.random.RandomState(123)
+    ops = []
+    for _ in range(60):
+        r = rng.rand()
+        if r < 0.6:
+            ops.append(('train', int(rng.randint(nb)), rng.choice(['right', 'wrong', 'none'])))
+        elif r < 0.72:
+            ops.append(('eval', int(rng.randint(nb))))
+        elif r < 0.80:
+            ops.append(('set_b',))
+        elif r < 0.88:
+            ops.append(('get',))
+        else:
+            ops.append(('many', [int(v) for v in rng.randint(nb, size=3)]))
+    # "right" announces the batch of the next train op (if the next op is one)
+    results = []
+    for hinted in (False, True):
+        eng = mk()
+        eng.upload_dataset(C.SPLIT_TRAIN, p['X'], y_int=p['y'], w=p['w'])
+        out = []
+        for i, op in enumerate(ops):
+            if op[0] == 'train':
+                if hinted and op[2] != 'none':
+                    nxt = ops[i + 1] if i + 1 < len(ops) else None
+                    if op[2] == 'right' and nxt is not None and nxt[0] == 'train':
+                        eng.hint_next_batch(nxt[1])
+                    elif op[2] == 'right' and nxt is not None and nxt[0] == 'many':
+                        eng.hint_next_batch(nxt[1][0])
+                    else:
+                        eng.hint_next_batch((op[1] + 1 + i) % nb)
+                out.append(float(eng.train_batch(op[1])))
+            elif op[0] == 'eval':
+                out.append(float(eng.eval_batch(C.SPLIT_TRAIN, op[1])))
+            elif op[0] == 'set_b':
+                b = eng.get_tensor(C.T_B)
+                eng.set_tensor(C.T_B, (b * 0.5).astype(np.float32))
+            elif op[0] == 'get':
+                out.append(float(np.abs(eng.get_tensor(C.T_RW)).sum()))
+            else:
+                out.extend(float(v) for v in eng.train_batches(op[1]))
+        out.append(eng.get_tensor(C.T_RW).copy())
+        out.append(eng.get_tensor(C.T_W).copy())
+        eng.close()
+        results.append(out)
+    a, b = results
+    assert a[:-2] == b[:-2]
+    assert np.array_equal(a[-2], b[-2]) and np.array_equal(a[-1], b[-1])

@@ -475,11 +475,35 @@ __global__ __launch_bounds__(256) void ll_dzu_combine(float* __restrict__ dZu, c
 // In-place row log-softmax, log P = (z - max) - log(sum exp(z - max)), one wave per row --
 // the per-token phase of ll_fused_row, hoisted to run ONCE per distinct word when the step
 // works on the distinct-word logit table (same formula, same __expf).
+template <int EPL>
 __global__ __launch_bounds__(256) void ll_logsoftmax_rows(float* __restrict__ Z, int64_t rows, int V) {
     const int lane = threadIdx.x & 63;
     const int64_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
     float* z = Z + (size_t)r * V;
+    if (EPL > 0) {
+        // V <= 64*EPL: the row stays in registers -- one read, one write
+        float x[EPL > 0 ? EPL : 1];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < EPL; ++u) {
+            const int e = lane + 64 * u;
+            x[u] = (e < V) ? z[e] : -INFINITY;
+            mx = fmaxf(mx, x[u]);
+        }
+        mx = wave_max(mx);
+        float sm = 0.f;
+#pragma unroll
+        for (int u = 0; u < EPL; ++u) sm += __expf(x[u] - mx);     // exp(-inf) = 0 for the padding
+        sm = wave_sum(sm);
+        const float lsm = logf(sm);
+#pragma unroll
+        for (int u = 0; u < EPL; ++u) {
+            const int e = lane + 64 * u;
+            if (e < V) z[e] = (x[u] - mx) - lsm;
+        }
+        return;
+    }
     float mx = -INFINITY;
 #pragma unroll 4
     for (int e = lane; e < V; e += 64) mx = fmaxf(mx, z[e]);

@@ -806,7 +806,11 @@ static int ll_forward(sert_model* m, const DataSplit& ds, int64_t batch_index) {
     if (fused) {
         ScopedTimer t(m, TG_LOSS);
         if (m->ll_dedup)   // the per-token log-softmax, once per distinct word
-            hipLaunchKernelGGL(ll_logsoftmax_rows, dim3(cdiv(grows, 4)), dim3(256), 0, m->stream, m->Zu, grows, V);
+        {
+            if (V <= 64 * 16)      hipLaunchKernelGGL((ll_logsoftmax_rows<16>), dim3(cdiv(grows, 4)), dim3(256), 0, m->stream, m->Zu, grows, V);
+            else if (V <= 64 * 32) hipLaunchKernelGGL((ll_logsoftmax_rows<32>), dim3(cdiv(grows, 4)), dim3(256), 0, m->stream, m->Zu, grows, V);
+            else                   hipLaunchKernelGGL((ll_logsoftmax_rows<0>), dim3(cdiv(grows, 4)), dim3(256), 0, m->stream, m->Zu, grows, V);
+        }
         // 512 threads per row: 302 us at 256 (too few waves to hide the slab load), 228 at
         // 512, 320 at 640 (one wave per token, but only two workgroups fit a CU)
         // (distinct-word mode: the kernel writes dJ_i into J and r_ik into ll_r instead of dL/dZ)

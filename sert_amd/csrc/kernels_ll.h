@@ -788,17 +788,14 @@ __global__ __launch_bounds__(256) void ll_s_rsum(const float* __restrict__ rpart
 template <bool V4>
 __global__ __launch_bounds__(256) void ll_s_dz(float* __restrict__ Z, const float* __restrict__ lse,
                                                const float* __restrict__ dJ, const float* __restrict__ r,
-                                               int n, int V, int nseg, const float* __restrict__ Zu,
-                                               const int32_t* __restrict__ slot) {
+                                               int n, int V, int nseg) {
     const int64_t row = blockIdx.x / nseg;
     const int seg = (int)(blockIdx.x - row * nseg);
     const int64_t i = row / n;
     const float LOGLO = logf(SERT_CLIP_LO), LOGHI = logf(SERT_CLIP_HI);
-    // slot: logits and lse come from the distinct-word tables, dZ still goes to Z[row]
-    const int64_t srow = slot ? (int64_t)slot[row] : row;
-    const float l = lse[srow], rk = r[row];
+    const float l = lse[row], rk = r[row];
     float x[16], dj[16];
-    seg_load<V4>((slot ? Zu : Z) + (size_t)srow * V, V, seg, x, 0.f);
+    seg_load<V4>(Z + (size_t)row * V, V, seg, x, 0.f);
     seg_load<V4>(dJ + (size_t)i * V, V, seg, dj, 0.f);
 #pragma unroll
     for (int u = 0; u < 16; ++u) {

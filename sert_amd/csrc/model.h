@@ -139,7 +139,6 @@ struct sert_model {
     float* zpart = nullptr;       // V_e-wide partial rows of the per-word sum tree
     size_t zpart_rows = 0;
     bool ll_dedup = false;        // this step ran on the distinct-word table
-    bool ll_dj_level = false;     // ... and the loss kernel emitted dJ_i + r_ik (fused path)
     float* ll_rsum = nullptr;     // (U) per-word sums of r_ik
     int ll_U = 0;
     float* skbuf = nullptr;       // split-K partials of the long-K dX GEMMs (grown on demand)

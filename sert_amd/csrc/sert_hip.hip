@@ -216,33 +216,11 @@ static int word_grad_segsum(sert_model* m, const DataSplit& ds, int64_t batch_in
     return 0;
 }
 
-// Loglinear on the distinct-word table: dZu[slot(word), :] = sum of dL/dZ over the word's
-// occurrences in the batch -- the same order-fixed tree as the word gradient, over
-// V_e-wide rows, destination = the word's rank among the batch's distinct words.
-static int dz_word_sums(sert_model* m, const DataSplit& ds, int64_t batch_index) {
-    const int V = m->cfg.num_entities;
-    const BatchIndex& bx = ds.idx_batches[(size_t)batch_index];
-    for (int l = 0; l < bx.nlevels; ++l) {
-        const int nitems = bx.item_cnt[l];
-        if (nitems == 0) continue;
-        const float* in = (l == 0) ? m->Z : m->zpart + (size_t)bx.part_off[l - 1] * V;
-        const int32_t* rows = (l == 0) ? ds.idx_rows + bx.rows_off : nullptr;
-        const int4* items = ds.idx_items + bx.item_off[l];
-        float* pout = m->zpart + (size_t)bx.part_off[l] * V;
-        if (V % 4 == 0)
-            hipLaunchKernelGGL((segsum_rows<64, true>), dim3(cdiv(nitems, 4), cdiv(V / 4, 64)), dim3(256), 0,
-                               m->stream, in, rows, items, nitems, m->dZu, pout, V, 1.0f, (unsigned char*)nullptr);
-        else
-            hipLaunchKernelGGL((segsum_rows_scalar<true>), dim3(cdiv(nitems, 4)), dim3(256), 0, m->stream, in,
-                               rows, items, nitems, m->dZu, pout, V, 1.0f, (unsigned char*)nullptr);
-    }
-    return 0;
-}
-
-// Same result from 1/n of the bytes (kernels_ll.h, ll_fused_row): per word, the sum of the
-// dJ rows of the batch rows it occurs in and the sum of its r_ik, then
-// dZu = mask dJsum - P rsum.  Both sums ride the word's occurrence tree (rows = positions,
-// source row of the V_e-wide sum = position / n).
+// Loglinear on the distinct-word tables (kernels_ll.h): per word, the sum of the dJ rows of the
+// batch rows it occurs in and the sum of its r_ik, then dZu = mask dJsum - P rsum.  Both sums
+// ride the word's occurrence tree -- the same order-fixed tree as the word gradient, over
+// V_e-wide rows (source row = batch row of the occurrence), destination = the word's rank
+// among the batch's distinct words.
 static int dzu_from_dj(sert_model* m, const DataSplit& ds, int64_t batch_index) {
     const int V = m->cfg.num_entities;
     const BatchIndex& bx = ds.idx_batches[(size_t)batch_index];
@@ -742,11 +720,10 @@ static int ll_stream_loss(sert_model* m, const DataSplit& ds, size_t row0, const
         // needs (dzu_from_dj); the per-token dL/dZ pass and its 2 x B*n*V_e floats are skipped.
         // The word rows must hold LOG-probabilities for the finishing transform:
         hipLaunchKernelGGL(ll_s_logp_rows, dim3((unsigned)(lrows * nseg)), dim3(256), 0, s, m->Zu, m->ll_lse, V, nseg);
-        m->ll_dj_level = true;
         return 0;
     }
     hipLaunchKernelGGL((ll_s_dz<V4>), dim3((unsigned)(rows * nseg)), dim3(256), 0, s, m->Z, m->ll_lse, m->J, m->ll_r, n,
-                       V, nseg, (const float*)m->Zu, slot);
+                       V, nseg);
     return 0;
 }
 
@@ -768,7 +745,6 @@ static int ll_forward(sert_model* m, const DataSplit& ds, int64_t batch_index) {
                   (size_t)batch_index < ds.idx_batches.size();
     const BatchIndex* bx = m->ll_dedup ? &ds.idx_batches[(size_t)batch_index] : nullptr;
     m->ll_U = bx ? bx->num_distinct : 0;
-    m->ll_dj_level = false;
     const int64_t grows = m->ll_dedup ? m->ll_U : rows;          // rows of the gathered operand
     {
         ScopedTimer t(m, TG_GATHER);
@@ -814,7 +790,6 @@ static int ll_forward(sert_model* m, const DataSplit& ds, int64_t batch_index) {
         // 512 threads per row: 302 us at 256 (too few waves to hide the slab load), 228 at
         // 512, 320 at 640 (one wave per token, but only two workgroups fit a CU)
         // (distinct-word mode: the kernel writes dJ_i into J and r_ik into ll_r instead of dL/dZ)
-        m->ll_dj_level = m->ll_dedup;
         static const bool slab = getenv("SERT_LL_SLAB") != nullptr;   // cross-check knob
         if (TRAIN && m->ll_dedup && n <= 64 && !slab) {
             // distinct-word mode: no LDS slab, the n table rows are read once, coalesced along e
@@ -851,8 +826,7 @@ static int ll_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
     if (m->ll_dedup) {
         // per-word sums of dL/dZ (the backward of "duplicate tokens share a logit row")
         ScopedTimer t(m, TG_EGRAD);
-        if (m->ll_dj_level) SERT_TRY(dzu_from_dj(m, ds, batch_index));
-        else                SERT_TRY(dz_word_sums(m, ds, batch_index));
+        SERT_TRY(dzu_from_dj(m, ds, batch_index));   // (every distinct-word step emits dJ_i + r_ik)
         dZ = m->dZu;
         rows = m->ll_U;
     }

@@ -255,6 +255,31 @@ def test_score_topk_fused_equals_materialised(hip_lib, monkeypatch):
         assert np.array_equal(val_f, ref['val'])
 
 
+def test_score_topk_big_tile_variant(hip_lib):
+    """SERT_SCORE_BIG_TILE=1 (gemm_big.h, ragged M and N): fused == materialised, both == oracle."""
+    rng = np.random.RandomState(17)
+    V, d, Q, k = 70001, 32, 300, 100
+    E = rng.randn(V, d).astype(np.float32)
+    Pj = np.tanh(rng.randn(Q, d)).astype(np.float32)
+    code = ("import numpy as np, sys; sys.path.insert(0, %r); from sert_amd import _capi as C;"
+            "d = np.load(sys.argv[1]); idx, val = C.score_topk(d['E'], d['Pj'], %d);"
+            "np.savez(sys.argv[2], idx=idx, val=val)" % (U.ROOT, k))
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        inp = os.path.join(tmp, 'in.npz')
+        np.savez(inp, E=E, Pj=Pj)
+        res = []
+        for extra in ({}, {'SERT_SCORE_MATERIALISE': '1'}):
+            out = os.path.join(tmp, 'o%d.npz' % len(res))
+            subprocess.run([sys.executable, '-c', code, inp, out], check=True,
+                           env=dict(os.environ, SERT_SCORE_BIG_TILE='1', **extra))
+            r = np.load(out)
+            res.append((r['idx'], r['val']))
+    assert np.array_equal(res[0][0], res[1][0])
+    assert np.array_equal(res[0][1], res[1][1])
+    _check_topk_against_oracle(E, Pj, res[0][0], res[0][1], k)
+
+
 def test_device_sampler_uniform_and_rank_invariant(hip_lib):
     """The Philox sampler draws iid uniform ids; training with it is finite."""
     B, n, z, Vw, Ve, dw, de = 512, 4, 8, 100, 16, 16, 16

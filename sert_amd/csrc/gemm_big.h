@@ -37,16 +37,22 @@ struct BigGemmArgs {
 // Any M, N (edge tiles load clamped rows and drop them in the epilogue); K % 16 == 0 and
 // 16-byte aligned rows (lda, ldb % 4 == 0).  The tile index runs along M first: the 256
 // workgroups in flight share a handful of B tiles and all of A.
-template <bool FILTER>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_big_nt(const BigGemmArgs g) {
+//
+// NBJ = 16-column blocks per wave: 8 -> tile 256x256, wave 128x128, 256 accumulators, one wave per
+// SIMD (gemm_big_nt); 4 -> tile 256x128, wave 128x64, 128 accumulators, two workgroups per CU
+// (gemm_mid_nt): half the MFMAs per fragment byte, but a second workgroup's MFMAs run under
+// this one's barrier, LDS stores and -- for FILTER -- its long epilogue.
+template <bool FILTER, int NBJ>
+__device__ __forceinline__ void gemm_big_body(const BigGemmArgs& g) {
+    constexpr int BNT = 32 * NBJ;          // tile columns: 2 waves x NBJ x 16
     __shared__ __attribute__((aligned(16))) float As[2][BM][BLD];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BN][BLD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BNT][BLD];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wr = w >> 1, wc = w & 1;
     const int lr = lane & 15, lg = lane >> 4;
     const int tile = blockIdx.x;
     const int tn = tile / g.tiles_m, tm = tile - tn * g.tiles_m;
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * BM, n0 = tn * BNT;
 
     // global -> registers: 256 rows x 4 k-quads per operand = 1024 float4, 4 per thread:
     // thread t loads k-quad (t & 3) of rows (t >> 2) + 64 i
@@ -72,8 +78,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         ra3 = *reinterpret_cast<const float4*>(Ap3 + (k0));                   \
         rb0 = *reinterpret_cast<const float4*>(Bp0 + (k0));                   \
         rb1 = *reinterpret_cast<const float4*>(Bp1 + (k0));                   \
-        rb2 = *reinterpret_cast<const float4*>(Bp2 + (k0));                   \
-        rb3 = *reinterpret_cast<const float4*>(Bp3 + (k0));                   \
+        if (NBJ == 8) {                                                       \
+            rb2 = *reinterpret_cast<const float4*>(Bp2 + (k0));               \
+            rb3 = *reinterpret_cast<const float4*>(Bp3 + (k0));               \
+        }                                                                     \
     } while (0)
 #define BIG_LSTORE(buf)                                                       \
     do {                                                                      \
@@ -83,26 +91,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         *reinterpret_cast<float4*>(&As[buf][lrow + 192][4 * lq]) = ra3;       \
         *reinterpret_cast<float4*>(&Bs[buf][lrow][4 * lq]) = rb0;             \
         *reinterpret_cast<float4*>(&Bs[buf][lrow + 64][4 * lq]) = rb1;        \
-        *reinterpret_cast<float4*>(&Bs[buf][lrow + 128][4 * lq]) = rb2;       \
-        *reinterpret_cast<float4*>(&Bs[buf][lrow + 192][4 * lq]) = rb3;       \
+        if (NBJ == 8) {                                                       \
+            *reinterpret_cast<float4*>(&Bs[buf][(lrow + 128) % BNT][4 * lq]) = rb2; \
+            *reinterpret_cast<float4*>(&Bs[buf][(lrow + 192) % BNT][4 * lq]) = rb3; \
+        }                                                                     \
     } while (0)
 
-    // FILTER: the 32 row thresholds of this lane, fetched now -- left to the epilogue they are
-    // 32 dependent-latency loads with nothing else on the SIMD to hide them (one wave per SIMD)
-    const int rbase = m0 + wr * 128 + 4 * lg, cbase = n0 + wc * 128 + lr;
-    float th[8][4];
-    if (FILTER) {
-#pragma unroll
-        for (int bi = 0; bi < 8; ++bi)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) th[bi][i] = g.thr[min(rbase + bi * 16 + i, g.M - 1)];
-    }
+    const int rbase = m0 + wr * 128 + 4 * lg, cbase = n0 + wc * (16 * NBJ) + lr;
 
-    f32x4 acc[8][8];
+    f32x4 acc[8][NBJ];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NBJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     BIG_GLOAD(0);
     BIG_LSTORE(0);
@@ -110,16 +111,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // Software pipeline over the two k-halves of a slab (k = 4 lg + {0,1} | {2,3}): the
     // fragment reads of one half are in flight under the 128 MFMAs of the other, and the
     // barrier + LDS store of the next slab sit between the halves, not at the loop edge.
-    float2 fa0[8], fb0[8], fa1[8], fb1[8];
+    float2 fa0[8], fb0[NBJ], fa1[8], fb1[NBJ];
 #define BIG_FRAG(fa, fb, buf, h)                                                                      \
-    _Pragma("unroll") for (int b = 0; b < 8; ++b) {                                                   \
+    _Pragma("unroll") for (int b = 0; b < 8; ++b)                                                     \
         fa[b] = *reinterpret_cast<const float2*>(&As[buf][wr * 128 + b * 16 + lr][4 * lg + 2 * (h)]); \
-        fb[b] = *reinterpret_cast<const float2*>(&Bs[buf][wc * 128 + b * 16 + lr][4 * lg + 2 * (h)]); \
-    }
+    _Pragma("unroll") for (int b = 0; b < NBJ; ++b)                                                   \
+        fb[b] = *reinterpret_cast<const float2*>(&Bs[buf][wc * (16 * NBJ) + b * 16 + lr][4 * lg + 2 * (h)]);
 #define BIG_MFMA(fa, fb)                                                                              \
     _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                     \
     _Pragma("unroll") for (int bi = 0; bi < 8; ++bi)                                                  \
-    _Pragma("unroll") for (int bj = 0; bj < 8; ++bj)                                                  \
+    _Pragma("unroll") for (int bj = 0; bj < NBJ; ++bj)                                                \
         asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0"                                          \
                      : "+a"(acc[bi][bj]) : "v"(j ? fa[bi].y : fa[bi].x), "v"(j ? fb[bj].y : fb[bj].x));
     int buf = 0;
@@ -160,43 +161,64 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 if (row >= g.M) continue;
                 float* Cr = g.C + (size_t)row * g.ldc;
 #pragma unroll
-                for (int bj = 0; bj < 8; ++bj)
+                for (int bj = 0; bj < NBJ; ++bj)
                     if (cbase + bj * 16 < g.N) Cr[cbase + bj * 16] = acc[bi][bj][i];
             }
     } else {
         // The 16 lanes of a quarter-wave hold 16 consecutive columns of one row, so an element's
         // slot in its group list is a ballot/popcount prefix over the group's four 16-column
         // blocks: no atomics, deterministic (ascending column) order.
-        const unsigned below = (1u << lr) - 1u;
-        const unsigned ucap = (unsigned)g.cap, ngr = (unsigned)g.ngr;
-        const unsigned g0 = (unsigned)(n0 / 64 + wc * 2);
+        float th[8][4];      // the lane's 32 row thresholds, one batch of loads
 #pragma unroll
         for (int bi = 0; bi < 8; ++bi)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = rbase + bi * 16 + i;
-                const float t = row < g.M ? th[bi][i] : INFINITY;
+                const float t = g.thr[min(row, g.M - 1)];
+                th[bi][i] = row < g.M ? t : INFINITY;
+            }
+        if (n0 + BNT > g.N) {   // edge tile: the (clamped, duplicated) columns beyond N never pass
+#pragma unroll
+            for (int bj = 0; bj < NBJ; ++bj)
+                if (cbase + bj * 16 >= g.N) {
+#pragma unroll
+                    for (int bi = 0; bi < 8; ++bi)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[bi][bj][i] = -INFINITY;
+                }
+        }
+        // The no-candidate case is compare + branch; all addresses are one 64-bit lane base + a
+        // 32-bit index built from uniform strides.
+        const unsigned below = (1u << lr) - 1u, sh = 16u * lg;
+        const unsigned ucap = (unsigned)g.cap, ngr = (unsigned)g.ngr, rstride = ngr * ucap;
+        const unsigned g0 = (unsigned)(n0 / 64 + wc * (NBJ / 4));
+        unsigned long long* cand_lane = g.cand + ((size_t)rbase * ngr + g0) * ucap;
+        unsigned char* cnt_lane = g.cnt + (size_t)rbase * ngr + g0;
+#pragma unroll
+        for (int bi = 0; bi < 8; ++bi)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned ro = (unsigned)(bi * 16 + i);
+                const float t = th[bi][i];
                 unsigned run = 0;
 #pragma unroll
-                for (int bj = 0; bj < 8; ++bj) {
+                for (int bj = 0; bj < NBJ; ++bj) {
                     if ((bj & 3) == 0) run = 0;
-                    const int col = cbase + bj * 16;
                     const float v = acc[bi][bj][i];
-                    const bool p = col < g.N && v >= t;
-                    const unsigned long long any = __ballot(p);
+                    const bool p = v >= t;
+                    const unsigned long long any = __builtin_amdgcn_ballot_w64(p);
                     if (any) {     // ~2/3 of the (4 row x 16 column) blocks hold no candidate at all
-                        const unsigned h = (unsigned)(any >> (16 * lg)) & 0xffffu;
-                        const unsigned gi = g0 + (bj >> 2);
+                        const unsigned h = (unsigned)(any >> sh) & 0xffffu;
                         if (p) {
                             const unsigned slot = run + __popc(h & below);
                             if (slot < ucap)
-                                g.cand[((size_t)row * ngr + gi) * ucap + slot] =
-                                    ((unsigned long long)desc_key(v) << 32) | (unsigned)col;
+                                cand_lane[ro * rstride + (unsigned)(bj >> 2) * ucap + slot] =
+                                    ((unsigned long long)desc_key(v) << 32) | (unsigned)(cbase + bj * 16);
                         }
                         run += __popc(h);
                     }
                     if ((bj & 3) == 3 && run && lr == 0)
-                        g.cnt[(size_t)row * ngr + g0 + (bj >> 2)] = (unsigned char)(run > 255u ? 255u : run);
+                        cnt_lane[ro * ngr + (unsigned)(bj >> 2)] = (unsigned char)(run > 255u ? 255u : run);
                 }
             }
     }
@@ -205,25 +227,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #undef BIG_GLOAD
 #undef BIG_LSTORE
 
+template <bool FILTER>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void gemm_big_nt(const BigGemmArgs g) {
+    gemm_big_body<FILTER, 8>(g);
+}
+template <bool FILTER>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_mid_nt(const BigGemmArgs g) {
+    gemm_big_body<FILTER, 4>(g);
+}
+
 inline bool gemm_big_ok(int K, int lda, int ldb) { return K >= BK && K % BK == 0 && lda % 4 == 0 && ldb % 4 == 0; }
 
+// mid = true: 256x128 tiles, two workgroups per CU
 inline void launch_gemm_big_nt(hipStream_t s, const float* A, const float* B, float* C, int M, int N, int K,
-                               int lda, int ldb, int ldc) {
+                               int lda, int ldb, int ldc, bool mid = false) {
     BigGemmArgs g = {};
     g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
-    g.tiles_m = cdiv(M, BM); g.tiles_n = cdiv(N, BN);
-    hipLaunchKernelGGL(gemm_big_nt<false>, dim3(g.tiles_m * g.tiles_n), dim3(256), 0, s, g);
+    g.tiles_m = cdiv(M, BM); g.tiles_n = cdiv(N, mid ? 128 : 256);
+    if (mid) hipLaunchKernelGGL(gemm_mid_nt<false>, dim3(g.tiles_m * g.tiles_n), dim3(256), 0, s, g);
+    else hipLaunchKernelGGL(gemm_big_nt<false>, dim3(g.tiles_m * g.tiles_n), dim3(256), 0, s, g);
 }
 
 // rows of A that reach thr[row] -> (row, 64-column group) candidate lists; ngr groups per row
 inline void launch_gemm_big_filter(hipStream_t s, const float* A, const float* B, const float* thr,
                                    unsigned long long* cand, unsigned char* cnt, int ngr, int cap,
-                                   int M, int N, int K, int lda, int ldb) {
+                                   int M, int N, int K, int lda, int ldb, bool mid = false) {
     BigGemmArgs g = {};
     g.A = A; g.B = B; g.C = nullptr; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = 0;
-    g.tiles_m = cdiv(M, BM); g.tiles_n = cdiv(N, BN);
+    g.tiles_m = cdiv(M, BM); g.tiles_n = cdiv(N, mid ? 128 : 256);
     g.thr = thr; g.cand = cand; g.cnt = cnt; g.ngr = ngr; g.cap = cap;
-    hipLaunchKernelGGL(gemm_big_nt<true>, dim3(g.tiles_m * g.tiles_n), dim3(256), 0, s, g);
+    if (mid) hipLaunchKernelGGL(gemm_mid_nt<true>, dim3(g.tiles_m * g.tiles_n), dim3(256), 0, s, g);
+    else hipLaunchKernelGGL(gemm_big_nt<true>, dim3(g.tiles_m * g.tiles_n), dim3(256), 0, s, g);
 }
 
 }  // namespace sert

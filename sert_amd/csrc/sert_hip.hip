@@ -1712,9 +1712,9 @@ int sert_scorer_destroy(sert_scorer* sc) {
 // SERT_SCORE_BIG_TILE=1 (opt-in, measured slower at d_e = 128 -- DESIGN.md): score through
 // gemm_big.h (256x256 tiles, one wave per SIMD).  Both the fused path and its exact fallback
 // then use that kernel, so a row's scores never depend on which path produced them.
-static bool scorer_big_tile(const sert_scorer* sc) {
-    static const bool big_tile = getenv("SERT_SCORE_BIG_TILE") != nullptr;
-    return big_tile && sc->V >= 32768 && gemm_big_ok(sc->dim, sc->dim, sc->dim);
+static int scorer_big_tile(const sert_scorer* sc) {   // 0 no, 1 = 256x256, 2 = 256x128 (two workgroups per CU)
+    static const int big_tile = getenv("SERT_SCORE_BIG_TILE") ? atoi(getenv("SERT_SCORE_BIG_TILE")) : 0;
+    return (sc->V >= 32768 && gemm_big_ok(sc->dim, sc->dim, sc->dim)) ? big_tile : 0;
 }
 
 // Materialising path: (QT, V) cosine slabs + per-row selection, for a device-resident
@@ -1749,7 +1749,7 @@ static int scorer_topk_materialised(sert_scorer* sc, const float* P, int64_t Q, 
         // S = P.E^T  (cosines), then per-row selection
         // (same kernel family as the fused path, so a row's scores do not depend on the path)
         if (scorer_big_tile(sc))
-            launch_gemm_big_nt(st, P + q0 * dim, sc->E, S, (int)qn, (int)V, dim, dim, dim, (int)V);
+            launch_gemm_big_nt(st, P + q0 * dim, sc->E, S, (int)qn, (int)V, dim, dim, dim, (int)V, scorer_big_tile(sc) == 2);
         else
             launch_gemm<false, true, EPI_STORE>(st, P + q0 * dim, sc->E, S, nullptr, (int)qn, (int)V, dim,
                                                 dim, dim, (int)V);
@@ -1811,7 +1811,8 @@ static int scorer_topk_fused(sert_scorer* sc, int64_t Q, int k, int rs) {
             hipLaunchKernelGGL(kth_largest_rows, dim3((unsigned)qn), dim3(256), 0, s, sc->Ss, (int)Vs, rs, sc->thr);
         // 2. full GEMM, filtering epilogue
         if (scorer_big_tile(sc))
-            launch_gemm_big_filter(s, P, sc->E, sc->thr, sc->cand, sc->cnt, ngroups, gcap, (int)qn, (int)V, dim, dim, dim);
+            launch_gemm_big_filter(s, P, sc->E, sc->thr, sc->cand, sc->cnt, ngroups, gcap, (int)qn, (int)V, dim, dim, dim,
+                                   scorer_big_tile(sc) == 2);
         else
             launch_gemm<false, true, EPI_FILTER>(s, P, sc->E, nullptr, sc->thr, (int)qn, (int)V, dim, dim, dim,
                                                  (int)V, 1, 0, 0, sc->cand, sc->cnt, gcap);
@@ -2047,9 +2048,9 @@ int sert_bench_gemm(int device, int ta, int tb, int epi, int M, int N, int K, in
     };
     SERT_HIP(fill(A, na)); SERT_HIP(fill(B, nb)); SERT_HIP(fill(bias, (size_t)N));
     const int lda = ta ? M : K, ldb = tb ? K : N;
-    const bool big = getenv("SERT_GEMM_BIG") && !ta && tb && gemm_big_ok(K, lda, ldb) && splits == 1;
+    const int big = (getenv("SERT_GEMM_BIG") && !ta && tb && gemm_big_ok(K, lda, ldb) && splits == 1) ? atoi(getenv("SERT_GEMM_BIG")) : 0;
     auto run = [&]() {
-        if (big) { launch_gemm_big_nt(s, A, B, C, M, N, K, lda, ldb, N); return; }
+        if (big) { launch_gemm_big_nt(s, A, B, C, M, N, K, lda, ldb, N, big == 2); return; }
 #define SERT_BG(TA, TB, E) launch_gemm<TA, TB, E>(s, A, B, C, bias, M, N, K, lda, ldb, N, splits, kper, (size_t)M * N)
         if (!ta && !tb) { if (epi == 2) SERT_BG(false, false, EPI_BIAS_TANH); else if (epi == 1) SERT_BG(false, false, EPI_BIAS); else SERT_BG(false, false, EPI_STORE); }
         else if (ta && !tb) SERT_BG(true, false, EPI_STORE);

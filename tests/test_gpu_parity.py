@@ -255,8 +255,9 @@ def test_score_topk_fused_equals_materialised(hip_lib, monkeypatch):
         assert np.array_equal(val_f, ref['val'])
 
 
-def test_score_topk_big_tile_variant(hip_lib):
-    """SERT_SCORE_BIG_TILE=1 (gemm_big.h, ragged M and N): fused == materialised, both == oracle."""
+@pytest.mark.parametrize('mode', ['1', '2'])
+def test_score_topk_big_tile_variant(hip_lib, mode):
+    """SERT_SCORE_BIG_TILE=1|2 (gemm_big.h, ragged M and N): fused == materialised, both == oracle."""
     rng = np.random.RandomState(17)
     V, d, Q, k = 70001, 32, 300, 100
     E = rng.randn(V, d).astype(np.float32)
@@ -272,7 +273,7 @@ def test_score_topk_big_tile_variant(hip_lib):
         for extra in ({}, {'SERT_SCORE_MATERIALISE': '1'}):
             out = os.path.join(tmp, 'o%d.npz' % len(res))
             subprocess.run([sys.executable, '-c', code, inp, out], check=True,
-                           env=dict(os.environ, SERT_SCORE_BIG_TILE='1', **extra))
+                           env=dict(os.environ, SERT_SCORE_BIG_TILE=mode, **extra))
             r = np.load(out)
             res.append((r['idx'], r['val']))
     assert np.array_equal(res[0][0], res[1][0])

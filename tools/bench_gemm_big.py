@@ -17,7 +17,7 @@ if __name__ == '__main__':
         from sert_amd import _capi as C
         for name, kw in SHAPES:
             us = C.bench_gemm(tb=1, iters=5, **kw)
-            print('%-10s %-28s %9.1f us %7.1f TF' % (sys.argv[1], name, us, 2.0 * kw['M'] * kw['N'] * kw['K'] / us / 1e6))
+            print('%-12s %-28s %9.1f us %7.1f TF' % (sys.argv[1], name, us, 2.0 * kw['M'] * kw['N'] * kw['K'] / us / 1e6))
     else:
-        for tag, env in (('production', {}), ('big-tile', {'SERT_GEMM_BIG': '1'})):
+        for tag, env in (('production', {}), ('big 256x256', {'SERT_GEMM_BIG': '1'}), ('mid 256x128', {'SERT_GEMM_BIG': '2'})):
             subprocess.run([sys.executable, os.path.abspath(__file__), tag], check=True, env=dict(os.environ, **env))

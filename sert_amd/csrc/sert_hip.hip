@@ -13,6 +13,7 @@
 #include "common.h"
 #include "gemm.h"
 #include "gemm_big.h"
+#include "kernels_score_bf16.h"
 #include "kernels_egrad.h"
 #include "kernels_ll.h"
 #include "kernels_opt.h"
@@ -1689,6 +1690,15 @@ int sert_scorer_create(int device, const float* entities, int64_t V, int32_t dim
     SERT_TRY(dmalloc(&sc->E, (size_t)V * dim));
     SERT_HIP(hipMemcpyAsync(sc->E, entities, (size_t)V * dim * sizeof(float), hipMemcpyHostToDevice, sc->stream));
     hipLaunchKernelGGL(l2_normalize_rows, dim3(cdiv(V, 4)), dim3(256), 0, sc->stream, sc->E, V, dim);
+    // large tables: bf16 copy for the prefilter GEMM (SERT_SCORE_FP32=1 keeps the fp32 filter)
+    static const bool fp32_only = getenv("SERT_SCORE_FP32") != nullptr;
+    sc->bf16 = !fp32_only && V >= 32768 && dim % 4 == 0;
+    if (sc->bf16) {
+        sc->kp = (int)round_up(dim, 32);
+        SERT_TRY(dmalloc(&sc->E16, (size_t)V * sc->kp));
+        hipLaunchKernelGGL(to_bf16_rows, dim3(grid_for(V * sc->kp)), dim3(256), 0, sc->stream, sc->E, V, dim,
+                           sc->kp, sc->E16);
+    }
     SERT_HIP(hipStreamSynchronize(sc->stream));
     *out = sc;
     return 0;
@@ -1700,7 +1710,7 @@ int sert_scorer_destroy(sert_scorer* sc) {
     (void)hipFree(sc->E); (void)hipFree(sc->P); (void)hipFree(sc->S); (void)hipFree(sc->val); (void)hipFree(sc->idx);
     (void)hipFree(sc->Ss); (void)hipFree(sc->thr); (void)hipFree(sc->cand); (void)hipFree(sc->cnt);
     (void)hipFree(sc->nflag); (void)hipFree(sc->flag_list); (void)hipFree(sc->Pc); (void)hipFree(sc->idx_c);
-    (void)hipFree(sc->val_c);
+    (void)hipFree(sc->val_c); (void)hipFree(sc->E16); (void)hipFree(sc->P16);
     if (sc->ev_ready) (void)hipEventDestroy(sc->ev_ready);
     if (sc->ev_done) (void)hipEventDestroy(sc->ev_done);
     if (sc->stream2) (void)hipStreamDestroy(sc->stream2);
@@ -1755,6 +1765,12 @@ static int scorer_topk_materialised(sert_scorer* sc, const float* P, int64_t Q, 
                                                 dim, dim, (int)V);
         hipLaunchKernelGGL(topk_rows, dim3((unsigned)qn), dim3(256), 0, st, S, (int)V, k, idx + q0 * k,
                            val + q0 * k, (float*)nullptr);
+        if (sc->bf16) {   // same exact_dot scores and order as the bf16-prefiltered path reports
+            int sn = 2;
+            while (sn < k) sn <<= 1;
+            hipLaunchKernelGGL(rescore_topk_rows, dim3((unsigned)qn), dim3(256), (size_t)sn * sizeof(unsigned long long),
+                               st, P + q0 * dim, sc->E, dim, k, idx + q0 * k, val + q0 * k);
+        }
     }
     SERT_HIP(hipEventRecord(sc->ev_done, sc->stream2));
     SERT_HIP(hipStreamWaitEvent(s, sc->ev_done, 0));
@@ -1797,6 +1813,11 @@ static int scorer_topk_fused(sert_scorer* sc, int64_t Q, int k, int rs) {
         SERT_TRY(dmalloc(&sc->nflag, (size_t)1));
         sc->cap_flag = Q;
     }
+    if (sc->bf16 && sc->cap_p16 < QT * sc->kp) {
+        (void)hipFree(sc->P16); sc->P16 = nullptr; sc->cap_p16 = 0;
+        SERT_TRY(dmalloc(&sc->P16, (size_t)(QT * sc->kp)));
+        sc->cap_p16 = QT * sc->kp;
+    }
     SERT_HIP(hipMemsetAsync(sc->nflag, 0, sizeof(int), s));
     for (int64_t q0 = 0; q0 < Q; q0 += QT) {
         const int64_t qn = std::min(QT, Q - q0);
@@ -1810,7 +1831,10 @@ static int scorer_topk_fused(sert_scorer* sc, int64_t Q, int k, int rs) {
         else
             hipLaunchKernelGGL(kth_largest_rows, dim3((unsigned)qn), dim3(256), 0, s, sc->Ss, (int)Vs, rs, sc->thr);
         // 2. full GEMM, filtering epilogue
-        if (scorer_big_tile(sc))
+        if (sc->bf16) {
+            hipLaunchKernelGGL(to_bf16_rows, dim3(grid_for(qn * sc->kp)), dim3(256), 0, s, P, qn, dim, sc->kp, sc->P16);
+            launch_score_filter_bf16(s, sc->P16, sc->E16, sc->thr, sc->cand, sc->cnt, ngroups, gcap, (int)qn, (int)V, sc->kp);
+        } else if (scorer_big_tile(sc))
             launch_gemm_big_filter(s, P, sc->E, sc->thr, sc->cand, sc->cnt, ngroups, gcap, (int)qn, (int)V, dim, dim, dim,
                                    scorer_big_tile(sc) == 2);
         else
@@ -1820,9 +1844,14 @@ static int scorer_topk_fused(sert_scorer* sc, int64_t Q, int k, int rs) {
         // candidate capacity: expected 2k+400, sigma ~ 16 sqrt(rs): the next power of two above +6 sigma
         int ccap = 1024;
         while (ccap < 2 * k + 400 + 6 * 16 * (int)ceilf(sqrtf((float)rs)) && ccap < kCandCap) ccap <<= 1;
-        hipLaunchKernelGGL(topk_from_groups, dim3((unsigned)qn), dim3(256), (size_t)ccap * sizeof(unsigned long long), s,
-                           sc->cand, sc->cnt, ngroups, gcap, k, sc->idx + q0 * k, sc->val + q0 * k, (int)q0,
-                           sc->nflag, sc->flag_list, ccap);
+        if (sc->bf16)
+            hipLaunchKernelGGL(topk_from_groups_rescore, dim3((unsigned)qn), dim3(256), (size_t)ccap * sizeof(unsigned long long), s,
+                               sc->cand, sc->cnt, ngroups, gcap, k, sc->idx + q0 * k, sc->val + q0 * k, (int)q0,
+                               sc->nflag, sc->flag_list, ccap, P, sc->E, dim, sc->thr);
+        else
+            hipLaunchKernelGGL(topk_from_groups, dim3((unsigned)qn), dim3(256), (size_t)ccap * sizeof(unsigned long long), s,
+                               sc->cand, sc->cnt, ngroups, gcap, k, sc->idx + q0 * k, sc->val + q0 * k, (int)q0,
+                               sc->nflag, sc->flag_list, ccap);
     }
     int nf = 0;
     SERT_HIP(hipMemcpyAsync(&nf, sc->nflag, sizeof(int), hipMemcpyDeviceToHost, s));

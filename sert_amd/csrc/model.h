@@ -198,7 +198,7 @@ struct sert_scorer {
     int64_t cap_ss = 0, cap_ft = 0, cap_cand = 0, cap_flag = 0, cap_c = 0, cap_ck = 0;
     // bf16 prefilter (kernels_score_bf16.h): bf16 copies of E and of the current query tile,
     // rows zero-padded to kp columns
-    bool bf16 = false;
+    bool bf16 = false, bf16_demoted = false;
     int kp = 0;
     uint16_t* E16 = nullptr; uint16_t* P16 = nullptr;
     int64_t cap_p16 = 0;

@@ -1813,7 +1813,10 @@ static int scorer_topk_fused(sert_scorer* sc, int64_t Q, int k, int rs) {
         SERT_TRY(dmalloc(&sc->nflag, (size_t)1));
         sc->cap_flag = Q;
     }
-    if (sc->bf16 && sc->cap_p16 < QT * sc->kp) {
+    // the bf16 prefilter needs a gap of 2 delta between the k-th score and the filter threshold;
+    // a table whose rows mostly lack it (very high d_e, heavy ties) is scored in fp32 from then on
+    const bool use_bf16 = sc->bf16 && !sc->bf16_demoted;
+    if (use_bf16 && sc->cap_p16 < QT * sc->kp) {
         (void)hipFree(sc->P16); sc->P16 = nullptr; sc->cap_p16 = 0;
         SERT_TRY(dmalloc(&sc->P16, (size_t)(QT * sc->kp)));
         sc->cap_p16 = QT * sc->kp;
@@ -1831,7 +1834,7 @@ static int scorer_topk_fused(sert_scorer* sc, int64_t Q, int k, int rs) {
         else
             hipLaunchKernelGGL(kth_largest_rows, dim3((unsigned)qn), dim3(256), 0, s, sc->Ss, (int)Vs, rs, sc->thr);
         // 2. full GEMM, filtering epilogue
-        if (sc->bf16) {
+        if (use_bf16) {
             hipLaunchKernelGGL(to_bf16_rows, dim3(grid_for(qn * sc->kp)), dim3(256), 0, s, P, qn, dim, sc->kp, sc->P16);
             launch_score_filter_bf16(s, sc->P16, sc->E16, sc->thr, sc->cand, sc->cnt, ngroups, gcap, (int)qn, (int)V, sc->kp);
         } else if (scorer_big_tile(sc))
@@ -1844,10 +1847,10 @@ static int scorer_topk_fused(sert_scorer* sc, int64_t Q, int k, int rs) {
         // candidate capacity: expected 2k+400, sigma ~ 16 sqrt(rs): the next power of two above +6 sigma
         int ccap = 1024;
         while (ccap < 2 * k + 400 + 6 * 16 * (int)ceilf(sqrtf((float)rs)) && ccap < kCandCap) ccap <<= 1;
-        if (sc->bf16)
+        if (use_bf16)
             hipLaunchKernelGGL(topk_from_groups_rescore, dim3((unsigned)qn), dim3(256), (size_t)ccap * sizeof(unsigned long long), s,
                                sc->cand, sc->cnt, ngroups, gcap, k, sc->idx + q0 * k, sc->val + q0 * k, (int)q0,
-                               sc->nflag, sc->flag_list, ccap, P, sc->E, dim, sc->thr);
+                               sc->nflag, sc->flag_list, ccap, P, sc->E, dim, sc->thr, bf16_delta(dim));
         else
             hipLaunchKernelGGL(topk_from_groups, dim3((unsigned)qn), dim3(256), (size_t)ccap * sizeof(unsigned long long), s,
                                sc->cand, sc->cnt, ngroups, gcap, k, sc->idx + q0 * k, sc->val + q0 * k, (int)q0,
@@ -1857,6 +1860,7 @@ static int scorer_topk_fused(sert_scorer* sc, int64_t Q, int k, int rs) {
     SERT_HIP(hipMemcpyAsync(&nf, sc->nflag, sizeof(int), hipMemcpyDeviceToHost, s));
     SERT_HIP(hipStreamSynchronize(s));
     if (nf == 0) return 0;
+    if (use_bf16 && (int64_t)nf * 4 > Q && Q >= 64) sc->bf16_demoted = true;
     // rows the sample misjudged: recompute exactly (ascending order, for reproducibility)
     std::vector<int> list((size_t)nf);
     SERT_HIP(hipMemcpy(list.data(), sc->flag_list, (size_t)nf * sizeof(int), hipMemcpyDeviceToHost));

@@ -309,3 +309,30 @@ def test_instances_to_arrays_matches_reference():
         assert y.indptr.tolist() == case['y_indptr']
         assert y.indices.tolist() == case['y_indices']
         assert [float(v) for v in y.data] == case['y_data']
+
+
+def test_bf16_prefilter_error_bound():
+    """kernels_score_bf16.h: |<bf16(a), bf16(b)> - <a, b>| <= kBf16Delta = 0.0079 whenever
+    |a|, |b| <= 1 (bf16 keeps 8 significant bits: round-to-nearest error <= 2^-8 relative per
+    operand, products exact in fp32).  The bound is attained to within 1 % by a = b with every
+    component just below a rounding boundary, and random unit vectors stay far inside it."""
+    def bf16(x):
+        u = x.astype(np.float32).view(np.uint32).astype(np.uint64)
+        u = (u + 0x7fff + ((u >> 16) & 1)) >> 16 << 16
+        return u.astype(np.uint32).view(np.float32)
+    delta = 0.0079
+    # worst case: v = 2^-4 (1 + 2^-8 - 2^-20) rounds down to 2^-4; 254 copies have norm < 1
+    v = np.float32(2.0 ** -4 * (1 + 2.0 ** -8 - 2.0 ** -20))
+    a = np.full(254, v, np.float32)
+    assert float(np.linalg.norm(a.astype(np.float64))) <= 1.0 and bf16(a)[0] == np.float32(2.0 ** -4)
+    err = abs(float(np.dot(bf16(a).astype(np.float64), bf16(a).astype(np.float64))) -
+              float(np.dot(a.astype(np.float64), a.astype(np.float64))))
+    assert 0.99 * 2.0 ** -7 < err <= delta
+    rng = np.random.RandomState(5)
+    for d in (32, 128, 300):
+        x = rng.randn(4000, d); y = rng.randn(4000, d)
+        x /= np.linalg.norm(x, axis=1, keepdims=True); y /= np.linalg.norm(y, axis=1, keepdims=True)
+        x32, y32 = x.astype(np.float32), y.astype(np.float32)
+        exact = np.einsum('ij,ij->i', x32.astype(np.float64), y32.astype(np.float64))
+        approx = np.einsum('ij,ij->i', bf16(x32).astype(np.float64), bf16(y32).astype(np.float64))
+        assert float(np.abs(approx - exact).max()) < delta / 4

@@ -255,6 +255,33 @@ def test_score_topk_fused_equals_materialised(hip_lib, monkeypatch):
         assert np.array_equal(val_f, ref['val'])
 
 
+def test_score_topk_bf16_prefilter_near_ties(hip_lib):
+    """bf16 cannot order a cluster of near-duplicate entities (score gaps ~1e-5 << 2^-8): the
+    prefilter may only decide what gets re-scored, the reported ranking is the fp32 one."""
+    rng = np.random.RandomState(23)
+    V, d, Q, k = 40000, 64, 24, 100
+    E = rng.randn(V, d).astype(np.float32)
+    u = rng.randn(d).astype(np.float32)
+    cluster = rng.choice(V, 1500, replace=False)
+    E[cluster] = u + 2e-3 * rng.randn(cluster.size, d).astype(np.float32)
+    Pj = (u + 0.05 * rng.randn(Q, d)).astype(np.float32)
+    idx, val = C.score_topk(E, Pj, k)
+    assert np.isin(idx, cluster).all()          # the top 100 all come from the cluster
+    _check_topk_against_oracle(E, Pj, idx, val, k)
+
+
+def test_score_topk_bf16_prefilter_no_gap_falls_back(hip_lib):
+    """Every entity within ~1e-2 of every other: no 2-delta gap between the k-th score and the
+    filter threshold, so the bf16 path must hand the rows to the exact fp32 path."""
+    rng = np.random.RandomState(29)
+    V, d, Q, k = 36000, 32, 9, 50
+    u = rng.randn(d).astype(np.float32)
+    E = (u + 5e-3 * rng.randn(V, d)).astype(np.float32)
+    Pj = (u + 0.05 * rng.randn(Q, d)).astype(np.float32)
+    idx, val = C.score_topk(E, Pj, k)
+    _check_topk_against_oracle(E, Pj, idx, val, k)
+
+
 @pytest.mark.parametrize('mode', ['1', '2'])
 def test_score_topk_big_tile_variant(hip_lib, mode):
     """SERT_SCORE_BIG_TILE=1|2 (gemm_big.h, ragged M and N): fused == materialised, both == oracle."""

@@ -1827,16 +1827,20 @@ static int scorer_topk_fused(sert_scorer* sc, int64_t Q, int k, int rs) {
         const float* P = sc->P + q0 * dim;
         SERT_HIP(hipMemsetAsync(sc->cnt, 0, (size_t)qn * ngroups, s));
         // 1. cosines against every kScoreStride-th entity; threshold = rs-th best of the sample
-        launch_gemm<false, true, EPI_STORE>(s, P, sc->E, sc->Ss, nullptr, (int)qn, (int)Vs, dim, dim,
-                                            dim * kScoreStride, (int)Vs);
+        // (bf16 scorer: approximate sample scores are as good for choosing a threshold)
+        if (use_bf16) {
+            hipLaunchKernelGGL(to_bf16_rows, dim3(grid_for(qn * sc->kp)), dim3(256), 0, s, P, qn, dim, sc->kp, sc->P16);
+            launch_score_sample_bf16(s, sc->P16, sc->E16, sc->Ss, (int)qn, (int)Vs, sc->kp, kScoreStride);
+        } else
+            launch_gemm<false, true, EPI_STORE>(s, P, sc->E, sc->Ss, nullptr, (int)qn, (int)Vs, dim, dim,
+                                                dim * kScoreStride, (int)Vs);
         if (rs <= 64 && Vs >= 2048)
             hipLaunchKernelGGL(approx_kth_rows, dim3((unsigned)qn), dim3(256), 0, s, sc->Ss, (int)Vs, rs, sc->thr);
         else
             hipLaunchKernelGGL(kth_largest_rows, dim3((unsigned)qn), dim3(256), 0, s, sc->Ss, (int)Vs, rs, sc->thr);
         // 2. full GEMM, filtering epilogue
         if (use_bf16) {
-            hipLaunchKernelGGL(to_bf16_rows, dim3(grid_for(qn * sc->kp)), dim3(256), 0, s, P, qn, dim, sc->kp, sc->P16);
-            launch_score_filter_bf16(s, sc->P16, sc->E16, sc->thr, sc->cand, sc->cnt, ngroups, gcap, (int)qn, (int)V, sc->kp);
+            launch_score_filter_bf16(s, sc->P16, sc->E16, sc->thr, (uint32_t*)sc->cand, sc->cnt, ngroups, gcap, (int)qn, (int)V, sc->kp);
         } else if (scorer_big_tile(sc))
             launch_gemm_big_filter(s, P, sc->E, sc->thr, sc->cand, sc->cnt, ngroups, gcap, (int)qn, (int)V, dim, dim, dim,
                                    scorer_big_tile(sc) == 2);
@@ -1849,7 +1853,7 @@ static int scorer_topk_fused(sert_scorer* sc, int64_t Q, int k, int rs) {
         while (ccap < 2 * k + 400 + 6 * 16 * (int)ceilf(sqrtf((float)rs)) && ccap < kCandCap) ccap <<= 1;
         if (use_bf16)
             hipLaunchKernelGGL(topk_from_groups_rescore, dim3((unsigned)qn), dim3(256), (size_t)ccap * sizeof(unsigned long long), s,
-                               sc->cand, sc->cnt, ngroups, gcap, k, sc->idx + q0 * k, sc->val + q0 * k, (int)q0,
+                               (const uint32_t*)sc->cand, sc->cnt, ngroups, gcap, k, sc->idx + q0 * k, sc->val + q0 * k, (int)q0,
                                sc->nflag, sc->flag_list, ccap, P, sc->E, dim, sc->thr, bf16_delta(dim));
         else
             hipLaunchKernelGGL(topk_from_groups, dim3((unsigned)qn), dim3(256), (size_t)ccap * sizeof(unsigned long long), s,

@@ -1779,32 +1779,42 @@ static int scorer_topk_materialised(sert_scorer* sc, const float* P, int64_t Q, 
 
 // Fused path (kernels_score.h): sampled thresholds, GEMM with a filtering epilogue,
 // selection from the candidate lists; flagged rows are redone by the materialising path.
-static int scorer_topk_fused(sert_scorer* sc, int64_t Q, int k, int rs) {
+// proj / idx_out / score_out: the caller's host arrays.  The projections are uploaded chunk
+// by chunk and each chunk's results are copied out while later chunks compute; *copied_out
+// tells the caller that the host arrays are complete (no row needed the exact fallback).
+static int scorer_topk_fused(sert_scorer* sc, const float* proj, int64_t Q, int k, int rs, int32_t* idx_out,
+                             float* score_out, bool* copied_out) {
+    *copied_out = false;
     hipStream_t s = sc->stream;
     const int64_t V = sc->V;
     const int dim = sc->dim;
     const int64_t Vs = cdiv(V, kScoreStride);
-    const int64_t QT = std::min<int64_t>(Q, 4096);
-    if (sc->cap_ss < QT * Vs) {
+    // Query chunks of <= 4096 rows alternate between two streams, each with its own set of
+    // scratch buffers: the selection kernel of one chunk (latency / random-row bound) runs under
+    // the filter GEMM of the next (VALU / L2 bound).  An even number of equal chunks.
+    const int64_t nchunks = Q <= 1024 ? 1 : 2 * cdiv(Q, (int64_t)2 * 4096);
+    const int64_t QT = std::min<int64_t>(Q, round_up(cdiv(Q, nchunks), 128));
+    if (sc->cap_ss < 2 * QT * Vs) {
         (void)hipFree(sc->Ss); sc->Ss = nullptr; sc->cap_ss = 0;
-        SERT_TRY(dmalloc(&sc->Ss, (size_t)(QT * Vs)));
-        sc->cap_ss = QT * Vs;
+        SERT_TRY(dmalloc(&sc->Ss, (size_t)(2 * QT * Vs)));
+        sc->cap_ss = 2 * QT * Vs;
     }
     // per-(row, 64-entity group) candidate lists: 8 slots for ~0.5 expected entries per
     // group (k <= 128), 16 beyond
     const int ngroups = 2 * cdiv((int)V, GN);
     const int gcap = k <= 128 ? 8 : 16;
-    if (sc->cap_ft < QT) {
+    if (sc->cap_ft < 2 * QT) {
         (void)hipFree(sc->thr); sc->thr = nullptr; sc->cap_ft = 0;
-        SERT_TRY(dmalloc(&sc->thr, (size_t)QT));
-        sc->cap_ft = QT;
+        SERT_TRY(dmalloc(&sc->thr, (size_t)(2 * QT)));
+        sc->cap_ft = 2 * QT;
     }
-    if (sc->cap_cand < QT * ngroups * gcap) {
+    const int64_t cand_set = QT * ngroups * gcap, cnt_set = QT * ngroups;
+    if (sc->cap_cand < 2 * cand_set) {
         (void)hipFree(sc->cand); (void)hipFree(sc->cnt);
         sc->cand = nullptr; sc->cnt = nullptr; sc->cap_cand = 0;
-        SERT_TRY(dmalloc(&sc->cand, (size_t)QT * ngroups * gcap));
-        SERT_TRY(dmalloc(&sc->cnt, (size_t)QT * ngroups * 16 / 8));   // sized for either gcap
-        sc->cap_cand = QT * ngroups * gcap;
+        SERT_TRY(dmalloc(&sc->cand, (size_t)(2 * cand_set)));
+        SERT_TRY(dmalloc(&sc->cnt, (size_t)(2 * QT * ngroups * 16 / 8)));   // sized for either gcap
+        sc->cap_cand = 2 * cand_set;
     }
     if (sc->cap_flag < Q) {
         (void)hipFree(sc->flag_list); (void)hipFree(sc->nflag);
@@ -1816,54 +1826,81 @@ static int scorer_topk_fused(sert_scorer* sc, int64_t Q, int k, int rs) {
     // the bf16 prefilter needs a gap of 2 delta between the k-th score and the filter threshold;
     // a table whose rows mostly lack it (very high d_e, heavy ties) is scored in fp32 from then on
     const bool use_bf16 = sc->bf16 && !sc->bf16_demoted;
-    if (use_bf16 && sc->cap_p16 < QT * sc->kp) {
+    if (use_bf16 && sc->cap_p16 < 2 * QT * sc->kp) {
         (void)hipFree(sc->P16); sc->P16 = nullptr; sc->cap_p16 = 0;
-        SERT_TRY(dmalloc(&sc->P16, (size_t)(QT * sc->kp)));
-        sc->cap_p16 = QT * sc->kp;
+        SERT_TRY(dmalloc(&sc->P16, (size_t)(2 * QT * sc->kp)));
+        sc->cap_p16 = 2 * QT * sc->kp;
     }
     SERT_HIP(hipMemsetAsync(sc->nflag, 0, sizeof(int), s));
-    for (int64_t q0 = 0; q0 < Q; q0 += QT) {
+    SERT_HIP(hipEventRecord(sc->ev_ready, s));           // nflag zeroed, earlier work on s done
+    SERT_HIP(hipStreamWaitEvent(sc->stream2, sc->ev_ready, 0));
+    auto copy_out = [&](int64_t q0, int64_t qn, hipStream_t st) {   // (pageable destination: returns when done)
+        hipError_t e = hipMemcpyAsync(idx_out + q0 * k, sc->idx + q0 * k, (size_t)qn * k * sizeof(int32_t), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(score_out + q0 * k, sc->val + q0 * k, (size_t)qn * k * sizeof(float), hipMemcpyDeviceToHost, st);
+        return e;
+    };
+    int64_t t = 0;
+    for (int64_t q0 = 0; q0 < Q; q0 += QT, ++t) {
         const int64_t qn = std::min(QT, Q - q0);
-        const float* P = sc->P + q0 * dim;
-        SERT_HIP(hipMemsetAsync(sc->cnt, 0, (size_t)qn * ngroups, s));
+        const int set = (int)(t & 1);
+        hipStream_t st = set ? sc->stream2 : s;
+        float* Pw = sc->P + q0 * dim;
+        SERT_HIP(hipMemcpyAsync(Pw, proj + q0 * dim, (size_t)qn * dim * sizeof(float), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(l2_normalize_rows, dim3(cdiv(qn, 4)), dim3(256), 0, st, Pw, qn, dim);
+        const float* P = Pw;
+        float* Ss = sc->Ss + (size_t)set * QT * Vs;
+        float* thr = sc->thr + (size_t)set * QT;
+        unsigned long long* cand = sc->cand + (size_t)set * cand_set;
+        unsigned char* cnt = sc->cnt + (size_t)set * cnt_set;
+        uint16_t* P16 = use_bf16 ? sc->P16 + (size_t)set * QT * sc->kp : nullptr;
+        SERT_HIP(hipMemsetAsync(cnt, 0, (size_t)qn * ngroups, st));
         // 1. cosines against every kScoreStride-th entity; threshold = rs-th best of the sample
         // (bf16 scorer: approximate sample scores are as good for choosing a threshold)
         if (use_bf16) {
-            hipLaunchKernelGGL(to_bf16_rows, dim3(grid_for(qn * sc->kp)), dim3(256), 0, s, P, qn, dim, sc->kp, sc->P16);
-            launch_score_sample_bf16(s, sc->P16, sc->E16, sc->Ss, (int)qn, (int)Vs, sc->kp, kScoreStride);
+            hipLaunchKernelGGL(to_bf16_rows, dim3(grid_for(qn * sc->kp)), dim3(256), 0, st, P, qn, dim, sc->kp, P16);
+            launch_score_sample_bf16(st, P16, sc->E16, Ss, (int)qn, (int)Vs, sc->kp, kScoreStride);
         } else
-            launch_gemm<false, true, EPI_STORE>(s, P, sc->E, sc->Ss, nullptr, (int)qn, (int)Vs, dim, dim,
+            launch_gemm<false, true, EPI_STORE>(st, P, sc->E, Ss, nullptr, (int)qn, (int)Vs, dim, dim,
                                                 dim * kScoreStride, (int)Vs);
         if (rs <= 64 && Vs >= 2048)
-            hipLaunchKernelGGL(approx_kth_rows, dim3((unsigned)qn), dim3(256), 0, s, sc->Ss, (int)Vs, rs, sc->thr);
+            hipLaunchKernelGGL(approx_kth_rows, dim3((unsigned)qn), dim3(256), 0, st, Ss, (int)Vs, rs, thr);
         else
-            hipLaunchKernelGGL(kth_largest_rows, dim3((unsigned)qn), dim3(256), 0, s, sc->Ss, (int)Vs, rs, sc->thr);
+            hipLaunchKernelGGL(kth_largest_rows, dim3((unsigned)qn), dim3(256), 0, st, Ss, (int)Vs, rs, thr);
         // 2. full GEMM, filtering epilogue
         if (use_bf16) {
-            launch_score_filter_bf16(s, sc->P16, sc->E16, sc->thr, (uint32_t*)sc->cand, sc->cnt, ngroups, gcap, (int)qn, (int)V, sc->kp);
+            launch_score_filter_bf16(st, P16, sc->E16, thr, (uint32_t*)cand, cnt, ngroups, gcap, (int)qn, (int)V, sc->kp);
         } else if (scorer_big_tile(sc))
-            launch_gemm_big_filter(s, P, sc->E, sc->thr, sc->cand, sc->cnt, ngroups, gcap, (int)qn, (int)V, dim, dim, dim,
+            launch_gemm_big_filter(st, P, sc->E, thr, cand, cnt, ngroups, gcap, (int)qn, (int)V, dim, dim, dim,
                                    scorer_big_tile(sc) == 2);
         else
-            launch_gemm<false, true, EPI_FILTER>(s, P, sc->E, nullptr, sc->thr, (int)qn, (int)V, dim, dim, dim,
-                                                 (int)V, 1, 0, 0, sc->cand, sc->cnt, gcap);
+            launch_gemm<false, true, EPI_FILTER>(st, P, sc->E, nullptr, thr, (int)qn, (int)V, dim, dim, dim,
+                                                 (int)V, 1, 0, 0, cand, cnt, gcap);
         // 3. selection from the candidate lists
         // candidate capacity: expected 2k+400, sigma ~ 16 sqrt(rs): the next power of two above +6 sigma
         int ccap = 1024;
         while (ccap < 2 * k + 400 + 6 * 16 * (int)ceilf(sqrtf((float)rs)) && ccap < kCandCap) ccap <<= 1;
         if (use_bf16)
-            hipLaunchKernelGGL(topk_from_groups_rescore, dim3((unsigned)qn), dim3(256), (size_t)ccap * sizeof(unsigned long long), s,
-                               (const uint32_t*)sc->cand, sc->cnt, ngroups, gcap, k, sc->idx + q0 * k, sc->val + q0 * k, (int)q0,
-                               sc->nflag, sc->flag_list, ccap, P, sc->E, dim, sc->thr, bf16_delta(dim));
+            hipLaunchKernelGGL(topk_from_groups_rescore, dim3((unsigned)qn), dim3(256), (size_t)ccap * sizeof(unsigned long long), st,
+                               (const uint32_t*)cand, cnt, ngroups, gcap, k, sc->idx + q0 * k, sc->val + q0 * k, (int)q0,
+                               sc->nflag, sc->flag_list, ccap, P, sc->E, dim, thr, bf16_delta(dim));
         else
-            hipLaunchKernelGGL(topk_from_groups, dim3((unsigned)qn), dim3(256), (size_t)ccap * sizeof(unsigned long long), s,
-                               sc->cand, sc->cnt, ngroups, gcap, k, sc->idx + q0 * k, sc->val + q0 * k, (int)q0,
+            hipLaunchKernelGGL(topk_from_groups, dim3((unsigned)qn), dim3(256), (size_t)ccap * sizeof(unsigned long long), st,
+                               cand, cnt, ngroups, gcap, k, sc->idx + q0 * k, sc->val + q0 * k, (int)q0,
                                sc->nflag, sc->flag_list, ccap);
+        // results of the previous chunk (other stream) travel while this one computes
+        if (t >= 1) SERT_HIP(copy_out(q0 - QT, QT, set ? s : sc->stream2));
     }
+    {
+        const int64_t q_last = (t - 1) * QT;
+        SERT_HIP(copy_out(q_last, Q - q_last, ((t - 1) & 1) ? sc->stream2 : s));
+    }
+    SERT_HIP(hipEventRecord(sc->ev_done, sc->stream2));
+    SERT_HIP(hipStreamWaitEvent(s, sc->ev_done, 0));
     int nf = 0;
     SERT_HIP(hipMemcpyAsync(&nf, sc->nflag, sizeof(int), hipMemcpyDeviceToHost, s));
     SERT_HIP(hipStreamSynchronize(s));
-    if (nf == 0) return 0;
+    if (nf == 0) { *copied_out = true; return 0; }
     if (use_bf16 && (int64_t)nf * 4 > Q && Q >= 64) sc->bf16_demoted = true;
     // rows the sample misjudged: recompute exactly (ascending order, for reproducibility)
     std::vector<int> list((size_t)nf);
@@ -1914,8 +1951,6 @@ int sert_scorer_topk(sert_scorer* sc, const float* proj, int64_t Q, int32_t k, i
         SERT_TRY(dmalloc(&sc->idx, (size_t)Q * k));
         sc->cap_qk = Q * k;
     }
-    SERT_HIP(hipMemcpyAsync(sc->P, proj, (size_t)Q * dim * sizeof(float), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(l2_normalize_rows, dim3(cdiv(Q, 4)), dim3(256), 0, s, sc->P, Q, dim);
     // fused path for large entity tables: the sample must be big enough for a stable
     // threshold: rank rs among the V/16 sampled entities, i.e. an expected 2k+400 (std ~
     // sqrt(rs)*16) candidates of V -- at k=100: 608 +- 99, >= k at 5 sigma, <= 1024 at 4
@@ -1923,9 +1958,15 @@ int sert_scorer_topk(sert_scorer* sc, const float* proj, int64_t Q, int32_t k, i
     static const bool never_fuse = getenv("SERT_SCORE_MATERIALISE") != nullptr;   // cross-check knob
     const bool fused = !never_fuse && V >= 32768 && dim % 4 == 0 && rs <= kTopKMax &&
                        cdiv(V, kScoreStride) >= 8 * (int64_t)rs;
-    if (fused) SERT_TRY(scorer_topk_fused(sc, Q, k, rs));
-    else       SERT_TRY(scorer_topk_materialised(sc, sc->P, Q, k, sc->idx, sc->val));
+    bool copied = false;
+    if (fused) SERT_TRY(scorer_topk_fused(sc, proj, Q, k, rs, idx_out, score_out, &copied));
+    else {
+        SERT_HIP(hipMemcpyAsync(sc->P, proj, (size_t)Q * dim * sizeof(float), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(l2_normalize_rows, dim3(cdiv(Q, 4)), dim3(256), 0, s, sc->P, Q, dim);
+        SERT_TRY(scorer_topk_materialised(sc, sc->P, Q, k, sc->idx, sc->val));
+    }
     SERT_HIP(hipGetLastError());
+    if (copied) return 0;
     SERT_HIP(hipMemcpyAsync(idx_out, sc->idx, (size_t)Q * k * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     SERT_HIP(hipMemcpyAsync(score_out, sc->val, (size_t)Q * k * sizeof(float), hipMemcpyDeviceToHost, s));
     SERT_HIP(hipStreamSynchronize(s));

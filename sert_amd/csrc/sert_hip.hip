@@ -1789,10 +1789,11 @@ static int scorer_topk_fused(sert_scorer* sc, const float* proj, int64_t Q, int 
     const int64_t V = sc->V;
     const int dim = sc->dim;
     const int64_t Vs = cdiv(V, kScoreStride);
-    // Query chunks of <= 4096 rows alternate between two streams, each with its own set of
+    // Query chunks of <= 8192 rows alternate between two streams, each with its own set of
     // scratch buffers: the selection kernel of one chunk (latency / random-row bound) runs under
     // the filter GEMM of the next (VALU / L2 bound).  An even number of equal chunks.
-    const int64_t nchunks = Q <= 1024 ? 1 : 2 * cdiv(Q, (int64_t)2 * 4096);
+    static const int64_t chunk_rows = getenv("SERT_SCORE_CHUNK") ? atoll(getenv("SERT_SCORE_CHUNK")) : 8192;   // tuning knob
+    const int64_t nchunks = Q <= 1024 ? 1 : 2 * cdiv(Q, 2 * chunk_rows);
     const int64_t QT = std::min<int64_t>(Q, round_up(cdiv(Q, nchunks), 128));
     if (sc->cap_ss < 2 * QT * Vs) {
         (void)hipFree(sc->Ss); sc->Ss = nullptr; sc->cap_ss = 0;

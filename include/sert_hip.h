@@ -199,7 +199,11 @@ int sert_scorer_destroy(sert_scorer* s);
  * (query.py:352-357) and return the k best per query, sorted by score
  * descending, ties by lowest entity index (replaces kneighbors / cdist+argsort,
  * query.py:304-318, and the Python candidate loop :348-365).
- *   proj (Q, d) f32 host;  idx_out (Q, k) int32;  score_out (Q, k) f32;  1 <= k <= min(V_e, 1024) */
+ *   proj (Q, d) f32 host;  idx_out (Q, k) int32;  score_out (Q, k) f32;  1 <= k <= min(V_e, 1024)
+ * The ranking and the scores are those of the fp32 cosine.  For large tables (V_e >= 32768) the
+ * candidates are found by a bf16 matrix-pipe pass whose proven error bound decides which
+ * entities get the fp32 score; rows where that bound cannot separate the top k are computed in
+ * fp32 throughout (csrc/kernels_score_bf16.h).  SERT_SCORE_FP32=1 disables the bf16 pass. */
 int sert_scorer_topk(sert_scorer* s, const float* proj, int64_t num_queries, int32_t k,
                      int32_t* idx_out, float* score_out);
 

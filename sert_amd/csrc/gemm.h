@@ -287,11 +287,7 @@ __global__ __launch_bounds__(256, SERT_GEMM_WAVES) void gemm_f32_mfma(const Gemm
             }
 #pragma unroll
             for (int kk = 0; kk < GK; kk += 2) {
-#ifdef SERT_GEMM_EXP_NOLDS
-                const int k = lh;          // EXPERIMENT (wrong results): one fragment set per slab
-#else
                 const int k = kk + lh;
-#endif
                 const float a0 = As[buf][k][wr * 64 + li];
                 const float a1 = As[buf][k][wr * 64 + 32 + li];
                 const float b0 = Bs[buf][k][wc * 64 + li];

@@ -201,7 +201,7 @@ def _check_topk_against_oracle(E, Pj, idx, val, k):
 
 
 @pytest.mark.parametrize('V,d,Q,k', [(40000, 16, 37, 10), (65536, 32, 130, 100), (50001, 64, 9, 1000),
-                                     (33333, 300, 21, 100)])
+                                     (33333, 300, 21, 100), (140001, 16, 5, 10)])
 def test_score_topk_fused_filter_path(hip_lib, V, d, Q, k):
     """V >= 32768: sampled thresholds + GEMM with a filtering epilogue + selection from
     the candidate lists (the score matrix is never materialised); same contract."""

@@ -87,7 +87,7 @@ KERNEL_OF_GROUP = {
     'word_grad_segsum': 'segsum_rows<32, false, false>', 'optimizer_word_table': 'adam_l2<false>',
     'optimizer_other': 'adam_l2<false>', 'entity_sort': 'csort_scatter',
 }
-PMC_FILE = 'profiles/r01_g_vs_c2_pmc.json'
+PMC_FILE = 'profiles/r01_h_vs_c2_pmc.json'
 
 
 def load_pmc():

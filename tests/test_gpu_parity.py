@@ -256,6 +256,26 @@ def test_score_topk_fused_equals_materialised(hip_lib, monkeypatch):
         assert np.array_equal(val_f, ref['val'])
 
 
+def test_score_topk_fp32_filter_path(hip_lib):
+    """SERT_SCORE_FP32=1: the fp32 filtering GEMM (gemm.h EPI_FILTER + topk_from_groups) that the
+    scorer falls back to when the bf16 prefilter is demoted -- same contract."""
+    rng = np.random.RandomState(31)
+    V, d, Q, k = 45001, 32, 70, 100
+    E = rng.randn(V, d).astype(np.float32)
+    Pj = np.tanh(rng.randn(Q, d)).astype(np.float32)
+    code = ("import numpy as np, sys; sys.path.insert(0, %r); from sert_amd import _capi as C;"
+            "d = np.load(sys.argv[1]); idx, val = C.score_topk(d['E'], d['Pj'], %d);"
+            "np.savez(sys.argv[2], idx=idx, val=val)" % (U.ROOT, k))
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        inp, out = os.path.join(tmp, 'in.npz'), os.path.join(tmp, 'out.npz')
+        np.savez(inp, E=E, Pj=Pj)
+        subprocess.run([sys.executable, '-c', code, inp, out], check=True,
+                       env=dict(os.environ, SERT_SCORE_FP32='1'))
+        r = np.load(out)
+        _check_topk_against_oracle(E, Pj, r['idx'], r['val'], k)
+
+
 def test_score_topk_bf16_prefilter_near_ties(hip_lib):
     """bf16 cannot order a cluster of near-duplicate entities (score gaps ~1e-5 << 2^-8): the
     prefilter may only decide what gets re-scored, the reported ranking is the fp32 one."""

@@ -175,6 +175,14 @@ int sert_train_batches(sert_model* m, const int64_t* batch_indices, int64_t coun
 int sert_eval_batch(sert_model* m, int split, int64_t batch_index,
                     const int64_t* negatives, float* loss_out);
 
+/* The same for `count` batches with ONE host synchronisation (device-drawn negatives): the
+ * error passes of bin/train.py (train_error / validation_error, models.py:649-668, run before
+ * training and after every epoch, train.py:262-348) are loops over all batches whose results
+ * are only averaged.  losses_out[i] = the value sert_eval_batch would return for
+ * batch_indices[i], in order; a non-finite value is reported by the caller after the call. */
+int sert_eval_batches(sert_model* m, int split, const int64_t* batch_indices, int64_t count,
+                      float* losses_out);
+
 /* vectorspace predict_fn (models.py:1107-1118), batched over Q queries:
  * out[q] = tanh(avg[q] . W + b)   (no clip).  avg (Q, d_w), out (Q, d_e). */
 int sert_predict_project(sert_model* m, const float* avg, int64_t num_queries, float* out);

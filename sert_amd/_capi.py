@@ -27,7 +27,7 @@ EXPORTS = [
     'sert_create', 'sert_destroy', 'sert_last_error', 'sert_device_info', 'sert_device_count',
     'sert_set_tensor', 'sert_get_tensor', 'sert_tensor_size', 'sert_set_step', 'sert_get_step',
     'sert_upload_dataset', 'sert_train_batch', 'sert_hint_next_batch', 'sert_train_batches',
-    'sert_eval_batch',
+    'sert_eval_batch', 'sert_eval_batches',
     'sert_predict_project', 'sert_predict_tokens', 'sert_score_topk',
     'sert_scorer_create', 'sert_scorer_destroy', 'sert_scorer_topk', 'sert_scorer_scores',
     'sert_comm_unique_id', 'sert_comm_init', 'sert_comm_init_host', 'sert_comm_destroy',
@@ -104,6 +104,7 @@ def load():
     lib.sert_train_batches.argtypes = [vp, fp, i64, fp]
     lib.sert_hint_next_batch.argtypes = [vp, i64]
     lib.sert_eval_batch.argtypes = [vp, ctypes.c_int, i64, fp, ctypes.POINTER(ctypes.c_float)]
+    lib.sert_eval_batches.argtypes = [vp, ctypes.c_int, ctypes.c_void_p, i64, ctypes.c_void_p]
     lib.sert_predict_project.argtypes = [vp, fp, i64, fp]
     lib.sert_predict_tokens.argtypes = [vp, fp, i64, fp]
     lib.sert_score_topk.argtypes = [ctypes.c_int, fp, i64, i32, fp, i64, i32, fp, fp]
@@ -260,6 +261,14 @@ class Engine(object):
         check(self._lib.sert_eval_batch(self._h, split, int(batch_index), _addr(negatives),
                                         ctypes.byref(loss)))
         return np.float32(loss.value)
+
+    def eval_batches(self, split, batch_indices):
+        """Unweighted batch-mean losses of several batches, one host synchronisation."""
+        idx = np.ascontiguousarray(batch_indices, dtype=np.int64)
+        out = np.empty(idx.shape[0], dtype=np.float32)
+        if idx.shape[0]:
+            check(self._lib.sert_eval_batches(self._h, split, idx.ctypes.data, idx.shape[0], out.ctypes.data))
+        return out
 
     def predict_project(self, avg):
         avg = np.ascontiguousarray(avg, dtype=np.float32)

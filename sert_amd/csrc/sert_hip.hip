@@ -1588,15 +1588,11 @@ int sert_train_batches(sert_model* m, const int64_t* batch_indices, int64_t coun
     return 0;
 }
 
-int sert_eval_batch(sert_model* m, int split, int64_t batch_index, const int64_t* negatives, float* loss_out) {
-    if (!m) SERT_FAIL("null model");
-    invalidate_speculation(m);   // evaluation reuses the activation buffers and the negatives
-    if (split != SERT_SPLIT_TRAIN && split != SERT_SPLIT_VALIDATE) SERT_FAIL("bad split");
-    SERT_HIP(hipSetDevice(m->cfg.device));
-    const DataSplit& ds = m->split[split];
+// One evaluation pass over a batch, enqueued on the main stream: forward + loss kernel, then the
+// unweighted, unregularised batch mean (models.py:751-752) into dst[0] (device).
+static int eval_step_async(sert_model* m, const DataSplit& ds, int64_t batch_index, const int64_t* negatives,
+                           float* dst) {
     const int B = m->cfg.batch_size;
-    if (m->cfg.inference_only) SERT_FAIL("model was created inference_only");
-    if (batch_index < 0 || (batch_index + 1) * (int64_t)B > ds.N) SERT_FAIL("batch_index out of range");
     if (is_fs(m)) {
         SERT_TRY(fs_forward<false>(m, ds, batch_index));
     } else if (is_vs(m)) {
@@ -1606,11 +1602,28 @@ int sert_eval_batch(sert_model* m, int split, int64_t batch_index, const int64_t
     } else {
         SERT_TRY(ll_forward<false>(m, ds, batch_index));
     }
-    // mean over the batch, no weights, no regulariser (models.py:751-752)
     const int nb = std::min(kOptBlocks, cdiv(B, 256));
     hipLaunchKernelGGL(sum_partial, dim3(nb), dim3(256), 0, m->stream, m->rowloss, (size_t)B, m->red_loss);
     hipLaunchKernelGGL(finalize_loss, dim3(1), dim3(256), 0, m->stream, m->red_loss, nb, m->red_loss, 0,
-                       1.0f / (float)B, 0.0f, m->d_loss);
+                       1.0f / (float)B, 0.0f, dst);
+    return 0;
+}
+
+static int eval_check_args(sert_model* m, int split) {
+    if (!m) SERT_FAIL("null model");
+    if (split != SERT_SPLIT_TRAIN && split != SERT_SPLIT_VALIDATE) SERT_FAIL("bad split");
+    if (m->cfg.inference_only) SERT_FAIL("model was created inference_only");
+    return 0;
+}
+
+int sert_eval_batch(sert_model* m, int split, int64_t batch_index, const int64_t* negatives, float* loss_out) {
+    SERT_TRY(eval_check_args(m, split));
+    invalidate_speculation(m);   // evaluation reuses the activation buffers and the negatives
+    SERT_HIP(hipSetDevice(m->cfg.device));
+    const DataSplit& ds = m->split[split];
+    const int B = m->cfg.batch_size;
+    if (batch_index < 0 || (batch_index + 1) * (int64_t)B > ds.N) SERT_FAIL("batch_index out of range");
+    SERT_TRY(eval_step_async(m, ds, batch_index, negatives, m->d_loss));
     SERT_HIP(hipMemcpyAsync(m->h_loss, m->d_loss, 3 * sizeof(float), hipMemcpyDeviceToHost, m->stream));
     SERT_HIP(hipStreamSynchronize(m->stream));
     float v = m->h_loss[0];
@@ -1626,6 +1639,43 @@ int sert_eval_batch(sert_model* m, int split, int64_t batch_index, const int64_t
     }
     timing_collect(m);
     if (loss_out) *loss_out = v;
+    return 0;
+}
+
+int sert_eval_batches(sert_model* m, int split, const int64_t* batch_indices, int64_t count, float* losses_out) {
+    SERT_TRY(eval_check_args(m, split));
+    if (!batch_indices || count < 0) SERT_FAIL("bad argument");
+    if (count == 0) return 0;
+    invalidate_speculation(m);
+    SERT_HIP(hipSetDevice(m->cfg.device));
+    const DataSplit& ds = m->split[split];
+    const int B = m->cfg.batch_size;
+    for (int64_t i = 0; i < count; ++i)
+        if (batch_indices[i] < 0 || (batch_indices[i] + 1) * (int64_t)B > ds.N) SERT_FAIL("batch_index out of range");
+    if (m->d_losses_cap < count) {
+        (void)hipFree(m->d_losses); m->d_losses = nullptr; m->d_losses_cap = 0;
+        SERT_TRY(dmalloc(&m->d_losses, (size_t)count * 3));
+        m->d_losses_cap = count;
+    }
+    // every batch writes its mean to its own slot: the host synchronises once per call
+    for (int64_t i = 0; i < count; ++i) {
+        SERT_TRY(eval_step_async(m, ds, batch_indices[i], nullptr, m->d_losses + 3 * i));
+        if (m->timing.enabled) {  // events are single-slot: drain per step when timing
+            SERT_HIP(hipStreamSynchronize(m->stream));
+            timing_collect(m);
+        }
+    }
+    if (is_dp(m)) {
+        // global mean = mean of the per-rank means (equal shares): one collective over all slots
+        if (m->host_ar) SERT_TRY(host_allreduce(m, m->d_losses, (size_t)count * 3, m->stream));
+        else            SERT_NCCL(g_rccl.AllReduce(m->d_losses, m->d_losses, (size_t)count * 3, 7, 0, m->comm, m->stream));
+    }
+    std::vector<float> tmp((size_t)count * 3);
+    SERT_HIP(hipMemcpyAsync(tmp.data(), m->d_losses, count * 3 * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+    SERT_HIP(hipStreamSynchronize(m->stream));
+    const float scale = is_dp(m) ? 1.0f / (float)m->world : 1.0f;
+    if (losses_out)
+        for (int64_t i = 0; i < count; ++i) losses_out[i] = tmp[3 * i] * scale;
     return 0;
 }
 

@@ -160,6 +160,11 @@ class ModelBase(ModelInterface):
     #: reference's behaviour (one host synchronisation and finite-check per batch,
     #: models.py:369-379); k > 1 defers the check by up to k-1 batches.
     steps_per_sync = 1
+    #: batches per host synchronisation in train_error() / validation_error().  Their
+    #: per-batch results are only averaged (models.py:649-668), so the passes issue
+    #: chunks of batches and check for non-finite values per chunk; 1 = one
+    #: synchronisation per batch as in the reference loop.  Same values either way.
+    eval_batches_per_sync = 32
 
     def __init__(self, batch_size,
                  training_set, validation_set,
@@ -352,13 +357,44 @@ class ModelBase(ModelInterface):
                      '0 minutes 0 seconds remaining.', len(results), len(results) / elapsed)
         return num_batches, results
 
+    def _iterate_eval(self, fn, split, num_instances):
+        """An error pass: _iterate_batches(fn, ...) semantics (batch order, tail drop,
+        RuntimeError text, log line) with chunked read-back when allowed."""
+        chunk = int(self.eval_batches_per_sync)
+        if chunk <= 1 or self.eval_negative_sampler is not None or \
+                not hasattr(self._engine, 'eval_batches'):
+            return self._iterate_batches(fn, num_instances)
+        start = time.time()
+        num_batches = self._number_of_batches(num_instances)
+        if num_instances % self.batch_size > 0:
+            logging.warning('\tIgnoring incomplete batch of size %d.',
+                            num_instances % self.batch_size)
+        results = []
+        for lo in range(0, num_batches, chunk):
+            losses = self._engine.eval_batches(
+                split, np.arange(lo, min(lo + chunk, num_batches), dtype=np.int64))
+            for loss in losses:
+                results.append(loss)
+                if not np.isfinite(loss):
+                    raise RuntimeError(
+                        'Encountered NaN or infinity ({error}) '
+                        'during batch iteration '
+                        '(batch {batches_finished}/{num_batches}).'.format(
+                            error=loss, batches_finished=len(results),
+                            num_batches=num_batches))
+        if num_batches:
+            elapsed = max(float(time.time() - start), 1e-9)
+            logging.info('\tProcessed %d batches; %.2f batches per second; '
+                         '0 minutes 0 seconds remaining.', len(results), len(results) / elapsed)
+        return num_batches, results
+
     def train_error(self):
         logging.info('Measuring error on %d training instances (%d batches).',
                      self.training_num_instances,
                      self._number_of_batches(self.training_num_instances))
 
-        num_batches, errors = self._iterate_batches(
-            self.test_fn, self.training_num_instances)
+        num_batches, errors = self._iterate_eval(
+            self.test_fn, _capi.SPLIT_TRAIN, self.training_num_instances)
 
         return np.mean(errors), np.std(errors)
 
@@ -368,8 +404,8 @@ class ModelBase(ModelInterface):
                      self.validation_num_instances,
                      self._number_of_batches(self.validation_num_instances))
 
-        num_batches, errors = self._iterate_batches(
-            self.validate_fn, self.validation_num_instances)
+        num_batches, errors = self._iterate_eval(
+            self.validate_fn, _capi.SPLIT_VALIDATE, self.validation_num_instances)
 
         return np.mean(errors), np.std(errors)
 

@@ -659,3 +659,36 @@ def test_run_ahead_randomised_differential(hip_lib, kind):
     a, b = results
     assert a[:-2] == b[:-2]
     assert np.array_equal(a[-2], b[-2]) and np.array_equal(a[-1], b[-1])
+
+
+@pytest.mark.parametrize('kind', ['vectorspace', 'loglinear'])
+def test_eval_batches_equals_eval_batch_loop(hip_lib, kind):
+    """sert_eval_batches (one host synchronisation per chunk -- what train_error() and
+    validation_error() use) returns exactly the per-batch values of sert_eval_batch, in order,
+    and leaves the sampler / model state identical."""
+    B, n, nb = 64, 4, 7
+    if kind == 'vectorspace':
+        p = U.make_vs_problem(41, B * nb, n, 5, 300, 40, 16, 16)
+        mk = lambda: U.vs_engine(p, B, n, 5, 0.01, keep_grads=0)
+    else:
+        p = U.make_ll_problem(41, B * nb, n, 300, 40, 16)
+        mk = lambda: U.ll_engine(p, B, n, 0.01, keep_grads=0)
+    out = []
+    for mode in ('loop', 'batched'):
+        eng = mk()
+        eng.upload_dataset(C.SPLIT_TRAIN, p['X'], y_int=p['y'], w=p['w'])
+        eng.upload_dataset(C.SPLIT_VALIDATE, p['X'][:B * 3], y_int=p['y'][:B * 3])
+        eng.train_batch(0)
+        order = [3, 0, 6, 1, 1, 5]
+        if mode == 'loop':
+            a = np.array([eng.eval_batch(C.SPLIT_TRAIN, i) for i in order], np.float32)
+            b = np.array([eng.eval_batch(C.SPLIT_VALIDATE, i) for i in (2, 0)], np.float32)
+        else:
+            a = eng.eval_batches(C.SPLIT_TRAIN, order)
+            b = eng.eval_batches(C.SPLIT_VALIDATE, [2, 0])
+        c = eng.train_batch(2)          # training continues identically afterwards
+        out.append((a, b, c))
+        eng.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    assert out[0][2] == out[1][2]
+    assert np.all(np.isfinite(out[0][0]))

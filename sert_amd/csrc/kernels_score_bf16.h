@@ -9,11 +9,12 @@
 //   |s^ - s| <= sum_i |a_i b_i| ((1 + 2^-8)^2 - 1) + fp32 accumulation  <=  delta = bf16_delta(d)
 //
 // for vectors of norm <= 1 (bf16 keeps 8 significant bits: round-to-nearest error <= 2^-8
-// relative per operand; products exact in fp32; tests/test_golden_host.py attains 99 % of it).  With s^_(k) the k-th largest approximate score of a row and T the filter threshold:
+// relative per operand; products exact in fp32; tests/test_golden_host.py attains 99 % of it).
+// With s^_(k) the k-th largest approximate score of a row and T the filter threshold:
 //   * every entity with s^ >= T is in the candidate lists (same lists as EPI_FILTER);
 //   * at least k candidates have exact score >= s^_(k) - delta, so the exact top k lies among
-//     the candidates with s^ >= s^_(k) - 2 delta -- those (~2 k of them) are re-scored in
-//     fp32 by exact_dot (one fixed summation order for every path) and sorted;
+//     the candidates with s^ >= s^_(k) - 2 delta -- those (~180 of ~600 at k = 100, C5) are
+//     re-scored in fp32 by exact_dot32 (one fixed summation order for every path) and sorted;
 //   * nothing outside the lists can reach the top k if s^_(k) - delta >= T + delta; a row that
 //     fails this is flagged and redone by the materialising fp32 path.
 // So the result is exactly the fp32 ranking; bf16 only decides where fp32 is spent.

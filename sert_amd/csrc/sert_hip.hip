@@ -552,7 +552,11 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         // few to hide their own latencies) -- side by side they fill each other's bubbles.
         hipStream_t sd = (m->timing.enabled || m->nstreams < 3) ? m->stream : m->stream3;
         if (sd != m->stream) SERT_HIP(hipStreamWaitEvent(sd, m->ev_fork, 0));
-        static const int want_splits = [] { const char* e = getenv("SERT_DW_SPLITS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
+        // ~512 workgroup items in all (tuned at one output tile: 512 slabs of 128 rows); with more
+        // output tiles (d = 300: nine) proportionally fewer, larger slabs -- 256 slabs of 16 rows
+        // at batch 4096 made the combine read 92 MB of partials
+        static const int user_splits = [] { const char* e = getenv("SERT_DW_SPLITS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
+        const int want_splits = user_splits ? user_splits : std::max(16, cdiv(512, cdiv(dw, GM) * cdiv(de, GN)));
         int splits = std::min(want_splits, cdiv(B, GK));
         int kper = (int)round_up(cdiv(B, splits), GK);
         splits = cdiv(B, kper);

@@ -552,11 +552,13 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         // few to hide their own latencies) -- side by side they fill each other's bubbles.
         hipStream_t sd = (m->timing.enabled || m->nstreams < 3) ? m->stream : m->stream3;
         if (sd != m->stream) SERT_HIP(hipStreamWaitEvent(sd, m->ev_fork, 0));
-        // ~512 workgroup items in all (tuned at one output tile: 512 slabs of 128 rows); with more
-        // output tiles (d = 300: nine) proportionally fewer, larger slabs -- 256 slabs of 16 rows
-        // at batch 4096 made the combine read 92 MB of partials
+        // ~1024 workgroup items in all, at most 512 slabs (the optimum at one output tile: 512 slabs
+        // of 128 rows) and at least 64 rows per slab.  With nine output tiles (d = 300) that is 114
+        // slabs at batch >= 16384 and 64 at 4096 -- 512 / 256 slabs made the combine read up to 92 MB
+        // of partials (sweep in DESIGN.md section 7.5).
         static const int user_splits = [] { const char* e = getenv("SERT_DW_SPLITS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
-        const int want_splits = user_splits ? user_splits : std::max(16, cdiv(512, cdiv(dw, GM) * cdiv(de, GN)));
+        const int auto_splits = std::max(1, std::min(std::min(512, cdiv(1024, cdiv(dw, GM) * cdiv(de, GN))), B / 64));
+        const int want_splits = user_splits ? user_splits : auto_splits;
         int splits = std::min(want_splits, cdiv(B, GK));
         int kper = (int)round_up(cdiv(B, splits), GK);
         splits = cdiv(B, kper);

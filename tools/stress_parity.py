@@ -29,3 +29,26 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 30):
         fails += 1
         print('FAIL ll', lld, repr(e)[:200], flush=True)
 print('failures:', fails)
+
+# scoring: random (V_e, d_e, Q, k) through the oracle check of the fused / materialising paths
+for it in range(12):
+    V = int(rng.choice([300, 5000, 33000, 40000, 70001, 131073]))
+    d = int(rng.choice([4, 8, 20, 32, 64, 100, 128, 256]))
+    Q = int(rng.choice([1, 3, 40, 129, 300]))
+    k = int(min(V, rng.choice([1, 5, 100, 129, 500, 1000])))
+    if V * d > 1.2e7:
+        continue
+    r2 = np.random.RandomState(rng.randint(1 << 30))
+    E = r2.randn(V, d).astype(np.float32)
+    if rng.rand() < 0.3:      # near-duplicate cluster
+        c = r2.choice(V, min(V, 800), replace=False)
+        E[c] = E[c[0]] + 1e-3 * r2.randn(c.size, d).astype(np.float32)
+    Pj = np.tanh(r2.randn(Q, d)).astype(np.float32)
+    try:
+        idx, val = T.C.score_topk(E, Pj, k)
+        T._check_topk_against_oracle(E, Pj, idx, val, k)
+        print('ok  score', dict(V=V, d=d, Q=Q, k=k), flush=True)
+    except Exception as e:
+        fails += 1
+        print('FAIL score', dict(V=V, d=d, Q=Q, k=k), repr(e)[:200], flush=True)
+print('failures incl. scoring:', fails)

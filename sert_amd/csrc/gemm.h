@@ -420,6 +420,107 @@ __global__ __launch_bounds__(256, SERT_GEMM_WAVES) void gemm_f32_mfma(const Gemm
     }
 }
 
+// ---- 64x64-tile variant for SMALL problems -------------------------------------------
+// A GEMM with fewer 128x128 tiles than CUs (the projection and its backward at batch 4096:
+// 32 x 3 tiles at d = 300) leaves most of the chip idle and every tile latency-bound: 35-40 us
+// for 0.7 GFLOP.  Same arithmetic on 64x64 tiles (four waves of one 32x32 MFMA block each, the
+// same k order, so the results are bit-identical to the kernel above): 4x the workgroups, one
+// per tile, A row-major only, no split-K / column sums / filter.
+constexpr int SM = 64, SLD = 68;
+
+template <bool TB, int EPI, bool VEC>
+__global__ __launch_bounds__(256, 4) void gemm_f32_mfma_small(const GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float As[2][GK][SLD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GK][SLD];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int wr = w >> 1, wc = w & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int tm = blockIdx.x / g.tiles_n, tn = blockIdx.x - tm * g.tiles_n;
+    const int m0 = tm * SM, n0 = tn * SM;
+    // row-major operand (rows = tile rows, contiguous along k): thread -> row t / 4, k-quad t % 4
+    const int cr = t >> 2, ck = (t & 3) * 4;
+    // k-major operand (B stored (K, N)): thread -> k row t / 16, column quad t % 16
+    const int kr = t >> 4, kc = (t & 15) * 4;
+    auto load_rows = [&](const float* __restrict__ X, int ld, int r0, int R, int k0) -> float4 {
+        const int row = r0 + cr, k = k0 + ck;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < R) {
+            const float* px = X + (size_t)row * ld + k;
+            if (VEC) { if (k < g.K) v = *reinterpret_cast<const float4*>(px); }
+            else {
+                if (k + 0 < g.K) v.x = px[0];
+                if (k + 1 < g.K) v.y = px[1];
+                if (k + 2 < g.K) v.z = px[2];
+                if (k + 3 < g.K) v.w = px[3];
+            }
+        }
+        return v;
+    };
+    auto load_kmajor = [&](int k0) -> float4 {
+        const int k = k0 + kr, c = n0 + kc;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < g.K) {
+            const float* pb = g.B + (size_t)k * g.ldb + c;
+            if (VEC) { if (c < g.N) v = *reinterpret_cast<const float4*>(pb); }
+            else {
+                if (c + 0 < g.N) v.x = pb[0];
+                if (c + 1 < g.N) v.y = pb[1];
+                if (c + 2 < g.N) v.z = pb[2];
+                if (c + 3 < g.N) v.w = pb[3];
+            }
+        }
+        return v;
+    };
+    auto store_rows = [&](float (*dst)[SLD], const float4& v) {
+        dst[ck + 0][cr] = v.x; dst[ck + 1][cr] = v.y; dst[ck + 2][cr] = v.z; dst[ck + 3][cr] = v.w;
+    };
+    float bv = 0.f;
+    if (EPI == EPI_BIAS || EPI == EPI_BIAS_TANH) {
+        const int col = n0 + wc * 32 + li;
+        bv = col < g.N ? g.bias[col] : 0.f;
+    }
+    float4 ra = load_rows(g.A, g.lda, m0, g.M, 0);
+    float4 rb = TB ? load_rows(g.B, g.ldb, n0, g.N, 0) : load_kmajor(0);
+    store_rows(As[0], ra);
+    if (TB) store_rows(Bs[0], rb); else *reinterpret_cast<float4*>(&Bs[0][kr][kc]) = rb;
+    __syncthreads();
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    int buf = 0;
+    for (int k0 = 0; k0 < g.K; k0 += GK) {
+        const bool next = k0 + GK < g.K;
+        if (next) {
+            ra = load_rows(g.A, g.lda, m0, g.M, k0 + GK);
+            rb = TB ? load_rows(g.B, g.ldb, n0, g.N, k0 + GK) : load_kmajor(k0 + GK);
+        }
+#pragma unroll
+        for (int kk = 0; kk < GK; kk += 2) {
+            const float a = As[buf][kk + lh][wr * 32 + li];
+            const float b = Bs[buf][kk + lh][wc * 32 + li];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        if (next) {
+            store_rows(As[buf ^ 1], ra);
+            if (TB) store_rows(Bs[buf ^ 1], rb); else *reinterpret_cast<float4*>(&Bs[buf ^ 1][kr][kc]) = rb;
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    const int col = n0 + wc * 32 + li;
+    if (col < g.N) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            float v = acc[r];
+            if (EPI == EPI_BIAS) v = v + bv;
+            if (EPI == EPI_BIAS_TANH) v = fast_tanh(v + bv);
+            if (row < g.M) g.C[(size_t)row * g.ldc + col] = v;
+        }
+    }
+}
+
 template <bool TA, bool TB, int EPI, bool CSB = false>
 inline void launch_gemm(hipStream_t s, const float* A, const float* B, float* C, const float* bias,
                         int M, int N, int K, int lda, int ldb, int ldc, int splits = 1,
@@ -427,6 +528,21 @@ inline void launch_gemm(hipStream_t s, const float* A, const float* B, float* C,
                         unsigned char* cnt = nullptr, int cap = 0) {
     if (splits <= 1) { splits = 1; kper = K; }
     GemmArgs g;
+    // small problem (less than 3/4 of a 128x128 tile per CU): 64x64 tiles, one workgroup each
+    static const bool no_small = getenv("SERT_GEMM_NO_SMALL") != nullptr;
+    if (!TA && !CSB && EPI != EPI_FILTER && splits == 1 && !no_small &&
+        (long long)cdiv(M, GM) * cdiv(N, GN) < 192 && (long long)M * N >= 4 * SM * SM) {
+        g.cand = nullptr; g.cnt = nullptr; g.cap = 0;
+        g.A = A; g.B = B; g.C = C; g.bias = bias;
+        g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+        g.kper = K; g.splits = 1; g.c_split_stride = 0; g.vecA = g.vecB = 0;
+        g.tiles_m = cdiv(M, SM); g.tiles_n = cdiv(N, SM);
+        const bool vecs = (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A) % 16 == 0) &&
+                          (((uintptr_t)B) % 16 == 0) && (K % 4 == 0) && (TB ? true : (N % 4 == 0));
+        if (vecs) hipLaunchKernelGGL((gemm_f32_mfma_small<TB, EPI == EPI_FILTER ? EPI_STORE : EPI, true>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, s, g);
+        else      hipLaunchKernelGGL((gemm_f32_mfma_small<TB, EPI == EPI_FILTER ? EPI_STORE : EPI, false>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, s, g);
+        return;
+    }
     g.cand = cand; g.cnt = cnt; g.cap = cap;
     g.A = A; g.B = B; g.C = C; g.bias = bias;
     g.M = M; g.N = N; g.K = K;

@@ -530,8 +530,9 @@ inline void launch_gemm(hipStream_t s, const float* A, const float* B, float* C,
     GemmArgs g;
     // small problem (less than 3/4 of a 128x128 tile per CU): 64x64 tiles, one workgroup each
     static const bool no_small = getenv("SERT_GEMM_NO_SMALL") != nullptr;
+    static const long long small_below = getenv("SERT_GEMM_SMALL_BELOW") ? atoll(getenv("SERT_GEMM_SMALL_BELOW")) : 192;   // tuning knob
     if (!TA && !CSB && EPI != EPI_FILTER && splits == 1 && !no_small &&
-        (long long)cdiv(M, GM) * cdiv(N, GN) < 192 && (long long)M * N >= 4 * SM * SM) {
+        (long long)cdiv(M, GM) * cdiv(N, GN) < small_below && (long long)M * N >= 4 * SM * SM) {
         g.cand = nullptr; g.cnt = nullptr; g.cap = 0;
         g.A = A; g.B = B; g.C = C; g.bias = bias;
         g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;

@@ -87,7 +87,9 @@ __global__ __launch_bounds__(256) void segsum_rows(const float* __restrict__ src
     }
 }
 
-// Scalar variant for d % 4 != 0: one wave per item, lanes stride over columns.
+// Scalar variant for d % 4 != 0 (and for scalars, d = 1): one wave per (item, 64-column group),
+// gridDim.y column groups; four entries in flight per trip.  Same summation order as one entry
+// at a time (left to right), so the result does not depend on the unrolling.
 template <bool DST_SLOT = false>
 __global__ __launch_bounds__(256) void segsum_rows_scalar(const float* __restrict__ src,
                                                           const int32_t* __restrict__ rows,
@@ -101,10 +103,20 @@ __global__ __launch_bounds__(256) void segsum_rows_scalar(const float* __restric
     const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (item >= nitems) return;
     const int4 it = items[item];
-    if (touched && lane == 0 && it.z >= 0) touched[it.z] = 1;
-    for (int c = lane; c < d; c += 64) {
+    if (touched && lane == 0 && blockIdx.y == 0 && it.z >= 0) touched[it.z] = 1;
+    for (int c = blockIdx.y * 64 + lane; c < d; c += 64 * gridDim.y) {
         float a = 0.f;
-        for (int e = it.x; e < it.y; ++e) {
+        int e = it.x;
+        for (; e + 4 <= it.y; e += 4) {
+            int r0, r1, r2, r3;
+            if (rows) { r0 = rows[e]; r1 = rows[e + 1]; r2 = rows[e + 2]; r3 = rows[e + 3]; }
+            else      { r0 = e; r1 = e + 1; r2 = e + 2; r3 = e + 3; }
+            if (rows && rdiv > 1) { r0 /= rdiv; r1 /= rdiv; r2 /= rdiv; r3 /= rdiv; }
+            const float v0 = src[(size_t)r0 * d + c], v1 = src[(size_t)r1 * d + c];
+            const float v2 = src[(size_t)r2 * d + c], v3 = src[(size_t)r3 * d + c];
+            a += v0; a += v1; a += v2; a += v3;
+        }
+        for (; e < it.y; ++e) {
             const int r = rows ? (rdiv > 1 ? rows[e] / rdiv : rows[e]) : e;
             a += src[(size_t)r * d + c];
         }

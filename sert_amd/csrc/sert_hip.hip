@@ -211,7 +211,7 @@ static int word_grad_segsum(sert_model* m, const DataSplit& ds, int64_t batch_in
                 hipLaunchKernelGGL((segsum_rows<64>), dim3(cdiv(nitems, 4)), dim3(256), 0, m->stream,
                                    in, rows, items, nitems, m->g_rw, pout, d, divisor, touched);
         } else {
-            hipLaunchKernelGGL((segsum_rows_scalar<false>), dim3(cdiv(nitems, 4)), dim3(256), 0, m->stream, in,
+            hipLaunchKernelGGL((segsum_rows_scalar<false>), dim3(cdiv(nitems, 4), cdiv(d, 64)), dim3(256), 0, m->stream, in,
                                rows, items, nitems, m->g_rw, pout, d, divisor, touched);
         }
     }
@@ -250,7 +250,7 @@ static int dzu_from_dj(sert_model* m, const DataSplit& ds, int64_t batch_index) 
                                (unsigned char*)nullptr, 1, (const float*)m->Zu,
                                (const float*)m->ll_rsum);
         } else {
-            hipLaunchKernelGGL((segsum_rows_scalar<true>), dim3(cdiv(nitems, 4)), dim3(256), 0, m->stream, in,
+            hipLaunchKernelGGL((segsum_rows_scalar<true>), dim3(cdiv(nitems, 4), cdiv(V, 64)), dim3(256), 0, m->stream, in,
                                rows, items, nitems, m->dZu, pout, V, 1.0f, (unsigned char*)nullptr, 1);
         }
     }

@@ -13,7 +13,10 @@ from sert_amd import _capi as C  # noqa: E402
 import util as U  # noqa: E402
 
 if __name__ == '__main__':
-    B, n, Vw, Ve, d, nb = 1024, 5, 10000, 100, 64, 100
+    # optional: B n Vw Ve d   (e.g. the W3C expert-finding shape: 1024 8 100000 715 300)
+    a = [int(x) for x in sys.argv[1:6]]
+    B, n, Vw, Ve, d = (a + [1024, 5, 10000, 100, 64][len(a):])[:5]
+    nb = 100 if B * n * 100 <= 2e7 else 20
     for labels in ('int', 'csr'):
         p = U.make_ll_problem(3, B * nb, n, Vw, Ve, d, labels=labels)
         eng = U.ll_engine(p, B, n, 0.01, keep_grads=0)
@@ -29,5 +32,5 @@ if __name__ == '__main__':
             eng.hint_next_batch((i + 1) % nb)
             eng.train_batch(i % nb)
         dt = time.perf_counter() - t0
-        print('C1 loglinear (%s labels): %.1f us/step, %.2f M pairs/s' % (labels, 1e6 * dt / steps, B * steps / dt / 1e6))
+        print('loglinear B=%d n=%d V_w=%d V_e=%d d=%d (%s labels): %.1f us/step, %.2f M pairs/s' % (B, n, Vw, Ve, d, labels, 1e6 * dt / steps, B * steps / dt / 1e6))
         eng.close()

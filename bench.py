@@ -248,6 +248,7 @@ def main():
     ap.add_argument('--vocab', type=int, default=100000)
     ap.add_argument('--entities', type=int, default=1000)
     ap.add_argument('--dim', type=int, default=128)
+    ap.add_argument('--entity-dim', type=int, default=None, help='d_e (default: --dim)')
     ap.add_argument('--window', type=int, default=10)
     ap.add_argument('--negatives', type=int, default=10)
     ap.add_argument('--num-batches', type=int, default=8)
@@ -277,9 +278,10 @@ def main():
     Bl = args.batch or (65536 if kind == 'vectorspace' else 8192)
     Bg = Bl * N
     n, Vw, Ve, d, z = args.window, args.vocab, args.entities, args.dim, args.negatives
+    de = args.entity_dim or d
     rng = np.random.RandomState(0)
     X, y, w = synth_data(rng, args.num_batches * Bg, n, Vw, Ve)
-    model = build_model(kind, models, Bg, n, Vw, Ve, d, d, z, X, y, w, seed=0)
+    model = build_model(kind, models, Bg, n, Vw, Ve, d, de, z, X, y, w, seed=0)
 
     # pass 1 (the number): K untimed steps.  pass 2: the same K steps again with HIP
     # events around every kernel (serialised, slower) for the per-kernel table.
@@ -306,7 +308,7 @@ def main():
     out = None
     if ctx.rank == 0:
         s = X.dtype.itemsize
-        work = group_work(kind, Bl, n, s, d, d, Ve, Vw, z)
+        work = group_work(kind, Bl, n, s, d, de, Ve, Vw, z)
         kernels = {}
         for name, us in timings.items():
             if us <= 0 or name not in work:
@@ -408,7 +410,7 @@ def main():
         out['query'] = query_bench(_capi, cpu=not args.no_cpu_baseline)
 
     if ctx.rank == 0 and N == 1 and not args.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline(kind, Bl, n, Vw, Ve, d, d, z, args.cpu_budget)
+        out['cpu_baseline'] = cpu_baseline(kind, Bl, n, Vw, Ve, d, de, z, args.cpu_budget)
     elif ctx.rank == 0:
         out['cpu_baseline'] = None
 

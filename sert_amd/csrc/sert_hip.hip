@@ -207,8 +207,8 @@ static int word_grad_segsum(sert_model* m, const DataSplit& ds, int64_t batch_in
             if (d / 4 <= 32)
                 hipLaunchKernelGGL((segsum_rows<32>), dim3(cdiv(nitems, 8)), dim3(256), 0, m->stream,
                                    in, rows, items, nitems, m->g_rw, pout, d, divisor, touched);
-            else
-                hipLaunchKernelGGL((segsum_rows<64>), dim3(cdiv(nitems, 4)), dim3(256), 0, m->stream,
+            else   // rows wider than 64 float4 chunks (d = 300: 75): the rest goes to further column groups
+                hipLaunchKernelGGL((segsum_rows<64>), dim3(cdiv(nitems, 4), cdiv(d / 4, 64)), dim3(256), 0, m->stream,
                                    in, rows, items, nitems, m->g_rw, pout, d, divisor, touched);
         } else {
             hipLaunchKernelGGL((segsum_rows_scalar<false>), dim3(cdiv(nitems, 4), cdiv(d, 64)), dim3(256), 0, m->stream, in,

@@ -355,7 +355,7 @@ def main():
                 'workload': ('C2 LSE: %s V_w=%d V_e=%d d=%d window=%d batch/GPU=%d%s' % (
                     'VectorSpaceLanguageModel (NCE z=%d, Adam)' % z if kind == 'vectorspace'
                     else 'LanguageModel (full softmax, Adadelta)',
-                    Vw, Ve, d, n, Bl, '' if N == 1 else ' global_batch=%d' % Bg)),
+                    Vw, Ve, d, n, Bl, ('' if de == d else ' d_e=%d' % de) + ('' if N == 1 else ' global_batch=%d' % Bg))),
                 'global_batch': Bg, 'parallelism': 'dp%d' % N,
                 'id_dtype': str(X.dtype), 'lambda': 0.01,
             },

@@ -519,12 +519,22 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         }
         {
             ScopedTimer t(m, TG_EFIX, st);
-            if (de % 4 == 0)
-                hipLaunchKernelGGL((egrad_fixup<4>), fgrid, blk, 0, st, m->run_start, m->run_end, V, de,
+            const bool few = V < 256 && de <= 512;   // few entities: one workgroup per entity (long runs)
+            if (de % 4 == 0) {
+                if (few) {
+                    hipLaunchKernelGGL((egrad_fixup_wg<4>), dim3(V), blk, 0, st, m->run_start, m->run_end, V, de,
+                                       m->ehead, m->etail, m->g_re);
+                } else {
+                    hipLaunchKernelGGL((egrad_fixup<4>), fgrid, blk, 0, st, m->run_start, m->run_end, V, de,
+                                       m->ehead, m->etail, m->g_re);
+                }
+            } else if (few) {
+                hipLaunchKernelGGL((egrad_fixup_wg<1>), dim3(V), blk, 0, st, m->run_start, m->run_end, V, de,
                                    m->ehead, m->etail, m->g_re);
-            else
+            } else {
                 hipLaunchKernelGGL((egrad_fixup<1>), fgrid, blk, 0, st, m->run_start, m->run_end, V, de,
                                    m->ehead, m->etail, m->g_re);
+            }
         }
 #undef SERT_EG_ARGS
     }

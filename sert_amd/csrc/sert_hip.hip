@@ -812,9 +812,18 @@ static int ll_forward(sert_model* m, const DataSplit& ds, int64_t batch_index) {
         if (TRAIN && m->ll_dedup && n <= 64 && !slab) {
             // distinct-word mode: no LDS slab, the n table rows are read once, coalesced along e
             const size_t lds = ((size_t)V + n) * sizeof(float);
-            hipLaunchKernelGGL((ll_row_from_table<512>), dim3(B), dim3(512), lds, m->stream, (const float*)m->Zu,
-                               slot, y, indptr, ds.csr_indices, ds.csr_data, w, m->rowloss, n, V, inv_batch,
-                               m->J, m->ll_r);
+            // a row is latency-bound (a handful of barriers), not work-bound: 128-thread workgroups
+            // put four times as many rows on a CU -- loss kernel 307 -> 111 us at batch 65536, V_e = 100;
+            // 86 -> 75 us at V_e = 1000, 139 -> 134 us at 2000 (batch 8192)
+            static const int nt128_below = getenv("SERT_LL_NT128_BELOW") ? atoi(getenv("SERT_LL_NT128_BELOW")) : 2048;   // tuning knob
+            if (V <= nt128_below)
+                hipLaunchKernelGGL((ll_row_from_table<128>), dim3(B), dim3(128), lds, m->stream, (const float*)m->Zu,
+                                   slot, y, indptr, ds.csr_indices, ds.csr_data, w, m->rowloss, n, V, inv_batch,
+                                   m->J, m->ll_r);
+            else
+                hipLaunchKernelGGL((ll_row_from_table<512>), dim3(B), dim3(512), lds, m->stream, (const float*)m->Zu,
+                                   slot, y, indptr, ds.csr_indices, ds.csr_data, w, m->rowloss, n, V, inv_batch,
+                                   m->J, m->ll_r);
         } else {
             hipLaunchKernelGGL((ll_fused_row<TRAIN, 512>), dim3(B), dim3(512), fused_lds, m->stream,
                                m->ll_dedup ? m->J : m->Z, (const float*)m->Zu, slot, y, indptr, ds.csr_indices,

@@ -759,7 +759,9 @@ static int ll_forward(sert_model* m, const DataSplit& ds, int64_t batch_index) {
     // the per-token slot, and dL/dZ is summed per word before the backward GEMMs.
     static const bool no_dedup = getenv("SERT_LL_NODEDUP") != nullptr;   // cross-check knob
     static const bool rowwise = getenv("SERT_LL_ROWWISE") != nullptr;
-    m->ll_dedup = TRAIN && (fused || !rowwise) && !no_dedup && ds.idx_slots != nullptr &&
+    // (evaluation passes over the TRAINING split -- train_error() -- have the index too)
+    static const bool eval_dedup = getenv("SERT_LL_NO_EVAL_DEDUP") == nullptr;
+    m->ll_dedup = (TRAIN || eval_dedup) && (fused || !rowwise) && !no_dedup && ds.idx_slots != nullptr &&
                   (size_t)batch_index < ds.idx_batches.size();
     const BatchIndex* bx = m->ll_dedup ? &ds.idx_batches[(size_t)batch_index] : nullptr;
     m->ll_U = bx ? bx->num_distinct : 0;

@@ -3,24 +3,30 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One "step" = one call of train_fn(batch_index) (sert/models.py:581-588): forward,
-backward, L2, dense optimiser update on one batch of synthetic (window, entity)
-pairs, INCLUDING the per-step loss read-back the reference's epoch loop performs
-(sert/models.py:369-379).  Workload at N=1: BASELINE.json configs[1] -- the LSE
-config |V_w|=100k, |V_e|=1k, d=128, window=10, batch=65536 -- run with the
-reference's LSE model (VectorSpaceLanguageModel: NCE, z=10, Adam).  N>1: weak
-scaling, one process per GPU (launched by torch.distributed.run), per-GPU batch
-fixed at 65536, gradients summed by one RCCL all-reduce per step.
+One "step" = one call of train_fn(batch_index) (sert/models.py:581-588): forward, backward,
+L2, dense optimiser update on one batch of synthetic (window, entity) pairs, INCLUDING the
+per-step loss read-back the reference's epoch loop performs (sert/models.py:369-379).
 
-Prints ONE JSON line (rank 0).  `roofline` describes the dominant kernel group
-(HIP events on the model's stream, measured live in the timed region),
-`cpu_baseline` the oracle (numpy restatement of the reference graph) timed on
-this node's host cores on a bounded sample.
+Workload at N = 1: BASELINE.json configs[1] -- the LSE config |V_w| = 100k, |V_e| = 1k, d = 128,
+window = 10, batch = 65536 -- run with the reference's LSE model (VectorSpaceLanguageModel: NCE,
+z = 10, Adam).  N > 1: one process per GPU (``python bench.py --gpus N`` starts them itself; a
+launcher that sets RANK / LOCAL_RANK / WORLD_SIZE -- e.g. ``python -m torch.distributed.run`` --
+works too; nothing here imports PyTorch), weak scaling: the per-GPU batch stays 65536, the word
+table's gradient is reduce-scattered, its optimiser sharded, its rows all-gathered (RCCL).
+
+Prints ONE JSON line (rank 0).  ``roofline`` describes the LONGEST kernel group of the step (HIP
+events on the model's stream, measured live; ``traffic`` from two rocprofv3 --pmc passes this
+script runs on itself), ``cpu_baseline`` the CPU restatements of the same step timed on this
+node's host cores on a bounded sample: a multithreaded C implementation pinned to one socket
+(the headline baseline) and the single-threaded numpy oracle.
 """
 import argparse
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -28,8 +34,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured achievable)
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 MFMA dense peak
+COMMITTED_PMC = 'profiles/r02_vs_c2_pmc.json'
 
 
 def synth_data(rng, N, n, Vw, Ve):
@@ -48,18 +55,16 @@ def glorot(rng, shape):
     return rng.uniform(-a, a, size=shape).astype(np.float32)
 
 
-def group_work(kind, B, n, s, dw, de, Ve, Vw, z):
-    """Algorithmic bytes / flops per timed kernel (SURVEY 8(d) per-pair figures x
-    the pairs one step processes; per-step optimiser term 32 B per parameter).
-    Keys = timing group names of libsert_hip.so (sert_timing_name)."""
-    if kind == 'vectorspace':
-        return {
+def group_work(kind, B, n, s, dw, de, Ve, Vw, z, distinct_words=None):
+    """Algorithmic bytes / flops per timed kernel group (SURVEY 8(d) per-pair figures x the pairs
+    one step processes; per-step optimiser term 32 B per parameter).  Keys = timing group names
+    of libsert_hip.so (sert_timing_name).  Loglinear: the GEMMs and the gather run on the
+    batch's DISTINCT words (duplicate tokens share a logit row), so their EXECUTED work is
+    counted with U = distinct_words rows instead of B n."""
+    if kind in ('vectorspace', 'vectorspace_softmax'):
+        w = {
             'gather':               ('hbm', B * (n * s + 4 * n * dw)),          # vs_gather_mean
             'gemm_fwd':             ('mfma', 2.0 * B * dw * de),               # gemm_f32_mfma NN+tanh
-            'loss':                 ('hbm', B * (8 + 4 * (1 + z) * de)),       # vs_nce
-            'entity_sort':          ('hbm', B * (1 + z) * 16.0),               # csort_* (keys+values r/w)
-            'entity_grad_reduce':   ('hbm', B * (8 * (1 + z) * de)),           # egrad_chunk_reduce
-            'entity_grad_fixup':    ('hbm', 8.0 * Ve * de),                    # egrad_fixup
             'gemm_dW':              ('mfma', 2.0 * B * dw * de),               # gemm_f32_mfma TN split-K
             'splitk_combine':       ('hbm', 4.0 * 1024 * (dw * de + de)),      # reduce_partials
             'gemm_dX':              ('mfma', 2.0 * B * dw * de),               # gemm_f32_mfma NT
@@ -67,49 +72,41 @@ def group_work(kind, B, n, s, dw, de, Ve, Vw, z):
             'optimizer_word_table': ('hbm', 32.0 * Vw * dw),                   # adam_l2 (R_w)
             'optimizer_other':      ('hbm', 32.0 * (Ve * de + dw * de + de)),  # adam_l2 (R_e, W, b)
         }
+        if kind == 'vectorspace':
+            w.update({
+                'loss':               ('hbm', B * (8 + 4 * (1 + z) * de)),     # vs_nce
+                'entity_sort':        ('hbm', B * (1 + z) * 16.0),             # csort_* (keys+values r/w)
+                'entity_grad_reduce': ('hbm', B * (8 * (1 + z) * de)),         # egrad_chunk_reduce
+                'entity_grad_fixup':  ('hbm', 8.0 * Ve * de),                  # egrad_fixup
+            })
+        else:   # full softmax over the entity vocabulary: logits / dR_e / dp GEMMs dominate
+            w['gemm_fwd'] = ('mfma', 2.0 * B * dw * de + 2.0 * B * de * Ve)
+            w['entity_grad_reduce'] = ('mfma', 2.0 * B * de * Ve)
+            w['gemm_dX'] = ('mfma', 2.0 * B * dw * de + 2.0 * B * de * Ve)
+            w['loss'] = ('hbm', B * 8.0 * Ve)
+        return w
+    U = distinct_words if distinct_words else B * n
     return {
-        'gather':               ('hbm', B * (n * s + 4 * n * dw)),
-        'gemm_fwd':             ('mfma', 2.0 * B * n * dw * Ve),
-        'loss':                 ('hbm', B * (8.0 * n * Ve)),                     # Z read + dZ write
-        'gemm_dW':              ('mfma', 2.0 * B * n * dw * Ve),
-        'gemm_dX':              ('mfma', 2.0 * B * n * dw * Ve),
-        'word_grad_segsum':     ('hbm', B * (8 * n * dw)),
+        'gather':               ('hbm', U * (s + 4.0 * dw)),
+        'gemm_fwd':             ('mfma', 2.0 * U * dw * Ve),
+        'loss':                 ('hbm', B * (4.0 * n * Ve + 4.0 * Ve)),          # n table rows read, dJ written
+        'per_word_dz_sums':     ('hbm', B * n * 4.0 * Ve + U * 4.0 * Ve),
+        'gemm_dW':              ('mfma', 2.0 * U * dw * Ve),
+        'gemm_dX':              ('mfma', 2.0 * U * dw * Ve),
+        'word_grad_segsum':     ('hbm', U * (8.0 * dw)),
         'optimizer_word_table': ('hbm', 32.0 * Vw * dw),
         'optimizer_other':      ('hbm', 32.0 * (dw * Ve + Ve)),
     }
 
 
+# timing group -> HIP kernel that dominates it (for matching rocprofv3 rows)
 KERNEL_OF_GROUP = {
-    'gather': 'vs_gather_mean<unsigned int, 4>', 'gemm_fwd': 'gemm_f32_mfma<false, false, 2, false, true, true>',
-    'loss': 'vs_nce<2, true>', 'entity_grad_reduce': 'egrad_chunk_reduce<4, 2>',
-    'entity_grad_fixup': 'egrad_fixup<4>', 'gemm_dW': 'gemm_f32_mfma<true, false, 0, true, true, true>',
-    'splitk_combine': 'reduce_partials', 'gemm_dX': 'gemm_f32_mfma<false, true, 0, false, true, true>',
-    'word_grad_segsum': 'segsum_rows<32, false, false>', 'optimizer_word_table': 'adam_l2<false>',
-    'optimizer_other': 'adam_l2<false>', 'entity_sort': 'csort_scatter',
+    'gather': 'vs_gather_mean', 'gemm_fwd': 'gemm_f32_mfma<false, false, 2', 'loss': 'vs_nce',
+    'entity_grad_reduce': 'egrad_chunk_reduce', 'entity_grad_fixup': 'egrad_fixup',
+    'gemm_dW': 'gemm_f32_mfma<true, false, 0', 'splitk_combine': 'reduce_partials',
+    'gemm_dX': 'gemm_f32_mfma<false, true, 0', 'word_grad_segsum': 'segsum_rows',
+    'optimizer_word_table': 'adam_l2', 'optimizer_other': 'optimizer_small', 'entity_sort': 'csort_scatter',
 }
-PMC_FILE = 'profiles/r01_h_vs_c2_pmc.json'
-
-
-def load_pmc():
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2
-    per the gfx950 correction + WRITE_SIZE; tools/rocpd_pmc.py)."""
-    path = os.path.join(ROOT, PMC_FILE)
-    if not os.path.exists(path):
-        return {}
-    with open(path) as f:
-        return json.load(f)
-
-
-def pmc_traffic(pmc, hip_kernel, avg_us):
-    """HBM bytes of the profiled launch of `hip_kernel` whose duration is closest to
-    the measured one (the PMC file is keyed 'kernel @grid_size')."""
-    best = None
-    for key, rec in pmc.items():
-        if hip_kernel and key.split(' @')[0].startswith(hip_kernel.split('(')[0]):
-            d = abs(rec.get('avg_us_profiled', 0.0) - avg_us)
-            if best is None or d < best[0]:
-                best = (d, rec.get('hbm_bytes'))
-    return best[1] if best else None
 
 
 def build_model(kind, models, B_global, n, Vw, Ve, dw, de, z, X, y, w, seed):
@@ -167,38 +164,218 @@ def timed_steps(model, dist, num_batches, steps, warmup, timing=True):
     return dist.all_reduce_max(dt), timings, float(last)
 
 
-def cpu_baseline(kind, B, n, Vw, Ve, dw, de, z, budget_s=15.0):
-    """The oracle (numpy restatement of the reference graph -- NOT Theano, which
-    cannot run here) timed on this node's host cores."""
+def kernel_table(timings, work):
+    """Per timing group: HIP-event average, algorithmic work, achieved rate and its fraction of
+    the bounding peak.  A memory-bound group whose ALGORITHMIC byte rate exceeds the HBM peak is
+    served from the Infinity Cache / L2 (its tables fit the 256 MB die cache): labelled
+    bound = 'cache' -- its fraction says how far above an HBM-only execution it runs, not how
+    well it uses HBM."""
+    kernels = {}
+    for name, us in timings.items():
+        if us <= 0:
+            continue
+        if name not in work:
+            kernels[name] = dict(us=round(us, 2))
+            continue
+        bound, amount = work[name]
+        if bound == 'hbm':
+            ach = amount / (us * 1e-6) / 1e9
+            kernels[name] = dict(us=round(us, 2), bound='cache' if ach > HBM_PEAK_GBS else 'hbm',
+                                 achieved=round(ach, 1), unit='GB/s', frac=round(ach / HBM_PEAK_GBS, 4),
+                                 algorithmic_bytes=amount)
+        else:
+            ach = amount / (us * 1e-6) / 1e12
+            kernels[name] = dict(us=round(us, 2), bound='mfma', achieved=round(ach, 2), unit='TFLOP/s',
+                                 frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), algorithmic_flops=amount)
+    return kernels
+
+
+def roofline_of(kernels, traffic_by_group=None, traffic_source=None):
+    """The LONGEST kernel group (whatever it is).  frac = achieved / peak with achieved =
+    algorithmic work / measured time (the contract's definition); frac_counter = the same with
+    the PMC-counted bytes (what the memory system really moved)."""
+    cand = [k for k in kernels if 'bound' in kernels[k]]
+    dom = max(cand, key=lambda k: kernels[k]['us'])
+    kd = kernels[dom]
+    mem = kd['bound'] != 'mfma'
+    out = dict(kernel=dom, hip_kernel=KERNEL_OF_GROUP.get(dom), bound='hbm' if mem else 'mfma',
+               achieved=kd['achieved'], peak=HBM_PEAK_GBS if mem else MFMA_F32_PEAK_TFLOPS,
+               unit=kd['unit'], frac=kd['frac'], avg_us=kd['us'], traffic=None)
+    if kd['bound'] == 'cache':
+        out['served_from'] = 'Infinity Cache / L2 (the algorithmic byte rate exceeds the HBM peak)'
+    tr = (traffic_by_group or {}).get(dom)
+    if tr:
+        out['traffic'] = tr['hbm_bytes']
+        out['traffic_source'] = traffic_source
+        out['avg_us_profiled'] = tr['avg_us_profiled']
+        if mem:
+            out['frac_counter'] = round(tr['hbm_bytes'] / (kd['us'] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+            out['traffic_over_algorithmic'] = round(tr['hbm_bytes'] / kd['algorithmic_bytes'], 3)
+    return out
+
+
+# ---- live PMC passes --------------------------------------------------------------------
+def pmc_traffic_live(args, timeout=240):
+    """HBM bytes per launch of every kernel of the C2 step: two rocprofv3 passes (FETCH_SIZE and
+    WRITE_SIZE do not fit one TCC pass; --kernel-trace only beside them, as
+    MI355X_MICROARCH.md prescribes) over a short run of THIS script's headline workload, read
+    back with tools/rocpd_pmc.py's corrections (FETCH_SIZE x 2 on gfx950)."""
+    if shutil.which('rocprofv3') is None:
+        return None, 'rocprofv3 not found'
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import rocpd_pmc
+    tmp = tempfile.mkdtemp(prefix='sert_pmc_')
+    try:
+        dbs = {}
+        for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+            out = os.path.join(tmp, counter)
+            cmd = ['rocprofv3', '--kernel-trace', '--pmc', counter, '-d', out, '-o', 'p', '--',
+                   sys.executable, os.path.abspath(__file__), '--profile-inner', '--steps', '12', '--warmup', '3',
+                   '--batch', str(args.batch or 65536), '--vocab', str(args.vocab), '--entities', str(args.entities),
+                   '--dim', str(args.dim), '--window', str(args.window), '--negatives', str(args.negatives)]
+            env = dict(os.environ, TMPDIR='/tmp')
+            for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+                env.pop(k, None)
+            r = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout)
+            found = [os.path.join(d, f) for d, _, fs in os.walk(out) for f in fs if f.endswith('.db')]
+            if r.returncode != 0 or not found:
+                return None, 'rocprofv3 --pmc %s failed (rc %d): %s' % (counter, r.returncode, r.stderr.decode()[-300:])
+            dbs[counter] = found[0]
+        fetch = rocpd_pmc.per_kernel(dbs['FETCH_SIZE'], 'FETCH_SIZE')
+        write = rocpd_pmc.per_kernel(dbs['WRITE_SIZE'], 'WRITE_SIZE')
+        per = {}
+        for k in set(fetch) | set(write):
+            f = fetch.get(k, {}).get('kib', 0.0) * 1024
+            w = write.get(k, {}).get('kib', 0.0) * 1024
+            per[k] = dict(hbm_bytes=2 * f + w, fetch_bytes_corrected=2 * f, write_bytes=w,
+                          avg_us_profiled=fetch.get(k, write.get(k, {})).get('us', 0.0),
+                          calls=fetch.get(k, write.get(k, {})).get('calls', 0))
+        return per, 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run by this bench (12 steps each)'
+    except Exception as e:   # noqa: BLE001 -- profiling is best effort, the bench line must still appear
+        return None, 'live PMC passes failed: %r' % (e,)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def traffic_by_group(per_kernel, kernels):
+    """Match the profiled kernels ('name @grid') to the timing groups: the launch of the group's
+    dominant kernel whose profiled duration is closest to the live HIP-event average."""
+    out = {}
+    for group, kd in kernels.items():
+        prefix = KERNEL_OF_GROUP.get(group)
+        if not prefix or not per_kernel:
+            continue
+        best = None
+        for key, rec in per_kernel.items():
+            if key.startswith(prefix):
+                d = abs(rec.get('avg_us_profiled', 0.0) - kd['us'])
+                if best is None or d < best[0]:
+                    best = (d, rec)
+        if best:
+            out[group] = best[1]
+    return out
+
+
+# ---- CPU baselines ----------------------------------------------------------------------
+def cpu_baseline_port(B, n, Vw, Ve, dw, de, z, budget_s):
+    """The numpy oracle (single-threaded restatement of the reference graph)."""
     from oracle import sert_oracle as O
     rng = np.random.RandomState(123)
     X, y, w = synth_data(rng, B, n, Vw, Ve)
-    Rw = glorot(rng, (Vw, dw))
-    if kind == 'vectorspace':
-        ora = O.VectorSpaceOracle(B, n, z, Rw, glorot(rng, (Ve, de)), glorot(rng, (dw, de)),
-                                  np.zeros(de, np.float32), 0.01)
-        step = lambda: ora.train_step(X, y, w, rng.randint(0, Ve, size=(B, z)))
-    else:
-        ora = O.LogLinearOracle(B, n, Rw, glorot(rng, (dw, Ve)), np.zeros(Ve, np.float32), 0.01)
-        step = lambda: ora.train_step(X, y, w)
+    ora = O.VectorSpaceOracle(B, n, z, glorot(rng, (Vw, dw)), glorot(rng, (Ve, de)), glorot(rng, (dw, de)),
+                              np.zeros(de, np.float32), 0.01)
     t0 = time.perf_counter()
     steps = 0
     while True:
-        step()
+        ora.train_step(X, y, w, rng.randint(0, Ve, size=(B, z)))
         steps += 1
         dt = time.perf_counter() - t0
         if dt > budget_s or steps >= 8:
             break
-    # cores: what the port really uses.  Its time goes to single-threaded NumPy kernels
-    # (fancy-index gather, ufunc.at scatter-add, elementwise optimiser); only the two small
-    # projections call the multi-threaded BLAS (< 2 % of a step) -- like the reference's
-    # Theano CPU path (C loops + BLAS).  host_cores = what the node offers.
-    return dict(value=steps * B / dt, unit='pairs/s', cores=1,
-                host_cores=len(os.sched_getaffinity(0)), kind='port',
-                sample='%d steps of B=%d (%d pairs, %.1f s) of the same workload; NumPy restatement of '
-                       'the reference graph (oracle/), not Theano; effectively single-threaded '
-                       '(BLAS-threaded matmuls are < 2 %% of the step)' %
-                       (steps, B, steps * B, dt))
+    return dict(value=steps * B / dt, unit='pairs/s', cores=1, kind='port',
+                sample='%d steps of B=%d (%.1f s): numpy restatement of the reference graph (oracle/sert_oracle.py), '
+                       'effectively single-threaded (fancy-index gather, ufunc.at scatter-add and the elementwise '
+                       'optimiser are serial numpy kernels; the BLAS-threaded matmuls are < 2 %% of a step)' % (steps, B, dt))
+
+
+CPU_MT_WORKER = r'''
+import json, os, sys, time
+import numpy as np
+sys.path.insert(0, %(root)r)
+from oracle import cpu_baseline as CB
+cores = CB.one_socket_cores()
+os.sched_setaffinity(0, cores)
+import bench
+B, n, Vw, Ve, dw, de, z, budget = %(B)d, %(n)d, %(Vw)d, %(Ve)d, %(dw)d, %(de)d, %(z)d, %(budget)f
+rng = np.random.RandomState(123)
+nb = 4
+X, y, w = bench.synth_data(rng, nb * B, n, Vw, Ve)
+try:
+    cpu = CB.VectorSpaceCPU(B, n, z, bench.glorot(rng, (Vw, dw)), bench.glorot(rng, (Ve, de)), bench.glorot(rng, (dw, de)),
+                            np.zeros(de, np.float32), 0.01, native=True, out_dir=%(tmp)r)
+    build = 'gcc -O3 -march=native -fopenmp (built on this node)'
+except Exception:
+    cpu = CB.VectorSpaceCPU(B, n, z, bench.glorot(rng, (Vw, dw)), bench.glorot(rng, (Ve, de)), bench.glorot(rng, (dw, de)),
+                            np.zeros(de, np.float32), 0.01)
+    build = 'gcc -O3 -march=x86-64-v3 -fopenmp (prebuilt)'
+Xi = X.astype(np.int32)
+for s in range(nb):
+    cpu.index_batch(s, Xi[s * B:(s + 1) * B])          # static slices: indexed once, as the GPU engine does at upload
+negs = [rng.randint(0, Ve, size=(B, z)).astype(np.int32) for _ in range(4)]
+for s in range(2):
+    cpu.train_step(Xi[s * B:(s + 1) * B], y[s * B:(s + 1) * B], w[s * B:(s + 1) * B], negs[s], slot=s)
+t0 = time.perf_counter(); steps = 0; loss = 0.0
+while True:
+    s = steps %% nb
+    loss = cpu.train_step(Xi[s * B:(s + 1) * B], y[s * B:(s + 1) * B], w[s * B:(s + 1) * B], negs[steps %% 4], slot=s)
+    steps += 1
+    dt = time.perf_counter() - t0
+    if dt > budget or steps >= 400:
+        break
+assert np.isfinite(loss)
+print('RESULT ' + json.dumps(dict(value=steps * B / dt, steps=steps, seconds=dt, cores=len(cores), threads=cpu.threads,
+                                  build=build, ms_per_step=1000 * dt / steps)))
+'''
+
+
+def cpu_baseline_mt(B, n, Vw, Ve, dw, de, z, budget_s):
+    """oracle/sert_cpu.c (OpenMP) in its own process, pinned to the physical cores of socket 0."""
+    tmp = tempfile.mkdtemp(prefix='sert_cpu_')
+    try:
+        code = CPU_MT_WORKER % dict(root=ROOT, B=B, n=n, Vw=Vw, Ve=Ve, dw=dw, de=de, z=z, budget=budget_s, tmp=tmp)
+        from oracle import cpu_baseline as CB
+        env = dict(os.environ, OMP_NUM_THREADS=str(len(CB.one_socket_cores())), OMP_PROC_BIND='close',
+                   OMP_PLACES='cores')
+        for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+            env.pop(k, None)
+        r = subprocess.run([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=ROOT,
+                           env=env, timeout=max(120.0, 6 * budget_s))
+        lines = [l for l in r.stdout.decode().splitlines() if l.startswith('RESULT ')]
+        if r.returncode != 0 or not lines:
+            return dict(value=None, kind='port', error=r.stderr.decode()[-400:])
+        res = json.loads(lines[-1][len('RESULT '):])
+        return dict(value=res['value'], unit='pairs/s', cores=res['cores'], kind='port',
+                    ms_per_step=res['ms_per_step'],
+                    sample='%d steps of B=%d (%.1f s) of the same workload: multithreaded C restatement of the reference '
+                           'graph (oracle/sert_cpu.c, %s; OpenMP, %d threads pinned to the %d physical cores of socket 0; '
+                           'order-fixed segmented sums, fused L2 + Adam) -- not Theano, which cannot run here'
+                           % (res['steps'], B, res['seconds'], res['build'], res['threads'], res['cores']))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def cpu_baseline(B, n, Vw, Ve, dw, de, z, budget_s):
+    host = len(os.sched_getaffinity(0))
+    mt = cpu_baseline_mt(B, n, Vw, Ve, dw, de, z, budget_s)
+    port = cpu_baseline_port(B, n, Vw, Ve, dw, de, z, min(budget_s, 12.0))
+    if mt.get('value'):
+        out = dict(mt)
+        out['single_thread_numpy'] = port
+    else:
+        out = dict(port)
+        out['multithreaded_error'] = mt.get('error')
+    out['host_cores'] = host
+    return out
 
 
 def query_bench(_capi, Q=10000, V=100000, d=128, k=100, reps=3, cpu_budget=8.0, cpu=True):
@@ -232,10 +409,50 @@ def query_bench(_capi, Q=10000, V=100000, d=128, k=100, reps=3, cpu_budget=8.0, 
             n += 1
         dt = time.perf_counter() - t0
         out['cpu_baseline'] = {'value': n / dt, 'unit': 'queries/s', 'cores': 1,
-                               'host_cores': len(os.sched_getaffinity(0)), 'kind': 'port', 'sample': '%d of the %d queries (%.1f s), numpy oracle' % (n, Q, dt),
+                               'host_cores': len(os.sched_getaffinity(0)), 'kind': 'port',
+                               'sample': '%d of the %d queries (%.1f s), numpy oracle' % (n, Q, dt),
                                'top10_identical': '%d/%d' % (agree, n)}
+        try:   # the multithreaded C scorer on a sample of the queries, every core the process may use
+            from oracle import cpu_baseline as CB
+            qs = min(Q, 512)
+            CB.score_topk(E[:1000], P[:8], 10)
+            t0 = time.perf_counter()
+            ci = CB.score_topk(E, P[:qs], k)
+            dt = time.perf_counter() - t0
+            out['cpu_baseline_multithreaded'] = {
+                'value': qs / dt, 'unit': 'queries/s', 'cores': len(os.sched_getaffinity(0)), 'kind': 'port',
+                'sample': '%d of the %d queries (%.1f s), oracle/sert_cpu.c (OpenMP)' % (qs, Q, dt),
+                'top10_identical': '%d/%d' % (int((ci[:, :10] == idx[:qs, :10]).all(axis=1).sum()), qs)}
+        except Exception as e:   # noqa: BLE001
+            out['cpu_baseline_multithreaded'] = {'error': repr(e)}
     sc.close()
     return out
+
+
+def c4_record(models, dist, steps):
+    """BASELINE configs[3]: V_w=500k, V_e=100k, d=300 with the reference's LSE model at the full
+    batch.  The dense L2 + dense Adam of sert/models.py:764-795, :548-549 make every row of both
+    tables live every step: 32 B x 180 M parameters = 5.8 GB per step is the HBM wall."""
+    Vw, Ve, d, n, z, B = 500000, 100000, 300, 10, 10, 65536
+    rng = np.random.RandomState(4)
+    X, y, w = synth_data(rng, 2 * B, n, Vw, Ve)
+    m = build_model('vectorspace', models, B, n, Vw, Ve, d, d, z, X, y, w, seed=4)
+    dt, _, loss = timed_steps(m, dist, 2, steps, 2, timing=False)
+    _, tm, _ = timed_steps(m, dist, 2, steps, 1, timing=True)
+    work = group_work('vectorspace', B, n, X.dtype.itemsize, d, d, Ve, Vw, z)
+    work['optimizer_other'] = ('hbm', 32.0 * (Ve * d + d * d + d))
+    kernels = kernel_table(tm, work)
+    total_bytes = sum(v for k, (b, v) in work.items() if b == 'hbm' and k in tm)
+    rec = {
+        'workload': 'C4 LSE: VectorSpaceLanguageModel (NCE z=%d, Adam) V_w=%d V_e=%d d=%d window=%d batch=%d' % (z, Vw, Ve, d, n, B),
+        'value': steps * B / dt, 'unit': 'pairs/s', 'ms_per_step': 1000 * dt / steps, 'last_loss': loss,
+        'kernels': kernels, 'roofline': roofline_of(kernels),
+        'whole_step': {'algorithmic_bytes': total_bytes,
+                       'achieved_GBps': round(total_bytes / (dt / steps) / 1e9, 1),
+                       'frac_of_hbm_peak': round(total_bytes / (dt / steps) / 1e9 / HBM_PEAK_GBS, 4)},
+    }
+    del m
+    return rec
 
 
 def main():
@@ -244,7 +461,7 @@ def main():
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--model', choices=['vectorspace', 'loglinear'], default='vectorspace')
-    ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default 65536; loglinear 8192)')
+    ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default 65536)')
     ap.add_argument('--vocab', type=int, default=100000)
     ap.add_argument('--entities', type=int, default=1000)
     ap.add_argument('--dim', type=int, default=128)
@@ -253,10 +470,18 @@ def main():
     ap.add_argument('--negatives', type=int, default=10)
     ap.add_argument('--num-batches', type=int, default=8)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-budget', type=float, default=15.0)
+    ap.add_argument('--cpu-budget', type=float, default=12.0)
     ap.add_argument('--no-loglinear-extra', action='store_true')
     ap.add_argument('--no-query-extra', action='store_true')
+    ap.add_argument('--no-c4-extra', action='store_true')
+    ap.add_argument('--no-live-pmc', action='store_true')
+    ap.add_argument('--profile-inner', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # one process per GPU, started here; this process only waits for them
+        from sert_amd import distributed as launcher
+        sys.exit(launcher.launch([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
 
     # stdout carries exactly ONE line, the JSON record: everything else that writes to
     # fd 1 (RCCL prints a version banner there at communicator creation) goes to stderr
@@ -270,18 +495,21 @@ def main():
     from sert_amd import models, _capi
 
     ctx = dist.init_from_env()
-    if ctx.world_size != args.gpus and not (args.gpus == 1 and ctx.world_size == 1):
-        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run '
-                         '--nproc-per-node %d' % (args.gpus, ctx.world_size, args.gpus))
+    if ctx.world_size != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, ctx.world_size))
     N = ctx.world_size
     kind = args.model
-    Bl = args.batch or (65536 if kind == 'vectorspace' else 8192)
+    Bl = args.batch or 65536
     Bg = Bl * N
     n, Vw, Ve, d, z = args.window, args.vocab, args.entities, args.dim, args.negatives
     de = args.entity_dim or d
     rng = np.random.RandomState(0)
     X, y, w = synth_data(rng, args.num_batches * Bg, n, Vw, Ve)
     model = build_model(kind, models, Bg, n, Vw, Ve, d, de, z, X, y, w, seed=0)
+
+    if args.profile_inner:     # the workload of the rocprofv3 --pmc passes: the steps and nothing else
+        timed_steps(model, dist, args.num_batches, args.steps, args.warmup, timing=False)
+        return
 
     # pass 1 (the number): K untimed steps.  pass 2: the same K steps again with HIP
     # events around every kernel (serialised, slower) for the per-kernel table.
@@ -304,48 +532,45 @@ def main():
     eng.synchronize()
     dist.barrier()
     dt_async = dist.all_reduce_max(time.perf_counter() - t0)
+    device_info = _capi.device_info(model._engine.cfg.device)
+    del model, eng
+
+    # N > 1: the same total work split over the ranks (global batch fixed at 65536)
+    strong = None
+    if N > 1 and Bl % N == 0:
+        ms = build_model(kind, models, Bl, n, Vw, Ve, d, de, z, X[:args.num_batches * Bl], y[:args.num_batches * Bl],
+                         w[:args.num_batches * Bl], seed=0)
+        dts, _, _ = timed_steps(ms, dist, args.num_batches, args.steps, args.warmup, timing=False)
+        strong = {'value': args.steps * Bl / dts, 'unit': 'pairs/s', 'ms_per_step': 1000.0 * dts / args.steps,
+                  'global_batch': Bl, 'per_gpu_batch': Bl // N,
+                  'note': 'strong scaling: the global batch stays %d; with the reference\'s dense update the '
+                          'per-step exchange and the optimiser do not shrink with the per-GPU batch' % Bl}
+        del ms
 
     out = None
+    s = X.dtype.itemsize
     if ctx.rank == 0:
-        s = X.dtype.itemsize
-        work = group_work(kind, Bl, n, s, d, de, Ve, Vw, z)
-        kernels = {}
-        for name, us in timings.items():
-            if us <= 0 or name not in work:
-                continue
-            bound, amount = work[name]
-            if bound == 'hbm':
-                ach = amount / (us * 1e-6) / 1e9
-                kernels[name] = dict(us=round(us, 2), bound='hbm', achieved=round(ach, 1),
-                                     unit='GB/s', frac=round(ach / HBM_PEAK_GBS, 4))
-            else:
-                ach = amount / (us * 1e-6) / 1e12
-                kernels[name] = dict(us=round(us, 2), bound='mfma', achieved=round(ach, 2),
-                                     unit='TFLOP/s', frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4))
-        for name, us in timings.items():
-            if us > 0 and name not in kernels:
-                kernels[name] = dict(us=round(us, 2))
-        pmc = load_pmc()
-        dom = max((k for k in kernels if 'bound' in kernels[k]), key=lambda k: kernels[k]['us'])
-        # three launches tie at C2 (entity/word gradient reductions and the word-table
-        # optimiser, 59-61 us each, order varying run to run): among kernels within 5 % of the
-        # longest, report the one
-        # that streams the most real HBM bytes (the PMC file) -- the reductions gather
-        # cache-resident rows, their algorithmic rate is not an HBM rate
-        ties = [k for k in kernels if 'bound' in kernels[k] and kernels[k]['us'] >= 0.95 * kernels[dom]['us']]
-        if len(ties) > 1 and pmc:
-            hbm_of = lambda k: (pmc_traffic(pmc, KERNEL_OF_GROUP.get(k), kernels[k]['us']) or 0.0)
-            # prefer the kernel whose PMC bytes are closest to (not far above) its algorithmic bytes
-            dom = min(ties, key=lambda k: abs(1.0 - hbm_of(k) / max(1.0, work[k][1])))
-        kd = kernels[dom]
-        roofline = dict(kernel=dom, hip_kernel=KERNEL_OF_GROUP.get(dom), bound=kd['bound'],
-                        achieved=kd['achieved'],
-                        peak=HBM_PEAK_GBS if kd['bound'] == 'hbm' else MFMA_F32_PEAK_TFLOPS,
-                        unit=kd['unit'], frac=kd['frac'],
-                        traffic=pmc_traffic(pmc, KERNEL_OF_GROUP.get(dom), kd['us']) if kind == 'vectorspace' else None,
-                        traffic_source=PMC_FILE if pmc else None, avg_us=kd['us'],
-                        note='achieved = algorithmic bytes (SURVEY 8d) / HIP-event time; tables that fit the '
-                             '256 MB Infinity Cache can exceed the HBM peak')
+        distinct = None
+        if kind == 'loglinear':
+            distinct = float(np.mean([len(np.unique(X[j * Bg:j * Bg + Bl])) for j in range(args.num_batches)]))
+        work = group_work(kind, Bl, n, s, d, de, Ve, Vw, z, distinct)
+        kernels = kernel_table(timings, work)
+        per_kernel, traffic_source = (None, None)
+        if N == 1 and kind == 'vectorspace' and not args.no_live_pmc:
+            per_kernel, traffic_source = pmc_traffic_live(args)
+        if per_kernel is None and os.path.exists(os.path.join(ROOT, COMMITTED_PMC)):
+            why = traffic_source
+            with open(os.path.join(ROOT, COMMITTED_PMC)) as f:
+                per_kernel = json.load(f)
+            traffic_source = COMMITTED_PMC + ' (committed earlier; live passes unavailable: %s)' % why
+        tbg = traffic_by_group(per_kernel, kernels) if (kind == 'vectorspace' and Bl == 65536) else {}
+        for g, rec in tbg.items():
+            kernels[g]['hbm_bytes_pmc'] = rec['hbm_bytes']
+        roofline = roofline_of(kernels, tbg, traffic_source)
+        if per_kernel is None or not tbg:
+            roofline['traffic_note'] = traffic_source
+        step_bytes = sum(v for k, (b, v) in work.items() if b == 'hbm' and k in kernels)
+        step_flops = sum(v for k, (b, v) in work.items() if b == 'mfma' and k in kernels)
         out = {
             'metric': 'training_pairs_per_sec', 'value': value, 'unit': 'pairs/s',
             'n_gpus': N, 'steps': args.steps, 'warmup': args.warmup,
@@ -356,10 +581,17 @@ def main():
                     'VectorSpaceLanguageModel (NCE z=%d, Adam)' % z if kind == 'vectorspace'
                     else 'LanguageModel (full softmax, Adadelta)',
                     Vw, Ve, d, n, Bl, ('' if de == d else ' d_e=%d' % de) + ('' if N == 1 else ' global_batch=%d' % Bg))),
-                'global_batch': Bg, 'parallelism': 'dp%d' % N,
+                'global_batch': Bg, 'parallelism': 'dp%d' % N if N == 1 else 'dp%d, ZeRO-1 word table (reduce-scatter + sharded Adam + all-gather)' % N,
                 'id_dtype': str(X.dtype), 'lambda': 0.01,
             },
             'roofline': roofline,
+            'whole_step': {
+                'algorithmic_bytes': step_bytes, 'algorithmic_flops': step_flops,
+                'achieved_GBps': round(step_bytes / (dt / args.steps) / 1e9, 1),
+                'frac_of_hbm_peak': round(step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                'note': 'sum of the groups\' algorithmic bytes / ms_per_step; much of it is served by the Infinity '
+                        'Cache (tables of 51 MB + 33 MB activations), so this is not an HBM utilisation',
+            },
             'ms_per_step_instrumented': 1000.0 * dt_instr / args.steps,
             'deferred_loss_readback': {'value': args.steps * Bg / dt_async, 'unit': 'pairs/s',
                                        'ms_per_step': 1000.0 * dt_async / args.steps,
@@ -367,26 +599,33 @@ def main():
                                                'value keeps the per-step read-back of the reference loop)'},
             'kernels': kernels,
             'last_loss': last_loss,
-            'device': _capi.device_info(model._engine.cfg.device),
+            'device': device_info,
         }
+        if strong is not None:
+            out['strong_scaling'] = strong
 
-    # extra: the reference's full-softmax model (loglinear) at the same dims
+    # extra: the reference's full-softmax model (loglinear) at the C2 dims AND the C2 batch
     if N == 1 and kind == 'vectorspace' and not args.no_loglinear_extra:
-        del model
-        Bll = 8192
+        Bll = 65536
         rng2 = np.random.RandomState(1)
-        X2, y2, w2 = synth_data(rng2, 4 * Bll, n, Vw, Ve)
+        nb2 = 2
+        X2, y2, w2 = synth_data(rng2, nb2 * Bll, n, Vw, Ve)
         m2 = build_model('loglinear', models, Bll, n, Vw, Ve, d, d, z, X2, y2, w2, seed=1)
         st = max(5, min(20, args.steps))
-        dt2, _, _ = timed_steps(m2, dist, 4, st, 3, timing=False)
-        _, tm2, _ = timed_steps(m2, dist, 4, st, 1, timing=True)
-        work2 = group_work('loglinear', Bll, n, X2.dtype.itemsize, d, d, Ve, Vw, z)
-        fl = sum(v for k, (b, v) in work2.items() if b == 'mfma')
+        dt2, _, _ = timed_steps(m2, dist, nb2, st, 3, timing=False)
+        _, tm2, _ = timed_steps(m2, dist, nb2, st, 1, timing=True)
+        U = float(np.mean([len(np.unique(X2[j * Bll:(j + 1) * Bll])) for j in range(nb2)]))
+        work2 = group_work('loglinear', Bll, n, X2.dtype.itemsize, d, d, Ve, Vw, z, U)
+        k2 = kernel_table(tm2, work2)
+        fl_exec = sum(v for k, (b, v) in work2.items() if b == 'mfma')
         out['loglinear'] = {
             'workload': 'LanguageModel (full softmax over V_e, Adadelta) V_w=%d V_e=%d d=%d window=%d batch=%d' % (Vw, Ve, d, n, Bll),
             'value': st * Bll / dt2, 'unit': 'pairs/s', 'ms_per_step': 1000 * dt2 / st,
-            'kernels_us': {k: round(v, 1) for k, v in tm2.items() if v > 0},
-            'mfma_tflops_whole_step': fl / (dt2 / st) / 1e12,
+            'kernels': k2, 'roofline': roofline_of(k2),
+            'distinct_words_per_batch': U,
+            'mfma_tflops_executed': fl_exec / (dt2 / st) / 1e12,
+            'note': 'the three GEMMs run on the %.0f distinct words of a batch of %d tokens (duplicate tokens share '
+                    'their logit row); mfma_tflops_executed counts those flops only' % (U, Bll * n),
         }
         del m2
         # extra: the ADDITIVE full-softmax LSE variant (BASELINE.json configs[1] wording:
@@ -395,22 +634,27 @@ def main():
                          w[:4 * Bl], seed=2)
         dt3, _, _ = timed_steps(m3, dist, 4, st, 3, timing=False)
         _, tm3, _ = timed_steps(m3, dist, 4, st, 1, timing=True)
+        work3 = group_work('vectorspace_softmax', Bl, n, s, d, d, Ve, Vw, z)
+        k3 = kernel_table(tm3, work3)
         fl3 = 6.0 * Bl * d * d + 6.0 * Bl * d * Ve
         out['lse_full_softmax'] = {
             'workload': 'VectorSpaceSoftmaxLanguageModel (additive, not in the reference): gather + mean-pool + '
                         'tanh projection + full softmax over V_e=%d, Adam; V_w=%d d=%d window=%d batch=%d' % (
                             Ve, Vw, d, n, Bl),
             'value': st * Bl / dt3, 'unit': 'pairs/s', 'ms_per_step': 1000 * dt3 / st,
-            'kernels_us': {k: round(v, 1) for k, v in tm3.items() if v > 0},
+            'kernels': k3, 'roofline': roofline_of(k3),
             'mfma_tflops_whole_step': fl3 / (dt3 / st) / 1e12,
         }
         del m3
 
+    if ctx.rank == 0 and N == 1 and kind == 'vectorspace' and not args.no_c4_extra:
+        out['c4'] = c4_record(models, dist, max(5, min(10, args.steps)))
+
     if ctx.rank == 0 and N == 1 and not args.no_query_extra:
         out['query'] = query_bench(_capi, cpu=not args.no_cpu_baseline)
 
-    if ctx.rank == 0 and N == 1 and not args.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline(kind, Bl, n, Vw, Ve, d, de, z, args.cpu_budget)
+    if ctx.rank == 0 and N == 1 and not args.no_cpu_baseline and kind == 'vectorspace':
+        out['cpu_baseline'] = cpu_baseline(Bl, n, Vw, Ve, d, de, z, args.cpu_budget)
     elif ctx.rank == 0:
         out['cpu_baseline'] = None
 

@@ -15,8 +15,11 @@ Output: ``<model_output>_<epoch>.bin`` = pickle stream [args, predict_fn, R_w,
 
 Additive: --type vectorspace_softmax, --ignore_weights (the reference reads
 args.ignore_weights but never defines it, train.py:81), --seed, --device,
---save_optimizer_state.  Data-parallel: launch with
-``python -m torch.distributed.run --nproc-per-node N`` (--batch_size is global).
+--save_optimizer_state, --resume <model_k.bin> (continue behind epoch k of a run that was
+dumped with --save_optimizer_state: same results as the uninterrupted run), --gpus N
+(data parallel over N GPUs of this node, one process each, started by this script;
+--batch_size is the GLOBAL batch).  Any launcher that sets RANK / LOCAL_RANK / WORLD_SIZE
+works as well.
 """
 import argparse
 import logging
@@ -61,6 +64,8 @@ FLAGS = [
     ('--seed', dict(type=int, default=None)),
     ('--device', dict(type=int, default=None)),
     ('--save_optimizer_state', dict(action='store_true', default=False)),
+    ('--resume', dict(type=au.existing_file_path, default=None)),
+    ('--gpus', dict(type=au.positive_int, default=1)),
 ]
 
 
@@ -110,6 +115,11 @@ def main(argv=None):
         return -1
     logging_utils.log_module_info(np, scipy)
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # one process per GPU, started here; this process only waits for them
+        command = [sys.executable, os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
+        return distributed.launch(command, args.gpus)
+
     ctx = distributed.init_from_env()
     if args.seed is not None:
         np.random.seed(args.seed)
@@ -147,12 +157,20 @@ def main(argv=None):
 
     if args.device is not None:
         args.type.device = args.device
+    checkpoint = None
+    if args.resume:
+        checkpoint = training.read_checkpoint(args.resume)
+        if checkpoint['trailer'] is not None:   # the sampler seed is fixed at construction
+            args.type.sampler_seed = checkpoint['trailer']['sampler_state']['seed']
     model = args.type(**options)
+    if checkpoint is not None:
+        training.restore(model, checkpoint)
 
     train(model, args.iterations, args.model_output,
           abort_threshold=1e-5, early_stopping=False,
           additional_args=[args],
-          save_optimizer_state=args.save_optimizer_state)
+          save_optimizer_state=args.save_optimizer_state,
+          resume_from=checkpoint)
 
     distributed.shutdown()
 

@@ -123,6 +123,13 @@ size_t sert_tensor_size(sert_model* m, int which);
 int sert_set_step(sert_model* m, int64_t t);
 int64_t sert_get_step(sert_model* m);
 
+/* Position of the EVALUATION negative stream (the reference keeps a second RandomStreams for
+ * the evaluation loss, models.py:751 -> :1074; here: the odd Philox stream, advanced once per
+ * evaluated batch).  With sert_set_step -- the training stream's position is the optimiser
+ * step -- a resumed run draws what the uninterrupted run would have drawn. */
+int sert_set_eval_draws(sert_model* m, int64_t n);
+int64_t sert_get_eval_draws(sert_model* m);
+
 /* ---- data set ---------------------------------------------------------- */
 
 /* Replaces theano.shared(x/y/w) of the whole data set (models.py:470-480):
@@ -229,7 +236,15 @@ int sert_score_topk(int device, const float* entities, int64_t num_entities, int
 #define SERT_COMM_ID_BYTES 128
 /* ncclGetUniqueId; rank 0 calls it and ships the bytes to the other ranks. */
 int sert_comm_unique_id(char id[SERT_COMM_ID_BYTES]);
-/* ncclCommInitRank on this handle's device/stream. */
+/* ncclCommInitRank on this handle's device.  From here on the model is data parallel
+ * (SURVEY 8-e, 8-f4): rank r trains rows [r*B_l, (r+1)*B_l) of every global batch; the word
+ * table (and any other tensor beyond 4 M elements) is owned ZeRO-1 style -- its gradient is
+ * reduce-scattered, each rank runs the dense optimiser (sert/models.py:548-549: every element,
+ * every step) on the 1/world of the rows it owns, keeping only that share of the optimiser
+ * state, and the updated rows are all-gathered; the small tensors' gradients and the loss sum
+ * are all-reduced and those tensors updated identically everywhere.  SERT_AR_CHUNKS=k pipelines
+ * the exchange of a big tensor in k slabs.  sert_get_tensor of a SERT_T_STATE* tensor is then a
+ * COLLECTIVE call (every rank, same order). */
 int sert_comm_init(sert_model* m, const char id[SERT_COMM_ID_BYTES], int rank, int world);
 /* Host-mediated exchange: every gradient/loss all-reduce becomes device -> pinned host
  * -> fn (in-place SUM over ranks of host_buf[count]; returns 0 on success) -> device,

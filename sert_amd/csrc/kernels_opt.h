@@ -201,6 +201,23 @@ __global__ __launch_bounds__(256) void sum_partial(const float* __restrict__ in,
     if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }
 
+// Sum of squares over the `nch` pieces of `sc` elements (sc % 4 == 0) that start at p and lie
+// `slab` elements apart (the pieces of a ZeRO-sharded tensor one rank owns): per-block
+// partials, fixed grid => fixed tree.
+__global__ __launch_bounds__(256) void sumsq_pieces(const float* __restrict__ p, size_t sc, size_t slab,
+                                                    int nch, float* __restrict__ partial) {
+    __shared__ float red[4];
+    float ss = 0.f;
+    const size_t sc4 = sc >> 2, total4 = sc4 * (size_t)nch;
+    for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < total4; j += (size_t)gridDim.x * blockDim.x) {
+        const size_t c = j / sc4, o = j - c * sc4;
+        const float4 v = reinterpret_cast<const float4*>(p + c * slab)[o];
+        ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    const float tot = block_sum_256(ss, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
 // out[0] = sum of n partials (fp64, fixed order): the local loss sum that travels in
 // the flat gradient buffer of a data-parallel step
 __global__ __launch_bounds__(256) void partials_to_scalar(const float* __restrict__ partials, int n,
@@ -227,7 +244,8 @@ __global__ __launch_bounds__(256) void finalize_loss(const float* __restrict__ l
                                                      int n_sq, float inv_batch, float reg_scale,
                                                      float* __restrict__ out,
                                                      unsigned* __restrict__ host_flag = nullptr,
-                                                     unsigned seq = 0) {
+                                                     unsigned seq = 0,
+                                                     const float* __restrict__ extra_sq = nullptr) {
     __shared__ double red[256];
     double a = 0.0;
     for (int i = threadIdx.x; i < n_loss; i += 256) a += (double)loss_partials[i];
@@ -249,7 +267,8 @@ __global__ __launch_bounds__(256) void finalize_loss(const float* __restrict__ l
     }
     if (threadIdx.x == 0) {
         const float data = (float)loss_sum * inv_batch;
-        const float reg = reg_scale * (float)red[0];
+        // (data parallel: + the all-reduced sum of squares of the ZeRO-sharded tensors)
+        const float reg = reg_scale * (float)(red[0] + (extra_sq ? (double)extra_sq[0] : 0.0));
         out[0] = data + reg;
         out[1] = data;
         out[2] = reg;

@@ -40,7 +40,9 @@ enum TimingGroup {
     TG_SPLITK,        // reduce_partials                                      (1 launch)
     TG_GEMM_DX,       // gemm_f32_mfma<NT>: dh / dG                           (1 launch)
     TG_SCATTER,       // segsum_rows, one launch per tree level
-    TG_ALLREDUCE,     // RCCL gradient exchange
+    TG_ALLREDUCE,     // RCCL all-reduce of the small (replicated) tensors' gradients + loss scalars
+    TG_REDUCE_SCATTER,// RCCL reduce-scatter of the big tensors' gradients (ZeRO-1 ownership)
+    TG_ALLGATHER,     // RCCL all-gather of the big tensors' updated parameters
     TG_OPT_WORD,      // adam_l2 / adadelta_l2 on the word table R_w          (1 launch)
     TG_OPTIMIZER,     // the other tensors (R_e, W, b)                        (2-3 launches)
     TG_FINALIZE,      // loss reduction
@@ -155,23 +157,44 @@ struct sert_model {
     int64_t step = 0;             // optimiser step counter t (Adam) / training sampler position
     int64_t eval_draws = 0;       // evaluation sampler position
 
+    // ---- the four parameter tensors as the optimiser sees them: [R_w, R_e, W, b] ----
+    // A "big" tensor (the word table always; R_e / W beyond 4 M elements) is updated by its own
+    // streaming launch.  Data parallel, big tensors are owned ZeRO-1 style: the padded tensor
+    // (pt_pad elements) is cut into `chunks` slabs of world * pt_sc elements and rank r owns
+    // [c*world*sc + r*sc, + sc) of every slab c -- reduce-scatter of the gradient slab, the
+    // optimiser on the owned piece, all-gather of the parameter slab, slab after slab.  The
+    // optimiser state of a sharded tensor exists for the owned pieces only (chunks * sc
+    // elements, slab-major) -- 1/world of the replicated state.
+    size_t pt_pad[4] = {0, 0, 0, 0};   // allocated elements of p and g (>= n, multiple of 4)
+    size_t pt_sc[4] = {0, 0, 0, 0};    // owned elements per slab (sharded tensors)
+    bool pt_big[4] = {false, false, false, false};
+    bool pt_sharded[4] = {false, false, false, false};
+    size_t ar_split = 0;          // gflat[0, ar_split) = word-table gradient (incl. its padding)
+    size_t rest_off = 0;          // gflat[rest_off, gflat_count) = replicated tensors' gradients + scalars
+    float* g_sq = nullptr;        // scalar slot: sum of squares of the sharded tensors (all-reduced)
+    float* sq_scratch = nullptr;  // per-block partials nobody reads (sharded optimiser launches)
+
     // data parallel
     int rank = 0, world = 1;
     void* comm = nullptr;         // ncclComm_t
+    bool comm_dead = false;       // communicator destroyed: the (sharded) model can no longer train
     // host-mediated exchange (sert_comm_init_host): verification transport
     int (*host_ar)(void*, float*, size_t) = nullptr;
     void* host_ar_user = nullptr;
     float* host_ar_buf = nullptr;   // pinned staging
     size_t host_ar_cap = 0;
     hipStream_t comm_stream = nullptr;          // all collectives are issued here, in one fixed order
-    hipEvent_t ev_rw_ready = nullptr, ev_rest_ready = nullptr, ev_ar_done = nullptr;
-    size_t ar_split = 0;          // gflat[0, ar_split) = word-table gradient
-    // the word-table exchange is cut into ar_chunks slices so that the optimiser of
-    // slice c runs while slice c+1 is still on the links
+    hipEvent_t ev_rest_ready = nullptr, ev_ar_done = nullptr;
+    // the exchange of a big tensor is cut into ar_chunks slabs so that the optimiser of
+    // slab c runs while slab c+1 is still on the links
     static constexpr int kMaxArChunks = 16;
     int ar_chunks = 1;
-    hipEvent_t ev_rw_chunk[kMaxArChunks] = {};
-    bool rw_chunked = false;      // this step's word-table all-reduce was issued in slices
+    hipEvent_t ev_grad_ready[4] = {};                 // tensor i's gradient is complete (producer stream)
+    hipEvent_t ev_rs_done[4][kMaxArChunks] = {};      // slab c of tensor i reduce-scattered (comm stream)
+    hipEvent_t ev_opt_done[4][kMaxArChunks] = {};     // owned piece of slab c updated (main stream)
+    hipEvent_t ev_ag_done = nullptr;                  // every parameter slab of this step all-gathered
+    bool rs_issued[4] = {false, false, false, false}; // this step's reduce-scatter of tensor i is in flight
+    hipStream_t sq_stream = nullptr;                  // (the side stream the shard sum-of-squares runs on)
 
     sert::Timing timing;
 };

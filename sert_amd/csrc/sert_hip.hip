@@ -29,7 +29,7 @@ thread_local std::string g_last_error;
 static const char* kTimingNames[TG_COUNT] = {
     "gather",        "gemm_fwd", "loss",      "entity_sort",          "entity_grad_reduce",
     "entity_grad_fixup", "gemm_dW", "splitk_combine", "gemm_dX",      "word_grad_segsum",
-    "allreduce",     "optimizer_word_table",  "optimizer_other",      "finalize"};
+    "allreduce",     "reduce_scatter", "all_gather", "optimizer_word_table",  "optimizer_other",      "finalize"};
 
 // ---- timing ----------------------------------------------------------------
 struct ScopedTimer {
@@ -73,6 +73,8 @@ struct Rccl {
     int (*CommInitRank)(void**, int, /*ncclUniqueId by value*/ UniqueId, int) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*ReduceScatter)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 };
 static Rccl g_rccl;
@@ -91,9 +93,13 @@ static int rccl_load() {
     g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(lib, "ncclCommInitRank");
     g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(lib, "ncclCommDestroy");
     g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(lib, "ncclAllReduce");
+    g_rccl.ReduceScatter = (decltype(g_rccl.ReduceScatter))dlsym(lib, "ncclReduceScatter");
+    g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(lib, "ncclAllGather");
     g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(lib, "ncclGetErrorString");
-    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllReduce)
-        SERT_FAIL("librccl is missing ncclGetUniqueId/ncclCommInitRank/ncclCommDestroy/ncclAllReduce");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllReduce ||
+        !g_rccl.ReduceScatter || !g_rccl.AllGather)
+        SERT_FAIL("librccl is missing ncclGetUniqueId/ncclCommInitRank/ncclCommDestroy/ncclAllReduce/"
+                  "ncclReduceScatter/ncclAllGather");
     g_rccl.lib = lib;
     return 0;
 }
@@ -317,16 +323,38 @@ static int gemm_long_k(sert_model* m, hipStream_t s, const float* A, const float
     return 0;
 }
 
-// ---- data-parallel gradient exchange ---------------------------------------------
-// Sum-all-reduces over the flat gradient buffer, all issued on comm_stream in the
-// same order on every rank: (1) the word-table part, as soon as the segmented
-// reduction has produced it, in ar_chunks slices -- it overlaps whatever is left of
-// the backward, and the optimiser of slice c overlaps the exchange of slice c+1 --
-// (2) the remainder (entity table, dense weights, bias, loss sum) once complete.
+// ---- data-parallel exchange (new: the reference is single-device) ---------
+// ZeRO-1 over the big tensors (model.h): reduce-scatter of a gradient slab -> the optimiser on
+// the owned piece (1/world of the launch, 1/world of the state) -> all-gather of the parameter
+// slab; the small tensors' gradients, the loss sum and the owned pieces' sum of squares travel
+// in ONE all-reduce and the small tensors are updated identically on every rank.  Every
+// collective is issued on comm_stream, in the same order on every rank:
+//   RS(R_w) as soon as the segmented reduction has produced dR_w (it overlaps the rest of the
+//   backward), RS(other big tensors), AR(rest), then AG(R_w), AG(others) behind the optimiser.
 static inline bool is_dp(const sert_model* m) { return m->comm != nullptr || m->host_ar != nullptr; }
 
-// device -> pinned host -> callback (sum over ranks) -> device, synchronously on `st`
-static int host_allreduce(sert_model* m, float* dev, size_t count, hipStream_t st) {
+struct ParamTensor {
+    float *p, *g, *s0, *s1;
+    size_t n;
+    bool l2;
+};
+static ParamTensor param_tensor(sert_model* m, int i) {
+    switch (i) {
+        case 0: return {m->rw, m->g_rw, m->s0_rw, m->s1_rw, m->n_rw, true};
+        case 1: return {m->re, m->g_re, m->s0_re, m->s1_re, m->n_re, true};
+        case 2: return {m->W, m->g_w, m->s0_w, m->s1_w, m->n_w, true};
+        default: return {m->b, m->g_b, m->s0_b, m->s1_b, m->n_b, false};   // bias: not regularised
+    }
+}
+static inline size_t slab_elems(const sert_model* m, int i) { return m->pt_sc[i] * (size_t)m->world; }
+static inline size_t piece_off(const sert_model* m, int i, int c) {
+    return (size_t)c * slab_elems(m, i) + (size_t)m->rank * m->pt_sc[i];
+}
+
+// device -> pinned host -> callback (sum over ranks) -> device, synchronously on `st`.
+// own_only: everything outside this rank's pieces of sharded tensor `own_tensor` is zeroed on
+// the host first, so that the sum is an all-gather.
+static int host_allreduce(sert_model* m, float* dev, size_t count, hipStream_t st, int own_tensor = -1) {
     if (count == 0) return 0;
     if (m->host_ar_cap < count) {
         if (m->host_ar_buf) (void)hipHostFree(m->host_ar_buf);
@@ -336,43 +364,54 @@ static int host_allreduce(sert_model* m, float* dev, size_t count, hipStream_t s
     }
     SERT_HIP(hipMemcpyAsync(m->host_ar_buf, dev, count * sizeof(float), hipMemcpyDeviceToHost, st));
     SERT_HIP(hipStreamSynchronize(st));
+    if (own_tensor >= 0) {
+        const size_t sc = m->pt_sc[own_tensor], slab = slab_elems(m, own_tensor);
+        for (size_t o = 0; o < count; o += slab)
+            for (int r = 0; r < m->world; ++r)
+                if (r != m->rank) memset(m->host_ar_buf + o + (size_t)r * sc, 0, sc * sizeof(float));
+    }
     if (m->host_ar(m->host_ar_user, m->host_ar_buf, count) != 0) SERT_FAIL("host all-reduce callback failed");
     SERT_HIP(hipMemcpyAsync(dev, m->host_ar_buf, count * sizeof(float), hipMemcpyHostToDevice, st));
     SERT_HIP(hipStreamSynchronize(st));
     return 0;
 }
 
-static inline size_t word_chunk_lo(const sert_model* m, int c) {
-    if (c >= m->ar_chunks) return m->n_rw;
-    return ((m->n_rw * (size_t)c) / (size_t)m->ar_chunks) & ~(size_t)3;   // 16-byte aligned slices
-}
-static int allreduce_word_grad(sert_model* m) {
-    if (!is_dp(m)) return 0;
-    m->rw_chunked = false;
-    if (m->host_ar) return host_allreduce(m, m->gflat, m->ar_split, m->stream);
+// Reduce-scatter of big tensor i's gradient (complete on the main stream at this point).
+static int exchange_grad(sert_model* m, int i) {
+    if (!is_dp(m) || !m->pt_sharded[i]) return 0;
+    if (m->comm_dead) SERT_FAIL("the communicator of this data-parallel model was destroyed");
+    const ParamTensor t = param_tensor(m, i);
+    const size_t sc = m->pt_sc[i];
+    m->rs_issued[i] = false;
+    // verification transport: the whole padded gradient is summed through the host (every rank
+    // then holds the full sum; only the owned pieces are read)
+    if (m->host_ar) return host_allreduce(m, t.g, m->pt_pad[i], m->stream);
     if (m->timing.enabled) {   // timing mode: serial, on the main stream
-        ScopedTimer t(m, TG_ALLREDUCE);
-        SERT_NCCL(g_rccl.AllReduce(m->gflat, m->gflat, m->ar_split, /*ncclFloat32*/ 7, /*ncclSum*/ 0,
-                                   m->comm, m->stream));
+        ScopedTimer tm(m, TG_REDUCE_SCATTER);
+        for (int c = 0; c < m->ar_chunks; ++c)
+            SERT_NCCL(g_rccl.ReduceScatter(t.g + (size_t)c * slab_elems(m, i), t.g + piece_off(m, i, c), sc,
+                                           /*ncclFloat32*/ 7, /*ncclSum*/ 0, m->comm, m->stream));
         return 0;
     }
-    SERT_HIP(hipEventRecord(m->ev_rw_ready, m->stream));
-    SERT_HIP(hipStreamWaitEvent(m->comm_stream, m->ev_rw_ready, 0));
+    SERT_HIP(hipEventRecord(m->ev_grad_ready[i], m->stream));
+    SERT_HIP(hipStreamWaitEvent(m->comm_stream, m->ev_grad_ready[i], 0));
     for (int c = 0; c < m->ar_chunks; ++c) {
-        const size_t lo = word_chunk_lo(m, c);
-        // the last slice also carries the alignment padding up to ar_split
-        const size_t hi = (c == m->ar_chunks - 1) ? m->ar_split : word_chunk_lo(m, c + 1);
-        if (hi > lo)
-            SERT_NCCL(g_rccl.AllReduce(m->gflat + lo, m->gflat + lo, hi - lo, 7, 0, m->comm, m->comm_stream));
-        SERT_HIP(hipEventRecord(m->ev_rw_chunk[c], m->comm_stream));
+        SERT_NCCL(g_rccl.ReduceScatter(t.g + (size_t)c * slab_elems(m, i), t.g + piece_off(m, i, c), sc, 7, 0,
+                                       m->comm, m->comm_stream));
+        SERT_HIP(hipEventRecord(m->ev_rs_done[i][c], m->comm_stream));
     }
-    m->rw_chunked = true;
+    m->rs_issued[i] = true;
     return 0;
 }
+static int allreduce_word_grad(sert_model* m) { return exchange_grad(m, 0); }
+
+// The other big tensors' reduce-scatters, then the all-reduce of the replicated remainder
+// [small tensors' gradients | loss sum | owned sum of squares].
 static int allreduce_rest(sert_model* m) {
     if (!is_dp(m)) return 0;
-    float* rest = m->gflat + m->ar_split;
-    const size_t count = m->gflat_count - m->ar_split;
+    for (int i = 1; i < 4; ++i) SERT_TRY(exchange_grad(m, i));
+    float* rest = m->gflat + m->rest_off;
+    const size_t count = m->gflat_count - m->rest_off;
     if (m->host_ar) return host_allreduce(m, rest, count, m->stream);
     if (m->timing.enabled) {
         ScopedTimer t(m, TG_ALLREDUCE);
@@ -383,7 +422,26 @@ static int allreduce_rest(sert_model* m) {
     SERT_HIP(hipStreamWaitEvent(m->comm_stream, m->ev_rest_ready, 0));
     SERT_NCCL(g_rccl.AllReduce(rest, rest, count, 7, 0, m->comm, m->comm_stream));
     SERT_HIP(hipEventRecord(m->ev_ar_done, m->comm_stream));
-    // the main stream waits for it in optimizer_and_loss, after the word-table slices
+    // the main stream waits for it in optimizer_and_loss, behind the big tensors' updates
+    return 0;
+}
+
+// Sum of squares of the pieces this rank owns (pre-update values: the L2 term of the loss the
+// step returns, sert/models.py:773-791) into the scalar slot that rides in the all-reduce.
+// Launched behind the zeroing of the gradient buffer, on the stream that did it.
+static int owned_sum_of_squares(sert_model* m, hipStream_t st) {
+    if (!is_dp(m)) return 0;
+    int nparts = 0;
+    for (int i = 0; i < 4; ++i) {
+        if (!m->pt_sharded[i]) continue;
+        const ParamTensor t = param_tensor(m, i);
+        const size_t owned = m->pt_sc[i] * (size_t)m->ar_chunks;
+        const int nb = (int)std::min<size_t>(kOptBlocks / 2, std::max<size_t>(1, owned / 1024));
+        hipLaunchKernelGGL(sumsq_pieces, dim3(nb), dim3(256), 0, st, (const float*)t.p + (size_t)m->rank * m->pt_sc[i],
+                           m->pt_sc[i], slab_elems(m, i), m->ar_chunks, m->sq_scratch + 4 * kOptBlocks + nparts);
+        nparts += nb;
+    }
+    if (nparts) hipLaunchKernelGGL(partials_to_scalar, dim3(1), dim3(256), 0, st, m->sq_scratch + 4 * kOptBlocks, nparts, m->g_sq);
     return 0;
 }
 
@@ -395,6 +453,10 @@ static int vs_negatives(sert_model* m, const int64_t* negatives, uint64_t stream
     const int64_t count = (int64_t)c.batch_size * c.num_negatives;
     if (count == 0) return 0;
     if (negatives) {
+        // (parity path: the device sampler cannot produce an id outside [0, V_e))
+        const int64_t Ve = c.num_entities;
+        for (int64_t i = 0; i < count; ++i)
+            if (negatives[i] < 0 || negatives[i] >= Ve) SERT_FAIL("negative sample out of range [0, num_entities)");
         SERT_HIP(hipMemcpyAsync(m->neg_stage, negatives, count * sizeof(int64_t),
                                 hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(convert_i64_to_i32, dim3(grid_for(count)), dim3(256), 0, st,
@@ -915,12 +977,25 @@ static int reduce_rowloss(sert_model* m, hipStream_t st) {
     return 0;
 }
 
+// One streaming optimiser launch over `count` elements (kernels_opt.h).
+static void launch_stream_opt(sert_model* m, hipStream_t st, float* p, float* g, float* s0, float* s1, size_t count,
+                              int nb, const AdamArgs& aa, const AdadeltaArgs& da, float* sq,
+                              const unsigned char* touched, unsigned row_len) {
+    const bool keep = m->cfg.keep_grads != 0;
+    if (is_vs(m)) {
+        if (keep) hipLaunchKernelGGL((adam_l2<true>), dim3(nb), dim3(256), 0, st, p, g, s0, s1, count, aa, sq, touched, row_len);
+        else      hipLaunchKernelGGL((adam_l2<false>), dim3(nb), dim3(256), 0, st, p, g, s0, s1, count, aa, sq, touched, row_len);
+    } else {
+        if (keep) hipLaunchKernelGGL((adadelta_l2<true>), dim3(nb), dim3(256), 0, st, p, g, s0, s1, count, da, sq, touched, row_len);
+        else      hipLaunchKernelGGL((adadelta_l2<false>), dim3(nb), dim3(256), 0, st, p, g, s0, s1, count, da, sq, touched, row_len);
+    }
+}
+
 // loss_dst: device [3], or the pinned host block (publish = true: its sequence number is
 // stored after the values, for the host to spin on)
 static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = false) {
     const int n_loss_partials = m->n_loss_partials;
     const auto& c = m->cfg;
-    const bool keep = c.keep_grads != 0;
     const float l2k = c.lambda_ > 0.f ? c.lambda_ / (float)c.global_batch_size : 0.f;
     m->step += 1;
     AdamArgs aa{l2k, 0.f, c.beta1, c.beta2, c.eps};
@@ -941,68 +1016,82 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
         SERT_HIP(hipEventRecord(m->ev_opt_fork, m->stream));
         SERT_HIP(hipStreamWaitEvent(ss, m->ev_opt_fork, 0));
     }
-    {
-        // the word table: one streaming launch -- or, data parallel, one per exchanged
-        // slice, each as soon as its all-reduce has landed
-        ScopedTimer t(m, TG_OPT_WORD);
-        const int nchunks = (exchanged && m->rw_chunked) ? m->ar_chunks : 1;
-        for (int ch = 0; ch < nchunks; ++ch) {
-            const size_t lo = nchunks == 1 ? 0 : word_chunk_lo(m, ch);
-            const size_t hi = nchunks == 1 ? m->n_rw : word_chunk_lo(m, ch + 1);
-            if (exchanged && m->rw_chunked) SERT_HIP(hipStreamWaitEvent(m->stream, m->ev_rw_chunk[ch], 0));
-            if (hi <= lo) continue;
-            const size_t cnt = hi - lo;
-            const int nb = (int)std::min<int64_t>(std::max(1, kOptBlocks / nchunks), cdiv(cdiv(cnt, 4), 256));
-            float* sq = m->red_sq + n_sq;
-            float *p = m->rw + lo, *g = m->g_rw + lo, *s0 = m->s0_rw + lo, *s1 = m->s1_rw + lo;
-            const unsigned char* tf = m->use_touched ? m->rw_touched : nullptr;   // (never with slices)
-            const unsigned rl = (unsigned)c.word_dim;
-            if (is_vs(m)) {
-                if (keep) hipLaunchKernelGGL((adam_l2<true>), dim3(nb), dim3(256), 0, m->stream, p, g, s0, s1, cnt, aa, sq, tf, rl);
-                else      hipLaunchKernelGGL((adam_l2<false>), dim3(nb), dim3(256), 0, m->stream, p, g, s0, s1, cnt, aa, sq, tf, rl);
-            } else {
-                if (keep) hipLaunchKernelGGL((adadelta_l2<true>), dim3(nb), dim3(256), 0, m->stream, p, g, s0, s1, cnt, da, sq, tf, rl);
-                else      hipLaunchKernelGGL((adadelta_l2<false>), dim3(nb), dim3(256), 0, m->stream, p, g, s0, s1, cnt, da, sq, tf, rl);
-            }
+    // ---- the big tensors, in the reference's parameter order (models.py:542-543, :1105; the
+    // tensors are independent): one streaming launch each -- or, data parallel, one launch per
+    // owned piece as soon as its gradient slab has been reduce-scattered, the all-gather of the
+    // updated slab right behind it
+    bool any_ag = false;
+    for (int i = 0; i < 4; ++i) {
+        if (!m->pt_big[i]) continue;
+        const ParamTensor t = param_tensor(m, i);
+        if (t.n == 0) continue;
+        const int tg = i == 0 ? TG_OPT_WORD : TG_OPTIMIZER;
+        if (!(is_dp(m) && m->pt_sharded[i])) {
+            ScopedTimer tm(m, tg);
+            const int nb = (int)std::min<int64_t>(kOptBlocks, cdiv(cdiv(t.n, 4), 256));
+            const unsigned char* tf = (i == 0 && m->use_touched) ? m->rw_touched : nullptr;
+            launch_stream_opt(m, m->stream, t.p, t.g, t.s0, t.s1, t.n, nb, aa, da, m->red_sq + n_sq, tf,
+                              i == 0 ? (unsigned)c.word_dim : 1u);
             n_sq += nb;
+            continue;
+        }
+        const size_t sc = m->pt_sc[i];
+        const int nch = m->ar_chunks;
+        {
+            ScopedTimer tm(m, tg);
+            for (int ch = 0; ch < nch; ++ch) {
+                if (exchanged && m->rs_issued[i]) SERT_HIP(hipStreamWaitEvent(m->stream, m->ev_rs_done[i][ch], 0));
+                const size_t off = piece_off(m, i, ch);
+                const int nb = (int)std::min<int64_t>(std::max(1, kOptBlocks / nch), cdiv(cdiv(sc, 4), 256));
+                // (the padding behind the tensor's last element is zero with a zero gradient: it stays zero)
+                launch_stream_opt(m, m->stream, t.p + off, t.g + off, t.s0 + (size_t)ch * sc, t.s1 + (size_t)ch * sc, sc,
+                                  nb, aa, da, m->sq_scratch, nullptr, 1u);
+                if (exchanged) {
+                    SERT_HIP(hipEventRecord(m->ev_opt_done[i][ch], m->stream));
+                    SERT_HIP(hipStreamWaitEvent(m->comm_stream, m->ev_opt_done[i][ch], 0));
+                    SERT_NCCL(g_rccl.AllGather(t.p + off, t.p + (size_t)ch * slab_elems(m, i), sc, /*ncclFloat32*/ 7,
+                                               m->comm, m->comm_stream));
+                    any_ag = true;
+                }
+            }
+        }
+        m->rs_issued[i] = false;
+        if (m->host_ar) {
+            SERT_TRY(host_allreduce(m, t.p, m->pt_pad[i], m->stream, i));
+        } else if (m->comm && m->timing.enabled) {
+            ScopedTimer tm(m, TG_ALLGATHER);
+            for (int ch = 0; ch < nch; ++ch)
+                SERT_NCCL(g_rccl.AllGather(t.p + piece_off(m, i, ch), t.p + (size_t)ch * slab_elems(m, i), sc, 7, m->comm,
+                                           m->stream));
         }
     }
     if (exchanged) SERT_HIP(hipStreamWaitEvent(m->stream, m->ev_ar_done, 0));
     {
-        // parameters of the reference: [R_e, R_w, W, b] (models.py:542-543, :1105); the
-        // tensors are independent.  A large entity table streams like the word table;
-        // everything small goes into one launch.
+        // everything small goes into one launch (a kernel boundary costs more than updating it)
         ScopedTimer t(m, TG_OPTIMIZER);
-        const bool big_re = m->n_re > ((size_t)1 << 22);
-        if (big_re) {
-            const int nb = std::min<int64_t>(kOptBlocks, cdiv(cdiv(m->n_re, 4), 256));
-            float* sq = m->red_sq + n_sq;
-            if (keep) hipLaunchKernelGGL((adam_l2<true>), dim3(nb), dim3(256), 0, m->stream, m->re, m->g_re, m->s0_re, m->s1_re, m->n_re, aa, sq, (const unsigned char*)nullptr, 1u);
-            else      hipLaunchKernelGGL((adam_l2<false>), dim3(nb), dim3(256), 0, m->stream, m->re, m->g_re, m->s0_re, m->s1_re, m->n_re, aa, sq, (const unsigned char*)nullptr, 1u);
-            n_sq += nb;
-        }
         SmallTensors st;
         int k = 0, blocks = 0;
-        auto add = [&](float* p, float* g, float* s0, float* s1, size_t count, float l2) {
-            if (count == 0) return;
-            st.p[k] = p; st.g[k] = g; st.s0[k] = s0; st.s1[k] = s1; st.count[k] = count; st.l2k[k] = l2;
+        for (int i = 1; i < 4; ++i) {
+            const ParamTensor t2 = param_tensor(m, i);
+            if (m->pt_big[i] || t2.n == 0) continue;
+            st.p[k] = t2.p; st.g[k] = t2.g; st.s0[k] = t2.s0; st.s1[k] = t2.s1; st.count[k] = t2.n;
+            st.l2k[k] = t2.l2 ? l2k : 0.f;
             st.first_block[k] = blocks;
-            blocks += (int)std::min<int64_t>(512, cdiv(count, 256));
+            blocks += (int)std::min<int64_t>(512, cdiv(t2.n, 256));
             ++k;
-        };
-        if (!big_re) add(m->re, m->g_re, m->s0_re, m->s1_re, m->n_re, l2k);
-        add(m->W, m->g_w, m->s0_w, m->s1_w, m->n_w, l2k);
-        add(m->b, m->g_b, m->s0_b, m->s1_b, m->n_b, 0.f);
-        for (int i = k; i < 3; ++i) { st.p[i] = st.g[i] = st.s0[i] = st.s1[i] = nullptr; st.count[i] = 0; st.l2k[i] = 0.f; st.first_block[i] = blocks; }
-        st.first_block[3] = blocks;
+        }
+        for (int i = k; i < 3; ++i) { st.p[i] = st.g[i] = st.s0[i] = st.s1[i] = nullptr; st.count[i] = 0; st.l2k[i] = 0.f; }
         for (int i = k; i <= 3; ++i) st.first_block[i] = blocks;
         float* sq = m->red_sq + n_sq;
-        if (is_vs(m)) {
-            if (keep) hipLaunchKernelGGL((optimizer_small<true, true>), dim3(blocks), dim3(256), 0, ss, st, aa, da, sq);
-            else      hipLaunchKernelGGL((optimizer_small<true, false>), dim3(blocks), dim3(256), 0, ss, st, aa, da, sq);
-        } else {
-            if (keep) hipLaunchKernelGGL((optimizer_small<false, true>), dim3(blocks), dim3(256), 0, ss, st, aa, da, sq);
-            else      hipLaunchKernelGGL((optimizer_small<false, false>), dim3(blocks), dim3(256), 0, ss, st, aa, da, sq);
+        if (blocks > 0) {
+            const bool keep = c.keep_grads != 0;
+            if (is_vs(m)) {
+                if (keep) hipLaunchKernelGGL((optimizer_small<true, true>), dim3(blocks), dim3(256), 0, ss, st, aa, da, sq);
+                else      hipLaunchKernelGGL((optimizer_small<true, false>), dim3(blocks), dim3(256), 0, ss, st, aa, da, sq);
+            } else {
+                if (keep) hipLaunchKernelGGL((optimizer_small<false, true>), dim3(blocks), dim3(256), 0, ss, st, aa, da, sq);
+                else      hipLaunchKernelGGL((optimizer_small<false, false>), dim3(blocks), dim3(256), 0, ss, st, aa, da, sq);
+            }
         }
         n_sq += blocks;
         if (side_small) {
@@ -1014,12 +1103,19 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
         ScopedTimer t(m, TG_FINALIZE);
         const float inv_batch = 1.0f / (float)c.global_batch_size;
         const float reg_scale = c.lambda_ > 0.f ? c.lambda_ / (2.0f * (float)c.global_batch_size) : 0.f;
-        // single GPU: the loss partials directly; data parallel: the all-reduced scalar
+        // single GPU: the loss partials directly; data parallel: the all-reduced scalars (loss
+        // sum; sum of squares of the sharded tensors -- the replicated ones come from red_sq)
         const float* lp = is_dp(m) ? m->g_loss : m->red_loss;
         const int nl = is_dp(m) ? 1 : n_loss_partials;
         unsigned* flag = publish ? reinterpret_cast<unsigned*>(loss_dst + 4) : nullptr;
         hipLaunchKernelGGL(finalize_loss, dim3(1), dim3(256), 0, m->stream, lp, nl, m->red_sq,
-                           n_sq, inv_batch, reg_scale, loss_dst, flag, publish ? ++m->loss_seq : 0u);
+                           n_sq, inv_batch, reg_scale, loss_dst, flag, publish ? ++m->loss_seq : 0u,
+                           is_dp(m) ? (const float*)m->g_sq : (const float*)nullptr);
+    }
+    if (any_ag) {
+        // the loss leaves first; the next kernel that reads a parameter waits for the last slab
+        SERT_HIP(hipEventRecord(m->ev_ag_done, m->comm_stream));
+        SERT_HIP(hipStreamWaitEvent(m->stream, m->ev_ag_done, 0));
     }
     return 0;
 }
@@ -1087,6 +1183,7 @@ static int step_forward_backward(sert_model* m, const DataSplit& ds, int64_t bat
         } else {
             SERT_HIP(hipMemsetAsync(m->gflat, 0, m->gflat_alloc * sizeof(float), pre));
         }
+        SERT_TRY(owned_sum_of_squares(m, pre));
     }
     if (is_fs(m)) {
         SERT_TRY(fs_forward<true>(m, ds, batch_index));
@@ -1123,6 +1220,7 @@ static int train_step_async(sert_model* m, int64_t batch_index, const int64_t* n
     const DataSplit& ds = m->split[SERT_SPLIT_TRAIN];
     const int B = m->cfg.batch_size;
     if (m->cfg.inference_only) SERT_FAIL("model was created inference_only");
+    if (m->comm_dead) SERT_FAIL("the communicator of this data-parallel model was destroyed");
     if (ds.N == 0) SERT_FAIL("no training data uploaded");
     if (batch_index < 0 || (batch_index + 1) * (int64_t)B > ds.N) SERT_FAIL("batch_index out of range");
     // what the previous call already ran ahead for this step (sert_hint_next_batch)
@@ -1168,6 +1266,87 @@ int sert_device_info(int device, char* buf, size_t buflen) {
 }
 
 static int create_resources(sert_model* m);
+static int layout_gradients(sert_model* m);
+
+// Data parallel: give every big tensor its ZeRO-1 geometry for (world, ar_chunks): parameters and
+// gradients are re-allocated with the padding that makes the slabs equal, the optimiser state
+// shrinks to the owned pieces (whatever it held so far is kept).
+static int shard_setup(sert_model* m) {
+    if (m->cfg.inference_only) SERT_FAIL("model was created inference_only");
+    for (int i = 0; i < 4; ++i)
+        if (m->pt_sharded[i]) SERT_FAIL("this model already has a data-parallel communicator");
+    hipStream_t s = m->stream;
+    SERT_HIP(hipStreamSynchronize(s));
+    SERT_HIP(hipStreamSynchronize(m->stream2));
+    SERT_HIP(hipStreamSynchronize(m->stream3));
+    float** P[4] = {&m->rw, &m->re, &m->W, &m->b};
+    float** S0[4] = {&m->s0_rw, &m->s0_re, &m->s0_w, &m->s0_b};
+    float** S1[4] = {&m->s1_rw, &m->s1_re, &m->s1_w, &m->s1_b};
+    const size_t n[4] = {m->n_rw, m->n_re, m->n_w, m->n_b};
+    for (int i = 0; i < 4; ++i) {
+        if (!m->pt_big[i]) continue;
+        const size_t unit = (size_t)m->world * (size_t)m->ar_chunks;
+        const size_t sc = round_up((n[i] + unit - 1) / unit, 64);
+        const size_t pad = sc * unit;
+        float *np = nullptr, *ns0 = nullptr, *ns1 = nullptr;
+        SERT_TRY(dzalloc(&np, pad, s));
+        SERT_HIP(hipMemcpyAsync(np, *P[i], n[i] * sizeof(float), hipMemcpyDeviceToDevice, s));
+        SERT_TRY(dzalloc(&ns0, sc * m->ar_chunks, s));
+        SERT_TRY(dzalloc(&ns1, sc * m->ar_chunks, s));
+        for (int c = 0; c < m->ar_chunks; ++c) {
+            const size_t off = (size_t)c * sc * m->world + (size_t)m->rank * sc;
+            if (off >= n[i]) continue;
+            const size_t cnt = std::min(sc, n[i] - off);
+            SERT_HIP(hipMemcpyAsync(ns0 + (size_t)c * sc, *S0[i] + off, cnt * sizeof(float), hipMemcpyDeviceToDevice, s));
+            SERT_HIP(hipMemcpyAsync(ns1 + (size_t)c * sc, *S1[i] + off, cnt * sizeof(float), hipMemcpyDeviceToDevice, s));
+        }
+        SERT_HIP(hipStreamSynchronize(s));
+        (void)hipFree(*P[i]); (void)hipFree(*S0[i]); (void)hipFree(*S1[i]);
+        *P[i] = np; *S0[i] = ns0; *S1[i] = ns1;
+        m->pt_pad[i] = pad;
+        m->pt_sc[i] = sc;
+        m->pt_sharded[i] = true;
+    }
+    return layout_gradients(m);
+}
+
+// Optimiser state of a sharded tensor <-> a full-size host array.  get is COLLECTIVE (every rank
+// calls it, in the same order): the owned pieces are all-gathered into a scratch tensor.
+static int sharded_state_io(sert_model* m, int i, int k, float* host_out, const float* host_in) {
+    const ParamTensor t = param_tensor(m, i);
+    float* st = k == 0 ? t.s0 : t.s1;
+    const size_t sc = m->pt_sc[i], pad = m->pt_pad[i], n = t.n;
+    hipStream_t s = m->stream;
+    if (host_in) {
+        for (int c = 0; c < m->ar_chunks; ++c) {
+            const size_t off = piece_off(m, i, c);
+            SERT_HIP(hipMemsetAsync(st + (size_t)c * sc, 0, sc * sizeof(float), s));
+            if (off < n)
+                SERT_HIP(hipMemcpyAsync(st + (size_t)c * sc, host_in + off, std::min(sc, n - off) * sizeof(float),
+                                        hipMemcpyHostToDevice, s));
+        }
+        SERT_HIP(hipStreamSynchronize(s));
+        return 0;
+    }
+    if (m->comm_dead) SERT_FAIL("the communicator of this data-parallel model was destroyed");
+    float* full = nullptr;
+    SERT_TRY(dzalloc(&full, pad, s));
+    for (int c = 0; c < m->ar_chunks; ++c)
+        SERT_HIP(hipMemcpyAsync(full + piece_off(m, i, c), st + (size_t)c * sc, sc * sizeof(float), hipMemcpyDeviceToDevice, s));
+    int rc = 0;
+    if (m->host_ar) {
+        rc = host_allreduce(m, full, pad, s);   // everything not owned is zero: the sum is the gather
+    } else {
+        for (int c = 0; c < m->ar_chunks && rc == 0; ++c)
+            if (g_rccl.AllGather(full + piece_off(m, i, c), full + (size_t)c * slab_elems(m, i), sc, 7, m->comm, s) != 0)
+                rc = fail(__FILE__, __LINE__, "ncclAllGather failed (optimiser state)");
+    }
+    if (rc == 0 && hipMemcpyAsync(host_out, full, n * sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess)
+        rc = fail(__FILE__, __LINE__, "copy of the gathered optimiser state failed");
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(full);
+    return rc;
+}
 
 int sert_create(const sert_config* cfg, sert_model** out) {
     if (!cfg || !out) SERT_FAIL("null argument");
@@ -1200,6 +1379,41 @@ int sert_create(const sert_config* cfg, sert_model** out) {
     return 0;
 }
 
+// (Re)build the flat gradient buffer [g_rw | g_re | g_w | g_b | loss sum, owned sum of squares,
+// pad | per-entity run bounds] for the current paddings pt_pad[] (every sub-tensor 16-byte aligned).
+static int layout_gradients(sert_model* m) {
+    const bool vs = is_vs(m);
+    const size_t V = m->cfg.num_entities;
+    size_t off[5];
+    off[0] = 0;
+    for (int i = 0; i < 4; ++i) off[i + 1] = off[i] + round_up(m->pt_pad[i], 4);
+    m->gflat_count = off[4] + 4;
+    m->ar_split = off[1];
+    // the replicated remainder starts at the first tensor that is not sharded (the sharded
+    // ones -- the big ones -- always form a prefix of [R_w, R_e, W, b])
+    int first_repl = 0;
+    while (first_repl < 4 && m->pt_sharded[first_repl]) ++first_repl;
+    for (int i = first_repl; i < 4; ++i)
+        if (m->pt_sharded[i]) SERT_FAIL("internal: sharded tensors must be a prefix of [R_w, R_e, W, b]");
+    m->rest_off = off[first_repl];
+    // tail of the same allocation (zeroed with the gradients every step, not part of any
+    // exchange): per-entity sorted-run bounds
+    m->gflat_alloc = m->gflat_count + (vs ? 2 * round_up(V, 4) : 0);
+    if (m->gflat) { SERT_HIP(hipStreamSynchronize(m->stream)); (void)hipFree(m->gflat); m->gflat = nullptr; }
+    SERT_TRY(dzalloc(&m->gflat, m->gflat_alloc, m->stream));
+    if (vs) {
+        m->run_start = (int32_t*)(m->gflat + m->gflat_count);
+        m->run_end = m->run_start + round_up(V, 4);
+    }
+    m->g_rw = m->gflat + off[0];
+    m->g_re = m->n_re ? m->gflat + off[1] : nullptr;
+    m->g_w = m->gflat + off[2];
+    m->g_b = m->gflat + off[3];
+    m->g_loss = m->gflat + off[4];
+    m->g_sq = m->g_loss + 1;
+    return 0;
+}
+
 static int create_resources(sert_model* m) {
     const auto& c = m->cfg;
     SERT_HIP(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
@@ -1222,6 +1436,15 @@ static int create_resources(sert_model* m) {
     m->n_w = vs ? dw * de : dw * V;
     m->n_b = vs ? de : V;
     hipStream_t s = m->stream;
+    {
+        const size_t n[4] = {m->n_rw, m->n_re, m->n_w, m->n_b};
+        for (int i = 0; i < 4; ++i) {
+            m->pt_pad[i] = n[i];
+            // the word table always has its own streaming launch; R_e / W beyond 4 M elements too
+            m->pt_big[i] = n[i] > 0 && (i == 0 || (i < 3 && n[i] > ((size_t)1 << 22)));
+            m->pt_sharded[i] = false;
+        }
+    }
     SERT_TRY(dzalloc(&m->rw, m->n_rw, s));  SERT_TRY(dzalloc(&m->re, m->n_re, s));
     SERT_TRY(dzalloc(&m->W, m->n_w, s));    SERT_TRY(dzalloc(&m->b, m->n_b, s));
     if (!c.inference_only) {
@@ -1229,24 +1452,7 @@ static int create_resources(sert_model* m) {
         SERT_TRY(dzalloc(&m->s0_w, m->n_w, s));   SERT_TRY(dzalloc(&m->s0_b, m->n_b, s));
         SERT_TRY(dzalloc(&m->s1_rw, m->n_rw, s)); SERT_TRY(dzalloc(&m->s1_re, m->n_re, s));
         SERT_TRY(dzalloc(&m->s1_w, m->n_w, s));   SERT_TRY(dzalloc(&m->s1_b, m->n_b, s));
-        // flat gradient buffer, every sub-tensor 16-byte aligned
-        const size_t o_rw = 0, o_re = o_rw + round_up(m->n_rw, 4), o_w = o_re + round_up(m->n_re, 4),
-                     o_b = o_w + round_up(m->n_w, 4), o_l = o_b + round_up(m->n_b, 4);
-        m->gflat_count = o_l + 4;
-        m->ar_split = o_re;
-        // tail of the same allocation (zeroed with the gradients every step, not
-        // part of the all-reduce): per-entity sorted-run bounds
-        m->gflat_alloc = m->gflat_count + (vs ? 2 * round_up(V, 4) : 0);
-        SERT_TRY(dzalloc(&m->gflat, m->gflat_alloc, s));
-        if (vs) {
-            m->run_start = (int32_t*)(m->gflat + m->gflat_count);
-            m->run_end = m->run_start + round_up(V, 4);
-        }
-        m->g_re = m->n_re ? m->gflat + o_re : nullptr;
-        m->g_rw = m->gflat + o_rw;
-        m->g_w = m->gflat + o_w;
-        m->g_b = m->gflat + o_b;
-        m->g_loss = m->gflat + o_l;
+        SERT_TRY(layout_gradients(m));
         SERT_TRY(dzalloc(&m->rowloss, B, s));
         size_t part = 0;
         if (vs) {
@@ -1302,6 +1508,7 @@ static int create_resources(sert_model* m) {
         SERT_TRY(dzalloc(&m->part, part, s));
         SERT_TRY(dzalloc(&m->red_loss, (size_t)kOptBlocks, s));
         SERT_TRY(dzalloc(&m->red_sq, (size_t)4 * kOptBlocks, s));  // partials of up to 4 tensors
+        SERT_TRY(dzalloc(&m->sq_scratch, (size_t)8 * kOptBlocks, s));
         SERT_TRY(dzalloc(&m->d_loss, (size_t)4, s));
     }
     // pinned, device-mapped: [loss, data, reg, -, seq]; the step's last kernel writes it directly
@@ -1337,11 +1544,17 @@ int sert_destroy(sert_model* m) {
     if (m->stream3) (void)hipStreamSynchronize(m->stream3);
     if (m->comm_stream) (void)hipStreamSynchronize(m->comm_stream);
     if (m->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(m->comm);
-    if (m->ev_rw_ready) (void)hipEventDestroy(m->ev_rw_ready);
     if (m->ev_rest_ready) (void)hipEventDestroy(m->ev_rest_ready);
     if (m->ev_ar_done) (void)hipEventDestroy(m->ev_ar_done);
-    for (int c = 0; c < sert_model::kMaxArChunks; ++c)
-        if (m->ev_rw_chunk[c]) (void)hipEventDestroy(m->ev_rw_chunk[c]);
+    if (m->ev_ag_done) (void)hipEventDestroy(m->ev_ag_done);
+    for (int i = 0; i < 4; ++i) {
+        if (m->ev_grad_ready[i]) (void)hipEventDestroy(m->ev_grad_ready[i]);
+        for (int c = 0; c < sert_model::kMaxArChunks; ++c) {
+            if (m->ev_rs_done[i][c]) (void)hipEventDestroy(m->ev_rs_done[i][c]);
+            if (m->ev_opt_done[i][c]) (void)hipEventDestroy(m->ev_opt_done[i][c]);
+        }
+    }
+    (void)hipFree(m->sq_scratch);
     if (m->comm_stream) (void)hipStreamDestroy(m->comm_stream);
     float* bufs[] = {m->rw, m->re, m->W, m->b, m->s0_rw, m->s0_re, m->s0_w, m->s0_b, m->s1_rw,
                      m->s1_re, m->s1_w, m->s1_b, m->gflat, m->H, m->T, m->DA, m->DH, m->rowloss,
@@ -1387,6 +1600,8 @@ int sert_set_tensor(sert_model* m, int which, const float* host, size_t count) {
     TensorRef t = tensor_ref(m, which);
     if (!t.ptr || t.count == 0) SERT_FAIL("tensor not present for this model kind");
     if (t.count != count) SERT_FAIL("element count mismatch");
+    if (which >= SERT_T_STATE0_RW && which <= SERT_T_STATE1_B && m->pt_sharded[(which - SERT_T_STATE0_RW) % 4])
+        return sharded_state_io(m, (which - SERT_T_STATE0_RW) % 4, (which - SERT_T_STATE0_RW) / 4, nullptr, host);
     SERT_HIP(hipMemcpyAsync(t.ptr, host, count * sizeof(float), hipMemcpyHostToDevice, m->stream));
     SERT_HIP(hipStreamSynchronize(m->stream));
     return 0;
@@ -1403,6 +1618,8 @@ int sert_get_tensor(sert_model* m, int which, float* host, size_t count) {
     // hold the NEXT batch (sert_hint_next_batch).  Refuse instead of returning something stale.
     if (which >= SERT_T_GRAD_RW && which <= SERT_T_ACT_ROWLOSS && !m->cfg.keep_grads)
         SERT_FAIL("gradients and activations are only readable from a model created with keep_grads = 1");
+    if (which >= SERT_T_STATE0_RW && which <= SERT_T_STATE1_B && m->pt_sharded[(which - SERT_T_STATE0_RW) % 4])
+        return sharded_state_io(m, (which - SERT_T_STATE0_RW) % 4, (which - SERT_T_STATE0_RW) / 4, host, nullptr);
     SERT_HIP(hipMemcpyAsync(host, t.ptr, count * sizeof(float), hipMemcpyDeviceToHost, m->stream));
     SERT_HIP(hipStreamSynchronize(m->stream));
     return 0;
@@ -1416,6 +1633,13 @@ int sert_set_step(sert_model* m, int64_t t) {
 }
 int64_t sert_get_step(sert_model* m) { return m ? m->step : -1; }
 
+int sert_set_eval_draws(sert_model* m, int64_t n) {
+    if (!m || n < 0) SERT_FAIL("bad argument");
+    m->eval_draws = n;
+    return 0;
+}
+int64_t sert_get_eval_draws(sert_model* m) { return m ? m->eval_draws : -1; }
+
 int sert_upload_dataset(sert_model* m, int split, const void* x, const int32_t* y_int,
                         const int64_t* csr_indptr, const int32_t* csr_indices,
                         const float* csr_data, const float* w, int64_t N) {
@@ -1428,6 +1652,33 @@ int sert_upload_dataset(sert_model* m, int split, const void* x, const int32_t* 
     if (N > 0 && !y_int && !(csr_indptr && csr_indices && csr_data)) SERT_FAIL("no labels given");
     if (is_vs(m) && N > 0 && !y_int) SERT_FAIL("vectorspace requires int labels (models.py:933-934)");
     SERT_HIP(hipSetDevice(m->cfg.device));
+    // Every id the kernels will index with is checked here, once, on the host: the reference
+    // raises IndexError for an out-of-range token or label (numpy / Theano advanced indexing);
+    // on the device it would be an out-of-bounds read, and in the backward a write.
+    if (N > 0) {
+        const size_t toks = (size_t)N * m->cfg.window_size;
+        const uint32_t Vw = (uint32_t)m->cfg.vocab_size;
+        bool ok = true;
+        SERT_ID_DISPATCH(m->cfg.id_bytes, {
+            const IdT* xi = (const IdT*)x;
+            uint32_t mx = 0;
+            for (size_t i = 0; i < toks; ++i) mx = std::max<uint32_t>(mx, (uint32_t)xi[i]);
+            ok = mx < Vw;
+        });
+        if (!ok) SERT_FAIL("token id >= vocab_size in x");
+        const int32_t Ve = m->cfg.num_entities;
+        if (y_int) {
+            for (int64_t i = 0; i < N; ++i)
+                if (y_int[i] < 0 || y_int[i] >= Ve) SERT_FAIL("label out of range [0, num_entities) in y");
+        } else {
+            if (csr_indptr[0] != 0) SERT_FAIL("csr_indptr[0] != 0");
+            for (int64_t r = 0; r < N; ++r)
+                if (csr_indptr[r + 1] < csr_indptr[r]) SERT_FAIL("csr_indptr is not non-decreasing");
+            const int64_t nnz = csr_indptr[N];
+            for (int64_t i = 0; i < nnz; ++i)
+                if (csr_indices[i] < 0 || csr_indices[i] >= Ve) SERT_FAIL("label column out of range [0, num_entities) in csr_indices");
+        }
+    }
     DataSplit& d = m->split[split];
     free_split(d);
     d.N = N;
@@ -1731,6 +1982,14 @@ int sert_predict_tokens(sert_model* m, const void* ids, int64_t rows, float* out
     const auto& c = m->cfg;
     const int n = c.window_size, d = c.word_dim, V = c.num_entities;
     const int64_t toks = rows * n;
+    {
+        bool ok = true;
+        SERT_ID_DISPATCH(c.id_bytes, {
+            const IdT* xi = (const IdT*)ids;
+            for (int64_t i = 0; i < toks && ok; ++i) ok = (uint32_t)xi[i] < (uint32_t)c.vocab_size;
+        });
+        if (!ok) SERT_FAIL("token id >= vocab_size in ids");
+    }
     void* d_ids = nullptr;
     float *dG = nullptr, *dZ = nullptr;
     SERT_HIP(hipMalloc(&d_ids, (size_t)toks * c.id_bytes));
@@ -2091,6 +2350,16 @@ int sert_score_topk(int device, const float* entities, int64_t V, int32_t dim, c
     return rc;
 }
 
+// Slabs per big tensor (model.h).  One by default: every extra collective adds its own start-up
+// latency to the exchange, which on a world of one costs more than the overlap of slab c's
+// optimiser with slab c+1's reduce-scatter returns; SERT_AR_CHUNKS=k is there to be tuned on a
+// multi-GPU node.
+static int exchange_slabs() {
+    const char* e = getenv("SERT_AR_CHUNKS");
+    const int want = e ? atoi(e) : 1;
+    return std::max(1, std::min(want, (int)sert_model::kMaxArChunks));
+}
+
 int sert_comm_unique_id(char id[SERT_COMM_ID_BYTES]) {
     SERT_TRY(rccl_load());
     SERT_NCCL(g_rccl.GetUniqueId(id));
@@ -2107,25 +2376,26 @@ int sert_comm_init(sert_model* m, const char id[SERT_COMM_ID_BYTES], int rank, i
     invalidate_speculation(m);
     UniqueId uid;
     memcpy(uid.internal, id, SERT_COMM_ID_BYTES);
+    for (int i = 0; i < 4; ++i)
+        if (m->pt_sharded[i]) SERT_FAIL("this model already has a data-parallel communicator");
     SERT_NCCL(g_rccl.CommInitRank(&m->comm, world, uid, rank));
     m->rank = rank;
     m->world = world;
     if (!m->comm_stream) {
         SERT_HIP(hipStreamCreateWithFlags(&m->comm_stream, hipStreamNonBlocking));
-        SERT_HIP(hipEventCreateWithFlags(&m->ev_rw_ready, hipEventDisableTiming));
         SERT_HIP(hipEventCreateWithFlags(&m->ev_rest_ready, hipEventDisableTiming));
         SERT_HIP(hipEventCreateWithFlags(&m->ev_ar_done, hipEventDisableTiming));
-        for (int c = 0; c < sert_model::kMaxArChunks; ++c)
-            SERT_HIP(hipEventCreateWithFlags(&m->ev_rw_chunk[c], hipEventDisableTiming));
+        SERT_HIP(hipEventCreateWithFlags(&m->ev_ag_done, hipEventDisableTiming));
+        for (int i = 0; i < 4; ++i) {
+            SERT_HIP(hipEventCreateWithFlags(&m->ev_grad_ready[i], hipEventDisableTiming));
+            for (int c = 0; c < sert_model::kMaxArChunks; ++c) {
+                SERT_HIP(hipEventCreateWithFlags(&m->ev_rs_done[i][c], hipEventDisableTiming));
+                SERT_HIP(hipEventCreateWithFlags(&m->ev_opt_done[i][c], hipEventDisableTiming));
+            }
+        }
     }
-    // One slice by default: every extra collective adds its own start-up latency to the
-    // exchange, which on a world of one costs more than the optimiser overlap returns
-    // (0.439 -> 0.464 ms/step at 4 slices); SERT_AR_CHUNKS=k turns the pipelining on for
-    // tuning on a multi-GPU node.
-    const char* e = getenv("SERT_AR_CHUNKS");
-    const int want = e ? atoi(e) : 1;
-    m->ar_chunks = std::max(1, std::min(want, (int)sert_model::kMaxArChunks));
-    return 0;
+    m->ar_chunks = exchange_slabs();
+    return shard_setup(m);
 }
 
 int sert_comm_init_host(sert_model* m, int rank, int world, sert_allreduce_fn fn, void* user) {
@@ -2134,26 +2404,31 @@ int sert_comm_init_host(sert_model* m, int rank, int world, sert_allreduce_fn fn
     if ((int64_t)m->cfg.batch_size * world != m->cfg.global_batch_size)
         SERT_FAIL("global_batch_size must equal batch_size * world");
     if (m->comm) SERT_FAIL("an RCCL communicator is already attached");
+    for (int i = 0; i < 4; ++i)
+        if (m->pt_sharded[i]) SERT_FAIL("this model already has a data-parallel communicator");
     m->host_ar = fn;
     m->host_ar_user = user;
     m->rank = rank;
     m->world = world;
     invalidate_speculation(m);
-    return 0;
+    m->ar_chunks = exchange_slabs();
+    return shard_setup(m);
 }
 
+// After this call the model keeps its parameters (identical on every rank) but can no longer
+// train or hand out its optimiser state: that state is sharded over ranks that are gone.
 int sert_comm_destroy(sert_model* m) {
-    if (m && m->host_ar) {
-        m->host_ar = nullptr;
-        m->host_ar_user = nullptr;
-        m->rank = 0;
-        m->world = 1;
-    }
-    if (m && m->comm) {
-        SERT_NCCL(g_rccl.CommDestroy(m->comm));
+    if (!m) return 0;
+    (void)hipSetDevice(m->cfg.device);
+    if (m->comm_stream) (void)hipStreamSynchronize(m->comm_stream);
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    if (m->host_ar || m->comm) m->comm_dead = true;
+    m->host_ar = nullptr;
+    m->host_ar_user = nullptr;
+    if (m->comm) {
+        void* cm = m->comm;
         m->comm = nullptr;
-        m->rank = 0;
-        m->world = 1;
+        SERT_NCCL(g_rccl.CommDestroy(cm));
     }
     return 0;
 }

@@ -1,20 +1,38 @@
 """Data-parallel host logic (new: the reference is single-device).
 
-One process per GPU, launched by ``python -m torch.distributed.run`` (or any
-launcher that sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).
-The training pairs of every GLOBAL batch are split evenly over the ranks; each
-rank runs forward/backward on its rows, the flat gradient buffer (plus the
-partial loss sum) is summed over ranks by ONE ``ncclAllReduce`` (RCCL over
-xGMI, called directly from libsert_hip.so on the model's HIP stream), and every
-rank applies the identical dense optimiser step to its replica.
+One process per GPU on ONE node.  Ranks are started either by ``launch()`` below
+(``python bench.py --gpus N`` / ``bin/train.py --gpus N`` spawn their own workers) or by
+any launcher that sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT
+(``python -m torch.distributed.run`` works, but nothing here imports PyTorch).
 
-torch.distributed (gloo, CPU) is used for rendezvous only: shipping the 128-byte
-ncclUniqueId, broadcasting initial parameters, barriers and host-side timing
-reductions.  No tensor on the data path ever touches PyTorch.
+The training pairs of every GLOBAL batch are split evenly over the ranks; each rank
+runs forward/backward on its rows; the word-table gradient is reduce-scattered, every
+rank applies the dense optimiser to ITS rows of the table and the updated rows are
+all-gathered (RCCL over xGMI, called directly from libsert_hip.so on the model's HIP
+streams; see csrc/sert_hip.hip).  The small tensors are all-reduced and updated
+identically on every rank.
+
+What the host needs beyond that is tiny -- the 128-byte ncclUniqueId, the initial
+parameters, barriers, a max over ranks of a wall time -- and goes through a
+rendezvous DIRECTORY on the node's shared memory file system (atomic renames, polling):
+no sockets, no port beyond the one the launcher already owns, no third-party package.
+``host_allreduce`` (the verification transport behind SERT_COMM=host, several ranks on
+one GPU) sums through the same directory.
 """
+import atexit
+import hashlib
 import os
+import pickle
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
 
 import numpy as np
+
+_POLL_S = 0.0005
+_TIMEOUT_S = float(os.environ.get('SERT_RDZV_TIMEOUT', '600'))
 
 
 class Context(object):
@@ -22,38 +40,110 @@ class Context(object):
         self.rank, self.local_rank, self.world_size = rank, local_rank, world_size
 
     def unique_id(self):
-        """A fresh ncclGetUniqueId from rank 0, shipped to everyone through gloo.
-        Collective: every rank calls it once per communicator (= per model), in
-        the same order; an id is never reused for a second communicator."""
+        """A fresh ncclGetUniqueId from rank 0, shipped to everyone.  Collective: every
+        rank calls it once per communicator (= per model), in the same order; an id is
+        never reused for a second communicator."""
         from sert_amd import _capi
         uid = _capi.comm_unique_id() if self.rank == 0 else None
         return broadcast_object(uid)
 
 
+class FileStore(object):
+    """Key -> bytes over a directory every rank of the node can see.  A value becomes
+    visible atomically (write to a private name, then rename); readers poll."""
+
+    def __init__(self, path, rank, world):
+        self.path, self.rank, self.world = path, rank, world
+        self.seq = 0
+        os.makedirs(path, exist_ok=True)
+
+    def _file(self, key):
+        return os.path.join(self.path, key)
+
+    def set(self, key, data):
+        tmp = self._file('.%s.%d.tmp' % (key, self.rank))
+        with open(tmp, 'wb') as f:
+            f.write(data)
+        os.replace(tmp, self._file(key))
+
+    def get(self, key, timeout=None):
+        path = self._file(key)
+        deadline = time.time() + (timeout or _TIMEOUT_S)
+        delay = _POLL_S
+        while True:
+            try:
+                with open(path, 'rb') as f:
+                    return f.read()
+            except FileNotFoundError:
+                if time.time() > deadline:
+                    raise RuntimeError('rendezvous timed out waiting for %r in %s (rank %d of %d)'
+                                       % (key, self.path, self.rank, self.world))
+                time.sleep(delay)
+                delay = min(0.01, delay * 1.5)
+
+    def drop(self, key):
+        try:
+            os.unlink(self._file(key))
+        except OSError:
+            pass
+
+    def next_generation(self):
+        self.seq += 1
+        return self.seq
+
+    def exchange(self, tag, data):
+        """Every rank contributes `data` (bytes); returns the list of all contributions in
+        rank order.  A rank's file of generation g-1 is removed once generation g is complete
+        (every rank has then finished reading g-1)."""
+        g = self.next_generation()
+        self.set('%s.%d.%d' % (tag, g, self.rank), data)
+        out = [data if r == self.rank else self.get('%s.%d.%d' % (tag, g, r)) for r in range(self.world)]
+        if g > 1:
+            self.drop('%s.%d.%d' % (self._last_tag, g - 1, self.rank))
+        self._last_tag = tag
+        return out
+
+    _last_tag = 'x'
+
+
 _context = Context()
-_pg_ready = False
+_store = None
 
 
 def get_context():
     return _context
 
 
-def init_from_env(backend='gloo'):
-    """Initialise from the launcher's environment.  No-op for WORLD_SIZE<=1."""
-    global _context, _pg_ready
+def _rendezvous_dir():
+    explicit = os.environ.get('SERT_RDZV_DIR')
+    if explicit:
+        return explicit
+    # ranks started by a foreign launcher share its pid as parent and its MASTER_PORT;
+    # torch's elastic agent also hands every worker a path inside one per-launch directory
+    parts = [os.environ.get('MASTER_ADDR', ''), os.environ.get('MASTER_PORT', ''), str(os.getppid())]
+    err_file = os.environ.get('TORCHELASTIC_ERROR_FILE')
+    if err_file:
+        parts.append(os.path.dirname(os.path.dirname(os.path.dirname(err_file))))
+    tag = hashlib.sha1('|'.join(parts).encode()).hexdigest()[:16]
+    base = '/dev/shm' if os.path.isdir('/dev/shm') and os.access('/dev/shm', os.W_OK) else tempfile.gettempdir()
+    return os.path.join(base, 'sert_rdzv_' + tag)
+
+
+def init_from_env():
+    """Initialise from the launcher's environment.  No-op for WORLD_SIZE <= 1."""
+    global _context, _store
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world <= 1:
         _context = Context()
         return _context
     rank = int(os.environ['RANK'])
     local_rank = int(os.environ.get('LOCAL_RANK', rank))
-    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-    import torch.distributed as dist
-    if not dist.is_initialized():
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
-    _pg_ready = True
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # RCCL over dmabuf IPC
+    if _store is None:
+        _store = FileStore(_rendezvous_dir(), rank, world)
+        atexit.register(_cleanup)
     _context = Context(rank, local_rank, world)
+    barrier()
     return _context
 
 
@@ -63,72 +153,107 @@ def set_context(ctx):
     _context = ctx
 
 
+def _cleanup():
+    global _store
+    if _store is not None and _store.rank == 0:
+        shutil.rmtree(_store.path, ignore_errors=True)
+    _store = None
+
+
 def shutdown():
-    global _context, _pg_ready
-    if _pg_ready:
-        import torch.distributed as dist
-        if dist.is_initialized():
-            dist.destroy_process_group()
-    _pg_ready = False
+    global _context
+    if _store is not None:
+        st = _store
+        barrier()
+        # rank 0 removes the directory: only after every other rank has LEFT the barrier
+        if st.rank != 0:
+            st.set('bye.%d' % st.rank, b'')
+        else:
+            for r in range(1, st.world):
+                st.get('bye.%d' % r)
+        _cleanup()
     _context = Context()
 
 
-def _dist():
-    import torch.distributed as dist
-    return dist
+def _need_store():
+    if _store is None:
+        raise RuntimeError('world_size > 1 but distributed.init_from_env() was not called')
+    return _store
 
 
 def broadcast_object(obj, src=0):
     if _context.world_size <= 1:
         return obj
-    box = [obj]
-    _dist().broadcast_object_list(box, src=src)
-    return box[0]
+    st = _need_store()
+    g = st.next_generation()
+    key = 'bc.%d' % g
+    if _context.rank == src:
+        st.set(key, pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL))
+        # (kept until shutdown: a broadcast has no completion signal, and they are small or rare)
+        return obj
+    return pickle.loads(st.get(key))
 
 
 def broadcast_array(a, src=0):
     """Make a host array identical on every rank (initial parameters)."""
     if _context.world_size <= 1:
         return a
-    import torch
-    t = torch.from_numpy(np.ascontiguousarray(a).copy())
-    _dist().broadcast(t, src=src)
-    return t.numpy()
+    a = np.ascontiguousarray(a)
+    st = _need_store()
+    g = st.next_generation()
+    key = 'ba.%d' % g
+    if _context.rank == src:
+        st.set(key, a.tobytes())
+        out = a
+    else:
+        out = np.frombuffer(st.get(key), dtype=a.dtype).reshape(a.shape).copy()
+    # the payload can be hundreds of MB: free it as soon as everyone has it
+    barrier()
+    if _context.rank == src:
+        st.drop(key)
+    return out
+
+
+def _all_gather_bytes(tag, data):
+    return _need_store().exchange(tag, data)
 
 
 def host_allreduce(array):
-    """In-place sum of a float32 numpy array over the ranks through gloo -- the callback
-    of the host-mediated exchange (SERT_COMM=host: several ranks on one GPU, for
-    verification; RCCL refuses duplicate devices)."""
+    """In-place sum of a float32 numpy array over the ranks, in rank order on every rank
+    (identical bits everywhere) -- the callback of the host-mediated exchange
+    (SERT_COMM=host: several ranks on one GPU, for verification; RCCL refuses duplicate
+    devices)."""
     if _context.world_size <= 1:
         return
-    import torch
-    t = torch.from_numpy(array)
-    _dist().all_reduce(t)
+    parts = _all_gather_bytes('ar', array.tobytes())
+    total = np.frombuffer(parts[0], dtype=array.dtype).copy()
+    for p in parts[1:]:
+        total += np.frombuffer(p, dtype=array.dtype)
+    array[...] = total.reshape(array.shape)
 
 
 def barrier():
     if _context.world_size > 1:
-        _dist().barrier()
+        _all_gather_bytes('bar', b'')
 
 
 def all_reduce_max(value):
     if _context.world_size <= 1:
         return float(value)
-    import torch
-    t = torch.tensor([float(value)], dtype=torch.float64)
-    _dist().all_reduce(t, op=_dist().ReduceOp.MAX)
-    return float(t.item())
+    parts = _all_gather_bytes('max', np.float64(value).tobytes())
+    return float(max(np.frombuffer(p, dtype=np.float64)[0] for p in parts))
 
 
 def all_reduce_sum_array(a):
-    """Sum a host array over ranks (CPU tests of the data-parallel algebra)."""
+    """Sum a host array over ranks (rank order; CPU tests of the data-parallel algebra)."""
     if _context.world_size <= 1:
         return a
-    import torch
-    t = torch.from_numpy(np.ascontiguousarray(a).copy())
-    _dist().all_reduce(t, op=_dist().ReduceOp.SUM)
-    return t.numpy()
+    a = np.ascontiguousarray(a)
+    parts = _all_gather_bytes('sum', a.tobytes())
+    total = np.frombuffer(parts[0], dtype=a.dtype).copy()
+    for p in parts[1:]:
+        total += np.frombuffer(p, dtype=a.dtype)
+    return total.reshape(a.shape)
 
 
 def shard_rows(num_instances, global_batch, rank, world):
@@ -139,3 +264,46 @@ def shard_rows(num_instances, global_batch, rank, world):
     base = (np.arange(nb, dtype=np.int64) * global_batch)[:, None]
     offs = np.arange(local, dtype=np.int64)[None, :] + rank * local
     return (base + offs).ravel()
+
+
+def launch(argv, nproc, env=None, timeout=None):
+    """Start `nproc` ranks of `argv` (a command line) on this node, one per GPU, and wait.
+    Rank 0 inherits stdout; every rank inherits stderr.  Returns the first non-zero exit
+    code (0 if all ranks succeeded); a rank that fails takes the others down."""
+    rdzv = tempfile.mkdtemp(prefix='sert_rdzv_', dir='/dev/shm' if os.path.isdir('/dev/shm') else None)
+    procs = []
+    try:
+        for rank in range(nproc):
+            e = dict(os.environ if env is None else env)
+            e.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(nproc), SERT_RDZV_DIR=rdzv,
+                     HSA_ENABLE_IPC_MODE_LEGACY=e.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+            procs.append(subprocess.Popen(argv, env=e, stdout=None if rank == 0 else subprocess.DEVNULL))
+        deadline = time.time() + timeout if timeout else None
+        rc = 0
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                r = p.poll()
+                if r is None:
+                    continue
+                pending.remove(p)
+                if r != 0 and rc == 0:
+                    rc = r
+                    for q in pending:       # one rank died: the others would wait forever
+                        q.terminate()
+            if deadline and time.time() > deadline:
+                for q in pending:
+                    q.kill()
+                return 124
+            time.sleep(0.02)
+        return rc
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        shutil.rmtree(rdzv, ignore_errors=True)
+
+
+if __name__ == '__main__':
+    # python -m sert_amd.distributed N prog args...   (a minimal one-node launcher)
+    sys.exit(launch([sys.executable] + sys.argv[2:], int(sys.argv[1])))

@@ -29,8 +29,57 @@ from sert_amd import _capi
 from sert_amd import distributed
 
 
+class _EpochPass(object):
+    """One pass over the complete batches of a split: which batches, in which order, the
+    per-result finite check and the throughput line.  Shared by every way this module walks
+    a split -- one host synchronisation per batch (the reference's loop, models.py:351-399)
+    or one per chunk of batches (train() with steps_per_sync > 1, the error passes).
+
+    Contract kept from the reference: N // B batches and a warning about a dropped tail;
+    training shuffles the batch ORDER with the global np.random; a non-finite result raises
+    RuntimeError naming the position; "batches per second" is logged every
+    ``report_interval`` results and at the end (pairs/s = that x batch_size)."""
+
+    def __init__(self, batch_size, num_instances, report_interval, shuffle):
+        self.started = time.time()
+        self.total = num_instances // batch_size
+        self.report_interval = report_interval
+        leftover = num_instances - self.total * batch_size
+        if leftover > 0:
+            logging.warning('\tIgnoring incomplete batch of size %d.', leftover)
+        self.order = list(range(self.total))
+        if shuffle:
+            logging.debug('Shuffling batches.')
+            np.random.shuffle(self.order)
+        self.results = []
+
+    def successor(self, position):
+        """Batch that follows the one at `position`, or None at the end of the pass."""
+        return self.order[position + 1] if position + 1 < self.total else None
+
+    def accept(self, value):
+        self.results.append(value)
+        done = len(self.results)
+        if not np.all(np.isfinite(value)):
+            raise RuntimeError(
+                'Encountered NaN or infinity ({error}) during batch iteration '
+                '(batch {batches_finished}/{num_batches}).'.format(
+                    error=value, batches_finished=done, num_batches=self.total))
+        if done % self.report_interval == 0 or done == self.total:
+            self._report(done)
+
+    def _report(self, done):
+        rate = done / max(float(time.time() - self.started), 1e-9)
+        eta = (self.total - done) / rate
+        logging.info('\tProcessed %d batches; %.2f batches per second; '
+                     '%d minutes %d seconds remaining.', done, rate, eta / 60, eta % 60)
+
+    def outcome(self):
+        return self.total, self.results
+
+
 class ModelInterface(object):
-    """sert/models.py:295-411."""
+    """sert/models.py:295-411: the abstract model the drivers talk to."""
 
     __DETECT_EXCEPTIONS__ = False
 
@@ -38,84 +87,41 @@ class ModelInterface(object):
 
     def __init__(self, batch_size):
         assert batch_size > 0
-
         self.batch_size = batch_size
-
         logging.debug('Batch size: %d', self.batch_size)
 
     @classmethod
     def _get_batch_slice(cls, batch_index, batch_size):
-        start = batch_index * batch_size
-        end = (batch_index + 1) * batch_size
-
-        return slice(start, end)
+        return slice(batch_index * batch_size, batch_index * batch_size + batch_size)
 
     def _number_of_batches(self, num_instances):
         return num_instances // self.batch_size
 
     def _iterate_batches(self, fn, num_instances,
                          report_interval=10000, shuffle=False):
-        """The epoch loop (models.py:351-399): N // B batches, incomplete tail
-        ignored, batch ORDER shuffled with the global np.random when asked,
-        RuntimeError on a non-finite loss, batches-per-second log line (the
-        reference's only throughput instrument; pairs/s = that x batch_size)."""
-        start = time.time()
+        """fn(batch_index) over one pass, one call (and one host synchronisation) per batch."""
+        walk = _EpochPass(self.batch_size, num_instances, report_interval, shuffle)
+        # The order is known up front: while training, tell the engine which batch follows,
+        # so that it can enqueue that batch's work before the host starts waiting for the
+        # current loss (no effect on results).
+        announce = None
+        if fn == getattr(self, 'train_fn', None):
+            announce = getattr(getattr(self, '_engine', None), 'hint_next_batch', None)
+        for position, batch_index in enumerate(walk.order):
+            if announce is not None:
+                announce(walk.successor(position))
+            walk.accept(fn(batch_index))
+        return walk.outcome()
 
-        num_batches = self._number_of_batches(num_instances)
-        incomplete_batch_size = num_instances % self.batch_size
-        if incomplete_batch_size > 0:
-            logging.warning('\tIgnoring incomplete batch of size %d.',
-                            incomplete_batch_size)
-
-        results = []
-
-        batch_indices = list(range(num_batches))
-        if shuffle:
-            logging.debug('Shuffling batches.')
-
-            np.random.shuffle(batch_indices)
-
-        # The order is known up front: while training, tell the engine which batch
-        # follows, so that it can enqueue that batch's parameter-only forward part
-        # before the host starts waiting for the current loss (no effect on results).
-        hint = getattr(getattr(self, '_engine', None), 'hint_next_batch', None) \
-            if fn == getattr(self, 'train_fn', None) else None
-
-        for position, batch_idx in enumerate(batch_indices):
-            if hint is not None:
-                hint(batch_indices[position + 1]
-                     if position + 1 < len(batch_indices) else None)
-            results.append(fn(batch_idx))
-
-            if not np.all(np.isfinite(results[-1])):
-                raise RuntimeError(
-                    'Encountered NaN or infinity ({error}) '
-                    'during batch iteration '
-                    '(batch {batches_finished}/{num_batches}).'.format(
-                        error=results[-1],
-                        batches_finished=len(results),
-                        num_batches=len(batch_indices)))
-
-            if results and (len(results) % report_interval == 0 or
-                            len(results) == num_batches):
-                time_since_measure_start = float(time.time() - start)
-                batches_per_second = len(results) / max(
-                    time_since_measure_start, 1e-9)
-
-                remaining_batches = num_batches - len(results)
-                estimated_remaining_seconds = (
-                    remaining_batches / batches_per_second)
-
-                minutes_remaining = estimated_remaining_seconds / 60
-                seconds_remaining = estimated_remaining_seconds % 60
-
-                logging.info(
-                    '\tProcessed %d batches; %.2f batches per second; '
-                    '%d minutes %d seconds remaining.',
-                    len(results), batches_per_second,
-                    minutes_remaining, seconds_remaining)
-
-        return num_batches, results
+    def _iterate_chunks(self, issue, num_instances, chunk, report_interval, shuffle):
+        """issue(list of batch indices) -> their results, one host synchronisation per chunk;
+        same order, results, log lines and exception as _iterate_batches (a non-finite result
+        surfaces at the end of the chunk that holds it)."""
+        walk = _EpochPass(self.batch_size, num_instances, report_interval, shuffle)
+        for first in range(0, walk.total, chunk):
+            for value in issue(walk.order[first:first + chunk]):
+                walk.accept(value)
+        return walk.outcome()
 
     def train(self):
         raise NotImplementedError()
@@ -170,38 +176,31 @@ class ModelBase(ModelInterface):
                  training_set, validation_set,
                  learning_method):
         super(ModelBase, self).__init__(batch_size)
-
         self.learning_method = learning_method
 
-        self.training_num_instances = training_set[1].shape[0]
-        self.validation_num_instances = validation_set[1].shape[0]
+        x_train, y_train = training_set[0], training_set[1]
+        x_validate, y_validate = validation_set[0], validation_set[1]
+        self.training_num_instances = y_train.shape[0]
+        self.validation_num_instances = y_validate.shape[0]
 
-        # Determine number of instance features.
-        self.num_instance_features = int(np.prod(training_set[0].shape[1:]))
-
-        assert self.num_instance_features == training_set[0].shape[1]
-
-        if np.prod(validation_set[0].shape):
-            assert self.num_instance_features == validation_set[0].shape[1]
+        # instances are rows of `num_instance_features` ids (models.py:437-446)
+        assert x_train.ndim == 2
+        self.num_instance_features = int(x_train.shape[1])
+        if x_validate.size:
+            assert x_validate.shape[1] == self.num_instance_features
         else:
-            validation_set = (
-                validation_set[0].reshape(
-                    0, self.num_instance_features),
-                validation_set[1])
+            # an empty validation split may arrive with any shape (models.py:448-454)
+            x_validate = x_validate.reshape(0, self.num_instance_features)
+            validation_set = (x_validate,) + tuple(validation_set[1:])
 
         logging.info('Data set contains %d training instances '
                      'and %d validation instances',
-                     self.training_num_instances,
-                     self.validation_num_instances)
+                     self.training_num_instances, self.validation_num_instances)
 
-        assert training_set[0].dtype == validation_set[0].dtype
-        assert training_set[1].dtype == validation_set[1].dtype
-
-        self.input_dtype = training_set[0].dtype
-        self.output_dtype = training_set[1].dtype
-
-        self.training_set = training_set
-        self.validation_set = validation_set
+        assert x_train.dtype == x_validate.dtype
+        assert y_train.dtype == y_validate.dtype
+        self.input_dtype, self.output_dtype = x_train.dtype, y_train.dtype
+        self.training_set, self.validation_set = training_set, validation_set
 
         self._engine = None
 
@@ -298,134 +297,98 @@ class ModelBase(ModelInterface):
                 split, x, csr=sparse.csr_matrix(np.asarray(y, dtype=np.float32)),
                 w=w)
 
+    def _local_negatives(self, sampler, batch_index):
+        """Explicit negatives of one batch as the engine wants them: this rank's rows of the
+        (global_batch, z) array a sampler returns (or the local block, if it already is one)."""
+        if sampler is None:
+            return None
+        neg = np.asarray(sampler(batch_index))
+        z = self._engine.cfg.num_negatives
+        if self._ctx.world_size > 1 and neg.shape == (self.batch_size, z):
+            first = self._ctx.rank * self._local_batch
+            neg = neg[first:first + self._local_batch]
+        assert neg.shape == (self._local_batch, z), \
+            'negative sampler returned %r, expected (%d, %d)' % (neg.shape, self._local_batch, z)
+        return neg
+
     # -- the three step functions (models.py:581-608) ---------------------------
     def train_fn(self, batch_index):
-        neg = self.negative_sampler(batch_index) \
-            if self.negative_sampler is not None else None
-        return self._engine.train_batch(batch_index, neg)
+        return self._engine.train_batch(
+            batch_index, self._local_negatives(self.negative_sampler, batch_index))
 
     def test_fn(self, batch_index):
-        neg = self.eval_negative_sampler(batch_index) \
-            if self.eval_negative_sampler is not None else None
-        return self._engine.eval_batch(_capi.SPLIT_TRAIN, batch_index, neg)
+        return self._engine.eval_batch(
+            _capi.SPLIT_TRAIN, batch_index,
+            self._local_negatives(self.eval_negative_sampler, batch_index))
 
     def validate_fn(self, batch_index):
-        neg = self.eval_negative_sampler(batch_index) \
-            if self.eval_negative_sampler is not None else None
-        return self._engine.eval_batch(_capi.SPLIT_VALIDATE, batch_index, neg)
+        return self._engine.eval_batch(
+            _capi.SPLIT_VALIDATE, batch_index,
+            self._local_negatives(self.eval_negative_sampler, batch_index))
 
+    # -- passes over a split (models.py:638-668) ----------------------------------
     def train(self):
+        count = self.training_num_instances
         logging.info('Training on %d training instances (%d batches).',
-                     self.training_num_instances,
-                     self._number_of_batches(self.training_num_instances))
-
+                     count, self._number_of_batches(count))
         if self.steps_per_sync > 1 and self.negative_sampler is None:
-            num_batches, errors = self._iterate_batches_deferred(
-                self.training_num_instances, self.steps_per_sync)
-        else:
-            num_batches, errors = self._iterate_batches(
-                self.train_fn, self.training_num_instances,
+            num_batches, losses = self._iterate_chunks(
+                self._engine.train_batches, count, int(self.steps_per_sync),
                 report_interval=1000, shuffle=True)
+        else:
+            num_batches, losses = self._iterate_batches(
+                self.train_fn, count, report_interval=1000, shuffle=True)
+        return num_batches, np.mean(losses)
 
-        return num_batches, np.mean(errors)
-
-    def _iterate_batches_deferred(self, num_instances, chunk):
-        """train() with the loss read-back deferred: same batch order (shuffled
-        with the global np.random), same results, same RuntimeError on a
-        non-finite loss -- raised at the end of the chunk that contains it."""
-        start = time.time()
-        num_batches = self._number_of_batches(num_instances)
-        if num_instances % self.batch_size > 0:
-            logging.warning('\tIgnoring incomplete batch of size %d.',
-                            num_instances % self.batch_size)
-        batch_indices = list(range(num_batches))
-        np.random.shuffle(batch_indices)
-        results = []
-        for lo in range(0, num_batches, chunk):
-            losses = self._engine.train_batches(batch_indices[lo:lo + chunk])
-            for loss in losses:
-                results.append(loss)
-                if not np.isfinite(loss):
-                    raise RuntimeError(
-                        'Encountered NaN or infinity ({error}) '
-                        'during batch iteration '
-                        '(batch {batches_finished}/{num_batches}).'.format(
-                            error=loss, batches_finished=len(results),
-                            num_batches=num_batches))
-        elapsed = max(float(time.time() - start), 1e-9)
-        logging.info('\tProcessed %d batches; %.2f batches per second; '
-                     '0 minutes 0 seconds remaining.', len(results), len(results) / elapsed)
-        return num_batches, results
-
-    def _iterate_eval(self, fn, split, num_instances):
-        """An error pass: _iterate_batches(fn, ...) semantics (batch order, tail drop,
-        RuntimeError text, log line) with chunked read-back when allowed."""
+    def _error_pass(self, fn, split, count):
+        """(mean, std) of the per-batch evaluation losses of a split."""
         chunk = int(self.eval_batches_per_sync)
-        if chunk <= 1 or self.eval_negative_sampler is not None or \
-                not hasattr(self._engine, 'eval_batches'):
-            return self._iterate_batches(fn, num_instances)
-        start = time.time()
-        num_batches = self._number_of_batches(num_instances)
-        if num_instances % self.batch_size > 0:
-            logging.warning('\tIgnoring incomplete batch of size %d.',
-                            num_instances % self.batch_size)
-        results = []
-        for lo in range(0, num_batches, chunk):
-            losses = self._engine.eval_batches(
-                split, np.arange(lo, min(lo + chunk, num_batches), dtype=np.int64))
-            for loss in losses:
-                results.append(loss)
-                if not np.isfinite(loss):
-                    raise RuntimeError(
-                        'Encountered NaN or infinity ({error}) '
-                        'during batch iteration '
-                        '(batch {batches_finished}/{num_batches}).'.format(
-                            error=loss, batches_finished=len(results),
-                            num_batches=num_batches))
-        if num_batches:
-            elapsed = max(float(time.time() - start), 1e-9)
-            logging.info('\tProcessed %d batches; %.2f batches per second; '
-                         '0 minutes 0 seconds remaining.', len(results), len(results) / elapsed)
-        return num_batches, results
+        if chunk > 1 and self.eval_negative_sampler is None:
+            _, losses = self._iterate_chunks(
+                lambda batches: self._engine.eval_batches(
+                    split, np.asarray(batches, dtype=np.int64)),
+                count, chunk, report_interval=10000, shuffle=False)
+        else:
+            _, losses = self._iterate_batches(fn, count)
+        return np.mean(losses), np.std(losses)
 
     def train_error(self):
+        count = self.training_num_instances
         logging.info('Measuring error on %d training instances (%d batches).',
-                     self.training_num_instances,
-                     self._number_of_batches(self.training_num_instances))
-
-        num_batches, errors = self._iterate_eval(
-            self.test_fn, _capi.SPLIT_TRAIN, self.training_num_instances)
-
-        return np.mean(errors), np.std(errors)
+                     count, self._number_of_batches(count))
+        return self._error_pass(self.test_fn, _capi.SPLIT_TRAIN, count)
 
     def validation_error(self):
-        logging.info('Measuring error on %d validation instances '
-                     '(%d batches).',
-                     self.validation_num_instances,
-                     self._number_of_batches(self.validation_num_instances))
-
-        num_batches, errors = self._iterate_eval(
-            self.validate_fn, _capi.SPLIT_VALIDATE, self.validation_num_instances)
-
-        return np.mean(errors), np.std(errors)
+        count = self.validation_num_instances
+        logging.info('Measuring error on %d validation instances (%d batches).',
+                     count, self._number_of_batches(count))
+        return self._error_pass(self.validate_fn, _capi.SPLIT_VALIDATE, count)
 
     def get_state(self):
-        state = [self.predict_fn]
-
-        all_representations = self.get_representations()
-        if not isinstance(all_representations, (tuple, list)):
-            all_representations = (all_representations, )
-
-        for representations in all_representations:
-            state.append(representations)
-
-        return state
+        """[predict_fn, R_w(, R_e)] -- what bin/train.py pickles behind its namespace
+        (models.py:670-680)."""
+        tables = self.get_representations()
+        if not isinstance(tables, (tuple, list)):
+            tables = (tables,)
+        return [self.predict_fn] + list(tables)
 
     def get_representations(self):
         raise RuntimeError()
 
     # -- additive: optimiser state for checkpoint / resume ---------------------
     _STATE_TENSORS = ()
+
+    def get_sampler_state(self):
+        """Seed and evaluation position of the device negative sampler (the training position
+        is the optimiser step).  A run resumed with the same seed and positions draws the
+        negatives the uninterrupted run would have drawn."""
+        return {'seed': int(self._engine.cfg.seed), 'eval_draws': self._engine.get_eval_draws()}
+
+    def set_sampler_state(self, st):
+        if int(st['seed']) != int(self._engine.cfg.seed):
+            raise RuntimeError('the sampler seed is fixed at construction: set %s.sampler_seed = %d '
+                               'before creating the model' % (type(self).__name__, st['seed']))
+        self._engine.set_eval_draws(st['eval_draws'])
 
     def get_optimizer_state(self):
         st = {'step': self._engine.get_step()}

@@ -120,16 +120,24 @@ class EpochDriver(object):
 
     def dump(self, epoch):
         state = list(self.model.get_state())      # every rank reads its replica
+        trailer = None
+        if self.save_optimizer_state and hasattr(self.model, 'get_optimizer_state'):
+            # (data parallel: the optimiser state is sharded over the ranks -- gathering it is
+            # a collective, so every rank takes part even though only rank 0 writes)
+            trailer = {'optimizer_state': self.model.get_optimizer_state(),
+                       'sampler_state': self.model.get_sampler_state(),
+                       'numpy_random_state': np.random.get_state(),
+                       'epoch': epoch,
+                       'errors': {'means': self.means, 'stddevs': self.stddevs}}
         if not self.writes_files:
             return
         filename = '{0}_{1}.bin'.format(self.output_path, epoch)
         with open(filename, 'wb') as f:
             for obj in self.extra_objects + state:
                 pickle.dump(obj, f, protocol=pickle.HIGHEST_PROTOCOL)
-            if self.save_optimizer_state and hasattr(self.model, 'get_optimizer_state'):
+            if trailer is not None:
                 # trailing pickle; readers that stop after the representations ignore it
-                pickle.dump({'optimizer_state': self.model.get_optimizer_state()}, f,
-                            protocol=pickle.HIGHEST_PROTOCOL)
+                pickle.dump(trailer, f, protocol=pickle.HIGHEST_PROTOCOL)
         logging.info('Saved model "%s" (%d megabyte).', filename,
                      os.path.getsize(filename) / 1024 / 1024)
 
@@ -148,16 +156,68 @@ class EpochDriver(object):
         return history[-1] > history[-2]
 
 
+def read_checkpoint(path):
+    """A dump written by EpochDriver.dump (or by the reference's bin/train.py:289-300 layout):
+    -> dict(args, predict_fn, tables=[R_w(, R_e)], trailer or None)."""
+    objects = []
+    with open(path, 'rb') as f:
+        while True:
+            try:
+                objects.append(pickle.load(f))
+            except EOFError:
+                break
+    if len(objects) < 3:
+        raise RuntimeError('%s does not look like a model dump (%d objects).' % (path, len(objects)))
+    trailer = None
+    if isinstance(objects[-1], dict) and 'optimizer_state' in objects[-1]:
+        trailer = objects.pop()
+    return {'args': objects[0], 'predict_fn': objects[1], 'tables': objects[2:], 'trailer': trailer}
+
+
+def restore(model, checkpoint):
+    """Put a model (freshly constructed on the same data, with the checkpoint's sampler seed)
+    into the state the dump was taken in: parameters, optimiser tensors and step, sampler
+    positions, the global numpy generator (the next epoch's batch shuffle draws from it).
+    Returns the epoch the dump belongs to, or None when it carries no resume trailer."""
+    from sert_amd import _capi
+    tables, fn = checkpoint['tables'], checkpoint['predict_fn']
+    state = fn.__getstate__()
+    model._engine.set_tensor(_capi.T_RW, tables[0])
+    if len(tables) > 1:
+        model._engine.set_tensor(_capi.T_RE, tables[1])
+    model.set_dense(state['W'], state['b'])
+    trailer = checkpoint['trailer']
+    if trailer is None:
+        logging.warning('Checkpoint holds no optimiser state (written without '
+                        '--save_optimizer_state): the optimiser restarts from zero moments.')
+        return None
+    model.set_optimizer_state(trailer['optimizer_state'])
+    model.set_sampler_state(trailer['sampler_state'])
+    np.random.set_state(trailer['numpy_random_state'])
+    return int(trailer['epoch'])
+
+
 def train(model, num_epochs, output_path,
           abort_threshold=1e-5, early_stopping=False,
-          additional_args=[], save_optimizer_state=False):
+          additional_args=[], save_optimizer_state=False, resume_from=None):
+    """The reference's epoch driver (train.py:262-348).  ``resume_from`` (additive): a
+    checkpoint from read_checkpoint already applied with restore(); the driver then continues
+    behind the epoch it was written at instead of starting with measure + dump 0."""
     assert isinstance(abort_threshold, float)
     run = EpochDriver(model, output_path, additional_args, save_optimizer_state)
 
-    run.measure()
-    run.dump(0)
+    first_epoch = 1
+    if resume_from is not None and resume_from.get('trailer') is not None:
+        trailer = resume_from['trailer']
+        run.means = {k: list(v) for k, v in trailer['errors']['means'].items()}
+        run.stddevs = {k: list(v) for k, v in trailer['errors']['stddevs'].items()}
+        first_epoch = int(trailer['epoch']) + 1
+        logging.info('Resuming behind epoch %d.', first_epoch - 1)
+    else:
+        run.measure()
+        run.dump(0)
 
-    for epoch in range(1, num_epochs + 1):
+    for epoch in range(first_epoch, num_epochs + 1):
         logging.info('Epoch %d.', epoch)
         num_batches, mean_cost = model.train()
         logging.info('Epoch %d: processed %d batches; average error=%f.',

@@ -2,7 +2,8 @@
 SERT_COMM=host), and the same run single-process -- used by
 test_gpu_models.py::test_two_ranks_on_one_gpu_match_single_process.
 
-    python -m torch.distributed.run --nproc-per-node 2 ... tests/dp_worker.py KIND OUT.npz
+    python -m sert_amd.distributed 2 tests/dp_worker.py KIND OUT.npz
+    (or any launcher that sets RANK / LOCAL_RANK / WORLD_SIZE, e.g. torch.distributed.run)
 """
 import os
 import sys
@@ -45,6 +46,11 @@ def run(kind):
     for name, which in (('Rw', C.T_RW), ('W', C.T_W), ('b', C.T_B)) + \
             ((('Re', C.T_RE),) if kind == 'vectorspace' else ()):
         out[name] = m._engine.get_tensor(which).copy()
+    # the optimiser state (data parallel: sharded over the ranks, gathered by this collective read)
+    st = m.get_optimizer_state()
+    out['step'] = np.int64(st.pop('step'))
+    for name, value in st.items():
+        out['opt_' + name] = value
     return out
 
 

@@ -1,4 +1,6 @@
-"""CPU, world_size 2 over gloo: the data-parallel algebra the HIP engine relies on.
+"""CPU, world_size 2: the data-parallel algebra the HIP engine relies on, over the product's
+own rendezvous (sert_amd.distributed: a shared-memory directory, no PyTorch) and, as a
+cross-check of that transport, over torch.distributed's gloo backend (tests only).
 
 Each rank owns rows [r*B_l, (r+1)*B_l) of every GLOBAL batch
 (distributed.shard_rows), computes the data-term gradient of its rows with the
@@ -14,6 +16,7 @@ import sys
 import textwrap
 
 import numpy as np
+import pytest
 
 from sert_amd import distributed
 
@@ -41,6 +44,15 @@ WORKER = textwrap.dedent('''
 
     ctx = D.init_from_env()
     assert ctx.world_size == 2
+    if sys.argv[1] == 'gloo':
+        # same algebra, sums carried by gloo instead of the product's store
+        import torch, torch.distributed as dist
+        dist.init_process_group('gloo', rank=ctx.rank, world_size=ctx.world_size)
+        def _gloo_sum(a):
+            t = torch.from_numpy(np.ascontiguousarray(a).copy())
+            dist.all_reduce(t)
+            return t.numpy()
+        D.all_reduce_sum_array = _gloo_sum
     rng = np.random.RandomState(0)            # same data on every rank
     B, n, z, Vw, Ve, dw, de = 16, 3, 4, 40, 9, 6, 5
     lam = 0.01
@@ -108,7 +120,8 @@ def _free_port():
     return port
 
 
-def test_two_rank_gloo_equals_single_process(tmp_path):
+@pytest.mark.parametrize('transport', ['store', 'gloo'])
+def test_two_ranks_equal_single_process(tmp_path, transport):
     script = tmp_path / 'worker.py'
     script.write_text(WORKER % {'root': ROOT})
     port = _free_port()
@@ -116,7 +129,7 @@ def test_two_rank_gloo_equals_single_process(tmp_path):
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE='2',
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, str(script)], env=env,
+        procs.append(subprocess.Popen([sys.executable, str(script), transport], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = []
     for p in procs:

@@ -233,10 +233,13 @@ def test_device_sampler_is_uniform(hip_lib):
 
 @pytest.mark.parametrize('chunks', [None, '1', '3', '16'])
 def test_rccl_single_rank_communicator(hip_lib, monkeypatch, chunks):
-    """ncclCommInitRank / ncclAllReduce through the C ABI with world=1 (all a
-    1-GPU box can run): the exchange path -- including the sliced word-table
-    exchange with the per-slice optimiser launches -- is exercised and is the
-    identity."""
+    """ncclCommInitRank / ncclReduceScatter / ncclAllGather / ncclAllReduce through the C ABI
+    with world=1 (all a 1-GPU box can run): the data-parallel exchange -- the word table's
+    gradient reduce-scattered slab by slab, the optimiser on the owned pieces with the
+    piece-sized state, the updated slabs all-gathered, the small tensors all-reduced -- is
+    exercised and is the identity.  The communicator is attached AFTER the parameters were set
+    (they move into the padded allocation) and the optimiser state is read back through the
+    collective gather."""
     if chunks is not None:
         monkeypatch.setenv('SERT_AR_CHUNKS', chunks)
     B, n, z, Vw, Ve, dw, de = 64, 3, 4, 101, 12, 16, 16
@@ -251,11 +254,17 @@ def test_rccl_single_rank_communicator(hip_lib, monkeypatch, chunks):
         l0 = eng.train_batch(0, neg)
         l1 = eng.train_batch(1, neg)
         ev = eng.eval_batch(C.SPLIT_TRAIN, 0, neg)
-        outs.append((l0, l1, ev, eng.get_tensor(C.T_RW).copy()))
+        outs.append((l0, l1, ev, eng.get_tensor(C.T_RW).copy(), eng.get_tensor(C.T_STATE0_RW).copy(),
+                     eng.get_tensor(C.T_STATE1_RW).copy(), eng.get_tensor(C.T_RE).copy()))
+        if use_comm:   # the state round-trips through the sharded layout
+            m0 = outs[-1][4]
+            eng.set_tensor(C.T_STATE0_RW, m0 * 2)
+            assert np.array_equal(eng.get_tensor(C.T_STATE0_RW), m0 * 2)
         eng.close()
-    # the regulariser's sum of squares is grouped per slice: losses agree to fp32 rounding
+    # the regulariser's sum of squares is grouped per piece: losses agree to fp32 rounding
     np.testing.assert_allclose(outs[0][:3], outs[1][:3], rtol=2e-6)
-    assert np.array_equal(outs[0][3], outs[1][3])
+    for a, b in zip(outs[0][3:], outs[1][3:]):
+        assert np.array_equal(a, b)
 
 
 def _write_tiny_corpus(tmp_path, kind):
@@ -335,6 +344,56 @@ def test_cli_train_then_query(hip_lib, tmp_path, kind):
     res = trec_utils.evaluate_run(run, qrels, k=100)
     assert res['ndcg_cut_100'] > 0.5, res
     assert os.path.exists(str(tmp_path / 'run_ep')) and os.path.exists(str(tmp_path / 'run_debug'))
+
+
+@pytest.mark.parametrize('kind', ['vectorspace', 'loglinear'])
+def test_resumed_run_equals_uninterrupted_run(hip_lib, tmp_path, kind):
+    """bin/train.py --iterations 2  ==  --iterations 1, then --resume model_1.bin --iterations 2:
+    parameters, optimiser tensors and step, sampler positions and the batch shuffle continue
+    exactly where the dump was taken (bit-identical tables and predict_fn weights; the reference
+    cannot resume, bin/train.py:289-300 only dumps).  bin/query.py still reads the file."""
+    _write_tiny_corpus(tmp_path, kind)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+
+    def train(prefix, iterations, resume=None):
+        cmd = [sys.executable, os.path.join(ROOT, 'bin', 'train.py'), '--data', str(tmp_path / 'data.npz'),
+               '--meta', str(tmp_path / 'meta'), '--type', kind, '--iterations', str(iterations),
+               '--batch_size', '64', '--word_representation_size', '16', '--regularization_lambda', '0.01',
+               '--model_output', str(tmp_path / prefix), '--seed', '11', '--save_optimizer_state',
+               '--loglevel', 'WARNING']
+        if kind == 'vectorspace':
+            cmd += ['--num_negative_samples', '3', '--one_hot_classes', '--entity_representation_size', '24']
+        if resume:
+            cmd += ['--resume', str(tmp_path / resume)]
+        subprocess.check_call(cmd, env=env)
+
+    def load(name):
+        from sert_amd import training
+        ck = training.read_checkpoint(str(tmp_path / name))
+        return ck['tables'], ck['predict_fn'].__getstate__(), ck['trailer']
+
+    train('full', 2)
+    train('part', 1)
+    train('cont', 2, resume='part_1.bin')
+    assert not os.path.exists(str(tmp_path / 'cont_0.bin')) and not os.path.exists(str(tmp_path / 'cont_1.bin'))
+    (ta, fa, tra), (tb, fb, trb) = load('full_2.bin'), load('cont_2.bin')
+    assert len(ta) == (2 if kind == 'vectorspace' else 1)
+    for a, b in zip(ta, tb):
+        assert np.array_equal(a, b)
+    assert np.array_equal(fa['W'], fb['W']) and np.array_equal(fa['b'], fb['b'])
+    assert tra['optimizer_state']['step'] == trb['optimizer_state']['step'] > 0
+    for k, v in tra['optimizer_state'].items():
+        assert np.array_equal(v, trb['optimizer_state'][k]), k
+    assert tra['sampler_state'] == trb['sampler_state']
+    assert tra['errors']['means'] == trb['errors']['means']          # error history carried over
+    # one epoch really happened in between
+    t1, _, _ = load('part_1.bin')
+    assert not np.array_equal(t1[0], ta[0])
+    cmdq = [sys.executable, os.path.join(ROOT, 'bin', 'query.py'), '--meta', str(tmp_path / 'meta'),
+            '--model', str(tmp_path / 'cont_2.bin'), '--topics', str(tmp_path / 'topics'),
+            '--run_out', str(tmp_path / 'run'), '--loglevel', 'WARNING']
+    subprocess.check_call(cmdq + (['--top', '5'] if kind == 'vectorspace' else []), env=env)
+    assert os.path.getsize(str(tmp_path / 'run_ef')) > 0
 
 
 def test_full_pipeline_prepare_train_query(hip_lib, tmp_path):
@@ -472,32 +531,63 @@ def test_full_size_known_answers(hip_lib):
     eng.close()
 
 
-@pytest.mark.parametrize('kind', ['vectorspace', 'loglinear'])
-def test_two_ranks_on_one_gpu_match_single_process(hip_lib, tmp_path, kind):
-    """The data-parallel step with TWO real ranks (torch.distributed.run, one process each)
-    on the one GPU of the test box, through the host-mediated exchange (RCCL refuses
-    duplicate devices): row sharding, global 1/B scaling, rank-invariant negatives, L2
-    applied once, the loss and eval-loss reductions -- against the same code run
-    single-process.  Tolerance: fp32 reassociation of the cross-rank sums."""
+@pytest.mark.parametrize('kind,launcher,chunks', [('vectorspace', 'own', None), ('loglinear', 'own', None),
+                                                  ('vectorspace', 'own', '3'), ('vectorspace', 'torchrun', None)])
+def test_two_ranks_on_one_gpu_match_single_process(hip_lib, tmp_path, kind, launcher, chunks):
+    """The data-parallel step with TWO real ranks (one process each) on the one GPU of the test
+    box, through the host-mediated exchange (RCCL refuses duplicate devices): row sharding,
+    global 1/B scaling, rank-invariant negatives, L2 applied once, the ZeRO-1 word table
+    (gradient reduce-scatter, optimiser and its state on the owned pieces only, parameter
+    all-gather; one slab or three), the loss and eval-loss reductions, the collective read-back
+    of the sharded optimiser state -- against the same code run single-process.  Ranks are
+    started by the product's own launcher (sert_amd.distributed, no PyTorch) and, once, by
+    torch.distributed.run as the driver does.  Tolerance: fp32 reassociation of the sums."""
     import socket
     from tests import dp_worker
-    with socket.socket() as s:
-        s.bind(('127.0.0.1', 0))
-        port = s.getsockname()[1]
     out = str(tmp_path / 'dp.npz')
     env = dict(os.environ, SERT_COMM='host', OMP_NUM_THREADS='1')
-    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+    if chunks:
+        env['SERT_AR_CHUNKS'] = chunks
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'SERT_RDZV_DIR'):
         env.pop(k, None)
-    subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
-                    '--master-addr', '127.0.0.1', '--master-port', str(port),
-                    os.path.join(U.ROOT, 'tests', 'dp_worker.py'), kind, out],
-                   check=True, env=env, cwd=U.ROOT, timeout=600)
+    worker = [os.path.join(U.ROOT, 'tests', 'dp_worker.py'), kind, out]
+    if launcher == 'own':
+        cmd = [sys.executable, '-m', 'sert_amd.distributed', '2'] + worker
+    else:
+        with socket.socket() as s:
+            s.bind(('127.0.0.1', 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+               '--master-addr', '127.0.0.1', '--master-port', str(port)] + worker
+    subprocess.run(cmd, check=True, env=env, cwd=U.ROOT, timeout=600)
     two = np.load(out)
     one = dp_worker.run(kind)
-    for key in ('epoch1', 'epoch2', 'train_error', 'validation_error'):
+    scalars = ('epoch1', 'epoch2', 'train_error', 'validation_error')
+    for key in scalars:
         assert abs(float(two[key]) - float(one[key])) <= 2e-5 * abs(float(one[key])), key
-    for key in [k for k in one if k not in ('epoch1', 'epoch2', 'train_error', 'validation_error')]:
+    for key in [k for k in one if k not in scalars]:
         assert U.rel_err(two[key], one[key]) < 2e-5, key
+    assert int(two['step']) == int(one['step'])
+
+
+def test_bench_launches_its_own_ranks(hip_lib):
+    """python bench.py --gpus 2 starts two ranks itself (no torch.distributed.run), runs the
+    data-parallel C2-shaped step through the host-mediated exchange on the one GPU and prints
+    exactly one JSON line."""
+    import json
+    env = dict(os.environ, SERT_COMM='host', SERT_DEVICE='0')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'SERT_RDZV_DIR'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(U.ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+                        '--batch', '4096', '--vocab', '20000', '--num-batches', '2'],
+                       env=env, cwd=U.ROOT, stdout=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0
+    lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['scaling'] == 'weak' and rec['config']['global_batch'] == 8192
+    assert rec['value'] > 0 and np.isfinite(rec['last_loss'])
+    assert rec['strong_scaling']['global_batch'] == 4096 and rec['strong_scaling']['per_gpu_batch'] == 2048
 
 
 def test_loglinear_distinct_word_path_is_deterministic_and_matches_per_token_path(hip_lib, tmp_path):

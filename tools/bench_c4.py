@@ -23,12 +23,13 @@ def main():
     ap.add_argument('--dim', type=int, default=300)
     ap.add_argument('--window', type=int, default=10)
     ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--batch', type=int, default=None, help='override the per-kind default batch')
     args = ap.parse_args()
     from sert_amd import distributed as dist, models
     batch = {'vectorspace': 65536, 'vectorspace_softmax': 8192, 'loglinear': 1024}
     out = {}
     for kind in args.kinds.split(','):
-        B = batch[kind]
+        B = args.batch or batch[kind]
         rng = np.random.RandomState(0)
         X, y, w = bench.synth_data(rng, 2 * B, args.window, args.vocab, args.entities)
         m = bench.build_model(kind, models, B, args.window, args.vocab, args.entities, args.dim,

@@ -35,17 +35,27 @@ __device__ __forceinline__ void adam_elem(float& p, float& g, float& m, float& v
     g = gv;
 }
 
+// Row filter of the streaming optimiser launches (word table, single GPU): `bits` holds one bit
+// per table row, set iff a token of the current batch points to the row (built once per batch at
+// upload, word_index.h).  The gradient of an unset row is zero and is NOT read (the table is
+// never zeroed either); kRowsAll updates every row, kRowsTouched / kRowsUntouched only the rows
+// whose bit is set / clear -- the untouched rows (56 % of the table at C2) are not read by the
+// batch's own forward, so their update runs beside it instead of behind the backward.
+enum { kRowsAll = 0, kRowsTouched = 1, kRowsUntouched = 2 };
+__device__ __forceinline__ bool row_bit(const uint32_t* __restrict__ bits, unsigned row) {
+    return (bits[row >> 5] >> (row & 31)) & 1u;
+}
+
 // 16-byte accesses (4 streams in, 3-4 out); tensors are 16-byte aligned, the
 // (< 4 element) tail is handled by the first threads of block 0.
-// touched/row_len (optional, word table without memset): the gradient of a row whose
-// flag is 0 is zero and is not read (row_len % 4 == 0, count < 2^32).
+// bits/row_len: see above (row_len % 4 == 0, count < 2^32).
 template <bool STORE_G>
 __global__ __launch_bounds__(256) void adam_l2(float* __restrict__ p, float* __restrict__ g,
                                                float* __restrict__ m, float* __restrict__ v,
                                                size_t count, AdamArgs a,
                                                float* __restrict__ sumsq_partial,
-                                               const unsigned char* __restrict__ touched = nullptr,
-                                               unsigned row_len = 1) {
+                                               const uint32_t* __restrict__ bits = nullptr,
+                                               unsigned row_len = 1, int rows_mode = kRowsAll) {
     __shared__ float red[4];
     float ss = 0.f;
     const float omb1 = 1.0f - a.b1, omb2 = 1.0f - a.b2;
@@ -60,9 +70,11 @@ __global__ __launch_bounds__(256) void adam_l2(float* __restrict__ p, float* __r
     const size_t lo = (size_t)blockIdx.x * per;
     const size_t hi = lo + per < n4 ? lo + per : n4;
     for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const bool hit = !bits || row_bit(bits, ((unsigned)i << 2) / row_len);
+        if (rows_mode != kRowsAll && hit != (rows_mode == kRowsTouched)) continue;
         float4 pp = p4[i], mm = m4[i], vv = v4[i];
         float4 gg = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!touched || touched[((unsigned)i << 2) / row_len]) gg = g4[i];
+        if (hit) gg = g4[i];
         adam_elem(pp.x, gg.x, mm.x, vv.x, a, omb1, omb2, ss);
         adam_elem(pp.y, gg.y, mm.y, vv.y, a, omb1, omb2, ss);
         adam_elem(pp.z, gg.z, mm.z, vv.z, a, omb1, omb2, ss);
@@ -70,7 +82,7 @@ __global__ __launch_bounds__(256) void adam_l2(float* __restrict__ p, float* __r
         p4[i] = pp; m4[i] = mm; v4[i] = vv;
         if (STORE_G) g4[i] = gg;
     }
-    if (blockIdx.x == 0) {
+    if (blockIdx.x == 0 && !bits) {   // (< 4 element tail; a row-filtered table has none)
         const size_t i = (n4 << 2) + threadIdx.x;
         if (i < count) {
             float pp = p[i], gg = g[i], mm = m[i], vv = v[i];
@@ -110,8 +122,8 @@ __global__ __launch_bounds__(256) void adadelta_l2(float* __restrict__ p, float*
                                                    float* __restrict__ delta, size_t count,
                                                    AdadeltaArgs a,
                                                    float* __restrict__ sumsq_partial,
-                                                   const unsigned char* __restrict__ touched = nullptr,
-                                                   unsigned row_len = 1) {
+                                                   const uint32_t* __restrict__ bits = nullptr,
+                                                   unsigned row_len = 1, int rows_mode = kRowsAll) {
     __shared__ float red[4];
     float ss = 0.f;
     const float omr = 1.0f - a.rho;
@@ -126,9 +138,11 @@ __global__ __launch_bounds__(256) void adadelta_l2(float* __restrict__ p, float*
     const size_t lo = (size_t)blockIdx.x * per;
     const size_t hi = lo + per < n4 ? lo + per : n4;
     for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const bool hit = !bits || row_bit(bits, ((unsigned)i << 2) / row_len);
+        if (rows_mode != kRowsAll && hit != (rows_mode == kRowsTouched)) continue;
         float4 pp = p4[i], aa = a4[i], dd = d4[i];
         float4 gg = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!touched || touched[((unsigned)i << 2) / row_len]) gg = g4[i];
+        if (hit) gg = g4[i];
         adadelta_elem(pp.x, gg.x, aa.x, dd.x, a, omr, ss);
         adadelta_elem(pp.y, gg.y, aa.y, dd.y, a, omr, ss);
         adadelta_elem(pp.z, gg.z, aa.z, dd.z, a, omr, ss);
@@ -136,7 +150,7 @@ __global__ __launch_bounds__(256) void adadelta_l2(float* __restrict__ p, float*
         p4[i] = pp; a4[i] = aa; d4[i] = dd;
         if (STORE_G) g4[i] = gg;
     }
-    if (blockIdx.x == 0) {
+    if (blockIdx.x == 0 && !bits) {
         const size_t i = (n4 << 2) + threadIdx.x;
         if (i < count) {
             float pp = p[i], gg = g[i], aa = accu[i], dd = delta[i];

@@ -25,6 +25,8 @@ struct DataSplit {
     int32_t* idx_uwords = nullptr;   // loglinear: distinct words of every batch (sorted)
     int32_t* idx_slots = nullptr;    // loglinear: per token position, rank of its word among them
     int32_t* idx_rows_div = nullptr; // loglinear: idx_rows / n (batch row of every level-0 entry)
+    uint32_t* idx_touched_bits = nullptr;   // per batch: bit w set iff word w occurs in it (word_index.h)
+    int64_t bit_words = 0;                  // 32-bit words per batch in idx_touched_bits
     std::vector<BatchIndex> idx_batches;
 };
 
@@ -129,11 +131,19 @@ struct sert_model {
     // loglinear streaming loss (kernels_ll.h, ll_s_*): per (row, segment) partials
     float2* ll_tokstat = nullptr; float* ll_lse = nullptr; float2* ll_jstat = nullptr;
     float4* ll_rowinfo = nullptr; float* ll_rpart = nullptr; float* ll_r = nullptr;
-    // touched-row flags of the word table for this step (single GPU): the word-gradient
-    // table is then neither zeroed nor read where no token of the batch points
-    unsigned char* rw_touched = nullptr;
-    size_t rw_touched_alloc = 0;   // bytes, multiple of 16
+    // single GPU: the word-gradient table is neither zeroed nor read where no token of the
+    // batch points (static per-batch row bitmaps, DataSplit::idx_touched_bits) ...
     bool use_touched = false;
+    // ... and the optimiser of those untouched rows -- rows the batch's own forward never reads --
+    // is issued at the START of the step on its own stream, beside forward and backward
+    // (SERT_ADAM_SPLIT=0: one launch over the whole table behind the backward, as in round 1)
+    hipStream_t stream4 = nullptr;
+    hipEvent_t ev_word_opt = nullptr;   // the touched rows' update of the previous step was issued (main stream)
+    hipEvent_t ev_early = nullptr;      // this step's untouched-row update is complete (stream4)
+    bool early_issued = false;          // this step's untouched-row launch is in flight
+    int early_sq = 0;                   // ... and wrote this many sum-of-squares partials to red_sq[0..)
+    // dW / db / loss partials on the side stream behind the entity chain (SERT_DW_SIDE=0: main stream)
+    bool dw_side = true;
     // loglinear, logits per DISTINCT word of the batch (duplicate tokens share a row):
     float* Zu = nullptr;          // (U, V_e) logits
     float* dZu = nullptr;         // (U, V_e) per-word sums of dL/dZ

@@ -201,7 +201,7 @@ static int word_grad_segsum(sert_model* m, const DataSplit& ds, int64_t batch_in
     const int d = m->cfg.word_dim;
     if ((size_t)batch_index >= ds.idx_batches.size()) SERT_FAIL("batch has no word index");
     const BatchIndex& bx = ds.idx_batches[(size_t)batch_index];
-    unsigned char* touched = m->use_touched ? m->rw_touched : nullptr;
+    unsigned char* touched = nullptr;   // (row flags are static per batch: DataSplit::idx_touched_bits)
     for (int l = 0; l < bx.nlevels; ++l) {
         const int nitems = bx.item_cnt[l];
         if (nitems == 0) continue;
@@ -952,7 +952,7 @@ static int ll_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
             const BatchIndex& bx = ds.idx_batches[(size_t)batch_index];
             hipLaunchKernelGGL(ll_scatter_rows, dim3(grid_for(rows * d)), dim3(256), 0, m->stream, m->DG,
                                ds.idx_uwords + bx.uw_off, rows, d, m->g_rw,
-                               m->use_touched ? m->rw_touched : (unsigned char*)nullptr);
+                               (unsigned char*)nullptr);
         } else {
             // dR_w[X[r],:] += dG[r,:]
             SERT_TRY(word_grad_segsum(m, ds, batch_index, m->DG, 1.0f));
@@ -980,31 +980,63 @@ static int reduce_rowloss(sert_model* m, hipStream_t st) {
 // One streaming optimiser launch over `count` elements (kernels_opt.h).
 static void launch_stream_opt(sert_model* m, hipStream_t st, float* p, float* g, float* s0, float* s1, size_t count,
                               int nb, const AdamArgs& aa, const AdadeltaArgs& da, float* sq,
-                              const unsigned char* touched, unsigned row_len) {
+                              const uint32_t* bits, unsigned row_len, int rows_mode = kRowsAll) {
     const bool keep = m->cfg.keep_grads != 0;
     if (is_vs(m)) {
-        if (keep) hipLaunchKernelGGL((adam_l2<true>), dim3(nb), dim3(256), 0, st, p, g, s0, s1, count, aa, sq, touched, row_len);
-        else      hipLaunchKernelGGL((adam_l2<false>), dim3(nb), dim3(256), 0, st, p, g, s0, s1, count, aa, sq, touched, row_len);
+        if (keep) hipLaunchKernelGGL((adam_l2<true>), dim3(nb), dim3(256), 0, st, p, g, s0, s1, count, aa, sq, bits, row_len, rows_mode);
+        else      hipLaunchKernelGGL((adam_l2<false>), dim3(nb), dim3(256), 0, st, p, g, s0, s1, count, aa, sq, bits, row_len, rows_mode);
     } else {
-        if (keep) hipLaunchKernelGGL((adadelta_l2<true>), dim3(nb), dim3(256), 0, st, p, g, s0, s1, count, da, sq, touched, row_len);
-        else      hipLaunchKernelGGL((adadelta_l2<false>), dim3(nb), dim3(256), 0, st, p, g, s0, s1, count, da, sq, touched, row_len);
+        if (keep) hipLaunchKernelGGL((adadelta_l2<true>), dim3(nb), dim3(256), 0, st, p, g, s0, s1, count, da, sq, bits, row_len, rows_mode);
+        else      hipLaunchKernelGGL((adadelta_l2<false>), dim3(nb), dim3(256), 0, st, p, g, s0, s1, count, da, sq, bits, row_len, rows_mode);
     }
+}
+
+// Optimiser hyper-parameters of optimiser step `t` (1-based; Adam's bias correction, models.py:922).
+static void optimizer_args(const sert_model* m, int64_t t, AdamArgs* aa, AdadeltaArgs* da) {
+    const auto& c = m->cfg;
+    const float l2k = c.lambda_ > 0.f ? c.lambda_ / (float)c.global_batch_size : 0.f;
+    *aa = AdamArgs{l2k, 0.f, c.beta1, c.beta2, c.eps};
+    *da = AdadeltaArgs{l2k, c.lr, c.beta1, c.eps};
+    if (is_vs(m)) {
+        const float tf = (float)t;
+        aa->a_t = c.lr * sqrtf(1.0f - powf(c.beta2, tf)) / (1.0f - powf(c.beta1, tf));
+    }
+}
+
+// The word-table rows no token of this batch points to (their gradient is the L2 term alone)
+// are not read by the batch's forward either: their update is issued NOW, at the start of the
+// committed step, on its own stream, and runs beside forward and backward; optimizer_and_loss
+// then only has the touched rows left on the critical path.
+static int issue_untouched_rows_update(sert_model* m, const uint32_t* bits) {
+    m->early_issued = false;
+    m->early_sq = 0;
+    static const bool split = !(getenv("SERT_ADAM_SPLIT") && atoi(getenv("SERT_ADAM_SPLIT")) == 0);   // cross-check knob
+    if (!split || !bits || !m->use_touched || is_dp(m) || m->timing.enabled || m->nstreams < 2) return 0;
+    AdamArgs aa; AdadeltaArgs da;
+    optimizer_args(m, m->step + 1, &aa, &da);
+    // (the previous step's touched-row launch may have updated rows this launch owns)
+    SERT_HIP(hipStreamWaitEvent(m->stream4, m->ev_word_opt, 0));
+    const int nb = (int)std::min<int64_t>(kOptBlocks, cdiv(cdiv(m->n_rw, 4), 256));
+    launch_stream_opt(m, m->stream4, m->rw, m->g_rw, m->s0_rw, m->s1_rw, m->n_rw, nb, aa, da, m->red_sq, bits,
+                      (unsigned)m->cfg.word_dim, kRowsUntouched);
+    SERT_HIP(hipEventRecord(m->ev_early, m->stream4));
+    m->early_issued = true;
+    m->early_sq = nb;
+    return 0;
 }
 
 // loss_dst: device [3], or the pinned host block (publish = true: its sequence number is
 // stored after the values, for the host to spin on)
-static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = false) {
+static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = false,
+                              const uint32_t* bits = nullptr) {
     const int n_loss_partials = m->n_loss_partials;
     const auto& c = m->cfg;
     const float l2k = c.lambda_ > 0.f ? c.lambda_ / (float)c.global_batch_size : 0.f;
     m->step += 1;
-    AdamArgs aa{l2k, 0.f, c.beta1, c.beta2, c.eps};
-    AdadeltaArgs da{l2k, c.lr, c.beta1, c.eps};
-    if (is_vs(m)) {
-        const float t = (float)m->step;
-        aa.a_t = c.lr * sqrtf(1.0f - powf(c.beta2, t)) / (1.0f - powf(c.beta1, t));
-    }
-    int n_sq = 0;
+    AdamArgs aa; AdadeltaArgs da;
+    optimizer_args(m, m->step, &aa, &da);
+    // (partials [0, early_sq) belong to the untouched-row launch issued at the start of the step)
+    int n_sq = m->early_issued ? m->early_sq : 0;
     const bool exchanged = m->comm && !m->timing.enabled;
     // single GPU: the small tensors are updated on the side stream WHILE the word table
     // streams on the main one (independent tensors; every gradient is complete here)
@@ -1029,10 +1061,13 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
         if (!(is_dp(m) && m->pt_sharded[i])) {
             ScopedTimer tm(m, tg);
             const int nb = (int)std::min<int64_t>(kOptBlocks, cdiv(cdiv(t.n, 4), 256));
-            const unsigned char* tf = (i == 0 && m->use_touched) ? m->rw_touched : nullptr;
+            const uint32_t* tf = (i == 0 && m->use_touched) ? bits : nullptr;
             launch_stream_opt(m, m->stream, t.p, t.g, t.s0, t.s1, t.n, nb, aa, da, m->red_sq + n_sq, tf,
-                              i == 0 ? (unsigned)c.word_dim : 1u);
+                              i == 0 ? (unsigned)c.word_dim : 1u,
+                              (i == 0 && tf && m->early_issued) ? kRowsTouched : kRowsAll);
             n_sq += nb;
+            // the next step's untouched-row launch (its own stream) starts behind this one
+            if (i == 0 && m->ev_word_opt && !m->timing.enabled) SERT_HIP(hipEventRecord(m->ev_word_opt, m->stream));
             continue;
         }
         const size_t sc = m->pt_sc[i];
@@ -1099,6 +1134,10 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
             SERT_HIP(hipStreamWaitEvent(m->stream, m->ev_small, 0));
         }
     }
+    if (m->early_issued) {   // the untouched rows' sum of squares (and their update) must have landed
+        SERT_HIP(hipStreamWaitEvent(m->stream, m->ev_early, 0));
+        m->early_issued = false;
+    }
     {
         ScopedTimer t(m, TG_FINALIZE);
         const float inv_batch = 1.0f / (float)c.global_batch_size;
@@ -1122,23 +1161,22 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
 
 static bool fused_prologue_applies_with(const sert_model* m, bool touched) {
     return is_vs(m) && !is_fs(m) && !m->timing.enabled && m->nstreams >= 2 && touched &&
-           m->cfg.num_negatives > 0 && (m->gflat_alloc - m->ar_split) % 4 == 0 && m->rw_touched_alloc % 16 == 0;
+           m->cfg.num_negatives > 0 && (m->gflat_alloc - m->ar_split) % 4 == 0;
 }
 static bool fused_prologue_applies(const sert_model* m) { return fused_prologue_applies_with(m, m->use_touched); }
-// sampler of optimiser step m->step + zeroing of the small gradient buffers and row flags
+// sampler of optimiser step m->step + zeroing of the small gradient buffers
 static void launch_fused_prologue(sert_model* m) {
     const int64_t count = (int64_t)m->cfg.batch_size * m->cfg.num_negatives;
     hipLaunchKernelGGL(vs_sample_negatives, dim3(grid_for((count + 3) / 4)), dim3(256), 0, m->stream, m->neg,
                        count, (int64_t)m->rank * count, (uint32_t)m->cfg.num_entities, m->cfg.seed,
                        (uint64_t)m->step * 2, reinterpret_cast<float4*>(m->gflat + m->ar_split),
-                       (m->gflat_alloc - m->ar_split) / 4, reinterpret_cast<uint4*>(m->rw_touched),
-                       m->rw_touched_alloc / 16);
+                       (m->gflat_alloc - m->ar_split) / 4, (uint4*)nullptr, (size_t)0);
 }
 
 static bool use_touched_now(const sert_model* m) {
     static const bool no_touched = getenv("SERT_NO_TOUCHED") != nullptr;   // cross-check knob
     return !no_touched && !is_dp(m) && !m->cfg.keep_grads && m->cfg.word_dim % 4 == 0 &&
-           m->n_rw < ((size_t)1 << 32) && m->rw_touched != nullptr;
+           m->n_rw < ((size_t)1 << 32) && m->split[SERT_SPLIT_TRAIN].idx_touched_bits != nullptr;
 }
 
 // Everything of a training step that does NOT change the model: forward, loss, backward into
@@ -1179,7 +1217,6 @@ static int step_forward_backward(sert_model* m, const DataSplit& ds, int64_t bat
         if (pre != m->stream) SERT_HIP(hipStreamWaitEvent(pre, m->ev_step_done, 0));
         if (m->use_touched) {
             SERT_HIP(hipMemsetAsync(m->gflat + m->ar_split, 0, (m->gflat_alloc - m->ar_split) * sizeof(float), pre));
-            SERT_HIP(hipMemsetAsync(m->rw_touched, 0, (size_t)m->cfg.vocab_size, pre));
         } else {
             SERT_HIP(hipMemsetAsync(m->gflat, 0, m->gflat_alloc * sizeof(float), pre));
         }
@@ -1229,9 +1266,13 @@ static int train_step_async(sert_model* m, int64_t batch_index, const int64_t* n
     bool fused_pre = true;   // (a speculated step always ran its prologue on the main stream)
     if (have_fb) m->spec_fb_batch = -1;     // consumed
     else discard_run_ahead(m);              // a run-ahead for something else: discard it cleanly
+    const uint32_t* bits = ds.idx_touched_bits ? ds.idx_touched_bits + (size_t)batch_index * ds.bit_words : nullptr;
+    // this step is committed: the rows its batch does not touch are updated beside it
+    if (!have_fb) m->use_touched = use_touched_now(m);
+    SERT_TRY(issue_untouched_rows_update(m, bits));
     if (!have_fb) SERT_TRY(step_forward_backward(m, ds, batch_index, negatives, &fused_pre));
     SERT_TRY(allreduce_rest(m));
-    SERT_TRY(optimizer_and_loss(m, loss_dst, publish));
+    SERT_TRY(optimizer_and_loss(m, loss_dst, publish, bits));
     SERT_HIP(hipGetLastError());   // a rejected launch (bad configuration) surfaces here, not as a hang
     // (an event record stalls its queue for ~6 us: steps with the fused prologue skip it)
     if (fused_pre) m->step_done_pending = true;
@@ -1419,6 +1460,9 @@ static int create_resources(sert_model* m) {
     SERT_HIP(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
     SERT_HIP(hipStreamCreateWithFlags(&m->stream2, hipStreamNonBlocking));
     SERT_HIP(hipStreamCreateWithFlags(&m->stream3, hipStreamNonBlocking));
+    SERT_HIP(hipStreamCreateWithFlags(&m->stream4, hipStreamNonBlocking));
+    SERT_HIP(hipEventCreateWithFlags(&m->ev_word_opt, hipEventDisableTiming));
+    SERT_HIP(hipEventCreateWithFlags(&m->ev_early, hipEventDisableTiming));
     SERT_HIP(hipEventCreateWithFlags(&m->ev_join3, hipEventDisableTiming));
     SERT_HIP(hipEventCreateWithFlags(&m->ev_step_done, hipEventDisableTiming));
     SERT_HIP(hipEventCreateWithFlags(&m->ev_neg, hipEventDisableTiming));
@@ -1503,8 +1547,6 @@ static int create_resources(sert_model* m) {
             part = splits * (dw * V + V);
         }
         m->part_count = part;
-        m->rw_touched_alloc = round_up((size_t)c.vocab_size, 16);
-        SERT_TRY(dzalloc(&m->rw_touched, m->rw_touched_alloc, s));
         SERT_TRY(dzalloc(&m->part, part, s));
         SERT_TRY(dzalloc(&m->red_loss, (size_t)kOptBlocks, s));
         SERT_TRY(dzalloc(&m->red_sq, (size_t)4 * kOptBlocks, s));  // partials of up to 4 tensors
@@ -1532,6 +1574,7 @@ static void free_split(DataSplit& d) {
     (void)hipFree(d.csr_indices); (void)hipFree(d.csr_data); (void)hipFree(d.w); (void)hipFree(d.labfix);
     (void)hipFree(d.idx_rows); (void)hipFree(d.idx_items);
     (void)hipFree(d.idx_uwords); (void)hipFree(d.idx_slots); (void)hipFree(d.idx_rows_div);
+    (void)hipFree(d.idx_touched_bits);
     d.idx_uwords = nullptr; d.idx_slots = nullptr; d.idx_rows_div = nullptr;
     d = DataSplit();
 }
@@ -1542,6 +1585,7 @@ int sert_destroy(sert_model* m) {
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     if (m->stream2) (void)hipStreamSynchronize(m->stream2);   // (work that ran ahead of the host)
     if (m->stream3) (void)hipStreamSynchronize(m->stream3);
+    if (m->stream4) (void)hipStreamSynchronize(m->stream4);
     if (m->comm_stream) (void)hipStreamSynchronize(m->comm_stream);
     if (m->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(m->comm);
     if (m->ev_rest_ready) (void)hipEventDestroy(m->ev_rest_ready);
@@ -1563,7 +1607,6 @@ int sert_destroy(sert_model* m) {
     for (float* p : bufs) (void)hipFree(p);
     (void)hipFree(m->ll_tokstat); (void)hipFree(m->ll_lse); (void)hipFree(m->ll_jstat);
     (void)hipFree(m->ll_rowinfo); (void)hipFree(m->ll_rpart); (void)hipFree(m->ll_r); (void)hipFree(m->ll_rsum);
-    (void)hipFree(m->rw_touched);
     (void)hipFree(m->Zu); (void)hipFree(m->dZu); (void)hipFree(m->zpart);
     (void)hipFree(m->neg); (void)hipFree(m->neg_stage);
     (void)hipFree(m->cand); (void)hipFree(m->cand_sorted); 
@@ -1583,6 +1626,9 @@ int sert_destroy(sert_model* m) {
     for (hipEvent_t e : {m->ev_step_done, m->ev_neg, m->ev_opt_fork, m->ev_small, m->ev_dense, m->ev_loss})
         if (e) (void)hipEventDestroy(e);
     if (m->stream3) (void)hipStreamDestroy(m->stream3);
+    if (m->stream4) (void)hipStreamDestroy(m->stream4);
+    for (hipEvent_t e : {m->ev_word_opt, m->ev_early})
+        if (e) (void)hipEventDestroy(e);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
     return 0;
@@ -1755,6 +1801,13 @@ int sert_upload_dataset(sert_model* m, int split, const void* x, const int32_t* 
             SERT_HIP(hipMalloc((void**)&d.idx_items, std::max<size_t>(1, wi.items.size()) * sizeof(SegItem)));
             SERT_HIP(hipMemcpyAsync(d.idx_items, wi.items.data(), wi.items.size() * sizeof(SegItem), hipMemcpyHostToDevice, s));
             SERT_HIP(hipStreamSynchronize(s));
+        }
+        if (!wi.touched_bits.empty()) {
+            SERT_TRY(dmalloc(&d.idx_touched_bits, wi.touched_bits.size()));
+            SERT_HIP(hipMemcpyAsync(d.idx_touched_bits, wi.touched_bits.data(), wi.touched_bits.size() * sizeof(uint32_t),
+                                    hipMemcpyHostToDevice, s));
+            SERT_HIP(hipStreamSynchronize(s));
+            d.bit_words = wi.bit_words;
         }
         d.idx_batches = wi.batches;
         if ((size_t)wi.max_part_rows + 1 > m->wpart_rows) {
@@ -2439,6 +2492,7 @@ int sert_synchronize(sert_model* m) {
     SERT_HIP(hipStreamSynchronize(m->stream));
     SERT_HIP(hipStreamSynchronize(m->stream2));
     SERT_HIP(hipStreamSynchronize(m->stream3));
+    SERT_HIP(hipStreamSynchronize(m->stream4));
     return 0;
 }
 

@@ -51,6 +51,11 @@ struct WordIndex {
     std::vector<int32_t> slots;           // all batches, B*n per batch (want_slots only)
     std::vector<int32_t> rows_div;        // rows[] / n: the batch row of every level-0 entry (want_slots only)
     int32_t max_distinct = 0;
+    // per batch: bit w = 1 iff word w occurs in the batch (words_per_batch 32-bit words each).
+    // The optimiser takes the gradient of every other row as zero without reading it, and the
+    // rows no token of the batch points to can be updated while the batch is still in flight.
+    std::vector<uint32_t> touched_bits;
+    int64_t bit_words = 0;
 };
 
 // ids: (num_batches*B*n) token ids of the complete batches, IdT wide.
@@ -67,6 +72,8 @@ bool build_word_index(const IdT* ids, int64_t num_batches, int B, int n, int voc
     std::vector<int32_t> touched;
     touched.reserve((size_t)std::min<int64_t>(T, vocab));
     std::vector<int32_t> start;  // per touched word
+    out.bit_words = ((((int64_t)vocab + 31) / 32) + 3) / 4 * 4;
+    out.touched_bits.assign((size_t)(num_batches * out.bit_words), 0u);
     for (int64_t bi = 0; bi < num_batches; ++bi) {
         const IdT* x = ids + bi * T;
         BatchIndex& bx = out.batches[(size_t)bi];
@@ -80,6 +87,10 @@ bool build_word_index(const IdT* ids, int64_t num_batches, int B, int n, int voc
             if (count[wid]++ == 0) touched.push_back(wid);
         }
         std::sort(touched.begin(), touched.end());
+        {
+            uint32_t* bits = out.touched_bits.data() + bi * out.bit_words;
+            for (int32_t wid : touched) bits[wid >> 5] |= 1u << (wid & 31);
+        }
         bx.uw_off = (int64_t)out.uwords.size();
         bx.num_distinct = (int32_t)touched.size();
         out.max_distinct = std::max(out.max_distinct, bx.num_distinct);

@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libsert_hip.so')
+# SERT_LIB: load another build of the library (A/B experiments with tools/build_variant.sh)
+LIB_PATH = os.environ.get('SERT_LIB') or os.path.join(_HERE, 'libsert_hip.so')
 
 KIND_LOGLINEAR, KIND_VECTORSPACE, KIND_VECTORSPACE_SOFTMAX = 0, 1, 2
 SPLIT_TRAIN, SPLIT_VALIDATE = 0, 1

@@ -1,0 +1,310 @@
+// Strip-streaming fp32 MFMA GEMMs for the PROJECTION shapes of the vectorspace step, gfx950:
+// a long, thin activation matrix (B rows x <= 128 columns) against the small dense weight
+// (<= 128 x 128) -- sert/models.py:1057-1061 (t = tanh(h.W + b)) and its autodiff
+// (dh = da.W^T, dW = h^T.da, db = sum da).  2 x B x 128 x 128 = 2.1 GFLOP each at C2.
+//
+// STATUS: OPT-IN (SERT_STRIP_GEMM=1), NOT the default.  Round 2 built this to lift the three
+// projection GEMMs off 0.38-0.45 of the fp32 MFMA peak (35 / 30 / 30 us at C2 against a 13.7 us
+// MFMA floor); every variant measured within +-3 us of gemm.h (best: forward 32.5 us, dh 31.1 us,
+// dW 36 us vs 34.5 / 29.7 / 29.4 us), so the default stays gemm.h.  The variants and their numbers
+// are in the comments below and in DESIGN.md; parity tests run both paths.
+//
+// The idea: a 128x128 output tile of these problems has K = 128, i.e. eight k-slabs -- the generic
+// kernel spends as long filling and draining its pipeline (first loads, the tanh epilogue, the
+// stores) as multiplying.  Here the SMALL operand never moves: every wave keeps its 32-column slice of W as MFMA
+// B-fragments in 64 VGPRs for the whole launch, and the activation streams through in 32-row
+// strips (16 KB): global -> registers while the previous strip multiplies, -> LDS (row-major,
+// stride K + 4: a lane's four consecutive k values are one conflict-free ds_read_b128) -> MFMA.
+// One barrier per strip, no k loop over global memory, and three to four workgroups per CU whose
+// epilogues (tanh, stores) run under each other's MFMAs.
+//
+// k order: the contraction index is consumed as (8j + i | 8j + 4 + i) pairs by the two
+// half-waves -- a fixed permutation of k (any order is a valid fp32 summation; it is the same
+// in every launch, so the results are run-to-run identical).
+#pragma once
+#include "gemm.h"
+
+namespace sert {
+
+constexpr int SG_ROWS = 32;       // rows per strip
+constexpr int SG_MAXK = 128;
+constexpr int SG_LD = SG_MAXK + 4;
+
+struct StripArgs {
+    const float* A;      // (M, K) row-major, lda
+    const float* B;      // TB = false: (K, N) row-major; TB = true: stored (N, K)
+    float* C;            // (M, N) row-major, ldc
+    const float* bias;   // (N) or null
+    int M, N, K, lda, ldb, ldc;
+};
+
+// A (M,K) . op(B) -> C (M,N), K = 8 K8 <= 128, N <= 128 (N % 32 == 0), lda % 4 == 0.
+//
+// Knock-outs of the first, single-role version (results wrong, timing only; C2 forward, 33.4 us):
+// no C stores 30.7, no tanh 28.3, no A loads 32.1, no MFMAs 15.1, none of them 8.2 -- the parts ADD
+// UP: the waves of a SIMD run in lock-step phases (all multiply, then all do tanh + stores), so the
+// matrix pipe idles through every epilogue although three workgroups share the CU.  Interleaving the
+// epilogue's VALU work between the dependent MFMAs of one wave made it worse (37.8 us): an issue
+// slot between two MFMAs on the SAME accumulator costs ~43 cycles (MI355X_MICROARCH.md).  What works
+// is the structure that guide describes for >= 95 % kernels: TWO waves per SIMD in fixed opposite
+// roles, separated by a barrier (ping-pong).  A 512-thread workgroup = two groups of four waves;
+// while group 0 multiplies strip p (64 dependent MFMAs per wave, back to back), group 1 runs the
+// epilogue of its previous strip (bias, tanh, stores) and stages its next strip into LDS; then the
+// roles swap.  The global loads of a group's next strip are issued at the START of its multiply
+// phase and consumed one phase later.
+template <bool TB, int EPI, int K8>
+__global__ __launch_bounds__(512, 1) void gemm_strip_nn(const StripArgs g) {
+    __shared__ __attribute__((aligned(16))) float As[2][SG_ROWS][SG_LD];   // As[gid]: group gid's current strip
+    const int t = threadIdx.x & 255, lane = t & 63, w = t >> 6;            // indices inside the group
+    const int gid = threadIdx.x >> 8;
+    const int li = lane & 31, lh = lane >> 5;
+    const int n0 = w * 32;                       // this wave's column slice
+    const bool wave_on = n0 < g.N;
+    constexpr int K = 8 * K8;
+    const int strips = (g.M + SG_ROWS - 1) / SG_ROWS;
+    // ---- B fragments, resident: breg[4j + i] = B[k = 8j + 4 lh + i][n0 + li]
+    float breg[4 * K8];
+#pragma unroll
+    for (int j = 0; j < K8; ++j) {
+        if (wave_on) {
+            if (TB) {
+                const float4 b4 = *reinterpret_cast<const float4*>(g.B + (size_t)(n0 + li) * g.ldb + 8 * j + 4 * lh);
+                breg[4 * j + 0] = b4.x; breg[4 * j + 1] = b4.y; breg[4 * j + 2] = b4.z; breg[4 * j + 3] = b4.w;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) breg[4 * j + i] = g.B[(size_t)(8 * j + 4 * lh + i) * g.ldb + n0 + li];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) breg[4 * j + i] = 0.f;
+        }
+    }
+    float bv = 0.f;
+    if ((EPI == EPI_BIAS || EPI == EPI_BIAS_TANH) && wave_on) bv = g.bias[n0 + li];
+
+    // ---- strip loader: 32 x K floats = 8 K float4, the group's 256 threads -> K/32 float4 each (<= 4)
+    constexpr int kq = K >> 2;                   // float4 per row
+    // Staging registers are four NAMED float4 filled by unconditional loads from clamped
+    // addresses: an array written under a run-time condition (or captured by a lambda) is not
+    // scalarised -- hipcc parks it in scratch memory, and the prefetch becomes global -> scratch
+    // -> LDS.  (strip base = workgroup-uniform pointer; lane offsets are 32-bit and rebuilt per
+    // strip from an opaque leading dimension, so nothing 64-bit is hoisted and spilled.)
+    float4 st0, st1, st2, st3;
+    constexpr int nf = SG_ROWS * kq;
+    auto ld1 = [&](int p, const float* Ab, unsigned ulda, int last) -> float4 {
+        const int f = min(t + 256 * p, nf - 1);
+        const int row = f / kq, c4 = f - row * kq;
+        return *reinterpret_cast<const float4*>(Ab + (unsigned)min(row, last) * ulda + 4u * (unsigned)c4);
+    };
+    auto st1f = [&](int p, const float4& v) {
+        const int f = t + 256 * p;
+        if (f < nf) {
+            const int row = f / kq, c4 = f - row * kq;
+            *reinterpret_cast<float4*>(&As[gid][row][4 * c4]) = v;
+        }
+    };
+#define SG_GLOAD(strip_)                                                     \
+    do {                                                                     \
+        const int m0_ = (strip_) * SG_ROWS;                                  \
+        const float* Ab_ = g.A + (size_t)m0_ * g.lda;                        \
+        unsigned ulda_ = (unsigned)g.lda;                                    \
+        asm volatile("" : "+s"(ulda_));                                      \
+        const int last_ = g.M - 1 - m0_; /* rows past the end repeat the last one */ \
+        st0 = ld1(0, Ab_, ulda_, last_); st1 = ld1(1, Ab_, ulda_, last_);    \
+        st2 = ld1(2, Ab_, ulda_, last_); st3 = ld1(3, Ab_, ulda_, last_);    \
+    } while (0)
+#define SG_LSTORE() do { st1f(0, st0); st1f(1, st1); st1f(2, st2); st1f(3, st3); } while (0)
+
+    // element r of a finished strip: C/D layout of the 32x32 MFMA: col = lane & 31,
+    // row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    auto emit_strip = [&](const f32x16& p, int strip_) {
+        const int pm0 = strip_ * SG_ROWS;
+        float* Cb = g.C + (size_t)pm0 * g.ldc;
+        unsigned uld = (unsigned)g.ldc;
+        asm volatile("" : "+s"(uld));
+        const int mrem = g.M - pm0;
+        unsigned off = (unsigned)(4 * lh) * uld + (unsigned)(n0 + li);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            float v = p[r];
+            if (EPI == EPI_BIAS) v = v + bv;
+            if (EPI == EPI_BIAS_TANH) v = fast_tanh(v + bv);
+            if (row < mrem) Cb[off] = v;
+            off += ((r & 3) == 3) ? 5u * uld : uld;
+        }
+    };
+
+    // the workgroup's strips are b, b + G, b + 2G, ...; group gid takes every other one of them
+    const int G = gridDim.x;
+    int mine = blockIdx.x + gid * G;             // the strip this group multiplies next
+    int done = -1;                               // the strip whose accumulators wait for their epilogue
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (mine < strips) { SG_GLOAD(mine); SG_LSTORE(); }
+    __syncthreads();
+    // number of phases: every strip of the workgroup is one multiply phase, plus one for the last epilogue
+    const int my_count = blockIdx.x < strips ? (strips - 1 - blockIdx.x) / G + 1 : 0;
+    bool staged = false;                         // st0..3 hold this group's next strip
+    for (int p = 0; p <= my_count; ++p) {
+        if ((p & 1) == gid) {
+            // ---- multiply role: strip `mine` (in As[gid]) ----
+            if (mine < strips) {
+                const int nxt = mine + 2 * G;
+                staged = nxt < strips;
+                if (staged) SG_GLOAD(nxt);       // lands during this phase, stored to LDS in the next
+                if (wave_on) {
+                    // (reading ALL fragments of the strip first -- 16 ds_read_b128, 64 more VGPRs --
+                    // and then issuing the 64 MFMAs back to back measured slower still: 51 us)
+#pragma unroll
+                    for (int j = 0; j < K8; ++j) {
+                        const float4 a4 = *reinterpret_cast<const float4*>(&As[gid][li][8 * j + 4 * lh]);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, breg[4 * j + 0], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, breg[4 * j + 1], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, breg[4 * j + 2], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, breg[4 * j + 3], acc, 0, 0, 0);
+                    }
+                }
+                done = mine;
+                mine = nxt;
+            }
+        } else {
+            // ---- support role: epilogue of the strip multiplied last phase, stage the next one ----
+            if (done >= 0) {
+                if (wave_on) {
+                    emit_strip(acc, done);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                }
+                done = -1;
+            }
+            if (staged) { SG_LSTORE(); staged = false; }
+        }
+        __syncthreads();
+    }
+    if (done >= 0 && wave_on) emit_strip(acc, done);   // (a group whose last multiply was the final phase)
+#undef SG_GLOAD
+#undef SG_LSTORE
+}
+
+// dW partials: P[wg] (Kd, N) = sum over the workgroup's strips of X^T (Kd, rows) . Y (rows, N),
+// followed by the column sums of Y (N) -- X = h (M, Kd), Y = da (M, N); Kd, N <= 128, multiples
+// of 32.  Slab wg of `part` has stride `pstride` >= Kd*N + N floats; the caller adds the slabs in
+// slab order (reduce_partials).  Workgroup wg owns the CONTIGUOUS strips [wg*spw, (wg+1)*spw).
+__global__ __launch_bounds__(256) void gemm_strip_tn(const float* __restrict__ X, const float* __restrict__ Y, int M,
+                                                     int Kd, int N, int ldx, int ldy, int strips_per_wg,
+                                                     float* __restrict__ part, size_t pstride) {
+    __shared__ __attribute__((aligned(16))) float Xs[2][SG_ROWS][SG_LD];
+    __shared__ __attribute__((aligned(16))) float Ys[2][SG_ROWS][SG_LD];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int n0 = w * 32;
+    const bool wave_on = n0 < N;
+    const int mtiles = Kd >> 5;                  // 32-row tiles of the output (<= 4)
+    const int strips = (M + SG_ROWS - 1) / SG_ROWS;
+    const int s_lo = blockIdx.x * strips_per_wg, s_hi = min(strips, s_lo + strips_per_wg);
+    const int xq = Kd >> 2, yq = N >> 2;
+    float4 sx[4], sy[4];
+    auto gload = [&](int strip, float4 (&sx)[4], float4 (&sy)[4]) {
+        const int m0 = strip * SG_ROWS;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int f = t + 256 * p;
+            if (f < SG_ROWS * xq) {
+                const int row = f / xq, c4 = f - row * xq;
+                const bool ok = m0 + row < M;                   // rows past the end contribute zeros
+                const float4 v = *reinterpret_cast<const float4*>(X + (size_t)min(m0 + row, M - 1) * ldx + 4 * c4);
+                sx[p] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (f < SG_ROWS * yq) {
+                const int row = f / yq, c4 = f - row * yq;
+                const bool ok = m0 + row < M;
+                const float4 v = *reinterpret_cast<const float4*>(Y + (size_t)min(m0 + row, M - 1) * ldy + 4 * c4);
+                sy[p] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    auto lstore = [&](int buf, const float4 (&sx)[4], const float4 (&sy)[4]) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int f = t + 256 * p;
+            if (f < SG_ROWS * xq) { const int row = f / xq, c4 = f - row * xq; *reinterpret_cast<float4*>(&Xs[buf][row][4 * c4]) = sx[p]; }
+            if (f < SG_ROWS * yq) { const int row = f / yq, c4 = f - row * yq; *reinterpret_cast<float4*>(&Ys[buf][row][4 * c4]) = sy[p]; }
+        }
+    };
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    float csum = 0.f;
+    if (s_lo < s_hi) {
+        gload(s_lo, sx, sy);
+        lstore(0, sx, sy);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int strip = s_lo; strip < s_hi; ++strip) {
+        const bool has_next = strip + 1 < s_hi;
+        if (has_next) gload(strip + 1, sx, sy);
+        if (wave_on) {
+            // contraction over the strip's 32 rows: the half-waves take rows (2s, 2s + 1)
+#pragma unroll
+            for (int s2 = 0; s2 < SG_ROWS / 2; ++s2) {
+                const int row = 2 * s2 + lh;
+                const float b = Ys[buf][row][n0 + li];
+                csum += b;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    if (mt < mtiles) {
+                        const float a = Xs[buf][row][32 * mt + li];
+                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[mt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (has_next) lstore(buf ^ 1, sx, sy);
+        __syncthreads();
+        buf ^= 1;
+    }
+    if (wave_on) {
+        float* P = part + (size_t)blockIdx.x * pstride;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            if (mt < mtiles) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    P[(size_t)row * N + n0 + li] = acc[mt][r];
+                }
+            }
+        }
+        // column sums: the two half-waves hold the even / odd rows' share
+        const float other = __shfl_xor(csum, 32, kWave);
+        if (lh == 0) P[(size_t)Kd * N + n0 + li] = csum + other;
+    }
+}
+
+inline bool gemm_strip_ok(int M, int N, int K, int lda, int ldb, bool tb, const void* A, const void* B) {
+    const char* e = getenv("SERT_STRIP_GEMM");     // opt-in (read per call: tests switch it)
+    return e && atoi(e) != 0 && M >= 1024 && K <= SG_MAXK && N <= 128 && K % 32 == 0 && N % 32 == 0 && lda % 4 == 0 &&
+           ((uintptr_t)A) % 16 == 0 && ((uintptr_t)B) % 16 == 0 && (!tb || ldb % 4 == 0);
+}
+
+template <bool TB, int EPI>
+inline void launch_gemm_strip(hipStream_t s, const float* A, const float* B, float* C, const float* bias, int M, int N,
+                              int K, int lda, int ldb, int ldc) {
+    StripArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc};
+    const int strips = (M + SG_ROWS - 1) / SG_ROWS;
+    static const int per_cu = getenv("SERT_STRIP_WGS") ? atoi(getenv("SERT_STRIP_WGS")) : 1;   // tuning knob
+    const int grid = std::min((strips + 1) / 2, 256 * std::max(1, per_cu));
+    switch (K / 8) {
+#define SG_CASE(K8) case K8: hipLaunchKernelGGL((gemm_strip_nn<TB, EPI, K8>), dim3(grid), dim3(512), 0, s, g); break;
+        SG_CASE(4) SG_CASE(8) SG_CASE(12) SG_CASE(16)
+#undef SG_CASE
+        default: break;   // (gemm_strip_ok admits K in {32, 64, 96, 128} only)
+    }
+}
+
+}  // namespace sert

@@ -114,6 +114,10 @@ struct sert_model {
     int32_t *cand = nullptr, *cand_sorted = nullptr, *pair_sorted = nullptr;
     float* coef = nullptr;
     float *ehead = nullptr, *etail = nullptr;  // (chunks, d_e) carries
+    // small entity vocabularies: the sort-free path (egrad_lds, kernels_egrad.h)
+    float* epart = nullptr;       // (groups, V_e, d_e) per-row-group partial entity gradients
+    int32_t *eg_entries = nullptr, *eg_offs = nullptr;   // pairs bucketed by entity range per sub-group; their offsets
+    int eg_sub_rows = 0, eg_num_sub = 0, eg_subs_per_group = 0, eg_groups = 0, eg_ranges = 0, eg_er_shift = 0;
     int32_t *sort_hist = nullptr, *sort_bin_total = nullptr;   // counting-sort scratch
     int32_t *sort_k_tmp = nullptr, *sort_v_tmp = nullptr;       // ping-pong (only if > 11 key bits)
     int sort_bits = 1;
@@ -136,14 +140,13 @@ struct sert_model {
     bool use_touched = false;
     // ... and the optimiser of those untouched rows -- rows the batch's own forward never reads --
     // is issued at the START of the step on its own stream, beside forward and backward
-    // (SERT_ADAM_SPLIT=0: one launch over the whole table behind the backward, as in round 1)
+    // (opt-in, SERT_ADAM_SPLIT=1: measured SLOWER than one launch behind the backward, see sert_hip.hip)
     hipStream_t stream4 = nullptr;
     hipEvent_t ev_word_opt = nullptr;   // the touched rows' update of the previous step was issued (main stream)
     hipEvent_t ev_early = nullptr;      // this step's untouched-row update is complete (stream4)
     bool early_issued = false;          // this step's untouched-row launch is in flight
     int early_sq = 0;                   // ... and wrote this many sum-of-squares partials to red_sq[0..)
-    // dW / db / loss partials on the side stream behind the entity chain (SERT_DW_SIDE=0: main stream)
-    bool dw_side = true;
+
     // loglinear, logits per DISTINCT word of the batch (duplicate tokens share a row):
     float* Zu = nullptr;          // (U, V_e) logits
     float* dZu = nullptr;         // (U, V_e) per-word sums of dL/dZ

@@ -13,6 +13,7 @@
 #include "common.h"
 #include "gemm.h"
 #include "gemm_big.h"
+#include "gemm_strip.h"
 #include "kernels_score_bf16.h"
 #include "kernels_egrad.h"
 #include "kernels_ll.h"
@@ -492,8 +493,11 @@ static int vs_project(sert_model* m, const DataSplit& ds, int64_t batch_index) {
     {
         ScopedTimer t(m, TG_GEMM_FWD);
         // t = tanh(h.W + b)   (models.py:1057-1061)
-        launch_gemm<false, false, EPI_BIAS_TANH>(m->stream, m->H, m->W, m->T, m->b, B, de, dw, dw,
-                                                 de, de);
+        if (gemm_strip_ok(B, de, dw, dw, de, false, m->H, m->W))
+            launch_gemm_strip<false, EPI_BIAS_TANH>(m->stream, m->H, m->W, m->T, m->b, B, de, dw, dw, de, de);
+        else
+            launch_gemm<false, false, EPI_BIAS_TANH>(m->stream, m->H, m->W, m->T, m->b, B, de, dw, dw,
+                                                     de, de);
     }
     return 0;
 }
@@ -556,9 +560,36 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         hipStream_t st = (m->timing.enabled || m->nstreams < 2) ? m->stream : m->stream2;
         SERT_HIP(hipEventRecord(m->ev_fork, m->stream));
         if (st != m->stream) SERT_HIP(hipStreamWaitEvent(st, m->ev_fork, 0));
-        // dR_e: stable sort of the (entity, pair) keys, chunked reduce, carry fix-up
         const int total = B * (c.num_negatives + 1);
         const int V = c.num_entities;
+        static const bool ko_egrad = getenv("SERT_KO_EGRAD") != nullptr;   // timing knock-out (wrong results)
+        if (ko_egrad) {
+        } else if (m->epart) {
+            // small entity vocabulary: no global sort -- pairs bucketed by entity range per sub-group,
+            // then row groups x entity ranges with the accumulators in LDS (kernels_egrad.h)
+            const int de4 = de / 4, c1 = c.num_negatives + 1;
+            const size_t lds = (size_t)4 * 16 * de * sizeof(float);
+            const int grid = 8 * cdiv(m->eg_groups, 8) * m->eg_ranges;
+            {
+                ScopedTimer t(m, TG_SORT, st);
+                hipLaunchKernelGGL(egrad_bucket, dim3(m->eg_num_sub), dim3(512), 0, st, m->cand, B, c1, m->eg_sub_rows,
+                                   m->eg_er_shift, m->eg_ranges, m->eg_entries, m->eg_offs);
+            }
+            {
+                ScopedTimer t(m, TG_EGRAD, st);
+#define SERT_EL_ARGS m->eg_entries, m->eg_offs, m->coef, m->T, c1, de, V, m->eg_sub_rows, m->eg_num_sub, \
+                     m->eg_subs_per_group, m->eg_groups, m->eg_ranges, m->epart
+                hipLaunchKernelGGL((egrad_acc<2>), dim3(grid), dim3(256), lds, st, SERT_EL_ARGS);
+#undef SERT_EL_ARGS
+            }
+            {
+                ScopedTimer t(m, TG_EFIX, st);
+                const size_t table4 = (size_t)V * de4;
+                hipLaunchKernelGGL(egrad_group_sum, dim3(grid_for((int64_t)table4)), dim3(256), 0, st, m->epart, m->eg_groups,
+                                   table4, m->g_re);
+            }
+        } else {
+        // dR_e: stable sort of the (entity, pair) keys, chunked reduce, carry fix-up
         {
             ScopedTimer t(m, TG_SORT, st);
             SERT_TRY(entity_key_sort(m, total, st));
@@ -599,13 +630,17 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
             }
         }
 #undef SERT_EG_ARGS
+        }   // sorted path
     }
     auto word_table_grad = [&]() -> int {
         {
             // dh = da.W^T
             ScopedTimer t(m, TG_GEMM_DX);
-            launch_gemm<false, true, EPI_STORE>(m->stream, m->DA, m->W, m->DH, nullptr, B, dw, de, de,
-                                                de, dw);
+            if (gemm_strip_ok(B, dw, de, de, de, true, m->DA, m->W))
+                launch_gemm_strip<true, EPI_STORE>(m->stream, m->DA, m->W, m->DH, nullptr, B, dw, de, de, de, dw);
+            else
+                launch_gemm<false, true, EPI_STORE>(m->stream, m->DA, m->W, m->DH, nullptr, B, dw, de, de,
+                                                    de, dw);
         }
         // From here on the main stream has produced dW, db and the loss partials AND is done
         // READING W (the dh GEMM): the side stream may update the small tensors.
@@ -623,7 +658,14 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         // Third stream: dW and dh are both 512-workgroup launches (2 waves per SIMD, too
         // few to hide their own latencies) -- side by side they fill each other's bubbles.
         hipStream_t sd = (m->timing.enabled || m->nstreams < 3) ? m->stream : m->stream3;
-        if (sd != m->stream) SERT_HIP(hipStreamWaitEvent(sd, m->ev_fork, 0));
+        // Single GPU, two streams: dW, db and the loss partials only feed the small-tensor
+        // optimiser and the loss, both of which already sit behind the entity chain on the side
+        // stream -- issued there (behind that chain) they leave the main stream with nothing but
+        // the dependency chain loss -> dh -> segmented sum -> word-table optimiser.
+        // (measured: 0.376 -> 0.386 ms at C2 -- off by default, SERT_DW_SIDE=1 to try it)
+        static const bool dw_side = getenv("SERT_DW_SIDE") && atoi(getenv("SERT_DW_SIDE")) != 0;
+        if (dw_side && m->lazy_join) sd = m->stream2;
+        if (sd != m->stream && sd != m->stream2) SERT_HIP(hipStreamWaitEvent(sd, m->ev_fork, 0));
         // ~1024 workgroup items in all, at most 512 slabs (the optimum at one output tile: 512 slabs
         // of 128 rows) and at least 64 rows per slab.  With nine output tiles (d = 300) that is 114
         // slabs at batch >= 16384 and 64 at 4096 -- 512 / 256 slabs made the combine read up to 92 MB
@@ -636,7 +678,16 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         splits = cdiv(B, kper);
         const size_t mn = (size_t)dw * de;
         const size_t stride = mn + de;
-        {
+        if (gemm_strip_ok(B, de, dw, dw, de, false, m->H, m->DA) && dw % 32 == 0 && de % 4 == 0) {
+            // strip kernel: every workgroup accumulates its contiguous strips' h^T.da (+ column sums)
+            ScopedTimer t(m, TG_GEMM_DW);
+            static const int want_wgs = getenv("SERT_STRIP_DW_WGS") ? atoi(getenv("SERT_STRIP_DW_WGS")) : 512;   // tuning knob
+            const int strips = cdiv(B, SG_ROWS);
+            const int spw = std::max(1, cdiv(strips, std::min(want_wgs, 1024)));
+            splits = cdiv(strips, spw);
+            hipLaunchKernelGGL(gemm_strip_tn, dim3(splits), dim3(256), 0, sd, (const float*)m->H, (const float*)m->DA, B,
+                               dw, de, dw, de, spw, m->part, stride);
+        } else {
             ScopedTimer t(m, TG_GEMM_DW);
             launch_gemm<true, false, EPI_STORE, true>(sd, m->H, m->DA, m->part, nullptr, dw, de,
                                                       B, dw, de, de, splits, kper, stride);
@@ -648,7 +699,7 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         }
         // the loss partials only depend on the NCE kernel too
         SERT_TRY(reduce_rowloss(m, sd));
-        if (sd != m->stream) SERT_HIP(hipEventRecord(m->ev_join3, sd));
+        if (sd != m->stream && sd != m->stream2) SERT_HIP(hipEventRecord(m->ev_join3, sd));
         return 0;
     };
     // On a single GPU the only consumer of dR_e is the small-tensor optimiser, which runs on
@@ -1007,10 +1058,18 @@ static void optimizer_args(const sert_model* m, int64_t t, AdamArgs* aa, Adadelt
 // are not read by the batch's forward either: their update is issued NOW, at the start of the
 // committed step, on its own stream, and runs beside forward and backward; optimizer_and_loss
 // then only has the touched rows left on the critical path.
+// Measured at C2 and C4 (profiles/r02b_variants.txt): SLOWER than one launch behind the backward
+// (0.376 -> 0.391 ms at C2, 2.13 -> 2.25 ms at C4) -- the step is memory-system-bound from end to
+// end, a second queue adds no bandwidth, and two row-filtered launches stream worse than one dense
+// one.  Kept as an opt-in (SERT_ADAM_SPLIT=1) with its tests; off by default.
+static bool adam_split_enabled() {
+    static const bool on = getenv("SERT_ADAM_SPLIT") && atoi(getenv("SERT_ADAM_SPLIT")) != 0;
+    return on;
+}
 static int issue_untouched_rows_update(sert_model* m, const uint32_t* bits) {
     m->early_issued = false;
     m->early_sq = 0;
-    static const bool split = !(getenv("SERT_ADAM_SPLIT") && atoi(getenv("SERT_ADAM_SPLIT")) == 0);   // cross-check knob
+    const bool split = adam_split_enabled();
     if (!split || !bits || !m->use_touched || is_dp(m) || m->timing.enabled || m->nstreams < 2) return 0;
     AdamArgs aa; AdadeltaArgs da;
     optimizer_args(m, m->step + 1, &aa, &da);
@@ -1066,8 +1125,6 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
                               i == 0 ? (unsigned)c.word_dim : 1u,
                               (i == 0 && tf && m->early_issued) ? kRowsTouched : kRowsAll);
             n_sq += nb;
-            // the next step's untouched-row launch (its own stream) starts behind this one
-            if (i == 0 && m->ev_word_opt && !m->timing.enabled) SERT_HIP(hipEventRecord(m->ev_word_opt, m->stream));
             continue;
         }
         const size_t sc = m->pt_sc[i];
@@ -1151,6 +1208,9 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
                            n_sq, inv_batch, reg_scale, loss_dst, flag, publish ? ++m->loss_seq : 0u,
                            is_dp(m) ? (const float*)m->g_sq : (const float*)nullptr);
     }
+    // (opt-in split optimiser: the next step's untouched-row launch, on its own stream, may start
+    // once this step has read its sum-of-squares partials and updated the rows it owns)
+    if (adam_split_enabled() && !is_dp(m) && !m->timing.enabled) SERT_HIP(hipEventRecord(m->ev_word_opt, m->stream));
     if (any_ag) {
         // the loss leaves first; the next kernel that reads a parameter waits for the last slab
         SERT_HIP(hipEventRecord(m->ev_ag_done, m->comm_stream));
@@ -1513,6 +1573,27 @@ static int create_resources(sert_model* m) {
                 part = std::max(part, sp * V * de);
             }
             const size_t total = B * (c.num_negatives + 1);
+            {
+                // sort-free entity gradient for small vocabularies (kernels_egrad.h); SERT_EGRAD_SORT=1
+                // keeps the sorted path (cross-check knob)
+                const bool force_sort = getenv("SERT_EGRAD_SORT") && atoi(getenv("SERT_EGRAD_SORT")) != 0;   // (read per model)
+                const size_t c1 = c.num_negatives + 1;
+                if (!force_sort && c.kind == SERT_KIND_VECTORSPACE && V <= 2048 && de % 4 == 0 && de <= 128 &&
+                    total < ((size_t)1 << 27) && c1 <= (size_t)kElSubPairs) {
+                    m->eg_er_shift = 4;                                      // 16 entities per range (egrad_acc)
+                    m->eg_ranges = cdiv(V, 16);                              // <= 128 = kElMaxRanges
+                    m->eg_sub_rows = (int)std::min<size_t>(256, kElSubPairs / c1);
+                    m->eg_num_sub = cdiv(B, m->eg_sub_rows);
+                    // row groups whose slice of T (rows x d_e floats) stays in one XCD's L2: <= 2 MB
+                    m->eg_subs_per_group = (int)std::max<size_t>(1, (((size_t)2 << 20) / (de * sizeof(float))) / m->eg_sub_rows);
+                    m->eg_groups = cdiv(m->eg_num_sub, m->eg_subs_per_group);
+                }
+                if (m->eg_groups > 0) {
+                    SERT_TRY(dzalloc(&m->epart, (size_t)m->eg_groups * V * de, s));
+                    SERT_TRY(dzalloc(&m->eg_entries, total, s));
+                    SERT_TRY(dzalloc(&m->eg_offs, (size_t)m->eg_num_sub * (m->eg_ranges + 1), s));
+                }
+            }
             SERT_TRY(dzalloc(&m->cand, total, s));        SERT_TRY(dzalloc(&m->cand_sorted, total + 1, s));
             SERT_TRY(dzalloc(&m->pair_sorted, total, s));
             SERT_TRY(dzalloc(&m->coef, total, s));
@@ -1611,7 +1692,7 @@ int sert_destroy(sert_model* m) {
     (void)hipFree(m->neg); (void)hipFree(m->neg_stage);
     (void)hipFree(m->cand); (void)hipFree(m->cand_sorted); 
     (void)hipFree(m->pair_sorted); (void)hipFree(m->coef); (void)hipFree(m->ehead);
-    (void)hipFree(m->etail); (void)hipFree(m->sort_hist); (void)hipFree(m->sort_bin_total);
+    (void)hipFree(m->etail); (void)hipFree(m->epart); (void)hipFree(m->eg_entries); (void)hipFree(m->eg_offs); (void)hipFree(m->sort_hist); (void)hipFree(m->sort_bin_total);
     (void)hipFree(m->sort_k_tmp); (void)hipFree(m->sort_v_tmp);
     if (m->h_loss) (void)hipHostFree(m->h_loss);
     if (m->host_ar_buf) (void)hipHostFree(m->host_ar_buf);

@@ -27,8 +27,22 @@ LOSS_TOL, ACT_TOL, GRAD_TOL, PARAM_TOL = 1e-5, 2e-5, 1e-4, 1e-4
     dict(B=130, n=4, z=10, Vw=70000, Ve=300, dw=300, de=128),   # uint32 ids, d=300
     dict(B=2100, n=2, z=5, Vw=300, Ve=5000, dw=16, de=32),      # 13 key bits: 2 sort passes, >1 tile/chunk carries
     dict(B=300, n=2, z=20, Vw=50, Ve=3, dw=8, de=300),          # heavy duplicate entities: long carry chains
+    dict(B=5000, n=2, z=10, Vw=300, Ve=2, dw=16, de=256),       # two entities, d_e = 256: LDS path with 2 float4 per lane, queue drains mid-scan
+    dict(B=4100, n=2, z=3, Vw=300, Ve=2048, dw=16, de=64),      # largest vocabulary of the LDS path, ragged last row group
+    dict(B=1100, n=3, z=4, Vw=2000, Ve=50, dw=128, de=128),     # strip GEMMs (gemm_strip.h), ragged last strip
+    dict(B=1030, n=2, z=3, Vw=500, Ve=40, dw=96, de=64),        # strip GEMMs with idle waves (N = 64 / 96), K = 96 / 64
 ])
-def test_vectorspace_steps(hip_lib, dims):
+@pytest.mark.parametrize('egrad', ['default', 'sorted', 'strip_gemm'])
+def test_vectorspace_steps(hip_lib, dims, egrad, monkeypatch):
+    # entity gradient: V_e <= 2048 takes the sort-free bucket + register-accumulator path by default;
+    # 'sorted' forces the counting-sort + chunked-reduce path every vocabulary size can take;
+    # 'strip_gemm' switches the opt-in strip-streaming projection GEMMs on (gemm_strip.h)
+    if egrad == 'sorted':
+        monkeypatch.setenv('SERT_EGRAD_SORT', '1')
+    if egrad == 'strip_gemm':
+        if dims['B'] < 1024:
+            pytest.skip('strip GEMMs take M >= 1024 only')
+        monkeypatch.setenv('SERT_STRIP_GEMM', '1')
     B, n, z = dims['B'], dims['n'], dims['z']
     steps = 3
     p = U.make_vs_problem(0, B * steps, n, z, dims['Vw'], dims['Ve'], dims['dw'], dims['de'],

@@ -1,0 +1,10 @@
+#!/bin/bash
+# Build an experimental variant of libsert_hip.so:  tools/build_variant.sh <name> [-DFOO=1 ...]
+# -> gpurun_out/variants/libsert_<name>.so ; run with SERT_LIB=<that path>
+set -e
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+NAME=$1; shift
+mkdir -p $ROOT/sert_amd/variants
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -munsafe-fp-atomics -I$ROOT/include "$@" \
+    $ROOT/sert_amd/csrc/sert_hip.hip -o $ROOT/sert_amd/variants/libsert_$NAME.so -ldl
+echo $ROOT/sert_amd/variants/libsert_$NAME.so

@@ -1,0 +1,10 @@
+cd $GRAFT_REPO_ROOT
+NOX="--no-cpu-baseline --no-query-extra --no-loglinear-extra --no-c4-extra --no-live-pmc"
+for v in "" ko_store ko_mfma ko_load ko_tanh ko_all; do
+  L=""; [ -n "$v" ] && L=$GRAFT_REPO_ROOT/sert_amd/variants/libsert_$v.so
+  SERT_LIB=$L python bench.py --steps 50 --warmup 10 $NOX 2>/dev/null | python -c "
+import sys,json
+d=json.loads(sys.stdin.read())
+k=d['kernels']
+print('variant=[$v] fwd %.1f dX %.1f' % (k['gemm_fwd']['us'], k['gemm_dX']['us']))"
+done

@@ -38,6 +38,7 @@ def load(native=False, out_dir=None):
     lib.sert_cpu_create.argtypes = [ci] * 7 + [cf] + [vp] * 4
     lib.sert_cpu_destroy.argtypes = [vp]
     lib.sert_cpu_threads.argtypes = [vp]
+    lib.sert_cpu_phases.argtypes = [vp, vp]
     lib.sert_cpu_get.argtypes = [vp] * 5
     lib.sert_cpu_train_step.restype = cf
     lib.sert_cpu_train_step.argtypes = [vp, ci] + [vp] * 4
@@ -80,6 +81,13 @@ class VectorSpaceCPU(object):
         return float(self.lib.sert_cpu_train_step(self.h, slot, X.ctypes.data, y.ctypes.data, w.ctypes.data,
                                                   neg.ctypes.data))
 
+    def phases_ms(self):
+        """Wall time of the last step by phase: forward + NCE + dh, dW, entity grouping, segmented
+        sums, L2 + Adam, total."""
+        out = np.zeros(6, dtype=np.float64)
+        self.lib.sert_cpu_phases(self.h, out.ctypes.data)
+        return dict(zip(('forward_nce_dh', 'dW', 'entity_grouping', 'segmented_sums', 'l2_adam', 'total'), out.tolist()))
+
     def params(self):
         out = [np.empty(s, dtype=np.float32) for s in self.shapes]
         self.lib.sert_cpu_get(self.h, *[a.ctypes.data for a in out])
@@ -105,8 +113,31 @@ def score_topk(entities, projections, k, native=False, out_dir=None):
     return idx
 
 
+def cpu_quota():
+    """CPUs' worth of time the container may use (cgroup v2 cpu.max / v1 cfs quota), or None when
+    unlimited: more busy threads than that get throttled in 100 ms periods."""
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:
+            quota, period = f.read().split()[:2]
+        if quota != 'max':
+            return max(1, int(int(quota) / float(period)))
+    except (OSError, ValueError):
+        pass
+    try:
+        with open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us') as f:
+            quota = int(f.read())
+        with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as f:
+            period = int(f.read())
+        if quota > 0:
+            return max(1, int(quota / float(period)))
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def one_socket_cores():
-    """Logical CPUs of socket 0 this process may use, one per physical core."""
+    """Logical CPUs of socket 0 this process may use, one per physical core, capped by the
+    container's CPU quota."""
     allowed = sorted(os.sched_getaffinity(0))
     picked, seen = [], set()
     for cpu in allowed:
@@ -122,4 +153,8 @@ def one_socket_cores():
             continue
         seen.add(core)
         picked.append(cpu)
-    return picked or allowed
+    picked = picked or allowed
+    quota = cpu_quota()
+    if quota is not None:
+        picked = picked[:max(1, quota)]
+    return picked

@@ -53,12 +53,30 @@ typedef struct {
     float* Wt;          /* W transposed, for dh = da . W^T */
     float* dW_part;     /* per-thread partial dW / db */
     int nthreads;
+    double phase_ms[6]; /* last step: forward+NCE+dh, dW, entity grouping, segmented sums, L2+Adam, total */
 } cpu_model;
 
+/* zero-filled, pages first touched by the threads that will stream them (static blocks, as the
+ * optimiser loop partitions them): on a multi-socket / multi-CCD host a table initialised by one
+ * thread lives on one memory node and every other core reads it remotely */
 static float* falloc(size_t n) {
     float* p = (float*)aligned_alloc(64, ((n * sizeof(float) + 63) / 64) * 64);
-    if (p) memset(p, 0, n * sizeof(float));
+    if (!p) return p;
+    const size_t nblk = (n + 4095) / 4096;
+#pragma omp parallel for schedule(static)
+    for (size_t blk = 0; blk < nblk; ++blk) {
+        const size_t lo = blk * 4096, hi = lo + 4096 < n ? lo + 4096 : n;
+        memset(p + lo, 0, (hi - lo) * sizeof(float));
+    }
     return p;
+}
+static void pcopy(float* dst, const float* src, size_t n) {
+    const size_t nblk = (n + 4095) / 4096;
+#pragma omp parallel for schedule(static)
+    for (size_t blk = 0; blk < nblk; ++blk) {
+        const size_t lo = blk * 4096, hi = lo + 4096 < n ? lo + 4096 : n;
+        memcpy(dst + lo, src + lo, (hi - lo) * sizeof(float));
+    }
 }
 
 cpu_model* sert_cpu_create(int B, int n, int z, int Vw, int Ve, int dw, int de, float lambda,
@@ -68,8 +86,8 @@ cpu_model* sert_cpu_create(int B, int n, int z, int Vw, int Ve, int dw, int de, 
     m->lambda = lambda; m->lr = 1e-3f; m->beta1 = 0.9f; m->beta2 = 0.999f; m->eps = 1e-8f;
     const size_t cnt[4] = {(size_t)Ve * de, (size_t)Vw * dw, (size_t)dw * de, (size_t)de};
     m->Re = falloc(cnt[0]); m->Rw = falloc(cnt[1]); m->W = falloc(cnt[2]); m->b = falloc(cnt[3]);
-    memcpy(m->Re, Re, cnt[0] * 4); memcpy(m->Rw, Rw, cnt[1] * 4);
-    memcpy(m->W, W, cnt[2] * 4); memcpy(m->b, b, cnt[3] * 4);
+    pcopy(m->Re, Re, cnt[0]); pcopy(m->Rw, Rw, cnt[1]);
+    pcopy(m->W, W, cnt[2]); pcopy(m->b, b, cnt[3]);
     for (int i = 0; i < 4; ++i) { m->m[i] = falloc(cnt[i]); m->v[i] = falloc(cnt[i]); m->g[i] = falloc(cnt[i]); }
     m->h = falloc((size_t)B * dw); m->t = falloc((size_t)B * de);
     m->da = falloc((size_t)B * de); m->dh = falloc((size_t)B * dw);
@@ -94,10 +112,17 @@ void sert_cpu_destroy(cpu_model* m) {
 }
 
 int sert_cpu_threads(const cpu_model* m) { return m->nthreads; }
+void sert_cpu_phases(const cpu_model* m, double* out6) { memcpy(out6, m->phase_ms, sizeof m->phase_ms); }
 
 void sert_cpu_get(const cpu_model* m, float* Rw, float* Re, float* W, float* b) {
     memcpy(Re, m->Re, (size_t)m->Ve * m->de * 4); memcpy(Rw, m->Rw, (size_t)m->Vw * m->dw * 4);
     memcpy(W, m->W, (size_t)m->dw * m->de * 4); memcpy(b, m->b, (size_t)m->de * 4);
+}
+
+/* the next random row of an activation / embedding table, requested a few iterations ahead (a
+ * 512-byte row = 8 cache lines; the hardware prefetcher cannot guess a gather) */
+static inline void prefetch_row(const float* row, int floats) {
+    for (int k = 0; k < floats; k += 16) __builtin_prefetch(row + k, 0, 1);
 }
 
 /* T.nnet.sigmoid, float32 C implementation of Theano 0.8.2 [upstream] */
@@ -150,16 +175,20 @@ static void group_by_small_key(const int32_t* keys, int count, int K, int32_t* s
         int32_t* h = hist + (size_t)tid * ((size_t)K + 1);
         for (int i = lo; i < hi; ++i) h[keys[i]]++;
 #pragma omp barrier
+        /* per key: counts of the threads -> exclusive prefix over the threads, total into start[k+1] */
+#pragma omp for schedule(static)
+        for (int k = 0; k < K; ++k) {
+            int run = 0;
+            for (int t = 0; t < T; ++t) { int32_t* ht = hist + (size_t)t * ((size_t)K + 1) + k; const int c = *ht; *ht = run; run += c; }
+            start[k + 1] = run;
+        }
+        /* (implicit barrier) exclusive scan of the K totals: K adds, one thread */
 #pragma omp single
         {
-            int run = 0;
-            for (int k = 0; k < K; ++k) {
-                start[k] = run;
-                for (int t = 0; t < T; ++t) { int32_t* ht = hist + (size_t)t * ((size_t)K + 1) + k; const int c = *ht; *ht = run; run += c; }
-            }
-            start[K] = run;
+            start[0] = 0;
+            for (int k = 0; k < K; ++k) start[k + 1] += start[k];
         }
-        for (int i = lo; i < hi; ++i) pos[h[keys[i]]++] = i;
+        for (int i = lo; i < hi; ++i) { const int k = keys[i]; pos[start[k] + h[k]++] = i; }
     }
 }
 
@@ -201,6 +230,7 @@ float sert_cpu_train_step(cpu_model* m, int slot, const int32_t* X, const int32_
     const float invB = 1.0f / (float)B, invn = 1.0f / (float)n;
     double loss_sum = 0.0;
 
+    const double t0 = omp_get_wtime();
     /* W^T for the backward projection */
     for (int k = 0; k < dw; ++k)
         for (int j = 0; j < de; ++j) m->Wt[(size_t)j * dw + k] = m->W[(size_t)k * de + j];
@@ -211,6 +241,8 @@ float sert_cpu_train_step(cpu_model* m, int slot, const int32_t* X, const int32_
         float* h = m->h + (size_t)i * dw;
         float acc[512];
         for (int k = 0; k < dw; ++k) acc[k] = 0.f;
+        if (i + 1 < B)
+            for (int q = 0; q < n; ++q) prefetch_row(m->Rw + (size_t)X[(size_t)(i + 1) * n + q] * dw, dw);
         for (int q = 0; q < n; ++q) {                       /* models.py:180, :226 */
             const float* row = m->Rw + (size_t)X[(size_t)i * n + q] * dw;
 #pragma omp simd
@@ -268,6 +300,7 @@ float sert_cpu_train_step(cpu_model* m, int slot, const int32_t* X, const int32_
         for (int k = 0; k < dw; ++k) dh[k] = acc[k];
     }
 
+    const double t1 = omp_get_wtime();
     /* dW = h^T . da and db = sum_i da_i: per-thread partials over a static row range, combined in
      * thread order (deterministic for a given thread count) */
     const size_t mn = (size_t)dw * de, stride = mn + de;
@@ -301,6 +334,7 @@ float sert_cpu_train_step(cpu_model* m, int slot, const int32_t* X, const int32_
         }
     }
 
+    const double t2 = omp_get_wtime();
     /* dR_w[word] = sum over its occurrences of dh_i / n, dR_e[e] = sum of coef * p: segmented
      * sums in occurrence order over a per-batch inverted index (no scatter-add with duplicates) */
     {
@@ -316,6 +350,7 @@ float sert_cpu_train_step(cpu_model* m, int slot, const int32_t* X, const int32_
             group_by_key(keys, B * c1, Ve, m->e_start, m->e_pos);
         free(keys);
     }
+    const double t3 = omp_get_wtime();
     const int32_t* w_start = m->w_start[slot];
     const int32_t* w_pos = m->w_pos[slot];
     const int32_t *pc_lo = m->pc_lo[slot], *pc_word = m->pc_word[slot], *w_piece0 = m->w_piece0[slot];
@@ -327,6 +362,7 @@ float sert_cpu_train_step(cpu_model* m, int slot, const int32_t* X, const int32_
         float* g = m->pc_part + (size_t)pc * dw;
         for (int k = 0; k < dw; ++k) g[k] = 0.f;
         for (int q = lo; q < hi; ++q) {
+            if (q + 4 < hi) prefetch_row(m->dh + (size_t)(w_pos[q + 4] / n) * dw, dw);
             const float* dh = m->dh + (size_t)(w_pos[q] / n) * dw;
 #pragma omp simd
             for (int k = 0; k < dw; ++k) g[k] += dh[k] * invn;
@@ -346,6 +382,7 @@ float sert_cpu_train_step(cpu_model* m, int slot, const int32_t* X, const int32_
             continue;
         }
         for (int q = w_start[u]; q < w_start[u + 1]; ++q) {
+            if (q + 4 < w_start[u + 1]) prefetch_row(m->dh + (size_t)(w_pos[q + 4] / n) * dw, dw);
             const float* dh = m->dh + (size_t)(w_pos[q] / n) * dw;
 #pragma omp simd
             for (int k = 0; k < dw; ++k) g[k] += dh[k] * invn;
@@ -356,6 +393,7 @@ float sert_cpu_train_step(cpu_model* m, int slot, const int32_t* X, const int32_
         float* g = m->g[0] + (size_t)e * de;
         for (int j = 0; j < de; ++j) g[j] = 0.f;
         for (int q = m->e_start[e]; q < m->e_start[e + 1]; ++q) {
+            if (q + 4 < m->e_start[e + 1]) prefetch_row(m->t + (size_t)(m->e_pos[q + 4] / c1) * de, de);
             const int pos = m->e_pos[q];
             const float cf = m->coef[pos];
             const float* t = m->t + (size_t)(pos / c1) * de;
@@ -364,6 +402,7 @@ float sert_cpu_train_step(cpu_model* m, int slot, const int32_t* X, const int32_
         }
     }
 
+    const double t4 = omp_get_wtime();
     /* dense L2 + dense Adam over every element of every tensor (models.py:764-795, :548-549), one
      * fused pass; sum of squares of the pre-update values for the returned loss */
     m->step += 1;
@@ -397,6 +436,9 @@ float sert_cpu_train_step(cpu_model* m, int slot, const int32_t* X, const int32_
         }
         if (ti != 3) sq += part;
     }
+    const double t5 = omp_get_wtime();
+    m->phase_ms[0] = 1e3 * (t1 - t0); m->phase_ms[1] = 1e3 * (t2 - t1); m->phase_ms[2] = 1e3 * (t3 - t2);
+    m->phase_ms[3] = 1e3 * (t4 - t3); m->phase_ms[4] = 1e3 * (t5 - t4); m->phase_ms[5] = 1e3 * (t5 - t0);
     const float reg = m->lambda > 0.f ? (m->lambda / (2.0f * (float)B)) * (float)sq : 0.f;
     return (float)(loss_sum) * invB + reg;
 }

@@ -32,6 +32,7 @@ EXPORTS = [
     'sert_eval_batch', 'sert_eval_batches',
     'sert_predict_project', 'sert_predict_tokens', 'sert_score_topk',
     'sert_scorer_create', 'sert_scorer_destroy', 'sert_scorer_topk', 'sert_scorer_scores',
+    'sert_host_alloc', 'sert_host_free',
     'sert_comm_unique_id', 'sert_comm_init', 'sert_comm_init_host', 'sert_comm_destroy',
     'sert_synchronize', 'sert_timing_enable', 'sert_timing_reset', 'sert_timing_count',
     'sert_timing_name', 'sert_timing_avg_us', 'sert_bench_gemm',
@@ -117,6 +118,8 @@ def load():
     lib.sert_scorer_destroy.argtypes = [vp]
     lib.sert_scorer_topk.argtypes = [vp, fp, i64, i32, fp, fp]
     lib.sert_scorer_scores.argtypes = [vp, fp, i64, fp]
+    lib.sert_host_alloc.argtypes = [ctypes.POINTER(vp), sz]
+    lib.sert_host_free.argtypes = [vp]
     lib.sert_comm_unique_id.argtypes = [ctypes.c_char_p]
     lib.sert_comm_init.argtypes = [vp, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
     lib.sert_comm_destroy.argtypes = [vp]
@@ -350,9 +353,57 @@ def score_topk(entities, projections, k, device=0):
     return idx, val
 
 
+class PinnedBuffer(object):
+    """Page-locked host memory (sert_host_alloc) viewed as a numpy array; grows on demand."""
+
+    def __init__(self, dtype):
+        self.dtype = np.dtype(dtype)
+        self._ptr = ctypes.c_void_p()
+        self._bytes = 0
+        self._lib = load()
+
+    def view(self, shape):
+        if os.environ.get('SERT_NO_PINNED'):     # cross-check knob: ordinary pageable arrays
+            return np.empty(shape, dtype=self.dtype)
+        need = int(np.prod(shape)) * self.dtype.itemsize
+        if need > self._bytes:
+            self.free()
+            cap = max(need, 1 << 16)
+            check(self._lib.sert_host_alloc(ctypes.byref(self._ptr), cap))
+            self._bytes = cap
+        raw = (ctypes.c_char * max(need, 1)).from_address(self._ptr.value)
+        return np.frombuffer(raw, dtype=self.dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def holds(self, array):
+        """Is `array` a view of this buffer (so that no staging copy is needed)?"""
+        if not self._ptr.value or not isinstance(array, np.ndarray) or not array.flags['C_CONTIGUOUS']:
+            return False
+        addr = array.ctypes.data
+        return self._ptr.value <= addr and addr + array.nbytes <= self._ptr.value + self._bytes
+
+    def free(self):
+        if self._ptr.value:
+            self._lib.sert_host_free(self._ptr)
+            self._ptr = ctypes.c_void_p()
+            self._bytes = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class Scorer(object):
     """Persistent device copy of the (L2-normalised) entity table + top-k scoring
-    (sert_scorer_* in include/sert_hip.h)."""
+    (sert_scorer_* in include/sert_hip.h).
+
+    Host arrays cross the boundary through page-locked buffers the scorer owns: fill
+    ``query_buffer(Q)`` in place (or pass any array: it is copied there) and read the result
+    views, which stay valid until the next call on this scorer."""
+
+    #: upper bound on Q_chunk * V_e floats materialised on the host when no device top-k applies
+    MAX_HOST_SCORES = 1 << 26
 
     def __init__(self, entities, device=0):
         e = np.ascontiguousarray(entities, dtype=np.float32)
@@ -362,15 +413,28 @@ class Scorer(object):
         self._h = ctypes.c_void_p()
         check(self._lib.sert_scorer_create(device, e.ctypes.data, e.shape[0], e.shape[1],
                                            ctypes.byref(self._h)))
+        self._pin_q, self._pin_idx, self._pin_val = PinnedBuffer(np.float32), PinnedBuffer(np.int32), PinnedBuffer(np.float32)
 
-    def topk(self, projections, k):
-        p = np.ascontiguousarray(projections, dtype=np.float32)
+    def query_buffer(self, num_queries):
+        """A page-locked (Q, d) float32 array to build the query block in (zero-copy upload)."""
+        return self._pin_q.view((num_queries, self.dim))
+
+    def _stage(self, projections):
+        p = np.asarray(projections, dtype=np.float32)
         if p.ndim == 1:
             p = p.reshape(1, -1)
         assert p.shape[1] == self.dim
+        if self._pin_q.holds(p):
+            return p
+        staged = self._pin_q.view(p.shape)
+        np.copyto(staged, p)
+        return staged
+
+    def topk(self, projections, k):
+        p = self._stage(projections)
         q = p.shape[0]
-        idx = np.empty((q, k), dtype=np.int32)
-        val = np.empty((q, k), dtype=np.float32)
+        idx = self._pin_idx.view((q, k))
+        val = self._pin_val.view((q, k))
         check(self._lib.sert_scorer_topk(self._h, p.ctypes.data, q, k, idx.ctypes.data,
                                          val.ctypes.data))
         return idx, val
@@ -388,16 +452,30 @@ class Scorer(object):
         """(idx, score) per query, best first; k=None ranks every entity."""
         if k is not None and k <= min(self.num_entities, 1024):
             return self.topk(projections, k)
-        sc = self.scores(projections)
-        order = np.argsort(-sc, axis=1, kind='stable')   # ties: lowest index first
-        if k is not None:
-            order = order[:, :k]
-        return order.astype(np.int32), np.take_along_axis(sc, order, axis=1)
+        # no device top-k for this k: full score rows, a bounded number of queries at a time
+        # (the reference scores one query at a time, query.py:304-318; 10k queries x 100k
+        # entities in one block would be 4 GB of host memory)
+        p = np.asarray(projections, dtype=np.float32)
+        if p.ndim == 1:
+            p = p.reshape(1, -1)
+        keep = self.num_entities if k is None else min(k, self.num_entities)
+        step = max(1, self.MAX_HOST_SCORES // self.num_entities)
+        idx = np.empty((p.shape[0], keep), dtype=np.int32)
+        val = np.empty((p.shape[0], keep), dtype=np.float32)
+        for lo in range(0, p.shape[0], step):
+            sc = self.scores(p[lo:lo + step])
+            order = np.argsort(-sc, axis=1, kind='stable')[:, :keep]   # ties: lowest index first
+            idx[lo:lo + step] = order
+            val[lo:lo + step] = np.take_along_axis(sc, order, axis=1)
+        return idx, val
 
     def close(self):
         if getattr(self, '_h', None) is not None and self._h:
             self._lib.sert_scorer_destroy(self._h)
             self._h = None
+        for b in (getattr(self, '_pin_q', None), getattr(self, '_pin_idx', None), getattr(self, '_pin_val', None)):
+            if b is not None:
+                b.free()
 
     def __del__(self):
         try:

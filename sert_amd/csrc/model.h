@@ -165,6 +165,12 @@ struct sert_model {
     float* d_losses = nullptr;    // multi-step loss ring
     int64_t d_losses_cap = 0;
 
+    // grow-only scratch of the predict functions (EmbeddingMapper calls predict_fn once per query:
+    // no hipMalloc / hipFree per call, nothing to leak on an error path)
+    float *pred_a = nullptr, *pred_b = nullptr;   // inputs / gathered rows; outputs
+    void* pred_ids = nullptr;
+    size_t pred_a_cap = 0, pred_b_cap = 0, pred_ids_cap = 0;
+
     sert::DataSplit split[2];
 
     int64_t step = 0;             // optimiser step counter t (Adam) / training sampler position

@@ -1690,6 +1690,7 @@ int sert_destroy(sert_model* m) {
     (void)hipFree(m->ll_rowinfo); (void)hipFree(m->ll_rpart); (void)hipFree(m->ll_r); (void)hipFree(m->ll_rsum);
     (void)hipFree(m->Zu); (void)hipFree(m->dZu); (void)hipFree(m->zpart);
     (void)hipFree(m->neg); (void)hipFree(m->neg_stage);
+    (void)hipFree(m->pred_a); (void)hipFree(m->pred_b); (void)hipFree(m->pred_ids);
     (void)hipFree(m->cand); (void)hipFree(m->cand_sorted); 
     (void)hipFree(m->pair_sorted); (void)hipFree(m->coef); (void)hipFree(m->ehead);
     (void)hipFree(m->etail); (void)hipFree(m->epart); (void)hipFree(m->eg_entries); (void)hipFree(m->eg_offs); (void)hipFree(m->sort_hist); (void)hipFree(m->sort_bin_total);
@@ -2091,20 +2092,29 @@ int sert_eval_batches(sert_model* m, int split, const int64_t* batch_indices, in
     return 0;
 }
 
+// grow-only device scratch (floats)
+static int pred_reserve(float** buf, size_t* cap, size_t count) {
+    if (*cap >= count) return 0;
+    (void)hipFree(*buf);
+    *buf = nullptr; *cap = 0;
+    SERT_TRY(dmalloc(buf, count));
+    *cap = count;
+    return 0;
+}
+
 int sert_predict_project(sert_model* m, const float* avg, int64_t Q, float* out) {
     if (!m || !avg || !out) SERT_FAIL("null argument");
     if (!is_vs(m)) SERT_FAIL("sert_predict_project is the vectorspace predict_fn");
     if (Q <= 0) return 0;
     SERT_HIP(hipSetDevice(m->cfg.device));
     const int dw = m->cfg.word_dim, de = m->cfg.entity_dim;
-    float *d_in = nullptr, *d_out = nullptr;
-    SERT_TRY(dmalloc(&d_in, (size_t)Q * dw));
-    SERT_TRY(dmalloc(&d_out, (size_t)Q * de));
-    SERT_HIP(hipMemcpyAsync(d_in, avg, (size_t)Q * dw * sizeof(float), hipMemcpyHostToDevice, m->stream));
-    launch_gemm<false, false, EPI_BIAS_TANH>(m->stream, d_in, m->W, d_out, m->b, (int)Q, de, dw, dw, de, de);
-    SERT_HIP(hipMemcpyAsync(out, d_out, (size_t)Q * de * sizeof(float), hipMemcpyDeviceToHost, m->stream));
+    SERT_HIP(hipStreamSynchronize(m->stream));          // (the scratch may be in use by an earlier call's copy)
+    SERT_TRY(pred_reserve(&m->pred_a, &m->pred_a_cap, (size_t)Q * dw));
+    SERT_TRY(pred_reserve(&m->pred_b, &m->pred_b_cap, (size_t)Q * de));
+    SERT_HIP(hipMemcpyAsync(m->pred_a, avg, (size_t)Q * dw * sizeof(float), hipMemcpyHostToDevice, m->stream));
+    launch_gemm<false, false, EPI_BIAS_TANH>(m->stream, m->pred_a, m->W, m->pred_b, m->b, (int)Q, de, dw, dw, de, de);
+    SERT_HIP(hipMemcpyAsync(out, m->pred_b, (size_t)Q * de * sizeof(float), hipMemcpyDeviceToHost, m->stream));
     SERT_HIP(hipStreamSynchronize(m->stream));
-    (void)hipFree(d_in); (void)hipFree(d_out);
     return 0;
 }
 
@@ -2124,14 +2134,19 @@ int sert_predict_tokens(sert_model* m, const void* ids, int64_t rows, float* out
         });
         if (!ok) SERT_FAIL("token id >= vocab_size in ids");
     }
-    void* d_ids = nullptr;
-    float *dG = nullptr, *dZ = nullptr;
-    SERT_HIP(hipMalloc(&d_ids, (size_t)toks * c.id_bytes));
-    SERT_TRY(dmalloc(&dG, (size_t)toks * d));
-    SERT_TRY(dmalloc(&dZ, (size_t)toks * V));
-    SERT_HIP(hipMemcpyAsync(d_ids, ids, (size_t)toks * c.id_bytes, hipMemcpyHostToDevice, m->stream));
+    SERT_HIP(hipStreamSynchronize(m->stream));
+    if (m->pred_ids_cap < (size_t)toks * c.id_bytes) {
+        (void)hipFree(m->pred_ids);
+        m->pred_ids = nullptr; m->pred_ids_cap = 0;
+        SERT_HIP(hipMalloc(&m->pred_ids, (size_t)toks * c.id_bytes));
+        m->pred_ids_cap = (size_t)toks * c.id_bytes;
+    }
+    SERT_TRY(pred_reserve(&m->pred_a, &m->pred_a_cap, (size_t)toks * d));
+    SERT_TRY(pred_reserve(&m->pred_b, &m->pred_b_cap, (size_t)toks * V));
+    float *dG = m->pred_a, *dZ = m->pred_b;
+    SERT_HIP(hipMemcpyAsync(m->pred_ids, ids, (size_t)toks * c.id_bytes, hipMemcpyHostToDevice, m->stream));
     SERT_ID_DISPATCH(c.id_bytes, {
-        const IdT* X = (const IdT*)d_ids;
+        const IdT* X = (const IdT*)m->pred_ids;
         if (d % 4 == 0)
             hipLaunchKernelGGL((ll_gather_rows<IdT, 4>), dim3(grid_for(toks * d / 4, 256, 1 << 20)), dim3(256), 0, m->stream, X, m->rw, dG, toks, d);
         else
@@ -2141,7 +2156,6 @@ int sert_predict_tokens(sert_model* m, const void* ids, int64_t rows, float* out
     hipLaunchKernelGGL(ll_softmax_rows, dim3(cdiv(toks, 4)), dim3(256), 0, m->stream, dZ, toks, V);
     SERT_HIP(hipMemcpyAsync(out, dZ, (size_t)toks * V * sizeof(float), hipMemcpyDeviceToHost, m->stream));
     SERT_HIP(hipStreamSynchronize(m->stream));
-    (void)hipFree(d_ids); (void)hipFree(dG); (void)hipFree(dZ);
     return 0;
 }
 
@@ -2472,6 +2486,18 @@ int sert_scorer_scores(sert_scorer* sc, const float* proj, int64_t Q, float* sco
         SERT_HIP(hipMemcpyAsync(score_out + q0 * V, sc->S, (size_t)qn * V * sizeof(float), hipMemcpyDeviceToHost, s));
         SERT_HIP(hipStreamSynchronize(s));
     }
+    return 0;
+}
+
+int sert_host_alloc(void** out, size_t bytes) {
+    if (!out || bytes == 0) SERT_FAIL("bad argument");
+    *out = nullptr;
+    static const int flags = getenv("SERT_PIN_FLAGS") ? atoi(getenv("SERT_PIN_FLAGS")) : (int)hipHostMallocDefault;   // tuning knob
+    SERT_HIP(hipHostMalloc(out, bytes, (unsigned)flags));
+    return 0;
+}
+int sert_host_free(void* p) {
+    if (p) SERT_HIP(hipHostFree(p));
     return 0;
 }
 

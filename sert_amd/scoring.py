@@ -126,8 +126,10 @@ class VectorSpaceCallback(Callback):
         self.rank_callback(topic_id, idx[0].astype(np.int64), score[0])
 
     def process_batch(self, payloads, projections, kwargs_list):
-        """Additive: all queued queries at once."""
-        queries = self._as_queries(projections, len(payloads))
+        """Additive: all queued queries at once (the query block is built in the scorer's
+        page-locked buffer, so it is uploaded without a staging copy)."""
+        queries = self.scorer.query_buffer(len(payloads))
+        np.copyto(queries, self._as_queries(projections, len(payloads)))
         for kw, q in zip(kwargs_list, queries):
             self._remember(kw['topic_id'], q)
         idx, score = self.scorer.rank(queries, self.n_neighbors)

@@ -38,10 +38,11 @@ def parse_query(text):
 
 
 def write_run(model_name, data, out_f, max_objects_per_query=None):
-    """data: query_id -> iterable of (score, object_id).  Ranked by score
-    descending (ties: object id ascending, trec_eval's own order)."""
+    """data: query_id -> iterable of (score, object_id).  Ranked by score descending; ties by
+    object id DESCENDING -- the order trec_eval itself imposes when it re-sorts a run (it ignores
+    the rank column), so the rank written here is the rank that gets evaluated (see _ranked)."""
     for query_id in data:
-        ranked = sorted(data[query_id], key=lambda so: (-float(so[0]), str(so[1])))
+        ranked = sorted(data[query_id], key=lambda so: (float(so[0]), str(so[1])), reverse=True)
         if max_objects_per_query:
             ranked = ranked[:max_objects_per_query]
         for rank, (score, object_id) in enumerate(ranked, 1):

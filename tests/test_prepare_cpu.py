@@ -114,7 +114,7 @@ def test_trec_utils_roundtrip_and_metrics():
     out = io.StringIO()
     trec_utils.write_run('m', {'0': [(0.2, 'B'), (0.9, 'A'), (0.2, 'C')]}, out)
     lines = out.getvalue().splitlines()
-    assert lines[0].split()[:4] == ['0', 'Q0', 'A', '1'] and lines[1].split()[2] == 'B'
+    assert lines[0].split()[:4] == ['0', 'Q0', 'A', '1'] and lines[1].split()[2] == 'C'   # ties: id descending, as trec_eval re-sorts
     run = trec_utils.parse_run(io.StringIO(out.getvalue()))
     qrels = trec_utils.parse_qrels(io.StringIO(u'0 0 A 1.0\n0 0 C 1.0\n'))
     res = trec_utils.evaluate_run(run, qrels, k=100)

@@ -122,10 +122,18 @@ __global__ __launch_bounds__(256) void vs_nce(const float* __restrict__ T,
                                               const float* __restrict__ w, float* __restrict__ DA,
                                               float* __restrict__ coef, int32_t* __restrict__ cand,
                                               float* __restrict__ rowloss, int B, int z, int de,
-                                              float inv_batch) {
+                                              float inv_batch, float* __restrict__ wg_loss = nullptr) {
+    // wg_loss (optional): wg_loss[blockIdx.x] = sum of this workgroup's sixteen (weighted) row
+    // losses, added in row order -- the first level of the loss reduction rides along instead of
+    // being a launch of its own on the step's critical path
+    __shared__ float wg_red[16];
     const int l = threadIdx.x & 15;
-    const int i = blockIdx.x * 16 + (threadIdx.x >> 4);
-    if (i >= B) return;
+    // Rows past the end (ragged last workgroup) are computed on a clamped row and never stored:
+    // no early return, so that every wave reaches the barrier below exactly once (a divergent
+    // return would make a half-active wave hit it on both paths).
+    const int i_raw = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool valid = i_raw < B;
+    const int i = valid ? i_raw : B - 1;
     const int chunks = de >> 2;  // de % 4 == 0 on this path
     float4 t[NCH], p[NCH], dp[NCH];
 #pragma unroll
@@ -169,7 +177,7 @@ __global__ __launch_bounds__(256) void vs_nce(const float* __restrict__ T,
                 dp[q].x += du * er[q].x; dp[q].y += du * er[q].y;
                 dp[q].z += du * er[q].z; dp[q].w += du * er[q].w;
             }
-            if (l == 0) {
+            if (l == 0 && valid) {
                 coef[(size_t)i * (z + 1) + j] = du;
                 cand[(size_t)i * (z + 1) + j] = e;
             }
@@ -179,7 +187,7 @@ __global__ __launch_bounds__(256) void vs_nce(const float* __restrict__ T,
 #pragma unroll
         for (int q = 0; q < NCH; ++q) {
             const int c = l + 16 * q;
-            if (c >= chunks) continue;
+            if (c >= chunks || !valid) continue;
             float4 o;
             o.x = (t[q].x >= -SERT_CLIP_HI && t[q].x <= SERT_CLIP_HI) ? dp[q].x * (1.0f - t[q].x * t[q].x) : 0.f;
             o.y = (t[q].y >= -SERT_CLIP_HI && t[q].y <= SERT_CLIP_HI) ? dp[q].y * (1.0f - t[q].y * t[q].y) : 0.f;
@@ -188,7 +196,17 @@ __global__ __launch_bounds__(256) void vs_nce(const float* __restrict__ T,
             *reinterpret_cast<float4*>(DA + (size_t)i * de + 4 * c) = o;
         }
     }
-    if (l == 0) rowloss[i] = wi * loss;
+    if (l == 0 && valid) rowloss[i] = wi * loss;
+    if (wg_loss) {
+        if (l == 0) wg_red[threadIdx.x >> 4] = valid ? wi * loss : 0.f;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += wg_red[r];
+            wg_loss[blockIdx.x] = s;
+        }
+    }
 }
 
 // Generic-width fallback (d_e % 4 != 0): one wave per row, scalar columns.

@@ -76,6 +76,7 @@ struct sert_model {
     bool step_done_pending = false;  // the previous step ended without recording ev_step_done
     bool lazy_join = false;          // this step: the main stream never waits for the entity chain
     int n_loss_partials = 0;
+    int nce_loss_partials = 0;       // > 0: vs_nce wrote this many per-workgroup loss partials into red_loss
     // SERT_STREAMS: 1 = everything on the main stream (0.423 ms/step at C2), 2 = + the entity
     // chain, the step prologue and the small-tensor optimiser on a side stream (0.396),
     // 3 = + dW on a third (0.403: every cross-queue dependency costs 15-25 us of idle GPU)
@@ -109,6 +110,10 @@ struct sert_model {
     float *H = nullptr, *T = nullptr, *DA = nullptr, *DH = nullptr, *rowloss = nullptr;
     float* DH2 = nullptr;         // full-softmax variant: p = clip(t)  (B, d_e)
     int32_t* neg = nullptr;       // (B, z) device negatives
+    // the NEXT training step's negatives, drawn at the end of this step on the side stream (they
+    // depend on (seed, step, row) only): the sampler leaves the next step's critical path
+    int32_t* neg_alt = nullptr;
+    int64_t neg_alt_step = -1;    // optimiser step the buffer was drawn for (-1: none)
     int64_t* neg_stage = nullptr; // (B, z) int64 staging for host-supplied negatives
     // entity-gradient machinery (kernels_egrad.h), all (B*(1+z)) long
     int32_t *cand = nullptr, *cand_sorted = nullptr, *pair_sorted = nullptr;

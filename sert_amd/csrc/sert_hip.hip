@@ -152,6 +152,7 @@ static void discard_run_ahead(sert_model* m) {
 static void invalidate_speculation(sert_model* m) {
     discard_run_ahead(m);
     m->projected_batch = -1;
+    m->neg_alt_step = -1;      // (step counter, seed-relevant state or data may change)
 }
 
 struct TensorRef {
@@ -521,7 +522,7 @@ static int vs_loss(sert_model* m, const DataSplit& ds, int64_t batch_index) {
     case N:                                                                                  \
         hipLaunchKernelGGL((vs_nce<N, TRAIN>), grid, block, 0, m->stream, m->T, m->re, y,   \
                            m->neg, w, m->DA, m->coef, m->cand, m->rowloss, B,               \
-                           c.num_negatives, de, inv_batch);                                  \
+                           c.num_negatives, de, inv_batch, TRAIN ? m->red_loss : (float*)nullptr); \
         break;
             switch (nch) {
                 SERT_NCE_CASE(1) SERT_NCE_CASE(2) SERT_NCE_CASE(3) SERT_NCE_CASE(4)
@@ -529,7 +530,10 @@ static int vs_loss(sert_model* m, const DataSplit& ds, int64_t batch_index) {
                 default: SERT_FAIL("entity_dim > 512 is not supported");
             }
 #undef SERT_NCE_CASE
+            // (training: the kernel left one loss partial per workgroup in red_loss)
+            m->nce_loss_partials = TRAIN ? cdiv(B, 16) : 0;
         } else {
+            m->nce_loss_partials = 0;
             const int npl = cdiv(de, 64);
             dim3 grid(cdiv(B, 4));
 #define SERT_NCE_CASE(N)                                                                     \
@@ -1020,8 +1024,9 @@ static int ll_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
 // gradient buffer so that the loss sum rides in the all-reduce.
 static int reduce_rowloss(sert_model* m, hipStream_t st) {
     const int B = m->cfg.batch_size;
-    const int nb = std::min(kOptBlocks, cdiv(B, 256));
-    hipLaunchKernelGGL(sum_partial, dim3(nb), dim3(256), 0, st, m->rowloss, (size_t)B, m->red_loss);
+    int nb = std::min(kOptBlocks, cdiv(B, 256));
+    if (is_vs(m) && !is_fs(m) && m->nce_loss_partials > 0) nb = m->nce_loss_partials;   // written by vs_nce
+    else hipLaunchKernelGGL(sum_partial, dim3(nb), dim3(256), 0, st, m->rowloss, (size_t)B, m->red_loss);
     if (is_dp(m))
         hipLaunchKernelGGL(partials_to_scalar, dim3(1), dim3(256), 0, st, m->red_loss, nb, m->g_loss);
     m->n_loss_partials = nb;
@@ -1158,6 +1163,14 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
         }
     }
     if (exchanged) SERT_HIP(hipStreamWaitEvent(m->stream, m->ev_ar_done, 0));
+    if (side_small && m->epart && c.kind == SERT_KIND_VECTORSPACE && c.num_negatives > 0) {
+        // the next step's negatives (Philox position = the step counter after this update), drawn
+        // here on the side stream: ev_small below orders them before anything of the next step
+        const int64_t count = (int64_t)c.batch_size * c.num_negatives;
+        hipLaunchKernelGGL(vs_sample_negatives, dim3(grid_for((count + 3) / 4)), dim3(256), 0, ss, m->neg_alt, count,
+                           (int64_t)m->rank * count, (uint32_t)c.num_entities, c.seed, (uint64_t)m->step * 2);
+        m->neg_alt_step = m->step;
+    }
     {
         // everything small goes into one launch (a kernel boundary costs more than updating it)
         ScopedTimer t(m, TG_OPTIMIZER);
@@ -1255,6 +1268,14 @@ static int step_forward_backward(sert_model* m, const DataSplit& ds, int64_t bat
     // One fused prologue launch on the MAIN stream (sampler + zeroing of the small gradient
     // buffers and the row flags) when nothing big has to be zeroed and the device draws the
     // negatives: no side-stream prologue, no cross-queue wait in front of the loss kernel.
+    // negatives drawn at the end of the previous step for exactly this step: nothing to do (the
+    // sort-free entity-gradient path needs no zeroed buffer either: every row it owns is written)
+    const bool have_neg = negatives == nullptr && m->epart && m->neg_alt_step == m->step && side_pre &&
+                          fused_prologue_applies(m);
+    if (have_neg) {
+        std::swap(m->neg, m->neg_alt);
+        m->neg_alt_step = -1;
+    }
     const bool fused_pre = side_pre && negatives == nullptr && fused_prologue_applies(m);
     hipStream_t pre = (side_pre && !fused_pre) ? m->stream2 : m->stream;
     *fused_pre_out = (pre == m->stream);   // no side-stream prologue: no end-of-step event needed
@@ -1270,7 +1291,9 @@ static int step_forward_backward(sert_model* m, const DataSplit& ds, int64_t bat
         if (m->projected_batch != batch_index) SERT_TRY(vs_project(m, ds, batch_index));
         m->projected_batch = -1;
     }
-    if (fused_pre) {
+    if (have_neg) {
+        // (no prologue launch at all)
+    } else if (fused_pre) {
         launch_fused_prologue(m);
     } else {
         // (the previous step's optimiser and loss kernels read what the prologue overwrites)
@@ -1563,6 +1586,7 @@ static int create_resources(sert_model* m) {
             SERT_TRY(dzalloc(&m->H, B * dw, s));  SERT_TRY(dzalloc(&m->T, B * de, s));
             SERT_TRY(dzalloc(&m->DA, B * de, s)); SERT_TRY(dzalloc(&m->DH, B * dw, s));
             SERT_TRY(dzalloc(&m->neg, std::max<size_t>(4, B * c.num_negatives), s));
+            SERT_TRY(dzalloc(&m->neg_alt, std::max<size_t>(4, B * c.num_negatives), s));
             SERT_TRY(dzalloc(&m->neg_stage, std::max<size_t>(4, B * c.num_negatives), s));
             part = (size_t)1024 * (dw * de + de);
             if (c.kind == SERT_KIND_VECTORSPACE_SOFTMAX) {
@@ -1629,7 +1653,7 @@ static int create_resources(sert_model* m) {
         }
         m->part_count = part;
         SERT_TRY(dzalloc(&m->part, part, s));
-        SERT_TRY(dzalloc(&m->red_loss, (size_t)kOptBlocks, s));
+        SERT_TRY(dzalloc(&m->red_loss, std::max<size_t>((size_t)kOptBlocks, (B + 15) / 16), s));
         SERT_TRY(dzalloc(&m->red_sq, (size_t)4 * kOptBlocks, s));  // partials of up to 4 tensors
         SERT_TRY(dzalloc(&m->sq_scratch, (size_t)8 * kOptBlocks, s));
         SERT_TRY(dzalloc(&m->d_loss, (size_t)4, s));
@@ -1689,7 +1713,7 @@ int sert_destroy(sert_model* m) {
     (void)hipFree(m->ll_tokstat); (void)hipFree(m->ll_lse); (void)hipFree(m->ll_jstat);
     (void)hipFree(m->ll_rowinfo); (void)hipFree(m->ll_rpart); (void)hipFree(m->ll_r); (void)hipFree(m->ll_rsum);
     (void)hipFree(m->Zu); (void)hipFree(m->dZu); (void)hipFree(m->zpart);
-    (void)hipFree(m->neg); (void)hipFree(m->neg_stage);
+    (void)hipFree(m->neg); (void)hipFree(m->neg_alt); (void)hipFree(m->neg_stage);
     (void)hipFree(m->pred_a); (void)hipFree(m->pred_b); (void)hipFree(m->pred_ids);
     (void)hipFree(m->cand); (void)hipFree(m->cand_sorted); 
     (void)hipFree(m->pair_sorted); (void)hipFree(m->coef); (void)hipFree(m->ehead);

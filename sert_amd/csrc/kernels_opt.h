@@ -72,14 +72,30 @@ __global__ __launch_bounds__(256) void adam_l2(float* __restrict__ p, float* __r
     for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         const bool hit = !bits || row_bit(bits, ((unsigned)i << 2) / row_len);
         if (rows_mode != kRowsAll && hit != (rows_mode == kRowsTouched)) continue;
+#ifndef SERT_ADAM_NO_NT
+        // the optimiser state is touched once per step and by nobody else: streaming (nt) accesses keep
+        // it out of the way of the tables the gathers live on (59.5 -> 58.5 us, step -1.5 % at C2)
+        typedef float nt_f4 __attribute__((ext_vector_type(4)));
+        float4 pp = p4[i];
+        const nt_f4 mr = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(m) + i);
+        const nt_f4 vr = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(v) + i);
+        float4 mm = make_float4(mr.x, mr.y, mr.z, mr.w), vv = make_float4(vr.x, vr.y, vr.z, vr.w);
+#else
         float4 pp = p4[i], mm = m4[i], vv = v4[i];
+#endif
         float4 gg = make_float4(0.f, 0.f, 0.f, 0.f);
         if (hit) gg = g4[i];
         adam_elem(pp.x, gg.x, mm.x, vv.x, a, omb1, omb2, ss);
         adam_elem(pp.y, gg.y, mm.y, vv.y, a, omb1, omb2, ss);
         adam_elem(pp.z, gg.z, mm.z, vv.z, a, omb1, omb2, ss);
         adam_elem(pp.w, gg.w, mm.w, vv.w, a, omb1, omb2, ss);
+#ifndef SERT_ADAM_NO_NT
+        p4[i] = pp;
+        { nt_f4 t; t.x = mm.x; t.y = mm.y; t.z = mm.z; t.w = mm.w; __builtin_nontemporal_store(t, reinterpret_cast<nt_f4*>(m) + i); }
+        { nt_f4 t; t.x = vv.x; t.y = vv.y; t.z = vv.z; t.w = vv.w; __builtin_nontemporal_store(t, reinterpret_cast<nt_f4*>(v) + i); }
+#else
         p4[i] = pp; m4[i] = mm; v4[i] = vv;
+#endif
         if (STORE_G) g4[i] = gg;
     }
     if (blockIdx.x == 0 && !bits) {   // (< 4 element tail; a row-filtered table has none)

@@ -38,7 +38,12 @@ __global__ __launch_bounds__(256) void segsum_rows(const float* __restrict__ src
     const int chunks = d >> 2;
     // gridDim.y > 1: wide rows (d/4 > LPI) are cut into gridDim.y column groups, one
     // workgroup row each -- more, shorter chains instead of one wave walking the whole row
-    for (int c = blockIdx.y * LPI + l; c < chunks; c += LPI * gridDim.y) {
+    // every lane of the LPI group walks the loop (the row numbers travel by lane permute, so no
+    // lane may drop out): a lane whose column group is past the row computes on group 0 and
+    // stores nothing
+    for (int c0 = blockIdx.y * LPI; c0 < chunks; c0 += LPI * gridDim.y) {
+        const bool on = c0 + l < chunks;
+        const int c = on ? c0 + l : 0;
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
         // LL_FINAL: the word's log-probabilities and r sum do not depend on the row sums --
         // fetch them now, in the shadow of the row loads, not after them
@@ -48,26 +53,54 @@ __global__ __launch_bounds__(256) void segsum_rows(const float* __restrict__ src
             lp_pre = *reinterpret_cast<const float4*>(logp + (size_t)it.w * d + 4 * c);
             rs_pre = rsum[it.w];
         }
-        int e = it.x;
-        for (; e + 4 <= it.y; e += 4) {
-            int r0, r1, r2, r3;
-            if (rows) { r0 = rows[e]; r1 = rows[e + 1]; r2 = rows[e + 2]; r3 = rows[e + 3]; }
-            else      { r0 = e; r1 = e + 1; r2 = e + 2; r3 = e + 3; }
-            if (rows && rdiv > 1) { r0 /= rdiv; r1 /= rdiv; r2 /= rdiv; r3 /= rdiv; }   // source row = entry / rdiv
-            const float4 v0 = *reinterpret_cast<const float4*>(src + (size_t)r0 * d + 4 * c);
-            const float4 v1 = *reinterpret_cast<const float4*>(src + (size_t)r1 * d + 4 * c);
-            const float4 v2 = *reinterpret_cast<const float4*>(src + (size_t)r2 * d + 4 * c);
-            const float4 v3 = *reinterpret_cast<const float4*>(src + (size_t)r3 * d + 4 * c);
-            a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
-            a.x += v1.x; a.y += v1.y; a.z += v1.z; a.w += v1.w;
-            a.x += v2.x; a.y += v2.y; a.z += v2.z; a.w += v2.w;
-            a.x += v3.x; a.y += v3.y; a.z += v3.z; a.w += v3.w;
+        // Row numbers: one coalesced load per LPI entries (lane k holds entry k), handed round
+        // with lane permutes -- not a broadcast load per entry in front of every row load.  Rows:
+        // eight in flight per trip (then four, then the last one to three), so a 64-entry chunk
+        // is 8 + 2 dependent memory round trips instead of 32.  Entries are added left to right
+        // whatever the batching, so the sums do not depend on it.
+        const int len = it.y - it.x;
+        for (int base = 0; base < len; base += LPI) {
+            const int cnt = min(LPI, len - base);
+            int myr = it.x + base + min(l, cnt - 1);
+            if (rows) {
+                myr = rows[myr];
+                if (rdiv > 1) myr /= rdiv;   // source row = entry / rdiv
+            }
+            int k = 0;
+            for (; k + 8 <= cnt; k += 8) {
+                float4 v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int r = __shfl(myr, k + q, LPI);
+                    v[q] = *reinterpret_cast<const float4*>(src + (size_t)r * d + 4 * c);
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { a.x += v[q].x; a.y += v[q].y; a.z += v[q].z; a.w += v[q].w; }
+            }
+            if (k + 4 <= cnt) {
+                float4 v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = __shfl(myr, k + q, LPI);
+                    v[q] = *reinterpret_cast<const float4*>(src + (size_t)r * d + 4 * c);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { a.x += v[q].x; a.y += v[q].y; a.z += v[q].z; a.w += v[q].w; }
+                k += 4;
+            }
+            if (k < cnt) {   // one to three left: the positions past the end repeat the last entry
+                float4 v[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int r = __shfl(myr, min(k + q, cnt - 1), LPI);
+                    v[q] = *reinterpret_cast<const float4*>(src + (size_t)r * d + 4 * c);
+                }
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    if (k + q < cnt) { a.x += v[q].x; a.y += v[q].y; a.z += v[q].z; a.w += v[q].w; }
+            }
         }
-        for (; e < it.y; ++e) {
-            const int r = rows ? (rdiv > 1 ? rows[e] / rdiv : rows[e]) : e;
-            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)r * d + 4 * c);
-            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
-        }
+        if (!on) continue;
         if (it.z >= 0 && LL_FINAL) {
             const float LOGLO = logf(SERT_CLIP_LO), LOGHI = logf(SERT_CLIP_HI);
             const size_t o = (size_t)it.w * d + 4 * c;

@@ -9,6 +9,9 @@ namespace sert {
 // One thread per (row, VEC-wide column chunk): consecutive lanes read
 // consecutive 16-byte pieces of one embedding row (coalesced); the (B,n,d)
 // gathered tensor is never materialised.
+#ifndef SERT_GATHER_GC
+#define SERT_GATHER_GC 10   // window positions fetched per trip (25 us vs 35 at C2)
+#endif
 template <typename IdT, int VEC>
 __global__ __launch_bounds__(256) void vs_gather_mean(const IdT* __restrict__ X,
                                                       const float* __restrict__ Rw,
@@ -23,10 +26,21 @@ __global__ __launch_bounds__(256) void vs_gather_mean(const IdT* __restrict__ X,
         const IdT* xr = X + (size_t)row * n;
         if (VEC == 4) {
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int k = 0; k < n; ++k) {
-                const size_t id = (size_t)xr[k];
-                const float4 v = *reinterpret_cast<const float4*>(Rw + id * d + c);
-                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            // five window positions per trip: their ids in one burst, their rows in a second -- two
+            // dependent memory round trips per trip instead of two per token (a token's id, then its
+            // row: 20 hops in series for a window of 10).  Positions past the window repeat the last
+            // one (no branch around a load) and are not added; the additions keep the window order.
+            constexpr int GC = SERT_GATHER_GC;
+            for (int k0 = 0; k0 < n; k0 += GC) {
+                size_t id[GC];
+#pragma unroll
+                for (int q = 0; q < GC; ++q) id[q] = (size_t)xr[min(k0 + q, n - 1)];
+                float4 v[GC];
+#pragma unroll
+                for (int q = 0; q < GC; ++q) v[q] = *reinterpret_cast<const float4*>(Rw + id[q] * d + c);
+#pragma unroll
+                for (int q = 0; q < GC; ++q)
+                    if (k0 + q < n) { a.x += v[q].x; a.y += v[q].y; a.z += v[q].z; a.w += v[q].w; }
             }
             a.x /= fn; a.y /= fn; a.z /= fn; a.w /= fn;
             *reinterpret_cast<float4*>(H + (size_t)row * d + c) = a;
@@ -151,20 +165,34 @@ __global__ __launch_bounds__(256) void vs_nce(const float* __restrict__ T,
     const float g = wi * inv_batch;
     float loss = 0.f;
     for (int j = 0; j <= z; ++j) {
+#ifdef KO_IDS
+        const int e = (i * 7 + j * 13) & 2047;
+#else
         const int e = (j == 0) ? y[i] : neg[(size_t)i * z + (j - 1)];
+#endif
         float4 er[NCH];
         float part = 0.f;
 #pragma unroll
         for (int q = 0; q < NCH; ++q) {
             const int c = l + 16 * q;
+#ifdef KO_ROWS
+            er[q] = make_float4(1.f * e, 0.5f, 0.25f * j, 0.f);
+#else
             er[q] = (c < chunks) ? *reinterpret_cast<const float4*>(Re + (size_t)e * de + 4 * c)
                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
             part += er[q].x * p[q].x + er[q].y * p[q].y + er[q].z * p[q].z + er[q].w * p[q].w;
         }
         const float u = row16_sum(part);
+#ifdef KO_MATH
+        const float sig = u * 0.01f + 0.5f;
+        const float s = fminf(fmaxf(sig, SERT_CLIP_LO), SERT_CLIP_HI);
+        loss -= s;
+#else
         const float sig = theano_sigmoid(u);
         const float s = fminf(fmaxf(sig, SERT_CLIP_LO), SERT_CLIP_HI);
         loss -= (j == 0) ? logf(s) : logf(1.0f - s);
+#endif
         if (TRAIN) {
             const bool inside = (sig >= SERT_CLIP_LO) && (sig <= SERT_CLIP_HI);
             float du = 0.f;
@@ -177,10 +205,12 @@ __global__ __launch_bounds__(256) void vs_nce(const float* __restrict__ T,
                 dp[q].x += du * er[q].x; dp[q].y += du * er[q].y;
                 dp[q].z += du * er[q].z; dp[q].w += du * er[q].w;
             }
+#ifndef KO_COEF
             if (l == 0 && valid) {
                 coef[(size_t)i * (z + 1) + j] = du;
                 cand[(size_t)i * (z + 1) + j] = e;
             }
+#endif
         }
     }
     if (TRAIN) {
@@ -205,6 +235,122 @@ __global__ __launch_bounds__(256) void vs_nce(const float* __restrict__ T,
 #pragma unroll
             for (int r = 0; r < 16; ++r) s += wg_red[r];
             wg_loss[blockIdx.x] = s;
+        }
+    }
+}
+
+// All candidates of a row in registers (z + 1 <= MAXC <= 16): the candidate ids arrive in one load
+// (lane j of the row's sixteen holds candidate j), their entity rows in one burst, and the sigmoid /
+// log / clip arithmetic runs ONCE per row with candidate j on lane j instead of once per candidate
+// on all sixteen lanes.  The per-candidate kernel above walks id -> row -> dot -> sigmoid z + 1 times
+// in series with two waves per SIMD in flight (B = 8192 is 2048 waves), which is what its 40 us
+// were; here a wave has two dependent memory round trips in all.
+template <int NCH, bool TRAIN, int MAXC>
+__global__ __launch_bounds__(256) void vs_nce_regs(const float* __restrict__ T,
+                                                   const float* __restrict__ Re,
+                                                   const int32_t* __restrict__ y,
+                                                   const int32_t* __restrict__ neg,
+                                                   const float* __restrict__ w, float* __restrict__ DA,
+                                                   float* __restrict__ coef, int32_t* __restrict__ cand,
+                                                   float* __restrict__ rowloss, int B, int z, int de,
+                                                   float inv_batch, float* __restrict__ wg_loss = nullptr) {
+    __shared__ float wg_red[16];
+    const int l = threadIdx.x & 15;
+    const int lane = threadIdx.x & 63;
+    const int i_raw = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool valid = i_raw < B;
+    const int i = valid ? i_raw : B - 1;
+    const int chunks = de >> 2;
+    // candidate l of this row (lanes past z repeat the last one and contribute nothing)
+    const int jl = min(l, z);
+    const int my_e = (jl == 0) ? y[i] : neg[(size_t)i * z + (jl - 1)];
+    float4 t[NCH];
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+        const int c = l + 16 * q;
+        t[q] = (c < chunks) ? *reinterpret_cast<const float4*>(T + (size_t)i * de + 4 * c)
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float4 er[MAXC][NCH];
+#pragma unroll
+    for (int u = 0; u < MAXC; ++u) {
+        const int e = __shfl(my_e, (lane & 48) | u);
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            const int c = l + 16 * q;
+            er[u][q] = (c < chunks) ? *reinterpret_cast<const float4*>(Re + (size_t)e * de + 4 * c)
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    float4 p[NCH];
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+        p[q].x = fminf(fmaxf(t[q].x, -SERT_CLIP_HI), SERT_CLIP_HI);
+        p[q].y = fminf(fmaxf(t[q].y, -SERT_CLIP_HI), SERT_CLIP_HI);
+        p[q].z = fminf(fmaxf(t[q].z, -SERT_CLIP_HI), SERT_CLIP_HI);
+        p[q].w = fminf(fmaxf(t[q].w, -SERT_CLIP_HI), SERT_CLIP_HI);
+    }
+    float my_u = 0.f;
+#pragma unroll
+    for (int u = 0; u < MAXC; ++u) {
+        float part = 0.f;
+#pragma unroll
+        for (int q = 0; q < NCH; ++q)
+            part += er[u][q].x * p[q].x + er[u][q].y * p[q].y + er[u][q].z * p[q].z + er[u][q].w * p[q].w;
+        const float uu = row16_sum(part);
+        my_u = (l == u) ? uu : my_u;
+    }
+    const float wi = TRAIN ? w[i] : 1.f;
+    const float g = wi * inv_batch;
+    const bool act = l <= z;
+    const float sig = theano_sigmoid(my_u);
+    const float s = fminf(fmaxf(sig, SERT_CLIP_LO), SERT_CLIP_HI);
+    const float term = (l == 0) ? logf(s) : logf(1.0f - s);
+    const float loss = -row16_sum(act ? term : 0.f);
+    if (TRAIN) {
+        const bool inside = (sig >= SERT_CLIP_LO) && (sig <= SERT_CLIP_HI);
+        float du = 0.f;
+        if (inside && act) {
+            const float ds = sig * (1.0f - sig);
+            du = (l == 0) ? -(g / s) * ds : (g / (1.0f - s)) * ds;
+        }
+        if (act && valid) {
+            coef[(size_t)i * (z + 1) + l] = du;
+            cand[(size_t)i * (z + 1) + l] = my_e;
+        }
+        float4 dp[NCH];
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) dp[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < MAXC; ++u) {
+            const float du_u = __shfl(du, (lane & 48) | u);   // 0 for candidates past z
+#pragma unroll
+            for (int q = 0; q < NCH; ++q) {
+                dp[q].x += du_u * er[u][q].x; dp[q].y += du_u * er[u][q].y;
+                dp[q].z += du_u * er[u][q].z; dp[q].w += du_u * er[u][q].w;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            const int c = l + 16 * q;
+            if (c >= chunks || !valid) continue;
+            float4 o;
+            o.x = (t[q].x >= -SERT_CLIP_HI && t[q].x <= SERT_CLIP_HI) ? dp[q].x * (1.0f - t[q].x * t[q].x) : 0.f;
+            o.y = (t[q].y >= -SERT_CLIP_HI && t[q].y <= SERT_CLIP_HI) ? dp[q].y * (1.0f - t[q].y * t[q].y) : 0.f;
+            o.z = (t[q].z >= -SERT_CLIP_HI && t[q].z <= SERT_CLIP_HI) ? dp[q].z * (1.0f - t[q].z * t[q].z) : 0.f;
+            o.w = (t[q].w >= -SERT_CLIP_HI && t[q].w <= SERT_CLIP_HI) ? dp[q].w * (1.0f - t[q].w * t[q].w) : 0.f;
+            *reinterpret_cast<float4*>(DA + (size_t)i * de + 4 * c) = o;
+        }
+    }
+    if (l == 0 && valid) rowloss[i] = wi * loss;
+    if (wg_loss) {
+        if (l == 0) wg_red[threadIdx.x >> 4] = valid ? wi * loss : 0.f;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sum += wg_red[r];
+            wg_loss[blockIdx.x] = sum;
         }
     }
 }
@@ -246,9 +392,15 @@ __global__ __launch_bounds__(256) void vs_nce_scalar(const float* __restrict__ T
             part += er[q] * p[q];
         }
         const float u = wave_sum(part);
+#ifdef KO_MATH
+        const float sig = u * 0.01f + 0.5f;
+        const float s = fminf(fmaxf(sig, SERT_CLIP_LO), SERT_CLIP_HI);
+        loss -= s;
+#else
         const float sig = theano_sigmoid(u);
         const float s = fminf(fmaxf(sig, SERT_CLIP_LO), SERT_CLIP_HI);
         loss -= (j == 0) ? logf(s) : logf(1.0f - s);
+#endif
         if (TRAIN) {
             const bool inside = (sig >= SERT_CLIP_LO) && (sig <= SERT_CLIP_HI);
             float du = 0.f;

@@ -524,11 +524,32 @@ static int vs_loss(sert_model* m, const DataSplit& ds, int64_t batch_index) {
                            m->neg, w, m->DA, m->coef, m->cand, m->rowloss, B,               \
                            c.num_negatives, de, inv_batch, TRAIN ? m->red_loss : (float*)nullptr); \
         break;
+#define SERT_NCE_REGS(N, C)                                                                  \
+    hipLaunchKernelGGL((vs_nce_regs<N, TRAIN, C>), grid, block, 0, m->stream, m->T, m->re, y, \
+                       m->neg, w, m->DA, m->coef, m->cand, m->rowloss, B, c.num_negatives,   \
+                       de, inv_batch, TRAIN ? m->red_loss : (float*)nullptr)
+            static const bool no_regs = getenv("SERT_NCE_PER_CANDIDATE") != nullptr;
+            const int nc = c.num_negatives + 1;
+            if (!no_regs && nch <= 4 && nc <= 12) {
+                // every candidate row of a row in registers (kernels_vs.h: vs_nce_regs)
+                const int key = nch * 2 + (nc > 6 ? 1 : 0);
+                switch (key) {
+                    case 2: SERT_NCE_REGS(1, 6); break;
+                    case 3: SERT_NCE_REGS(1, 12); break;
+                    case 4: SERT_NCE_REGS(2, 6); break;
+                    case 5: SERT_NCE_REGS(2, 12); break;
+                    case 6: SERT_NCE_REGS(3, 6); break;
+                    case 7: SERT_NCE_REGS(3, 12); break;
+                    case 8: SERT_NCE_REGS(4, 6); break;
+                    default: SERT_NCE_REGS(4, 12); break;
+                }
+            } else
             switch (nch) {
                 SERT_NCE_CASE(1) SERT_NCE_CASE(2) SERT_NCE_CASE(3) SERT_NCE_CASE(4)
                 SERT_NCE_CASE(5) SERT_NCE_CASE(6) SERT_NCE_CASE(7) SERT_NCE_CASE(8)
                 default: SERT_FAIL("entity_dim > 512 is not supported");
             }
+#undef SERT_NCE_REGS
 #undef SERT_NCE_CASE
             // (training: the kernel left one loss partial per workgroup in red_loss)
             m->nce_loss_partials = TRAIN ? cdiv(B, 16) : 0;

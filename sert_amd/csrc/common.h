@@ -1,9 +1,31 @@
 // Shared helpers for the gfx950 kernels of libsert_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
+
+// An event bound to a kernel's OWN completion signal (hipExtLaunchKernel's stop event) instead of
+// a barrier packet queued behind it: hipEventRecord stalls its queue for ~7 us on this system
+// (the next dispatch waits for the command processor to retire the barrier packet), the stop
+// event of the kernel itself does not.  set_stop_event(ev) arms the NEXT SERT_LAUNCH on this
+// host thread.
+inline hipEvent_t& pending_stop_event() {
+    static thread_local hipEvent_t ev = nullptr;
+    return ev;
+}
+inline void set_stop_event(hipEvent_t ev) { pending_stop_event() = ev; }
+#define SERT_LAUNCH(kernel, grid, block, shmem, stream, ...)                                   \
+    do {                                                                                       \
+        hipEvent_t sert_stop_ev_ = ::pending_stop_event();                                     \
+        ::pending_stop_event() = nullptr;                                                      \
+        if (sert_stop_ev_)                                                                     \
+            hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, nullptr, sert_stop_ev_,  \
+                                  0, __VA_ARGS__);                                             \
+        else                                                                                   \
+            hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);               \
+    } while (0)
 
 namespace sert {
 

@@ -540,8 +540,8 @@ inline void launch_gemm(hipStream_t s, const float* A, const float* B, float* C,
         g.tiles_m = cdiv(M, SM); g.tiles_n = cdiv(N, SM);
         const bool vecs = (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A) % 16 == 0) &&
                           (((uintptr_t)B) % 16 == 0) && (K % 4 == 0) && (TB ? true : (N % 4 == 0));
-        if (vecs) hipLaunchKernelGGL((gemm_f32_mfma_small<TB, EPI == EPI_FILTER ? EPI_STORE : EPI, true>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, s, g);
-        else      hipLaunchKernelGGL((gemm_f32_mfma_small<TB, EPI == EPI_FILTER ? EPI_STORE : EPI, false>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, s, g);
+        if (vecs) SERT_LAUNCH((gemm_f32_mfma_small<TB, EPI == EPI_FILTER ? EPI_STORE : EPI, true>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, s, g);
+        else      SERT_LAUNCH((gemm_f32_mfma_small<TB, EPI == EPI_FILTER ? EPI_STORE : EPI, false>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, s, g);
         return;
     }
     g.cand = cand; g.cnt = cnt; g.cap = cap;
@@ -565,9 +565,9 @@ inline void launch_gemm(hipStream_t s, const float* A, const float* B, float* C,
     }();
     const int grid = (int)std::min<long long>(total, max_grid);
     const bool full = (M % GM == 0) && (N % GN == 0) && EPI != EPI_FILTER;
-    if (vec && full) hipLaunchKernelGGL((gemm_f32_mfma<TA, TB, EPI, CSB, true, true>), dim3(grid), dim3(256), 0, s, g);
-    else if (vec)    hipLaunchKernelGGL((gemm_f32_mfma<TA, TB, EPI, CSB, true, false>), dim3(grid), dim3(256), 0, s, g);
-    else             hipLaunchKernelGGL((gemm_f32_mfma<TA, TB, EPI, CSB, false, false>), dim3(grid), dim3(256), 0, s, g);
+    if (vec && full) SERT_LAUNCH((gemm_f32_mfma<TA, TB, EPI, CSB, true, true>), dim3(grid), dim3(256), 0, s, g);
+    else if (vec)    SERT_LAUNCH((gemm_f32_mfma<TA, TB, EPI, CSB, true, false>), dim3(grid), dim3(256), 0, s, g);
+    else             SERT_LAUNCH((gemm_f32_mfma<TA, TB, EPI, CSB, false, false>), dim3(grid), dim3(256), 0, s, g);
 }
 
 // out[i] = sum_s part[s*stride + i] over the split-K partial slabs, in a fixed

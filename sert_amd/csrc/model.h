@@ -74,6 +74,7 @@ struct sert_model {
     hipEvent_t ev_loss = nullptr;    // the step's loss has been copied out
     hipEvent_t ev_dense = nullptr;   // dW, db and the loss partials are complete (main stream)
     bool step_done_pending = false;  // the previous step ended without recording ev_step_done
+    bool fork_bound = false;         // ev_fork rides on the NCE kernel's completion signal (no record needed)
     bool lazy_join = false;          // this step: the main stream never waits for the entity chain
     int n_loss_partials = 0;
     int nce_loss_partials = 0;       // > 0: vs_nce wrote this many per-workgroup loss partials into red_loss

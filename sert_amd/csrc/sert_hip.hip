@@ -503,6 +503,25 @@ static int vs_project(sert_model* m, const DataSplit& ds, int64_t batch_index) {
     return 0;
 }
 
+// Events that mark the end of ONE kernel ride on that kernel's completion signal
+// (SERT_EXT_EVENTS=0: plain hipEventRecord behind it, ~7 us of queue stall each).
+static bool ext_events() {
+    static const bool on = !(getenv("SERT_EXT_EVENTS") && atoi(getenv("SERT_EXT_EVENTS")) == 0);
+    return on;
+}
+
+// Single GPU, two streams: ONE fork per step, behind the dh GEMM (the last reader of W): the side
+// stream then takes the entity chain, dW / db and the small-tensor optimiser in a row with no
+// further event, the main stream keeps loss -> dh -> segmented sum -> word-table optimiser.
+// Every cross-queue event costs its queue ~5-7 us (the kernel that carries a completion signal
+// ends with a cache write-back): two per step instead of three.  SERT_FORK_LATE=0 restores the
+// fork right behind the NCE kernel with dW on the main stream.
+static bool fork_late_mode(const sert_model* m) {
+    static const bool on = !(getenv("SERT_FORK_LATE") && atoi(getenv("SERT_FORK_LATE")) == 0);
+    return on && ext_events() && !is_dp(m) && !m->timing.enabled && m->nstreams == 2 &&
+           m->n_re <= ((size_t)1 << 22) && m->cfg.kind == SERT_KIND_VECTORSPACE;
+}
+
 // NCE score / loss / gradient coefficients
 template <bool TRAIN>
 static int vs_loss(sert_model* m, const DataSplit& ds, int64_t batch_index) {
@@ -515,17 +534,24 @@ static int vs_loss(sert_model* m, const DataSplit& ds, int64_t batch_index) {
         const float* w = TRAIN ? ds.w + row0 : nullptr;
         const float inv_batch = 1.0f / (float)c.global_batch_size;
         dim3 block(256);
+        // training with a side stream: the fork event of the backward pass is this kernel's own
+        // completion signal (common.h: SERT_LAUNCH)
+        m->fork_bound = false;
+        if (TRAIN && ext_events() && !fork_late_mode(m) && !m->timing.enabled && m->nstreams >= 2 && de % 4 == 0) {
+            set_stop_event(m->ev_fork);
+            m->fork_bound = true;
+        }
         if (de % 4 == 0) {
             const int nch = cdiv(de / 4, 16);
             dim3 grid(cdiv(B, 16));
 #define SERT_NCE_CASE(N)                                                                     \
     case N:                                                                                  \
-        hipLaunchKernelGGL((vs_nce<N, TRAIN>), grid, block, 0, m->stream, m->T, m->re, y,   \
+        SERT_LAUNCH((vs_nce<N, TRAIN>), grid, block, 0, m->stream, m->T, m->re, y,          \
                            m->neg, w, m->DA, m->coef, m->cand, m->rowloss, B,               \
                            c.num_negatives, de, inv_batch, TRAIN ? m->red_loss : (float*)nullptr); \
         break;
 #define SERT_NCE_REGS(N, C)                                                                  \
-    hipLaunchKernelGGL((vs_nce_regs<N, TRAIN, C>), grid, block, 0, m->stream, m->T, m->re, y, \
+    SERT_LAUNCH((vs_nce_regs<N, TRAIN, C>), grid, block, 0, m->stream, m->T, m->re, y,       \
                        m->neg, w, m->DA, m->coef, m->cand, m->rowloss, B, c.num_negatives,   \
                        de, inv_batch, TRAIN ? m->red_loss : (float*)nullptr)
             static const bool no_regs = getenv("SERT_NCE_PER_CANDIDATE") != nullptr;
@@ -578,13 +604,17 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
     const auto& c = m->cfg;
     const int B = c.batch_size, n = c.window_size, dw = c.word_dim, de = c.entity_dim;
     const size_t row0 = (size_t)batch_index * B;
-    {
+    const bool fork_late = fork_late_mode(m);
+    auto entity_grad = [&]() -> int {
         // fork: this chain only depends on the NCE kernel and is independent of the
         // GEMMs / word-table reduction below, so it runs on the side stream
         // (timing mode measures every kernel alone: everything stays on the main stream)
         hipStream_t st = (m->timing.enabled || m->nstreams < 2) ? m->stream : m->stream2;
-        SERT_HIP(hipEventRecord(m->ev_fork, m->stream));
-        if (st != m->stream) SERT_HIP(hipStreamWaitEvent(st, m->ev_fork, 0));
+        if (!fork_late) {
+            if (!m->fork_bound) SERT_HIP(hipEventRecord(m->ev_fork, m->stream));
+            m->fork_bound = false;
+            if (st != m->stream) SERT_HIP(hipStreamWaitEvent(st, m->ev_fork, 0));
+        }
         const int total = B * (c.num_negatives + 1);
         const int V = c.num_entities;
         static const bool ko_egrad = getenv("SERT_KO_EGRAD") != nullptr;   // timing knock-out (wrong results)
@@ -656,12 +686,18 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         }
 #undef SERT_EG_ARGS
         }   // sorted path
-    }
-    auto word_table_grad = [&]() -> int {
+        return 0;
+    };
+    bool dense_bound = false;
+    auto dh_gemm = [&]() -> int {
         {
             // dh = da.W^T
             ScopedTimer t(m, TG_GEMM_DX);
-            if (gemm_strip_ok(B, dw, de, de, de, true, m->DA, m->W))
+            const bool strip = gemm_strip_ok(B, dw, de, de, de, true, m->DA, m->W);
+            // (ev_dense below: the completion signal of this GEMM, not a barrier packet behind it)
+            dense_bound = m->lazy_join && ext_events() && !strip;
+            if (dense_bound) set_stop_event(fork_late ? m->ev_fork : m->ev_dense);
+            if (strip)
                 launch_gemm_strip<true, EPI_STORE>(m->stream, m->DA, m->W, m->DH, nullptr, B, dw, de, de, de, dw);
             else
                 launch_gemm<false, true, EPI_STORE>(m->stream, m->DA, m->W, m->DH, nullptr, B, dw, de, de,
@@ -669,7 +705,11 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         }
         // From here on the main stream has produced dW, db and the loss partials AND is done
         // READING W (the dh GEMM): the side stream may update the small tensors.
-        if (m->lazy_join) SERT_HIP(hipEventRecord(m->ev_dense, m->stream));
+        if (m->lazy_join && !dense_bound) SERT_HIP(hipEventRecord(fork_late ? m->ev_fork : m->ev_dense, m->stream));
+        if (fork_late) SERT_HIP(hipStreamWaitEvent(m->stream2, m->ev_fork, 0));
+        return 0;
+    };
+    auto word_table_sum = [&]() -> int {
         {
             ScopedTimer t(m, TG_SCATTER);
             // dR_w[X[i,k],:] += dh[i,:] / n
@@ -732,15 +772,24 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
     // that chain, and the word-table optimiser starts straight after segsum instead of
     // idling ~12 us on a cross-queue dependency.
     m->lazy_join = !is_dp(m) && !m->timing.enabled && m->nstreams == 2 && m->n_re <= ((size_t)1 << 22);
-    if (is_dp(m)) {
+    if (fork_late) {
+        SERT_TRY(dh_gemm());           // main; its completion is the step's one fork
+        SERT_TRY(entity_grad());       // side
+        SERT_TRY(dense_grad());        // main (W and b are then updated on the main stream too)
+        SERT_TRY(word_table_sum());    // main
+    } else if (is_dp(m)) {
         // data parallel: the word-table gradient first, so that its all-reduce (the
         // big one) overlaps dW and the entity chain
-        SERT_TRY(word_table_grad());
+        SERT_TRY(entity_grad());
+        SERT_TRY(dh_gemm());
+        SERT_TRY(word_table_sum());
         SERT_TRY(dense_grad());
     } else {
         // single GPU: the MFMA-bound dW beside the latency-bound sort of the side stream
+        SERT_TRY(entity_grad());
         SERT_TRY(dense_grad());
-        SERT_TRY(word_table_grad());   // (records ev_dense behind the dX GEMM)
+        SERT_TRY(dh_gemm());           // (records ev_dense behind the dX GEMM)
+        SERT_TRY(word_table_sum());
     }
     // join the entity-gradient chain (and the dense gradients of a third stream)
     if (!m->lazy_join && !m->timing.enabled && m->nstreams >= 2) {
@@ -1127,7 +1176,9 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
     // streams on the main one (independent tensors; every gradient is complete here)
     const bool side_small = !is_dp(m) && !m->timing.enabled && m->nstreams >= 2;
     hipStream_t ss = side_small ? m->stream2 : m->stream;
-    if (side_small && m->lazy_join) {
+    if (side_small && m->lazy_join && fork_late_mode(m)) {
+        // (everything the small tensors need was issued on the side stream itself)
+    } else if (side_small && m->lazy_join) {
         SERT_HIP(hipStreamWaitEvent(ss, m->ev_dense, 0));
     } else if (side_small) {
         SERT_HIP(hipEventRecord(m->ev_opt_fork, m->stream));
@@ -1192,14 +1243,17 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
                            (int64_t)m->rank * count, (uint32_t)c.num_entities, c.seed, (uint64_t)m->step * 2);
         m->neg_alt_step = m->step;
     }
-    {
+    // Late fork (fork_late_mode): dW / db were produced on the main stream, dR_e on the side
+    // stream -- W and b are updated on the main stream, R_e on the side stream, no event between.
+    const bool split_small = side_small && m->lazy_join && fork_late_mode(m);
+    auto small_tensors = [&](hipStream_t ss, unsigned mask) {
         // everything small goes into one launch (a kernel boundary costs more than updating it)
         ScopedTimer t(m, TG_OPTIMIZER);
         SmallTensors st;
         int k = 0, blocks = 0;
         for (int i = 1; i < 4; ++i) {
             const ParamTensor t2 = param_tensor(m, i);
-            if (m->pt_big[i] || t2.n == 0) continue;
+            if (m->pt_big[i] || t2.n == 0 || !((mask >> i) & 1u)) continue;
             st.p[k] = t2.p; st.g[k] = t2.g; st.s0[k] = t2.s0; st.s1[k] = t2.s1; st.count[k] = t2.n;
             st.l2k[k] = t2.l2 ? l2k : 0.f;
             st.first_block[k] = blocks;
@@ -1220,10 +1274,16 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
             }
         }
         n_sq += blocks;
-        if (side_small) {
-            SERT_HIP(hipEventRecord(m->ev_small, ss));
-            SERT_HIP(hipStreamWaitEvent(m->stream, m->ev_small, 0));
-        }
+    };
+    if (split_small) {
+        small_tensors(m->stream, 0xCu);   // W, b
+        small_tensors(ss, 0x2u);          // R_e
+    } else {
+        small_tensors(ss, 0xEu);
+    }
+    if (side_small) {
+        SERT_HIP(hipEventRecord(m->ev_small, ss));
+        SERT_HIP(hipStreamWaitEvent(m->stream, m->ev_small, 0));
     }
     if (m->early_issued) {   // the untouched rows' sum of squares (and their update) must have landed
         SERT_HIP(hipStreamWaitEvent(m->stream, m->ev_early, 0));

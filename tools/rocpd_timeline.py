@@ -1,9 +1,8 @@
 #!/usr/bin/env python
-"""Timeline of ONE training step from a rocprofv3 kernel trace (rocpd sqlite):
-every dispatch between two consecutive launches of the anchor kernel, with its
-start/end relative to the first, the queue it ran on and the idle gap before it.
-
-    python tools/rocpd_timeline.py results.db [anchor-substring] [which-step]
+"""Timeline of ONE training step from a rocprofv3 rocpd database (kernel trace): every dispatch
+between two consecutive launches of the step's first kernel, with its start offset, duration,
+queue and the idle gap of its queue before it.
+    python tools/rocpd_timeline.py results.db [first_kernel_substring] [which_step_from_the_end]
 """
 import re
 import sqlite3
@@ -12,40 +11,26 @@ import sys
 
 def short(name):
     name = re.sub(r'\[clone .*\]', '', name).replace('sert::', '').replace('void ', '')
-    return name.split('(')[0][:60]
+    return name.split('(')[0][:70]
 
 
-def main(path, anchor='vs_gather_mean', which=60):
+def main(path, first='vs_gather_mean', back=3):
     db = sqlite3.connect(path)
     cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
-    qcol = 'queue_id' if 'queue_id' in cols else ('stream_id' if 'stream_id' in cols else None)
-    rows = db.execute("select name, start, end, %s from kernels order by start" % (qcol or '0')).fetchall()
-    anchors = [i for i, r in enumerate(rows) if anchor in r[0]]
-    if len(anchors) < which + 2:
-        which = len(anchors) // 2
-    i0, i1 = anchors[which], anchors[which + 1]
-    t0 = rows[i0][1]
-    print('step window: %.1f us, %d dispatches' % ((rows[i1][1] - t0) / 1e3, i1 - i0))
-    last_end = t0
-    busy = 0.0
-    for name, st, en, q in rows[i0:i1]:
-        gap = (st - last_end) / 1e3
-        print('%8.1f %8.1f %7.1f  q=%-4s gap=%6.1f  %s' % ((st - t0) / 1e3, (en - t0) / 1e3,
-                                                         (en - st) / 1e3, q, gap, short(name)))
-        last_end = max(last_end, en)
-    # union of busy intervals
-    iv = sorted((r[1], r[2]) for r in rows[i0:i1])
-    cur_s, cur_e = iv[0]
-    for s, e in iv[1:]:
-        if s > cur_e:
-            busy += cur_e - cur_s
-            cur_s, cur_e = s, e
-        else:
-            cur_e = max(cur_e, e)
-    busy += cur_e - cur_s
-    print('GPU busy (union of kernels): %.1f us of %.1f' % (busy / 1e3, (rows[i1][1] - t0) / 1e3))
+    q = 'queue_id' if 'queue_id' in cols else ('stream_id' if 'stream_id' in cols else 'tid')
+    rows = db.execute("select name, start, end, %s from kernels order by start" % q).fetchall()
+    starts = [i for i, r in enumerate(rows) if first in r[0]]
+    a, b = starts[-back - 1], starts[-back]
+    t0 = rows[a][1]
+    last_end = {}
+    print('%-70s %6s %10s %9s %9s' % ('kernel', 'queue', 'start_us', 'dur_us', 'gap_us'))
+    for name, s, e, qid in rows[a:b]:
+        gap = (s - last_end[qid]) / 1e3 if qid in last_end else float('nan')
+        print('%-70s %6s %10.1f %9.1f %9.1f' % (short(name), qid, (s - t0) / 1e3, (e - s) / 1e3, gap))
+        last_end[qid] = e
+    print('step span: %.1f us   sum of durations: %.1f us' % (
+        (rows[b][1] - t0) / 1e3, sum(r[2] - r[1] for r in rows[a:b]) / 1e3))
 
 
 if __name__ == '__main__':
-    a = sys.argv[1:]
-    main(a[0], a[1] if len(a) > 1 else 'vs_gather_mean', int(a[2]) if len(a) > 2 else 60)
+    main(sys.argv[1], *(sys.argv[2:3] or ['vs_gather_mean']), *[int(x) for x in sys.argv[3:4]])

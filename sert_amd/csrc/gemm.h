@@ -571,28 +571,52 @@ inline void launch_gemm(hipStream_t s, const float* A, const float* B, float* C,
 }
 
 // out[i] = sum_s part[s*stride + i] over the split-K partial slabs, in a fixed
-// association (4 interleaved groups of ascending s, then a fixed 4-way add)
+// association (G interleaved groups of ascending s, then a fixed G-way add)
 // => deterministic.  Elements i < n1 go to out1[i], the rest to out2[i-n1]
 // (dW followed by the fused db column sums).  64 elements per workgroup.
-__global__ __launch_bounds__(256) void reduce_partials(const float* __restrict__ part, int splits,
-                                                       size_t stride, size_t count,
-                                                       float* __restrict__ out1, size_t n1,
-                                                       float* __restrict__ out2) {
-    __shared__ float red[4][64];
+template <int G>
+__global__ __launch_bounds__(64 * G) void reduce_partials_g(const float* __restrict__ part, int splits,
+                                                            size_t stride, size_t count,
+                                                            float* __restrict__ out1, size_t n1,
+                                                            float* __restrict__ out2) {
+    __shared__ float red[G][64];
     const int l = threadIdx.x & 63, g = threadIdx.x >> 6;
     const size_t i = (size_t)blockIdx.x * 64 + l;
     float a = 0.f;
     if (i < count) {
 #pragma unroll 8
-        for (int s = g; s < splits; s += 4) a += part[(size_t)s * stride + i];
+        for (int s = g; s < splits; s += G) a += part[(size_t)s * stride + i];
     }
     red[g][l] = a;
     __syncthreads();
     if (g == 0 && i < count) {
-        const float v = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+        float v;
+        if (G == 4) {
+            v = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+        } else {
+            float q[G / 4];
+#pragma unroll
+            for (int k = 0; k < G / 4; ++k)
+                q[k] = (red[4 * k][l] + red[4 * k + 1][l]) + (red[4 * k + 2][l] + red[4 * k + 3][l]);
+            v = q[0];
+#pragma unroll
+            for (int k = 1; k < G / 4; ++k) v += q[k];
+        }
         if (i < n1) out1[i] = v;
         else out2[i - n1] = v;
     }
+}
+// Many slabs: sixteen interleaved groups of ascending s per output (1024 threads per 64 outputs)
+// -- 512 slabs are 32 loads per thread in four bursts instead of 128 in sixteen (the launch has
+// only count / 64 workgroups and is bound by that chain).  The association depends on the slab
+// count only (G = 4 below 64 slabs), never on the data.
+inline void launch_reduce_partials(hipStream_t s, const float* part, int splits, size_t stride, size_t count,
+                                   float* out1, size_t n1, float* out2) {
+    const dim3 grid((unsigned)((count + 63) / 64));
+    if (splits >= 64)
+        hipLaunchKernelGGL((reduce_partials_g<16>), grid, dim3(1024), 0, s, part, splits, stride, count, out1, n1, out2);
+    else
+        hipLaunchKernelGGL((reduce_partials_g<4>), grid, dim3(256), 0, s, part, splits, stride, count, out1, n1, out2);
 }
 
 }  // namespace sert

@@ -276,29 +276,36 @@ __global__ __launch_bounds__(256) void finalize_loss(const float* __restrict__ l
                                                      unsigned* __restrict__ host_flag = nullptr,
                                                      unsigned seq = 0,
                                                      const float* __restrict__ extra_sq = nullptr) {
-    __shared__ double red[256];
-    double a = 0.0;
-    for (int i = threadIdx.x; i < n_loss; i += 256) a += (double)loss_partials[i];
-    red[threadIdx.x] = a;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-        __syncthreads();
+    // eight partials per thread and trip in flight (the loop used to be one dependent load per
+    // partial: 16 + 9 round trips in series at C2), both sums reduced together: lanes by shuffle,
+    // the four waves through LDS -- one barrier instead of eighteen.  Fixed order throughout.
+    __shared__ double red[2][4];
+    auto strided_sum = [](const float* __restrict__ x, int n) {
+        double acc = 0.0;
+        for (int i0 = threadIdx.x; i0 < n; i0 += 8 * 256) {
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = (i0 + q * 256 < n) ? x[i0 + q * 256] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc += (double)v[q];
+        }
+        return acc;
+    };
+    double a = strided_sum(loss_partials, n_loss);
+    double b = strided_sum(sq_partials, n_sq);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        a += __shfl_xor(a, off);
+        b += __shfl_xor(b, off);
     }
-    const double loss_sum = red[0];
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
     __syncthreads();
-    double b = 0.0;
-    for (int i = threadIdx.x; i < n_sq; i += 256) b += (double)sq_partials[i];
-    red[threadIdx.x] = b;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-        __syncthreads();
-    }
+    const double loss_sum = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    const double sq_sum = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
     if (threadIdx.x == 0) {
         const float data = (float)loss_sum * inv_batch;
         // (data parallel: + the all-reduced sum of squares of the ZeRO-sharded tensors)
-        const float reg = reg_scale * (float)(red[0] + (extra_sq ? (double)extra_sq[0] : 0.0));
+        const float reg = reg_scale * (float)(sq_sum + (extra_sq ? (double)extra_sq[0] : 0.0));
         out[0] = data + reg;
         out[1] = data;
         out[2] = reg;

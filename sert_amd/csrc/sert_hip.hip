@@ -321,7 +321,7 @@ static int gemm_long_k(sert_model* m, hipStream_t s, const float* A, const float
         SERT_TRY(dmalloc(&m->skbuf, m->skbuf_count));
     }
     launch_gemm<TA, TB, EPI_STORE>(s, A, Bm, m->skbuf, nullptr, M, N, K, lda, ldb, N, splits, kper, mn);
-    hipLaunchKernelGGL(reduce_partials, dim3(cdiv(mn, 64)), dim3(256), 0, s, m->skbuf, splits, mn, mn, C, mn, C);
+    launch_reduce_partials(s, m->skbuf, splits, mn, mn, C, mn, C);
     return 0;
 }
 
@@ -759,7 +759,7 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         }
         {
             ScopedTimer t(m, TG_SPLITK);
-            hipLaunchKernelGGL(reduce_partials, dim3(cdiv(stride, 64)), dim3(256), 0, sd, m->part,
+            launch_reduce_partials(sd, m->part,
                                splits, stride, stride, m->g_w, mn, m->g_b);
         }
         // the loss partials only depend on the NCE kernel too
@@ -855,7 +855,7 @@ static int fs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         const size_t mn = (size_t)V * de;
         launch_gemm<true, false, EPI_STORE>(m->stream, m->Z, m->DH2, m->part, nullptr, V, de, B, V, de, de,
                                             splits, kper, mn);
-        hipLaunchKernelGGL(reduce_partials, dim3(cdiv(mn, 64)), dim3(256), 0, m->stream, m->part, splits, mn,
+        launch_reduce_partials(m->stream, m->part, splits, mn,
                            mn, m->g_re, mn, m->g_re);
     }
     {
@@ -879,7 +879,7 @@ static int fs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         }
         {
             ScopedTimer t(m, TG_SPLITK);
-            hipLaunchKernelGGL(reduce_partials, dim3(cdiv(stride, 64)), dim3(256), 0, m->stream, m->part, splits,
+            launch_reduce_partials(m->stream, m->part, splits,
                                stride, stride, m->g_w, mn, m->g_b);
         }
         launch_gemm<false, true, EPI_STORE>(m->stream, m->DA, m->W, m->DH, nullptr, B, dw, de, de, de, dw);
@@ -1061,7 +1061,7 @@ static int ll_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         }
         {
             ScopedTimer t(m, TG_SPLITK);
-            hipLaunchKernelGGL(reduce_partials, dim3(cdiv(stride, 64)), dim3(256), 0, m->stream, m->part,
+            launch_reduce_partials(m->stream, m->part,
                                splits, stride, stride, m->g_w, mn, m->g_b);
         }
         {

@@ -1,13 +1,13 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 NOX="--no-cpu-baseline --no-query-extra --no-loglinear-extra --no-c4-extra --no-live-pmc"
-for v in 1 0 1 0; do export SERT_FORK_LATE=$v;
+for v in 1 0 1 0; do export SERT_SEG_UNITS=$v;
   python bench.py --steps 200 --warmup 20 $NOX 2>/dev/null | python -c "
 import sys,json
 d=json.loads(sys.stdin.read())
-print('fork_late=$v ms/step %.4f' % d['ms_per_step'])"
+print('seg_units=$v ms/step %.4f' % d['ms_per_step'])"
 done
-unset SERT_FORK_LATE
+unset SERT_SEG_UNITS
 OUT=$GRAFT_REPO_ROOT/gpurun_out/tl21
 mkdir -p $OUT
 cd /tmp

@@ -99,14 +99,34 @@ def group_work(kind, B, n, s, dw, de, Ve, Vw, z, distinct_words=None):
     }
 
 
-# timing group -> HIP kernel that dominates it (for matching rocprofv3 rows)
-KERNEL_OF_GROUP = {
-    'gather': 'vs_gather_mean', 'gemm_fwd': 'gemm_f32_mfma<false, false, 2', 'loss': 'vs_nce',
-    'entity_grad_reduce': 'egrad_chunk_reduce', 'entity_grad_fixup': 'egrad_fixup',
-    'gemm_dW': 'gemm_f32_mfma<true, false, 0', 'splitk_combine': 'reduce_partials',
-    'gemm_dX': 'gemm_f32_mfma<false, true, 0', 'word_grad_segsum': 'segsum_rows',
-    'optimizer_word_table': 'adam_l2', 'optimizer_other': 'optimizer_small', 'entity_sort': 'csort_scatter',
+# timing group -> HIP kernel(s) that dominate it, per model kind (names as rocprofv3 prints them;
+# the first is the one a given configuration normally runs: e.g. the entity gradient is
+# egrad_acc up to 2048 entities and egrad_chunk_reduce above)
+_COMMON_KERNELS = {
+    'gemm_dW': ('gemm_f32_mfma<true, false, 0',), 'splitk_combine': ('reduce_partials',),
+    'gemm_dX': ('gemm_f32_mfma<false, true, 0',), 'word_grad_segsum': ('segsum_rows<',),
+    'optimizer_other': ('optimizer_small',), 'finalize': ('finalize_loss',),
 }
+KERNELS_OF_GROUP = {
+    'vectorspace': dict(_COMMON_KERNELS, **{
+        'gather': ('vs_gather_mean',), 'gemm_fwd': ('gemm_f32_mfma<false, false, 2',),
+        'loss': ('vs_nce_regs', 'vs_nce'), 'entity_sort': ('egrad_bucket', 'csort_scatter'),
+        'entity_grad_reduce': ('egrad_acc', 'egrad_chunk_reduce'),
+        'entity_grad_fixup': ('egrad_group_sum', 'egrad_fixup'), 'optimizer_word_table': ('adam_l2',)}),
+    'vectorspace_softmax': dict(_COMMON_KERNELS, **{
+        'gather': ('vs_gather_mean',), 'gemm_fwd': ('gemm_f32_mfma<false, false, 0', 'gemm_f32_mfma<false, false, 2'),
+        'loss': ('fs_softmax_ce',), 'entity_grad_reduce': ('gemm_f32_mfma<true, false, 0',),
+        'optimizer_word_table': ('adam_l2',)}),
+    'loglinear': dict(_COMMON_KERNELS, **{
+        'gather': ('ll_gather_rows',), 'gemm_fwd': ('gemm_f32_mfma<false, false, 1',),
+        'loss': ('ll_row_from_table', 'll_fused_row', 'll_s_'),
+        'per_word_dz_sums': ('segsum_rows<64, true, true', 'segsum_rows_scalar<true'),
+        'optimizer_word_table': ('adadelta_l2',)}),
+}
+
+
+def kernels_of_group(kind, group):
+    return KERNELS_OF_GROUP.get(kind, {}).get(group, ())
 
 
 def build_model(kind, models, B_global, n, Vw, Ve, dw, de, z, X, y, w, seed):
@@ -190,7 +210,7 @@ def kernel_table(timings, work):
     return kernels
 
 
-def roofline_of(kernels, traffic_by_group=None, traffic_source=None):
+def roofline_of(kernels, traffic_by_group=None, traffic_source=None, kind='vectorspace'):
     """The LONGEST kernel group (whatever it is).  frac = achieved / peak with achieved =
     algorithmic work / measured time (the contract's definition); frac_counter = the same with
     the PMC-counted bytes (what the memory system really moved)."""
@@ -198,13 +218,16 @@ def roofline_of(kernels, traffic_by_group=None, traffic_source=None):
     dom = max(cand, key=lambda k: kernels[k]['us'])
     kd = kernels[dom]
     mem = kd['bound'] != 'mfma'
-    out = dict(kernel=dom, hip_kernel=KERNEL_OF_GROUP.get(dom), bound='hbm' if mem else 'mfma',
+    names = kernels_of_group(kind, dom)
+    out = dict(kernel=dom, hip_kernel=names[0] if names else None, bound='hbm' if mem else 'mfma',
                achieved=kd['achieved'], peak=HBM_PEAK_GBS if mem else MFMA_F32_PEAK_TFLOPS,
                unit=kd['unit'], frac=kd['frac'], avg_us=kd['us'], traffic=None)
     if kd['bound'] == 'cache':
         out['served_from'] = 'Infinity Cache / L2 (the algorithmic byte rate exceeds the HBM peak)'
     tr = (traffic_by_group or {}).get(dom)
     if tr:
+        if tr.get('hip_kernel'):
+            out['hip_kernel'] = tr['hip_kernel']
         out['traffic'] = tr['hbm_bytes']
         out['traffic_source'] = traffic_source
         out['avg_us_profiled'] = tr['avg_us_profiled']
@@ -257,20 +280,23 @@ def pmc_traffic_live(args, timeout=240):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def traffic_by_group(per_kernel, kernels):
+def traffic_by_group(per_kernel, kernels, kind='vectorspace'):
     """Match the profiled kernels ('name @grid') to the timing groups: the launch of the group's
     dominant kernel whose profiled duration is closest to the live HIP-event average."""
     out = {}
     for group, kd in kernels.items():
-        prefix = KERNEL_OF_GROUP.get(group)
-        if not prefix or not per_kernel:
+        prefixes = kernels_of_group(kind, group)
+        if not prefixes or not per_kernel:
             continue
         best = None
-        for key, rec in per_kernel.items():
-            if key.startswith(prefix):
-                d = abs(rec.get('avg_us_profiled', 0.0) - kd['us'])
-                if best is None or d < best[0]:
-                    best = (d, rec)
+        for prefix in prefixes:
+            for key, rec in per_kernel.items():
+                if key.startswith(prefix):
+                    d = abs(rec.get('avg_us_profiled', 0.0) - kd['us'])
+                    if best is None or d < best[0]:
+                        best = (d, dict(rec, hip_kernel=key.split(' @')[0]))
+            if best:
+                break   # the configuration's own kernel was profiled: do not fall through to the alternative
         if best:
             out[group] = best[1]
     return out
@@ -583,7 +609,7 @@ def main():
         tbg = traffic_by_group(per_kernel, kernels) if (kind == 'vectorspace' and Bl == 65536) else {}
         for g, rec in tbg.items():
             kernels[g]['hbm_bytes_pmc'] = rec['hbm_bytes']
-        roofline = roofline_of(kernels, tbg, traffic_source)
+        roofline = roofline_of(kernels, tbg, traffic_source, kind=kind)
         if per_kernel is None or not tbg:
             roofline['traffic_note'] = traffic_source
         step_bytes = sum(v for k, (b, v) in work.items() if b == 'hbm' and k in kernels)
@@ -638,7 +664,7 @@ def main():
         out['loglinear'] = {
             'workload': 'LanguageModel (full softmax over V_e, Adadelta) V_w=%d V_e=%d d=%d window=%d batch=%d' % (Vw, Ve, d, n, Bll),
             'value': st * Bll / dt2, 'unit': 'pairs/s', 'ms_per_step': 1000 * dt2 / st,
-            'kernels': k2, 'roofline': roofline_of(k2),
+            'kernels': k2, 'roofline': roofline_of(k2, kind='loglinear'),
             'distinct_words_per_batch': U,
             'mfma_tflops_executed': fl_exec / (dt2 / st) / 1e12,
             'note': 'the three GEMMs run on the %.0f distinct words of a batch of %d tokens (duplicate tokens share '
@@ -659,7 +685,7 @@ def main():
                         'tanh projection + full softmax over V_e=%d, Adam; V_w=%d d=%d window=%d batch=%d' % (
                             Ve, Vw, d, n, Bl),
             'value': st * Bl / dt3, 'unit': 'pairs/s', 'ms_per_step': 1000 * dt3 / st,
-            'kernels': k3, 'roofline': roofline_of(k3),
+            'kernels': k3, 'roofline': roofline_of(k3, kind='vectorspace_softmax'),
             'mfma_tflops_whole_step': fl3 / (dt3 / st) / 1e12,
         }
         del m3

@@ -191,6 +191,12 @@ struct SmallTensors {
     unsigned long long count[3];
     int first_block[4];     // block range of tensor i = [first_block[i], first_block[i+1])
     float l2k[3];           // lambda/B, or 0 for a tensor without L2
+    // gradient still in `ngroups` partial tables `gstride` elements apart (the entity table behind
+    // egrad_acc): added here in group order -- the sum egrad_group_sum would have made in a launch
+    // of its own -- and stored to g as well
+    const float* gparts[3];
+    int ngroups[3];
+    unsigned long long gstride[3];
 };
 
 template <bool ADAM, bool STORE_G>
@@ -208,8 +214,19 @@ __global__ __launch_bounds__(256) void optimizer_small(SmallTensors t, AdamArgs 
     da.l2k = t.l2k[i];
     const float omb1 = 1.0f - aa.b1, omb2 = 1.0f - aa.b2, omr = 1.0f - da.rho;
     float ss = 0.f;
+    const float* parts = t.gparts[i];
+    const int ngroups = t.ngroups[i];
+    const size_t gstride = (size_t)t.gstride[i];
     for (size_t k = (size_t)b * 256 + threadIdx.x; k < count; k += (size_t)nb * 256) {
-        float pp = p[k], gg = g[k], a0 = s0[k], a1 = s1[k];
+        float pp = p[k], a0 = s0[k], a1 = s1[k];
+        float gg;
+        if (parts) {
+            gg = parts[k];
+            for (int q = 1; q < ngroups; ++q) gg += parts[(size_t)q * gstride + k];
+            if (!STORE_G) g[k] = gg;
+        } else {
+            gg = g[k];
+        }
         if (ADAM) adam_elem(pp, gg, a0, a1, aa, omb1, omb2, ss);
         else adadelta_elem(pp, gg, a0, a1, da, omr, ss);
         p[k] = pp; s0[k] = a0; s1[k] = a1;

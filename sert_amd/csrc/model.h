@@ -74,6 +74,7 @@ struct sert_model {
     hipEvent_t ev_loss = nullptr;    // the step's loss has been copied out
     hipEvent_t ev_dense = nullptr;   // dW, db and the loss partials are complete (main stream)
     bool step_done_pending = false;  // the previous step ended without recording ev_step_done
+    bool re_in_parts = false;        // this step: dR_e is still the row groups' partial tables (summed by the optimiser)
     bool fork_bound = false;         // ev_fork rides on the NCE kernel's completion signal (no record needed)
     bool lazy_join = false;          // this step: the main stream never waits for the entity chain
     int n_loss_partials = 0;

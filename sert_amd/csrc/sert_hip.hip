@@ -617,6 +617,7 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         }
         const int total = B * (c.num_negatives + 1);
         const int V = c.num_entities;
+        m->re_in_parts = false;
         static const bool ko_egrad = getenv("SERT_KO_EGRAD") != nullptr;   // timing knock-out (wrong results)
         if (ko_egrad) {
         } else if (m->epart) {
@@ -637,7 +638,12 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
                 hipLaunchKernelGGL((egrad_acc<2>), dim3(grid), dim3(256), lds, st, SERT_EL_ARGS);
 #undef SERT_EL_ARGS
             }
-            {
+            // Single GPU: the only reader of dR_e is the small-tensor optimiser, which adds the row
+            // groups' tables itself (same order) -- no launch for the sum.  Data parallel: the
+            // all-reduce needs the summed table.
+            static const bool no_fold = getenv("SERT_EGRAD_GROUP_SUM") != nullptr;
+            m->re_in_parts = !is_dp(m) && !m->pt_big[1] && !no_fold;
+            if (!m->re_in_parts) {
                 ScopedTimer t(m, TG_EFIX, st);
                 const size_t table4 = (size_t)V * de4;
                 hipLaunchKernelGGL(egrad_group_sum, dim3(grid_for((int64_t)table4)), dim3(256), 0, st, m->epart, m->eg_groups,
@@ -1255,12 +1261,16 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
             const ParamTensor t2 = param_tensor(m, i);
             if (m->pt_big[i] || t2.n == 0 || !((mask >> i) & 1u)) continue;
             st.p[k] = t2.p; st.g[k] = t2.g; st.s0[k] = t2.s0; st.s1[k] = t2.s1; st.count[k] = t2.n;
+            const bool parts = (i == 1) && m->re_in_parts;
+            st.gparts[k] = parts ? m->epart : nullptr;
+            st.ngroups[k] = parts ? m->eg_groups : 0;
+            st.gstride[k] = parts ? (unsigned long long)m->n_re : 0ull;
             st.l2k[k] = t2.l2 ? l2k : 0.f;
             st.first_block[k] = blocks;
             blocks += (int)std::min<int64_t>(512, cdiv(t2.n, 256));
             ++k;
         }
-        for (int i = k; i < 3; ++i) { st.p[i] = st.g[i] = st.s0[i] = st.s1[i] = nullptr; st.count[i] = 0; st.l2k[i] = 0.f; }
+        for (int i = k; i < 3; ++i) { st.p[i] = st.g[i] = st.s0[i] = st.s1[i] = nullptr; st.count[i] = 0; st.l2k[i] = 0.f; st.gparts[i] = nullptr; st.ngroups[i] = 0; st.gstride[i] = 0; }
         for (int i = k; i <= 3; ++i) st.first_block[i] = blocks;
         float* sq = m->red_sq + n_sq;
         if (blocks > 0) {

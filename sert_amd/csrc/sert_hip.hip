@@ -1698,9 +1698,14 @@ static int create_resources(sert_model* m) {
                     m->eg_er_shift = 4;                                      // 16 entities per range (egrad_acc)
                     m->eg_ranges = cdiv(V, 16);                              // <= 128 = kElMaxRanges
                     m->eg_sub_rows = (int)std::min<size_t>(256, kElSubPairs / c1);
+                    // small batches: finer sub-groups and row groups, so that the accumulation still
+                    // launches ~16 row groups x ranges workgroups with all four waves at work
+                    // (batch 4096 was ONE row group: 63 workgroups, 31 us; now 16 x 63)
+                    while (m->eg_sub_rows > 32 && (size_t)B < (size_t)64 * m->eg_sub_rows) m->eg_sub_rows /= 2;
                     m->eg_num_sub = cdiv(B, m->eg_sub_rows);
                     // row groups whose slice of T (rows x d_e floats) stays in one XCD's L2: <= 2 MB
                     m->eg_subs_per_group = (int)std::max<size_t>(1, (((size_t)2 << 20) / (de * sizeof(float))) / m->eg_sub_rows);
+                    m->eg_subs_per_group = std::max(1, std::min(m->eg_subs_per_group, m->eg_num_sub / 16));
                     m->eg_groups = cdiv(m->eg_num_sub, m->eg_subs_per_group);
                 }
                 if (m->eg_groups > 0) {

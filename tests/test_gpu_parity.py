@@ -706,3 +706,47 @@ def test_eval_batches_equals_eval_batch_loop(hip_lib, kind):
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
     assert out[0][2] == out[1][2]
     assert np.all(np.isfinite(out[0][0]))
+
+
+SCHEDULE_WORKER = r'''
+import sys, json, zlib
+sys.path.insert(0, %(root)r)
+import numpy as np
+from tests import util as U
+from sert_amd import _capi as C
+B, n, z, Vw, Ve, d = 8192, 10, 10, 20000, 1000, 128
+p = U.make_vs_problem(3, 2 * B, n, z, Vw, Ve, d, d, zipf=True)
+eng = U.vs_engine(p, B, n, z, 0.01, keep_grads=0, seed=11)
+eng.upload_dataset(C.SPLIT_TRAIN, p['X'], y_int=p['y'], w=p['w'])
+out = {'losses': [float(eng.train_batch(s %% 2)) for s in range(6)]}
+for name, which in (('Rw', C.T_RW), ('Re', C.T_RE), ('W', C.T_W), ('b', C.T_B),
+                    ('m_Re', C.T_STATE0_RE), ('v_W', C.T_STATE1_W)):
+    out['crc_' + name] = zlib.crc32(eng.get_tensor(which).tobytes())
+eng.close()
+print('RESULT ' + json.dumps(out))
+'''
+
+
+@pytest.mark.gpu
+def test_schedule_variants_do_not_change_a_bit(hip_lib):
+    """The stream schedule is only a schedule: one stream, the round-1 three-event schedule,
+    plain event records instead of kernel stop events, the entity group sum in a launch of its
+    own -- six steps (device-drawn negatives, pre-drawn on the side stream where there is one)
+    end in bit-identical parameters, optimiser state and losses, each in a fresh process (the
+    knobs are read once per process)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    code = SCHEDULE_WORKER % dict(root=U.ROOT)
+    variants = ({}, {'SERT_STREAMS': '1'}, {'SERT_FORK_LATE': '0'}, {'SERT_EXT_EVENTS': '0'},
+                {'SERT_EGRAD_GROUP_SUM': '1'})
+    outs = []
+    for extra in variants:
+        r = subprocess.run([sys.executable, '-c', code], check=True, env=dict(os.environ, **extra),
+                           cwd=U.ROOT, stdout=subprocess.PIPE, timeout=600)
+        line = [l for l in r.stdout.decode().splitlines() if l.startswith('RESULT ')][-1]
+        outs.append(json.loads(line[len('RESULT '):]))
+    for extra, o in zip(variants[1:], outs[1:]):
+        assert o == outs[0], 'schedule variant %r changed the results' % (extra,)
+    assert all(np.isfinite(outs[0]['losses']))

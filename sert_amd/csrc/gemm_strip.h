@@ -188,6 +188,253 @@ __global__ __launch_bounds__(512, 1) void gemm_strip_nn(const StripArgs g) {
 #undef SG_LSTORE
 }
 
+#ifdef SR_TIMELINE
+// (experiment builds only: per-wave shader-clock stamps of workgroup 0 -- tools/experiments)
+__device__ unsigned long long sr_dbg[8 * 16 * 2];
+#define SR_STAMP(slot_) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && it < 16) sr_dbg[((threadIdx.x >> 6) * 16 + it) * 2 + (slot_)] = clock64(); } while (0)
+#else
+#define SR_STAMP(slot_) do { } while (0)
+#endif
+// ---- role-specialised variant (SERT_STRIP_GEMM=2, opt-in) -------------------------------------
+// Measured at C2 (65536 x 128 x 128): dh 28.0 us (gemm.h 29.5), projection + tanh 33-35 us (32.0).
+// What the per-wave clock stamps of an experiment build (-DSR_TIMELINE, tools/experiments/
+// roles_timeline.py) and the knock-outs showed, and why this shape cannot do much better:
+//   * fp32 MFMA and VALU of the two waves of a SIMD do NOT overlap: with the MFMAs knocked out the
+//     kernel takes 15.7 us, with them 29.4 -- exactly the 13.7 us of MFMA issue on top, although the
+//     MFMAs sit in waves 0-3 and everything else in their SIMD partners 4-7.  A partner's ~300 VALU
+//     instructions per strip take ~5000 cycles beside a wave that issues MFMAs back to back
+//     (epilogue wave: 5450 cycles per iteration, alone: ~1000).  Every address computation, every
+//     tanh is paid on top of the MFMA time -- hence the hardware-reciprocal tanh (fwd 34.5 -> 32.0 us
+//     in gemm.h too) and the loop-constant offsets below.
+//   * under this load the shader clock reads ~1.95-2.0 GHz (57k cycles in 29 us), not 2.4: the
+//     64 MFMAs of a strip take 4096 cycles = 2.1 us, and the realistic fp32 MFMA ceiling of these
+//     kernels is ~131 TFLOP/s, i.e. 16.4 us for this GEMM, not 13.7.
+//   * a strip costs the compute wave ~4750 cycles (4096 MFMA + fragment-read latency + accumulator
+//     hand-off), an iteration ~5250 with the barrier, and a workgroup has only 8 strips (256 rows
+//     per CU) behind a two-iteration pipeline fill: 10 x 5250 cycles = 26 us + launch.
+//   * two independent accumulator chains per wave change nothing (dependent 32x32x2 MFMAs already
+//     issue back to back); reading all 16 A fragments up front needs __builtin_amdgcn_sched_barrier
+//     (hipcc sinks the reads back in front of their MFMAs otherwise) and changes nothing either.
+// The ping-pong kernel above still lets every wave do everything in turn.  Here the roles are
+// FIXED (MI355X_MICROARCH.md, "Two waves per SIMD"): waves 0-3 -- one per SIMD -- only read A
+// fragments from LDS, issue the 64 dependent MFMAs of a strip back to back and park the finished
+// accumulators in LDS; waves 4-7 -- their SIMD partners -- do everything that touches global
+// memory: the loads of strip k + 2 (issued two iterations = two strip-multiplies ahead, in two
+// alternating named register sets), the LDS store of strip k, and the epilogue (bias, tanh,
+// 16-byte coalesced stores) of strip k - 2 out of the LDS copy of its accumulators.  One barrier
+// per iteration; iteration `it`: memory waves stage strip `it` and finish strip `it - 2` while the
+// compute waves multiply strip `it - 1`.
+template <bool TB, int EPI, int K8>
+__global__ __launch_bounds__(512, 1) void gemm_roles_nn(const StripArgs g) {
+    __shared__ __attribute__((aligned(16))) float As[2][SG_ROWS][SG_LD];
+    __shared__ __attribute__((aligned(16))) float Cs[2][SG_ROWS][SG_LD];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool compute = wv < 4;
+    const int li = lane & 31, lh = lane >> 5;
+    constexpr int K = 8 * K8;
+    constexpr int kq = K >> 2;                   // float4 per A row
+    const int strips = (g.M + SG_ROWS - 1) / SG_ROWS;
+    const int G = gridDim.x;
+    const int cnt = (int)blockIdx.x < strips ? (strips - 1 - (int)blockIdx.x) / G + 1 : 0;
+    if (compute) {
+        const int n0 = wv * 32;
+        const bool wave_on = n0 < g.N;
+        // B fragments, resident: breg[4j + i] = B[k = 8j + 4 lh + i][n0 + li]
+        float breg[4 * K8];
+#pragma unroll
+        for (int j = 0; j < K8; ++j) {
+            if (wave_on) {
+                if (TB) {
+                    const float4 b4 = *reinterpret_cast<const float4*>(g.B + (size_t)(n0 + li) * g.ldb + 8 * j + 4 * lh);
+                    breg[4 * j + 0] = b4.x; breg[4 * j + 1] = b4.y; breg[4 * j + 2] = b4.z; breg[4 * j + 3] = b4.w;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) breg[4 * j + i] = g.B[(size_t)(8 * j + 4 * lh + i) * g.ldb + n0 + li];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) breg[4 * j + i] = 0.f;
+            }
+        }
+        for (int it = 0; it <= cnt + 1; ++it) {
+            SR_STAMP(0);
+            if (it >= 1 && it <= cnt && wave_on) {
+                const int buf = (it - 1) & 1;
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#ifdef SR_TWO_CHAINS
+                f32x16 acc2;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+#endif
+                // every A fragment of the strip is requested up front (16 ds_read_b128, 64 VGPRs): the
+                // MFMAs then only wait on the in-order LDS counter, not on a read issued just before
+                float4 af[K8];
+#pragma unroll
+                for (int j = 0; j < K8; ++j) af[j] = *reinterpret_cast<const float4*>(&As[buf][li][8 * j + 4 * lh]);
+                __builtin_amdgcn_sched_barrier(0);   // (hipcc otherwise sinks every read back in front of its MFMAs)
+#pragma unroll
+                for (int j = 0; j < K8; ++j) {
+#ifdef SR_KO_MFMA
+                    acc[j] += af[j].x * breg[4 * j] + af[j].y + af[j].z + af[j].w;
+#elif defined(SR_TWO_CHAINS)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].x, breg[4 * j + 0], acc, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].y, breg[4 * j + 1], acc2, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].z, breg[4 * j + 2], acc, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].w, breg[4 * j + 3], acc2, 0, 0, 0);
+#else
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].x, breg[4 * j + 0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].y, breg[4 * j + 1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].z, breg[4 * j + 2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j].w, breg[4 * j + 3], acc, 0, 0, 0);
+#endif
+                }
+#ifdef SR_TWO_CHAINS
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
+#endif
+                // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Cs[buf][(r & 3) + 8 * (r >> 2) + 4 * lh][n0 + li] = acc[r];
+            }
+            SR_STAMP(1);
+            __syncthreads();
+        }
+    } else if (wv < 6) {
+        // ---- loader waves (4, 5): global -> registers (two iterations ahead) -> LDS.  They issue
+        // nothing but loads, so their vmcnt stream is in order and a wait for strip k leaves the
+        // loads of strip k + 1 in flight (with the epilogue's stores in the same wave the compiler
+        // drained the whole queue every iteration: 2.8 us per strip instead of 1.7).
+        const int t = threadIdx.x - 256;             // 0..127
+        constexpr int nf = SG_ROWS * kq;             // float4 of an A strip (<= 1024)
+        // Plain, compiler-tracked loads into two alternating NAMED register sets.  (Issuing them
+        // through inline asm with a hand-written s_waitcnt vmcnt(8) -- so that a wait for set X
+        // leaves the other set's loads in flight; hipcc's own waitcnt pass drains the whole queue at
+        // the loop header -- was tried: no faster, the loader is not the slowest role, and not safe:
+        // the compiler may copy an asm output register before the hand-written wait, which it did in
+        // the K = 96 instantiation.)
+        float4 sa0, sa1, sa2, sa3, sa4, sa5, sa6, sa7, sb0, sb1, sb2, sb3, sb4, sb5, sb6, sb7;
+        sa0 = sa1 = sa2 = sa3 = sa4 = sa5 = sa6 = sa7 = make_float4(0.f, 0.f, 0.f, 0.f);
+        sb0 = sb1 = sb2 = sb3 = sb4 = sb5 = sb6 = sb7 = make_float4(0.f, 0.f, 0.f, 0.f);
+        // Address arithmetic costs MFMA time (no co-issue): the lane's eight byte offsets inside a
+        // strip are loop constants, the strip base is a scalar; rows past the end of a ragged last
+        // strip repeat its last row.
+        unsigned voff[8];
+        int vrow[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int f = min(t + 128 * p, nf - 1);
+            vrow[p] = f / kq;
+            voff[p] = ((unsigned)vrow[p] * (unsigned)g.lda + 4u * (unsigned)(f - vrow[p] * kq)) * 4u;
+        }
+        auto ld2 = [&](const char* base, int p, int last) -> float4 {
+            const unsigned off = vrow[p] <= last ? voff[p] : voff[p] - (unsigned)(vrow[p] - last) * (unsigned)g.lda * 4u;
+            return *reinterpret_cast<const float4*>(base + off);
+        };
+        auto st1f = [&](int buf, int p, const float4& v) {
+            const int f = t + 128 * p;
+            if (f < nf) {
+                const int row = f / kq, c4 = f - row * kq;
+                *reinterpret_cast<float4*>(&As[buf][row][4 * c4]) = v;
+            }
+        };
+#define SR_GLOAD(k_, X)                                                                \
+    do {                                                                               \
+        const int m0_ = ((int)blockIdx.x + (k_) * G) * SG_ROWS;                        \
+        const char* base_ = reinterpret_cast<const char*>(g.A + (size_t)m0_ * g.lda);  \
+        const int last_ = g.M - 1 - m0_;                                               \
+        X##0 = ld2(base_, 0, last_); X##1 = ld2(base_, 1, last_);                      \
+        X##2 = ld2(base_, 2, last_); X##3 = ld2(base_, 3, last_);                      \
+        X##4 = ld2(base_, 4, last_); X##5 = ld2(base_, 5, last_);                      \
+        X##6 = ld2(base_, 6, last_); X##7 = ld2(base_, 7, last_);                      \
+    } while (0)
+#define SR_LSTORE(buf_, X)                                                             \
+    do {                                                                               \
+        st1f(buf_, 0, X##0); st1f(buf_, 1, X##1); st1f(buf_, 2, X##2); st1f(buf_, 3, X##3); \
+        st1f(buf_, 4, X##4); st1f(buf_, 5, X##5); st1f(buf_, 6, X##6); st1f(buf_, 7, X##7); \
+    } while (0)
+        if (cnt > 0) SR_GLOAD(0, sa);
+        if (cnt > 1) SR_GLOAD(1, sb);
+        for (int it = 0; it <= cnt + 1; it += 2) {
+            SR_STAMP(0);
+            if (it < cnt) SR_LSTORE(it & 1, sa);
+            if (it + 2 < cnt) SR_GLOAD(it + 2, sa);
+            SR_STAMP(1);
+            __syncthreads();
+            const int io = it + 1;
+            if (io <= cnt + 1) {
+                { const int it = io; SR_STAMP(0); }
+                if (io < cnt) SR_LSTORE(io & 1, sb);
+                if (io + 2 < cnt) SR_GLOAD(io + 2, sb);
+                { const int it = io; SR_STAMP(1); }
+                __syncthreads();
+            }
+        }
+#undef SR_GLOAD
+#undef SR_LSTORE
+    } else {
+        // ---- epilogue waves (6, 7): accumulators of strip it - 2 out of LDS, bias / tanh, 16-byte stores
+        const int t = threadIdx.x - 384;             // 0..127
+        const int nq = g.N >> 2, nfc = SG_ROWS * nq; // float4 of a C strip
+        // lane constants of the full-width case (N = 128): rows (t >> 5) + 4 p, 16-byte column t & 31
+        const bool wide = nq == 32;
+        const int row0 = t >> 5, cc4 = t & 31;
+        float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (wide && (EPI == EPI_BIAS || EPI == EPI_BIAS_TANH)) bias4 = *reinterpret_cast<const float4*>(g.bias + 4 * cc4);
+        const unsigned coff = ((unsigned)row0 * (unsigned)g.ldc + 4u * (unsigned)cc4) * 4u;
+        const unsigned cstep = 4u * (unsigned)g.ldc * 4u;
+        for (int it = 0; it <= cnt + 1; ++it) {
+            SR_STAMP(0);
+            if (it >= 2 && wide && ((int)blockIdx.x + (it - 2) * G) * SG_ROWS + SG_ROWS <= g.M) {
+                const int k = it - 2, buf = k & 1;
+                const int m0 = ((int)blockIdx.x + k * G) * SG_ROWS;
+                char* Cb = reinterpret_cast<char*>(g.C + (size_t)m0 * g.ldc);
+                const float* cs = &Cs[buf][row0][4 * cc4];
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    float4 v = *reinterpret_cast<const float4*>(cs + 4 * p * SG_LD);
+                    if (EPI == EPI_BIAS || EPI == EPI_BIAS_TANH) { v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w; }
+                    if (EPI == EPI_BIAS_TANH) {
+                        v.x = fast_tanh(v.x); v.y = fast_tanh(v.y); v.z = fast_tanh(v.z); v.w = fast_tanh(v.w);
+                    }
+#ifdef SR_KO_STORE
+                    if (v.x == 123.456f)
+#endif
+                    *reinterpret_cast<float4*>(Cb + (coff + (unsigned)p * cstep)) = v;
+                }
+            } else if (it >= 2) {
+                const int k = it - 2, buf = k & 1;
+                const int m0 = ((int)blockIdx.x + k * G) * SG_ROWS;
+                const int mrem = g.M - m0;
+                float* Cb = g.C + (size_t)m0 * g.ldc;
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    const int f = t + 128 * p;
+                    if (f < nfc) {
+                        const int row = f / nq, c4 = f - row * nq;
+                        float4 v = *reinterpret_cast<const float4*>(&Cs[buf][row][4 * c4]);
+                        if (EPI == EPI_BIAS || EPI == EPI_BIAS_TANH) {
+                            const float4 b4 = *reinterpret_cast<const float4*>(g.bias + 4 * c4);
+                            v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+                        }
+                        if (EPI == EPI_BIAS_TANH) {
+                            v.x = fast_tanh(v.x); v.y = fast_tanh(v.y); v.z = fast_tanh(v.z); v.w = fast_tanh(v.w);
+                        }
+#ifdef SR_KO_STORE
+                        if (row < mrem && v.x == 123.456f) *reinterpret_cast<float4*>(Cb + (size_t)row * g.ldc + 4 * c4) = v;
+#else
+                        if (row < mrem) *reinterpret_cast<float4*>(Cb + (size_t)row * g.ldc + 4 * c4) = v;
+#endif
+                    }
+                }
+            }
+            SR_STAMP(1);
+            __syncthreads();
+        }
+    }
+}
+
 // dW partials: P[wg] (Kd, N) = sum over the workgroup's strips of X^T (Kd, rows) . Y (rows, N),
 // followed by the column sums of Y (N) -- X = h (M, Kd), Y = da (M, N); Kd, N <= 128, multiples
 // of 32.  Slab wg of `part` has stride `pstride` >= Kd*N + N floats; the caller adds the slabs in
@@ -299,8 +546,21 @@ inline void launch_gemm_strip(hipStream_t s, const float* A, const float* B, flo
     const int strips = (M + SG_ROWS - 1) / SG_ROWS;
     static const int per_cu = getenv("SERT_STRIP_WGS") ? atoi(getenv("SERT_STRIP_WGS")) : 1;   // tuning knob
     const int grid = std::min((strips + 1) / 2, 256 * std::max(1, per_cu));
+    const char* mode = getenv("SERT_STRIP_GEMM");
+    if (mode && atoi(mode) == 2 && N % 4 == 0 && ldc % 4 == 0 && ((uintptr_t)C) % 16 == 0 &&
+        (!bias || ((uintptr_t)bias) % 16 == 0)) {
+        // role-specialised variant: one persistent workgroup per CU
+        const int grid2 = std::min(strips, 256 * std::max(1, per_cu));
+        switch (K / 8) {
+#define SG_CASE(K8) case K8: SERT_LAUNCH((gemm_roles_nn<TB, EPI, K8>), dim3(grid2), dim3(512), 0, s, g); break;
+            SG_CASE(4) SG_CASE(8) SG_CASE(12) SG_CASE(16)
+#undef SG_CASE
+            default: break;
+        }
+        return;
+    }
     switch (K / 8) {
-#define SG_CASE(K8) case K8: hipLaunchKernelGGL((gemm_strip_nn<TB, EPI, K8>), dim3(grid), dim3(512), 0, s, g); break;
+#define SG_CASE(K8) case K8: SERT_LAUNCH((gemm_strip_nn<TB, EPI, K8>), dim3(grid), dim3(512), 0, s, g); break;
         SG_CASE(4) SG_CASE(8) SG_CASE(12) SG_CASE(16)
 #undef SG_CASE
         default: break;   // (gemm_strip_ok admits K in {32, 64, 96, 128} only)

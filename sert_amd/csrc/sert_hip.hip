@@ -2787,3 +2787,10 @@ int sert_bench_gemm(int device, int ta, int tb, int epi, int M, int N, int K, in
 }
 
 }  // extern "C"
+
+#ifdef SR_TIMELINE
+extern "C" int sert_debug_read(void* out, size_t bytes) {
+    (void)hipDeviceSynchronize();
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(sert::sr_dbg), bytes, 0, hipMemcpyDeviceToHost);
+}
+#endif

@@ -32,17 +32,18 @@ LOSS_TOL, ACT_TOL, GRAD_TOL, PARAM_TOL = 1e-5, 2e-5, 1e-4, 1e-4
     dict(B=1100, n=3, z=4, Vw=2000, Ve=50, dw=128, de=128),     # strip GEMMs (gemm_strip.h), ragged last strip
     dict(B=1030, n=2, z=3, Vw=500, Ve=40, dw=96, de=64),        # strip GEMMs with idle waves (N = 64 / 96), K = 96 / 64
 ])
-@pytest.mark.parametrize('egrad', ['default', 'sorted', 'strip_gemm'])
+@pytest.mark.parametrize('egrad', ['default', 'sorted', 'strip_gemm', 'roles_gemm'])
 def test_vectorspace_steps(hip_lib, dims, egrad, monkeypatch):
     # entity gradient: V_e <= 2048 takes the sort-free bucket + register-accumulator path by default;
     # 'sorted' forces the counting-sort + chunked-reduce path every vocabulary size can take;
     # 'strip_gemm' switches the opt-in strip-streaming projection GEMMs on (gemm_strip.h)
     if egrad == 'sorted':
         monkeypatch.setenv('SERT_EGRAD_SORT', '1')
-    if egrad == 'strip_gemm':
+    if egrad in ('strip_gemm', 'roles_gemm'):
         if dims['B'] < 1024:
             pytest.skip('strip GEMMs take M >= 1024 only')
-        monkeypatch.setenv('SERT_STRIP_GEMM', '1')
+        # 1: ping-pong strips; 2: role-specialised waves (compute / loader / epilogue)
+        monkeypatch.setenv('SERT_STRIP_GEMM', '1' if egrad == 'strip_gemm' else '2')
     B, n, z = dims['B'], dims['n'], dims['z']
     steps = 3
     p = U.make_vs_problem(0, B * steps, n, z, dims['Vw'], dims['Ve'], dims['dw'], dims['de'],

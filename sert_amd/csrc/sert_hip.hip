@@ -556,6 +556,8 @@ static int vs_loss(sert_model* m, const DataSplit& ds, int64_t batch_index) {
                        de, inv_batch, TRAIN ? m->red_loss : (float*)nullptr)
             static const bool no_regs = getenv("SERT_NCE_PER_CANDIDATE") != nullptr;
             const int nc = c.num_negatives + 1;
+            // (d_e = 300, five float4 per lane and candidate: 256 VGPRs + AGPR spills, one wave per SIMD --
+            //  191 us against 169 us for the per-candidate kernel at C4: the limit stays at four)
             if (!no_regs && nch <= 4 && nc <= 12) {
                 // every candidate row of a row in registers (kernels_vs.h: vs_nce_regs)
                 const int key = nch * 2 + (nc > 6 ? 1 : 0);

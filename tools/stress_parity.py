@@ -15,7 +15,7 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 30):
     if dims['B'] * dims['n'] * dims['dw'] > 3e6 or dims['Ve'] * dims['de'] > 6e6:
         continue
     try:
-        T.test_vectorspace_steps(None, dims)
+        T.test_vectorspace_steps(None, dims, 'default', None)
         print('ok  vs', dims, flush=True)
     except Exception as e:
         fails += 1

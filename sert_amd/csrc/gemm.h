@@ -59,8 +59,8 @@ __device__ __forceinline__ float fast_tanh(float x) {
     const float x2 = x * x;
     const float poly = x * (1.0f + x2 * (-0.33333334f + x2 * (0.13333334f + x2 * (-0.05396825f + x2 * 0.02186949f))));
     // exp(2|x|) = exp2(2 log2(e) |x|); 2 / (e + 1) through the hardware reciprocal (1 ulp) instead of
-    // the ~10-instruction IEEE division: fp32 MFMA and VALU do not co-issue on a SIMD (measured:
-    // gemm_strip.h), so every epilogue instruction is paid on top of the MFMA time
+    // the ~10-instruction IEEE division: the epilogue's VALU work is not hidden behind the MFMAs of
+    // these short-K GEMMs (gemm_strip.h), 64 tanh per lane and tile: 34.5 -> 32.0 us at C2
     const float e = __builtin_amdgcn_exp2f(2.8853900817779268f * fminf(ax, 10.0f));
     const float big = copysignf(1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f), x);
     return ax < 0.25f ? poly : big;

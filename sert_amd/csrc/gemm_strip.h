@@ -198,20 +198,26 @@ __device__ unsigned long long sr_dbg[8 * 16 * 2];
 // ---- role-specialised variant (SERT_STRIP_GEMM=2, opt-in) -------------------------------------
 // Measured at C2 (65536 x 128 x 128): dh 28.0 us (gemm.h 29.5), projection + tanh 33-35 us (32.0).
 // What the per-wave clock stamps of an experiment build (-DSR_TIMELINE, tools/experiments/
-// roles_timeline.py) and the knock-outs showed, and why this shape cannot do much better:
-//   * fp32 MFMA and VALU of the two waves of a SIMD do NOT overlap: with the MFMAs knocked out the
-//     kernel takes 15.7 us, with them 29.4 -- exactly the 13.7 us of MFMA issue on top, although the
-//     MFMAs sit in waves 0-3 and everything else in their SIMD partners 4-7.  A partner's ~300 VALU
-//     instructions per strip take ~5000 cycles beside a wave that issues MFMAs back to back
-//     (epilogue wave: 5450 cycles per iteration, alone: ~1000).  Every address computation, every
-//     tanh is paid on top of the MFMA time -- hence the hardware-reciprocal tanh (fwd 34.5 -> 32.0 us
-//     in gemm.h too) and the loop-constant offsets below.
-//   * under this load the shader clock reads ~1.95-2.0 GHz (57k cycles in 29 us), not 2.4: the
-//     64 MFMAs of a strip take 4096 cycles = 2.1 us, and the realistic fp32 MFMA ceiling of these
-//     kernels is ~131 TFLOP/s, i.e. 16.4 us for this GEMM, not 13.7.
-//   * a strip costs the compute wave ~4750 cycles (4096 MFMA + fragment-read latency + accumulator
-//     hand-off), an iteration ~5250 with the barrier, and a workgroup has only 8 strips (256 rows
-//     per CU) behind a two-iteration pipeline fill: 10 x 5250 cycles = 26 us + launch.
+// roles_timeline.py), the knock-outs and a micro-benchmark (tools/experiments/src/mfma_peak.hip)
+// showed about why this shape does not do much better:
+//   * the matrix pipe itself is fine: back-to-back 32x32x2 f32 MFMAs sustain 150-155 TFLOP/s with
+//     one or two issuing waves per SIMD, and a partner wave's dependent v_fma chain hides behind
+//     them completely (micro-benchmark);
+//   * in this kernel a strip costs the compute wave ~4750 ticks of the shader clock counter for its
+//     64 MFMAs (4096 if back to back: fragment-read latency in front, accumulator hand-off behind),
+//     an iteration 5250-5750 with the barrier, and a workgroup has only 8 strips (256 rows per CU)
+//     behind a two-iteration pipeline fill: 0.86 x 0.85 x 0.8 = ~0.6 of the MFMA rate, 26 us + launch;
+//   * knock-outs (dh): full 29.4 us | no MFMAs 15.7 | no global loads 28.8 | no stores 27.7 | none
+//     of the three 11.6 -- the MFMA issue time (13.7 us) comes off in full although it sits in other
+//     waves than everything else: the remaining per-iteration chain (barrier -> LDS hand-offs ->
+//     barrier) is as long as a strip's MFMAs and runs through the same barriers.  The epilogue
+//     wave's ~300 VALU instructions take ~5000 ticks per strip beside its MFMA-issuing partner
+//     (~1000 on their own): a busy partner is not free (MI355X_MICROARCH.md, items 2 and 7), so
+//     the epilogue is kept lean (hardware-reciprocal tanh: projection 34.5 -> 32.0 us in gemm.h
+//     too; loop-constant offsets below);
+//   * the clock counter advances 57k ticks in the 29.3 us of the kernel (1.95 GHz) against
+//     ~2.37 GHz implied by the micro-benchmark's 155 TFLOP/s: under the GEMM's memory traffic the
+//     chip clocks lower than under pure MFMA issue;
 //   * two independent accumulator chains per wave change nothing (dependent 32x32x2 MFMAs already
 //     issue back to back); reading all 16 A fragments up front needs __builtin_amdgcn_sched_barrier
 //     (hipcc sinks the reads back in front of their MFMAs otherwise) and changes nothing either.
@@ -317,7 +323,7 @@ __global__ __launch_bounds__(512, 1) void gemm_roles_nn(const StripArgs g) {
         float4 sa0, sa1, sa2, sa3, sa4, sa5, sa6, sa7, sb0, sb1, sb2, sb3, sb4, sb5, sb6, sb7;
         sa0 = sa1 = sa2 = sa3 = sa4 = sa5 = sa6 = sa7 = make_float4(0.f, 0.f, 0.f, 0.f);
         sb0 = sb1 = sb2 = sb3 = sb4 = sb5 = sb6 = sb7 = make_float4(0.f, 0.f, 0.f, 0.f);
-        // Address arithmetic costs MFMA time (no co-issue): the lane's eight byte offsets inside a
+        // Address arithmetic is not free beside an MFMA-issuing partner wave: the lane's eight byte offsets inside a
         // strip are loop constants, the strip base is a scalar; rows past the end of a ragged last
         // strip repeat its last row.
         unsigned voff[8];

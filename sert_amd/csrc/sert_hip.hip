@@ -522,6 +522,15 @@ static bool fork_late_mode(const sert_model* m) {
            m->n_re <= ((size_t)1 << 22) && m->cfg.kind == SERT_KIND_VECTORSPACE;
 }
 
+// Late fork + a THIRD queue for the MFMA-bound dW GEMM, its combine and the W, b update: they only
+// need da and h, so they can run beside the cache-bound segmented sum instead of in front of it.
+// The queue waits on the same completion signal as the side stream (free for the main stream) and
+// is joined in front of the loss finalisation.  SERT_DW_THIRD=0 keeps them on the main stream.
+static bool dw_third_queue(const sert_model* m) {
+    static const bool on = getenv("SERT_DW_THIRD") && atoi(getenv("SERT_DW_THIRD")) != 0;
+    return on && fork_late_mode(m);
+}
+
 // NCE score / loss / gradient coefficients
 template <bool TRAIN>
 static int vs_loss(sert_model* m, const DataSplit& ds, int64_t batch_index) {
@@ -715,6 +724,7 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         // READING W (the dh GEMM): the side stream may update the small tensors.
         if (m->lazy_join && !dense_bound) SERT_HIP(hipEventRecord(fork_late ? m->ev_fork : m->ev_dense, m->stream));
         if (fork_late) SERT_HIP(hipStreamWaitEvent(m->stream2, m->ev_fork, 0));
+        if (fork_late && dw_third_queue(m)) SERT_HIP(hipStreamWaitEvent(m->stream3, m->ev_fork, 0));
         return 0;
     };
     auto word_table_sum = [&]() -> int {
@@ -738,7 +748,8 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         // (measured: 0.376 -> 0.386 ms at C2 -- off by default, SERT_DW_SIDE=1 to try it)
         static const bool dw_side = getenv("SERT_DW_SIDE") && atoi(getenv("SERT_DW_SIDE")) != 0;
         if (dw_side && m->lazy_join) sd = m->stream2;
-        if (sd != m->stream && sd != m->stream2) SERT_HIP(hipStreamWaitEvent(sd, m->ev_fork, 0));
+        if (fork_late && m->lazy_join && dw_third_queue(m)) sd = m->stream3;
+        if (sd != m->stream && sd != m->stream2 && !fork_late) SERT_HIP(hipStreamWaitEvent(sd, m->ev_fork, 0));
         // ~1024 workgroup items in all, at most 512 slabs (the optimum at one output tile: 512 slabs
         // of 128 rows) and at least 64 rows per slab.  With nine output tiles (d = 300) that is 114
         // slabs at batch >= 16384 and 64 at 4096 -- 512 / 256 slabs made the combine read up to 92 MB
@@ -772,7 +783,7 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         }
         // the loss partials only depend on the NCE kernel too
         SERT_TRY(reduce_rowloss(m, sd));
-        if (sd != m->stream && sd != m->stream2) SERT_HIP(hipEventRecord(m->ev_join3, sd));
+        if (sd != m->stream && sd != m->stream2 && !fork_late) SERT_HIP(hipEventRecord(m->ev_join3, sd));
         return 0;
     };
     // On a single GPU the only consumer of dR_e is the small-tensor optimiser, which runs on
@@ -1287,7 +1298,12 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
         }
         n_sq += blocks;
     };
-    if (split_small) {
+    if (split_small && dw_third_queue(m)) {
+        small_tensors(m->stream3, 0xCu);  // W, b: behind dW and its combine on the third queue
+        SERT_HIP(hipEventRecord(m->ev_join3, m->stream3));
+        SERT_HIP(hipStreamWaitEvent(m->stream, m->ev_join3, 0));
+        small_tensors(ss, 0x2u);          // R_e
+    } else if (split_small) {
         small_tensors(m->stream, 0xCu);   // W, b
         small_tensors(ss, 0x2u);          // R_e
     } else {

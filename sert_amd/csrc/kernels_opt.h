@@ -12,7 +12,10 @@
 
 namespace sert {
 
-constexpr int kOptBlocks = 2048;  // fixed grid => fixed reduction tree => deterministic
+#ifndef SERT_OPT_BLOCKS
+#define SERT_OPT_BLOCKS 2048   // (1024 / 4096 / 8192 measured within noise of 2048 at C2 and C4)
+#endif
+constexpr int kOptBlocks = SERT_OPT_BLOCKS;  // fixed grid => fixed reduction tree => deterministic
 
 struct AdamArgs {
     float l2k;   // lambda / B

@@ -77,3 +77,20 @@ def test_product_never_imports_the_oracle():
     code = ("import sys; sys.path.insert(0, %r); import sert_amd.models, sert_amd.inference, "
             "sert_amd.scoring; assert not any(m.startswith('oracle') for m in sys.modules)" % ROOT)
     subprocess.check_call([sys.executable, '-c', code])
+
+
+def test_reference_import_name_binds_the_engine_and_needs_no_torch():
+    """`from sert import inference, math_utils, models` (bin/query.py:6, bin/train.py:6 of the
+    reference) resolves to the HIP-backed modules, with the reference's class names in place, and
+    importing the product (distributed launcher included) pulls in neither PyTorch nor the oracle."""
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from sert import inference, math_utils, models\n"
+        "import sert.models, sert_amd.distributed, sert_amd.training, sert_amd.scoring\n"
+        "assert sert.models is models and models.__name__ == 'sert_amd.models'\n"
+        "for name in ('LanguageModel', 'VectorSpaceLanguageModel', 'ModelBase', 'ModelInterface'):\n"
+        "    assert hasattr(models, name), name\n"
+        "assert hasattr(inference, 'create') and hasattr(math_utils, 'entropy')\n"
+        "assert 'torch' not in sys.modules, 'the product imported PyTorch'\n"
+        "assert not any(m.startswith('oracle') for m in sys.modules)\n" % ROOT)
+    subprocess.check_call([sys.executable, '-c', code])

@@ -522,13 +522,22 @@ static bool fork_late_mode(const sert_model* m) {
            m->n_re <= ((size_t)1 << 22) && m->cfg.kind == SERT_KIND_VECTORSPACE;
 }
 
+// Where the one fork of fork_late_mode sits: behind the dh GEMM (default) or, SERT_FORK_AT=nce,
+// behind the NCE kernel -- W and b are updated on the main stream, so nothing on the side stream
+// has to wait for the last reader of W any more, and the entity chain then runs beside the
+// MFMA-bound dh / dW GEMMs instead of beside the cache-bound segmented sum.
+static bool fork_at_nce(const sert_model* m) {
+    static const bool on = getenv("SERT_FORK_AT") && !strcmp(getenv("SERT_FORK_AT"), "nce");
+    return on && fork_late_mode(m);
+}
+
 // Late fork + a THIRD queue for the MFMA-bound dW GEMM, its combine and the W, b update: they only
 // need da and h, so they can run beside the cache-bound segmented sum instead of in front of it.
 // The queue waits on the same completion signal as the side stream (free for the main stream) and
 // is joined in front of the loss finalisation.  SERT_DW_THIRD=0 keeps them on the main stream.
 static bool dw_third_queue(const sert_model* m) {
     static const bool on = getenv("SERT_DW_THIRD") && atoi(getenv("SERT_DW_THIRD")) != 0;
-    return on && fork_late_mode(m);
+    return on && fork_late_mode(m) && !fork_at_nce(m);   // (the W update must stay behind the dh GEMM)
 }
 
 // NCE score / loss / gradient coefficients
@@ -546,7 +555,7 @@ static int vs_loss(sert_model* m, const DataSplit& ds, int64_t batch_index) {
         // training with a side stream: the fork event of the backward pass is this kernel's own
         // completion signal (common.h: SERT_LAUNCH)
         m->fork_bound = false;
-        if (TRAIN && ext_events() && !fork_late_mode(m) && !m->timing.enabled && m->nstreams >= 2 && de % 4 == 0) {
+        if (TRAIN && ext_events() && (!fork_late_mode(m) || fork_at_nce(m)) && !m->timing.enabled && m->nstreams >= 2 && de % 4 == 0) {
             set_stop_event(m->ev_fork);
             m->fork_bound = true;
         }
@@ -616,12 +625,13 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
     const int B = c.batch_size, n = c.window_size, dw = c.word_dim, de = c.entity_dim;
     const size_t row0 = (size_t)batch_index * B;
     const bool fork_late = fork_late_mode(m);
+    const bool fork_nce = fork_late && fork_at_nce(m);
     auto entity_grad = [&]() -> int {
         // fork: this chain only depends on the NCE kernel and is independent of the
         // GEMMs / word-table reduction below, so it runs on the side stream
         // (timing mode measures every kernel alone: everything stays on the main stream)
         hipStream_t st = (m->timing.enabled || m->nstreams < 2) ? m->stream : m->stream2;
-        if (!fork_late) {
+        if (!fork_late || fork_nce) {
             if (!m->fork_bound) SERT_HIP(hipEventRecord(m->ev_fork, m->stream));
             m->fork_bound = false;
             if (st != m->stream) SERT_HIP(hipStreamWaitEvent(st, m->ev_fork, 0));
@@ -712,7 +722,7 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
             ScopedTimer t(m, TG_GEMM_DX);
             const bool strip = gemm_strip_ok(B, dw, de, de, de, true, m->DA, m->W);
             // (ev_dense below: the completion signal of this GEMM, not a barrier packet behind it)
-            dense_bound = m->lazy_join && ext_events() && !strip;
+            dense_bound = m->lazy_join && ext_events() && !strip && !fork_nce;
             if (dense_bound) set_stop_event(fork_late ? m->ev_fork : m->ev_dense);
             if (strip)
                 launch_gemm_strip<true, EPI_STORE>(m->stream, m->DA, m->W, m->DH, nullptr, B, dw, de, de, de, dw);
@@ -722,8 +732,8 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         }
         // From here on the main stream has produced dW, db and the loss partials AND is done
         // READING W (the dh GEMM): the side stream may update the small tensors.
-        if (m->lazy_join && !dense_bound) SERT_HIP(hipEventRecord(fork_late ? m->ev_fork : m->ev_dense, m->stream));
-        if (fork_late) SERT_HIP(hipStreamWaitEvent(m->stream2, m->ev_fork, 0));
+        if (m->lazy_join && !dense_bound && !fork_nce) SERT_HIP(hipEventRecord(fork_late ? m->ev_fork : m->ev_dense, m->stream));
+        if (fork_late && !fork_nce) SERT_HIP(hipStreamWaitEvent(m->stream2, m->ev_fork, 0));
         if (fork_late && dw_third_queue(m)) SERT_HIP(hipStreamWaitEvent(m->stream3, m->ev_fork, 0));
         return 0;
     };
@@ -791,7 +801,12 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
     // that chain, and the word-table optimiser starts straight after segsum instead of
     // idling ~12 us on a cross-queue dependency.
     m->lazy_join = !is_dp(m) && !m->timing.enabled && m->nstreams == 2 && m->n_re <= ((size_t)1 << 22);
-    if (fork_late) {
+    if (fork_nce) {
+        SERT_TRY(entity_grad());       // side, forked on the NCE kernel's completion
+        SERT_TRY(dh_gemm());
+        SERT_TRY(dense_grad());
+        SERT_TRY(word_table_sum());
+    } else if (fork_late) {
         SERT_TRY(dh_gemm());           // main; its completion is the step's one fork
         SERT_TRY(entity_grad());       // side
         SERT_TRY(dense_grad());        // main (W and b are then updated on the main stream too)
@@ -1727,7 +1742,8 @@ static int create_resources(sert_model* m) {
                     m->eg_num_sub = cdiv(B, m->eg_sub_rows);
                     // row groups whose slice of T (rows x d_e floats) stays in one XCD's L2: <= 2 MB
                     m->eg_subs_per_group = (int)std::max<size_t>(1, (((size_t)2 << 20) / (de * sizeof(float))) / m->eg_sub_rows);
-                    m->eg_subs_per_group = std::max(1, std::min(m->eg_subs_per_group, m->eg_num_sub / 16));
+                    static const int want_groups = getenv("SERT_EG_GROUPS") ? std::max(1, atoi(getenv("SERT_EG_GROUPS"))) : 16;   // tuning knob
+                    m->eg_subs_per_group = std::max(1, std::min(m->eg_subs_per_group, m->eg_num_sub / want_groups));
                     m->eg_groups = cdiv(m->eg_num_sub, m->eg_subs_per_group);
                 }
                 if (m->eg_groups > 0) {

@@ -105,12 +105,10 @@ class WordBatcher(object):
         self.num_used_instances += num_instances
 
     def process(self):
-        if not self.requests:
+        if len(self.requests) == 0:
             return
-
         logging.debug('Processing batch (batch size=%d, current batch=%d).',
                       self.batch_size, self.num_used_instances)
-
         results = self.predict_fn(self.batch, self.mask)   # (B, n, V_e)
 
         row = 0
@@ -139,14 +137,12 @@ class EmbeddingMapper(object):
         self.callback = result_callback
 
     def process(self):
-        pass
+        return None   # (nothing is queued: submit() answers immediately)
 
     def submit(self, query_tokens, **kwargs):
-        avg_word_embedding = self.word_representations[
-            query_tokens, :].mean(axis=0)
-
-        self.callback(query_tokens, self.predict_fn(avg_word_embedding),
-                      **kwargs)
+        pooled = self.word_representations[query_tokens, :].mean(axis=0)
+        projection = self.predict_fn(pooled)
+        self.callback(query_tokens, projection, **kwargs)
 
 
 class BatchedEmbeddingMapper(object):

@@ -123,17 +123,11 @@ class ModelInterface(object):
                 walk.accept(value)
         return walk.outcome()
 
-    def train(self):
+    # the four methods every model supplies (sert/models.py:403-413)
+    def _not_here(self, *unused_args, **unused_kwargs):
         raise NotImplementedError()
 
-    def train_error(self):
-        raise NotImplementedError()
-
-    def validation_error(self):
-        raise NotImplementedError()
-
-    def get_state(self):
-        raise NotImplementedError()
+    train = train_error = validation_error = get_state = _not_here
 
 
 def _as_id_array(x):
@@ -211,12 +205,12 @@ class ModelBase(ModelInterface):
         model and upload the whole data set once (models.py:470-480)."""
         _capi.require_gpu()
 
-        is_training_y_sparse = sparse.isspmatrix_csr(self.training_set[1])
-        is_validation_y_sparse = sparse.isspmatrix_csr(self.validation_set[1])
-
-        if is_training_y_sparse != is_validation_y_sparse:
+        sparse_truths = [sparse.isspmatrix_csr(split[1])
+                         for split in (self.training_set, self.validation_set)]
+        if sparse_truths[0] != sparse_truths[1]:
             raise RuntimeError('Either training or validation truths are '
                                'sparse while the other is dense.')
+        is_training_y_sparse = sparse_truths[0]
 
         ctx = distributed.get_context()
         if self.batch_size % ctx.world_size != 0:
@@ -412,19 +406,12 @@ class LanguageModelBase(ModelBase):
                  regularization_fn,
                  **kwargs):
         super(LanguageModelBase, self).__init__(**kwargs)
-
         assert window_size >= 1
         self.window_size = window_size
-
         self.initial_representations = representations_init
-
-        self.vocabulary_size = representations_init.shape[0]
-        self.representation_size = representations_init.shape[1]
-
-        self.regularization_lambda = regularization_lambda
-
-        self.regularization_fn = regularization_fn
-
+        self.vocabulary_size, self.representation_size = representations_init.shape[:2]
+        self.regularization_lambda, self.regularization_fn = \
+            regularization_lambda, regularization_fn
         assert self.num_instance_features == self.window_size
 
     def get_representations(self):
@@ -623,16 +610,13 @@ class VectorSpaceLanguageModelBase(LanguageModelBase):
             training_set=training_set, validation_set=validation_set,
             learning_method='adam')
 
-        self.num_entities = entity_representations_init.shape[0]
-        self.entity_representation_size = entity_representations_init.shape[1]
-
-        assert self.training_set[1].ndim == 1, \
-            'Only one-hot vectors supported.'
-
-        assert num_negative_samples is None or num_negative_samples >= 0, \
-            'Number of negative samples should be None, zero or positive ' \
-            '(currently: {0}).'.format(num_negative_samples)
-
+        self.num_entities, self.entity_representation_size = \
+            entity_representations_init.shape[:2]
+        assert self.training_set[1].ndim == 1, 'Only one-hot vectors supported.'
+        if num_negative_samples is not None:
+            assert num_negative_samples >= 0, \
+                'Number of negative samples should be None, zero or positive ' \
+                '(currently: {0}).'.format(num_negative_samples)
         self.num_negative_samples = num_negative_samples
 
     def get_representations(self):

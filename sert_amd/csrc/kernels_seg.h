@@ -158,4 +158,63 @@ __global__ __launch_bounds__(256) void segsum_rows_scalar(const float* __restric
     }
 }
 
+// Levels 1 and 2 of a three-level tree in ONE launch (word_index.h: heavy_off).  Workgroups
+// [0, nb_normal) take 32 level-1 items each and store the final ones (a chunk item -- dst < 0 -- is
+// left to its word's workgroup); workgroup nb_normal + h sums the <= 32 chunk items of heavy word h,
+// one lane group each, and adds the chunk sums in chunk order out of LDS: exactly the additions the
+// separate level-2 launch makes, in the same order (bit-identical), without its ~6 us of launch.
+// (Used when no word of the batch has more than 32 chunk items = 131 072 occurrences; the bench's
+// synthetic batches, whose clipped Zipf tail piles 30 % of the tokens on one word, keep the two launches.)
+__global__ __launch_bounds__(1024) void segsum_upper_fused(const float* __restrict__ src,
+                                                           const int4* __restrict__ items, int nitems,
+                                                           int nb_normal, const int4* __restrict__ heavy,
+                                                           float* __restrict__ final_dst, int d, float divisor) {
+    __shared__ float4 red[64][32];
+    const int sub = threadIdx.x >> 5, l = threadIdx.x & 31;
+    const int chunks = d >> 2;               // <= 32
+    const bool on = l < chunks;
+    const int c = on ? l : 0;
+    auto sum_rows = [&](int lo, int hi) -> float4 {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        int e = lo;
+        for (; e + 8 <= hi; e += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const float4*>(src + (size_t)(e + q) * d + 4 * c);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { a.x += v[q].x; a.y += v[q].y; a.z += v[q].z; a.w += v[q].w; }
+        }
+        for (; e < hi; ++e) {
+            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)e * d + 4 * c);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        return a;
+    };
+    if ((int)blockIdx.x < nb_normal) {
+        const int item = blockIdx.x * 32 + sub;
+        if (item >= nitems) return;
+        const int4 it = items[item];
+        if (it.z < 0) return;
+        float4 a = sum_rows(it.x, it.y);
+        a.x /= divisor; a.y /= divisor; a.z /= divisor; a.w /= divisor;
+        if (on) *reinterpret_cast<float4*>(final_dst + (size_t)it.z * d + 4 * c) = a;
+        return;
+    }
+    const int4 h = heavy[blockIdx.x - nb_normal];     // {first chunk item, chunk items, word, -}
+    for (int q = sub; q < h.y; q += 32) {
+        const int4 it = items[h.x + q];
+        red[q][l] = sum_rows(it.x, it.y);
+    }
+    __syncthreads();
+    if (sub == 0 && on) {
+        float4 s = red[0][l];
+        for (int q = 1; q < h.y; ++q) {
+            const float4 x = red[q][l];
+            s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
+        }
+        s.x /= divisor; s.y /= divisor; s.z /= divisor; s.w /= divisor;
+        *reinterpret_cast<float4*>(final_dst + (size_t)h.z * d + 4 * c) = s;
+    }
+}
+
 }  // namespace sert

@@ -204,9 +204,20 @@ static int word_grad_segsum(sert_model* m, const DataSplit& ds, int64_t batch_in
     if ((size_t)batch_index >= ds.idx_batches.size()) SERT_FAIL("batch has no word index");
     const BatchIndex& bx = ds.idx_batches[(size_t)batch_index];
     unsigned char* touched = nullptr;   // (row flags are static per batch: DataSplit::idx_touched_bits)
+    static const bool no_fused_upper = getenv("SERT_SEG_NO_FUSED_UPPER") != nullptr;   // cross-check knob
+    const bool fused_upper = !no_fused_upper && bx.fused_upper_ok && ds.idx_heavy && d % 4 == 0 && d / 4 <= 32 &&
+                             bx.nlevels == 3 && bx.item_cnt[1] > 0;
     for (int l = 0; l < bx.nlevels; ++l) {
         const int nitems = bx.item_cnt[l];
         if (nitems == 0) continue;
+        if (fused_upper && l == 1) {
+            // levels 1 and 2 in one launch (kernels_seg.h: segsum_upper_fused)
+            const int nb_normal = cdiv(nitems, 32);
+            hipLaunchKernelGGL(segsum_upper_fused, dim3(nb_normal + bx.heavy_cnt), dim3(1024), 0, m->stream,
+                               m->wpart + (size_t)bx.part_off[0] * d, ds.idx_items + bx.item_off[1], nitems, nb_normal,
+                               ds.idx_heavy + bx.heavy_off, m->g_rw, d, divisor);
+            break;
+        }
         const float* in = (l == 0) ? src : m->wpart + (size_t)bx.part_off[l - 1] * d;
         const int32_t* rows = (l == 0) ? ds.idx_rows + bx.rows_off : nullptr;
         const int4* items = ds.idx_items + bx.item_off[l];
@@ -1812,6 +1823,7 @@ static void free_split(DataSplit& d) {
     (void)hipFree(d.x); (void)hipFree(d.y); (void)hipFree(d.csr_indptr);
     (void)hipFree(d.csr_indices); (void)hipFree(d.csr_data); (void)hipFree(d.w); (void)hipFree(d.labfix);
     (void)hipFree(d.idx_rows); (void)hipFree(d.idx_items);
+    (void)hipFree(d.idx_heavy); d.idx_heavy = nullptr;
     (void)hipFree(d.idx_uwords); (void)hipFree(d.idx_slots); (void)hipFree(d.idx_rows_div);
     (void)hipFree(d.idx_touched_bits);
     d.idx_uwords = nullptr; d.idx_slots = nullptr; d.idx_rows_div = nullptr;
@@ -2040,6 +2052,10 @@ int sert_upload_dataset(sert_model* m, int split, const void* x, const int32_t* 
             SERT_HIP(hipMemcpyAsync(d.idx_rows, wi.rows.data(), wi.rows.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
             SERT_HIP(hipMalloc((void**)&d.idx_items, std::max<size_t>(1, wi.items.size()) * sizeof(SegItem)));
             SERT_HIP(hipMemcpyAsync(d.idx_items, wi.items.data(), wi.items.size() * sizeof(SegItem), hipMemcpyHostToDevice, s));
+            if (!wi.heavy.empty()) {
+                SERT_HIP(hipMalloc((void**)&d.idx_heavy, wi.heavy.size() * sizeof(int32_t)));
+                SERT_HIP(hipMemcpyAsync(d.idx_heavy, wi.heavy.data(), wi.heavy.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+            }
             SERT_HIP(hipStreamSynchronize(s));
         }
         if (!wi.touched_bits.empty()) {

@@ -20,6 +20,8 @@ namespace sert {
 
 constexpr int kSegChunk = 64;
 constexpr int kSegMaxLevels = 6;
+constexpr int kFusedMaxChunks = 32;   // level-1 chunk items one workgroup of segsum_upper_fused combines: one per lane group
+                                      // (64, two per group, measured SLOWER than the separate level-2 launch: 19 vs 13 us)
 
 struct SegItem {       // 16 bytes, read as int4 on the device
     int32_t begin;     // first entry (level 0: index into rows[]; level>0: partial row)
@@ -38,12 +40,19 @@ struct BatchIndex {
     int64_t part_rows = 0;                // total partial rows of this batch
     int64_t uw_off = 0;                   // offset of this batch's distinct words in uwords[]
     int32_t num_distinct = 0;             // U: distinct words of the batch
+    // three-level trees only: the words whose level-1 chunks are summed again at level 2 ("heavy":
+    // more than kSegChunk^2 occurrences), so that levels 1 and 2 can run as ONE launch
+    // (segsum_upper_fused): {first level-1 item, number of chunk items, word, 0} per heavy word.
+    int64_t heavy_off = 0;                // offset into heavy[] (in entries of four ints)
+    int32_t heavy_cnt = 0;
+    bool fused_upper_ok = false;          // nlevels == 3 and every heavy word has <= kFusedMaxChunks chunks
 };
 
 struct WordIndex {
     std::vector<int32_t> rows;            // all batches, level-0 entries (source row ids)
     std::vector<SegItem> items;           // all batches, all levels
     std::vector<BatchIndex> batches;
+    std::vector<int32_t> heavy;           // all batches, four ints per heavy word (BatchIndex::heavy_off)
     int64_t max_part_rows = 0;
     // distinct words per batch (sorted) and, per token position, the rank of its word
     // among them: a gathered row is then computed ONCE per distinct word (loglinear)
@@ -154,6 +163,30 @@ bool build_word_index(const IdT* ids, int64_t num_batches, int B, int n, int voc
         }
         bx.nlevels = level;
         bx.part_rows = part_base;
+        bx.heavy_off = (int64_t)out.heavy.size() / 4;
+        bx.heavy_cnt = 0;
+        bx.fused_upper_ok = false;
+        if (level == 3) {
+            // level-2 items (all final) own consecutive runs of level-1 chunk items, in the same order
+            const SegItem* l1 = out.items.data() + bx.item_off[1];
+            const SegItem* l2 = out.items.data() + bx.item_off[2];
+            bool ok = true;
+            int32_t i1 = 0;
+            for (int32_t j = 0; j < bx.item_cnt[2] && ok; ++j) {
+                const SegItem& parent = l2[j];
+                while (i1 < bx.item_cnt[1] && l1[i1].dst >= 0) ++i1;          // skip the final level-1 items
+                const int32_t first = i1;
+                int32_t n = 0;
+                while (i1 < bx.item_cnt[1] && l1[i1].dst < 0 && -(l1[i1].dst + 1) < parent.end) {
+                    ok = ok && (-(l1[i1].dst + 1) == parent.begin + n);        // its partial rows, in order
+                    ++i1; ++n;
+                }
+                ok = ok && parent.dst >= 0 && n == parent.end - parent.begin && n >= 1 && n <= kFusedMaxChunks;
+                out.heavy.push_back(first); out.heavy.push_back(n); out.heavy.push_back(parent.dst); out.heavy.push_back(0);
+            }
+            bx.heavy_cnt = bx.item_cnt[2];
+            bx.fused_upper_ok = ok;
+        }
         if (part_base > out.max_part_rows) out.max_part_rows = part_base;
     }
     return true;

@@ -732,7 +732,8 @@ print('RESULT ' + json.dumps(out))
 def test_schedule_variants_do_not_change_a_bit(hip_lib):
     """The stream schedule is only a schedule: one stream, the round-1 three-event schedule,
     plain event records instead of kernel stop events, the entity group sum in a launch of its
-    own -- six steps (device-drawn negatives, pre-drawn on the side stream where there is one)
+    own, the fork behind the NCE kernel, the two upper levels of the word-gradient tree as two
+    launches -- six steps (device-drawn negatives, pre-drawn on the side stream where there is one)
     end in bit-identical parameters, optimiser state and losses, each in a fresh process (the
     knobs are read once per process)."""
     import json
@@ -741,7 +742,7 @@ def test_schedule_variants_do_not_change_a_bit(hip_lib):
     import sys
     code = SCHEDULE_WORKER % dict(root=U.ROOT)
     variants = ({}, {'SERT_STREAMS': '1'}, {'SERT_FORK_LATE': '0'}, {'SERT_EXT_EVENTS': '0'},
-                {'SERT_EGRAD_GROUP_SUM': '1'})
+                {'SERT_EGRAD_GROUP_SUM': '1'}, {'SERT_FORK_AT': 'nce'}, {'SERT_SEG_NO_FUSED_UPPER': '1'})
     outs = []
     for extra in variants:
         r = subprocess.run([sys.executable, '-c', code], check=True, env=dict(os.environ, **extra),

@@ -608,6 +608,7 @@ static int vs_loss(sert_model* m, const DataSplit& ds, int64_t batch_index) {
             }
 #undef SERT_NCE_REGS
 #undef SERT_NCE_CASE
+            set_stop_event(nullptr);   // (never leave an armed event behind a launch that did not happen)
             // (training: the kernel left one loss partial per workgroup in red_loss)
             m->nce_loss_partials = TRAIN ? cdiv(B, 16) : 0;
         } else {
@@ -740,6 +741,7 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
             else
                 launch_gemm<false, true, EPI_STORE>(m->stream, m->DA, m->W, m->DH, nullptr, B, dw, de, de,
                                                     de, dw);
+            set_stop_event(nullptr);
         }
         // From here on the main stream has produced dW, db and the loss partials AND is done
         // READING W (the dh GEMM): the side stream may update the small tensors.

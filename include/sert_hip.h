@@ -287,6 +287,22 @@ double sert_timing_avg_us(sert_model* m, int i);
 int sert_bench_gemm(int device, int ta, int tb, int epi, int M, int N, int K, int splits,
                     int iters, double* avg_us);
 
+/* Memory-system micro-benchmarks: the denominators a step's memory-bound kernels are priced
+ * against (no reference counterpart; measurement only).  Average launch time over `iters`
+ * launches (HIP events on the launching stream, 2 warm-ups) in *avg_us.
+ *   SERT_MEMBENCH_COPY       float4 stream copy: `bytes` read + `bytes` written per launch
+ *   SERT_MEMBENCH_READ       float4 stream read of `bytes`
+ *   SERT_MEMBENCH_GATHER     the step's own window gather (vs_gather_mean) over uniformly random
+ *                            rows: `bytes` of output rows of `row_bytes`, each the mean of `window`
+ *                            rows of a table of `table_bytes` -> bytes * window fetched per launch
+ *   SERT_MEMBENCH_OPTIMIZER  the dense Adam kernel over four arrays of `bytes` (4 read, 3 written),
+ *                            placed `gap_bytes` apart inside one allocation ((size_t)-1: four
+ *                            allocations of their own, as a model holds them)
+ * blocks: workgroups of the launch (0 = the kernel's default). */
+enum { SERT_MEMBENCH_COPY = 0, SERT_MEMBENCH_READ = 1, SERT_MEMBENCH_GATHER = 2, SERT_MEMBENCH_OPTIMIZER = 3 };
+int sert_bench_memory(int device, int kind, size_t bytes, size_t table_bytes, int row_bytes,
+                      int window, size_t gap_bytes, int blocks, int iters, double* avg_us);
+
 #ifdef __cplusplus
 }
 #endif

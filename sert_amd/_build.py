@@ -8,7 +8,7 @@ LIB = os.path.join(HERE, 'libsert_hip.so')
 INCLUDE = os.path.join(os.path.dirname(HERE), 'include')
 
 SOURCES = ['sert_hip.hip']
-HEADERS = ['common.h', 'gemm.h', 'gemm_big.h', 'gemm_strip.h', 'kernels_score_bf16.h', 'kernels_vs.h', 'kernels_ll.h', 'kernels_opt.h',
+HEADERS = ['common.h', 'gemm.h', 'kernels_membench.h', 'kernels_score_bf16.h', 'kernels_vs.h', 'kernels_ll.h', 'kernels_opt.h',
            'kernels_score.h', 'kernels_seg.h', 'kernels_egrad.h', 'kernels_sort.h', 'word_index.h', 'model.h']
 
 

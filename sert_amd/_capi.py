@@ -35,7 +35,7 @@ EXPORTS = [
     'sert_host_alloc', 'sert_host_free',
     'sert_comm_unique_id', 'sert_comm_init', 'sert_comm_init_host', 'sert_comm_destroy',
     'sert_synchronize', 'sert_timing_enable', 'sert_timing_reset', 'sert_timing_count',
-    'sert_timing_name', 'sert_timing_avg_us', 'sert_bench_gemm',
+    'sert_timing_name', 'sert_timing_avg_us', 'sert_bench_gemm', 'sert_bench_memory',
 ]
 
 
@@ -133,6 +133,8 @@ def load():
     lib.sert_timing_avg_us.argtypes = [vp, ctypes.c_int]
     lib.sert_timing_avg_us.restype = ctypes.c_double
     lib.sert_bench_gemm.argtypes = [ctypes.c_int] * 9 + [ctypes.POINTER(ctypes.c_double)]
+    lib.sert_bench_memory.argtypes = [ctypes.c_int, ctypes.c_int, sz, sz, ctypes.c_int, ctypes.c_int, sz, ctypes.c_int,
+                                      ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
     _lib = lib
     return lib
 
@@ -488,4 +490,18 @@ def bench_gemm(M, N, K, ta=0, tb=0, epi=0, splits=1, iters=20, device=0):
     """Average launch time (us) of the fp32 MFMA GEMM on random device operands."""
     us = ctypes.c_double()
     check(load().sert_bench_gemm(device, ta, tb, epi, M, N, K, splits, iters, ctypes.byref(us)))
+    return us.value
+
+
+MEMBENCH_COPY, MEMBENCH_READ, MEMBENCH_GATHER, MEMBENCH_OPTIMIZER = 0, 1, 2, 3
+SEPARATE_ALLOCATIONS = ctypes.c_size_t(-1).value
+
+
+def bench_memory(kind, nbytes, table_bytes=0, row_bytes=512, window=10, gap_bytes=0, blocks=0, iters=20, device=0):
+    """Average launch time (us) of a memory-system micro-benchmark (include/sert_hip.h:
+    sert_bench_memory): stream copy / read, the window gather over random rows, the dense
+    optimiser's seven streams."""
+    us = ctypes.c_double()
+    check(load().sert_bench_memory(device, kind, nbytes, table_bytes, row_bytes, window, gap_bytes, blocks, iters,
+                                   ctypes.byref(us)))
     return us.value

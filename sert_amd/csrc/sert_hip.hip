@@ -7,16 +7,20 @@
 
 #include <algorithm>
 #include <chrono>
+#include <functional>
 #include <string>
 #include <vector>
 
 #include "common.h"
 #include "gemm.h"
-#include "gemm_big.h"
-#include "gemm_strip.h"
+#ifdef SERT_VARIANTS   // opt-in GEMM variants that lost their A/B (csrc/variants/; tools/build_variant.sh -DSERT_VARIANTS)
+#include "variants/gemm_big.h"
+#include "variants/gemm_strip.h"
+#endif
 #include "kernels_score_bf16.h"
 #include "kernels_egrad.h"
 #include "kernels_ll.h"
+#include "kernels_membench.h"
 #include "kernels_opt.h"
 #include "kernels_score.h"
 #include "kernels_seg.h"
@@ -512,9 +516,11 @@ static int vs_project(sert_model* m, const DataSplit& ds, int64_t batch_index) {
     {
         ScopedTimer t(m, TG_GEMM_FWD);
         // t = tanh(h.W + b)   (models.py:1057-1061)
+#ifdef SERT_VARIANTS
         if (gemm_strip_ok(B, de, dw, dw, de, false, m->H, m->W))
             launch_gemm_strip<false, EPI_BIAS_TANH>(m->stream, m->H, m->W, m->T, m->b, B, de, dw, dw, de, de);
         else
+#endif
             launch_gemm<false, false, EPI_BIAS_TANH>(m->stream, m->H, m->W, m->T, m->b, B, de, dw, dw,
                                                      de, de);
     }
@@ -573,6 +579,7 @@ static int vs_loss(sert_model* m, const DataSplit& ds, int64_t batch_index) {
         // training with a side stream: the fork event of the backward pass is this kernel's own
         // completion signal (common.h: SERT_LAUNCH)
         m->fork_bound = false;
+        if (de > 512) SERT_FAIL("entity_dim > 512 is not supported");   // (before an event is armed)
         if (TRAIN && ext_events() && (!fork_late_mode(m) || fork_at_nce(m)) && !m->timing.enabled && m->nstreams >= 2 && de % 4 == 0) {
             set_stop_event(m->ev_fork);
             m->fork_bound = true;
@@ -739,13 +746,19 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         {
             // dh = da.W^T
             ScopedTimer t(m, TG_GEMM_DX);
+#ifdef SERT_VARIANTS
             const bool strip = gemm_strip_ok(B, dw, de, de, de, true, m->DA, m->W);
+#else
+            const bool strip = false;
+#endif
             // (ev_dense below: the completion signal of this GEMM, not a barrier packet behind it)
             dense_bound = m->lazy_join && ext_events() && !strip && !fork_nce;
             if (dense_bound) set_stop_event(fork_late ? m->ev_fork : m->ev_dense);
+#ifdef SERT_VARIANTS
             if (strip)
                 launch_gemm_strip<true, EPI_STORE>(m->stream, m->DA, m->W, m->DH, nullptr, B, dw, de, de, de, dw);
             else
+#endif
                 launch_gemm<false, true, EPI_STORE>(m->stream, m->DA, m->W, m->DH, nullptr, B, dw, de, de,
                                                     de, dw);
             set_stop_event(nullptr);
@@ -792,6 +805,7 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         splits = cdiv(B, kper);
         const size_t mn = (size_t)dw * de;
         const size_t stride = mn + de;
+#ifdef SERT_VARIANTS
         if (gemm_strip_ok(B, de, dw, dw, de, false, m->H, m->DA) && dw % 32 == 0 && de % 4 == 0) {
             // strip kernel: every workgroup accumulates its contiguous strips' h^T.da (+ column sums)
             ScopedTimer t(m, TG_GEMM_DW);
@@ -801,7 +815,9 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
             splits = cdiv(strips, spw);
             hipLaunchKernelGGL(gemm_strip_tn, dim3(splits), dim3(256), 0, sd, (const float*)m->H, (const float*)m->DA, B,
                                dw, de, dw, de, spw, m->part, stride);
-        } else {
+        } else
+#endif
+        {
             ScopedTimer t(m, TG_GEMM_DW);
             launch_gemm<true, false, EPI_STORE, true>(sd, m->H, m->DA, m->part, nullptr, dw, de,
                                                       B, dw, de, de, splits, kper, stride);
@@ -1656,18 +1672,20 @@ int sert_create(const sert_config* cfg, sert_model** out) {
 static int layout_gradients(sert_model* m) {
     const bool vs = is_vs(m);
     const size_t V = m->cfg.num_entities;
+    // Order inside the buffer: the word table first (gflat[0, ar_split)), then the other SHARDED
+    // tensors, then the replicated ones -- whatever their index: a loglinear model has no R_e and
+    // may have a big W (d_w V_e > 4 M), a vectorspace model a small R_e beside a big W -- so that
+    // the replicated remainder [rest_off, gflat_count) is one contiguous all-reduce.
     size_t off[5];
-    off[0] = 0;
-    for (int i = 0; i < 4; ++i) off[i + 1] = off[i] + round_up(m->pt_pad[i], 4);
+    size_t cur = 0;
+    auto place = [&](int i) { off[i] = cur; cur += round_up(m->pt_pad[i], 4); };
+    place(0);
+    m->ar_split = cur;
+    for (int i = 1; i < 4; ++i) if (m->pt_sharded[i]) place(i);
+    m->rest_off = m->pt_sharded[0] ? cur : 0;
+    for (int i = 1; i < 4; ++i) if (!m->pt_sharded[i]) place(i);
+    off[4] = cur;
     m->gflat_count = off[4] + 4;
-    m->ar_split = off[1];
-    // the replicated remainder starts at the first tensor that is not sharded (the sharded
-    // ones -- the big ones -- always form a prefix of [R_w, R_e, W, b])
-    int first_repl = 0;
-    while (first_repl < 4 && m->pt_sharded[first_repl]) ++first_repl;
-    for (int i = first_repl; i < 4; ++i)
-        if (m->pt_sharded[i]) SERT_FAIL("internal: sharded tensors must be a prefix of [R_w, R_e, W, b]");
-    m->rest_off = off[first_repl];
     // tail of the same allocation (zeroed with the gradients every step, not part of any
     // exchange): per-entity sorted-run bounds
     m->gflat_alloc = m->gflat_count + (vs ? 2 * round_up(V, 4) : 0);
@@ -2390,8 +2408,13 @@ int sert_scorer_destroy(sert_scorer* sc) {
 // gemm_big.h (256x256 tiles, one wave per SIMD).  Both the fused path and its exact fallback
 // then use that kernel, so a row's scores never depend on which path produced them.
 static int scorer_big_tile(const sert_scorer* sc) {   // 0 no, 1 = 256x256, 2 = 256x128 (two workgroups per CU)
+#ifdef SERT_VARIANTS
     static const int big_tile = getenv("SERT_SCORE_BIG_TILE") ? atoi(getenv("SERT_SCORE_BIG_TILE")) : 0;
     return (sc->V >= 32768 && gemm_big_ok(sc->dim, sc->dim, sc->dim)) ? big_tile : 0;
+#else
+    (void)sc;
+    return 0;
+#endif
 }
 
 // Materialising path: (QT, V) cosine slabs + per-row selection, for a device-resident
@@ -2425,9 +2448,11 @@ static int scorer_topk_materialised(sert_scorer* sc, const float* P, int64_t Q, 
         float* S = sc->S + (size_t)(t & 1) * QT * V;
         // S = P.E^T  (cosines), then per-row selection
         // (same kernel family as the fused path, so a row's scores do not depend on the path)
+#ifdef SERT_VARIANTS
         if (scorer_big_tile(sc))
             launch_gemm_big_nt(st, P + q0 * dim, sc->E, S, (int)qn, (int)V, dim, dim, dim, (int)V, scorer_big_tile(sc) == 2);
         else
+#endif
             launch_gemm<false, true, EPI_STORE>(st, P + q0 * dim, sc->E, S, nullptr, (int)qn, (int)V, dim,
                                                 dim, dim, (int)V);
         hipLaunchKernelGGL(topk_rows, dim3((unsigned)qn), dim3(256), 0, st, S, (int)V, k, idx + q0 * k,
@@ -2538,10 +2563,13 @@ static int scorer_topk_fused(sert_scorer* sc, const float* proj, int64_t Q, int 
         // 2. full GEMM, filtering epilogue
         if (use_bf16) {
             launch_score_filter_bf16(st, P16, sc->E16, thr, (uint32_t*)cand, cnt, ngroups, gcap, (int)qn, (int)V, sc->kp);
-        } else if (scorer_big_tile(sc))
+        } else
+#ifdef SERT_VARIANTS
+        if (scorer_big_tile(sc))
             launch_gemm_big_filter(st, P, sc->E, thr, cand, cnt, ngroups, gcap, (int)qn, (int)V, dim, dim, dim,
                                    scorer_big_tile(sc) == 2);
         else
+#endif
             launch_gemm<false, true, EPI_FILTER>(st, P, sc->E, nullptr, thr, (int)qn, (int)V, dim, dim, dim,
                                                  (int)V, 1, 0, 0, cand, cnt, gcap);
         // 3. selection from the candidate lists
@@ -2738,7 +2766,13 @@ int sert_comm_init(sert_model* m, const char id[SERT_COMM_ID_BYTES], int rank, i
         }
     }
     m->ar_chunks = exchange_slabs();
-    return shard_setup(m);
+    const int rc = shard_setup(m);
+    if (rc != 0) {   // never leave a communicator behind a model that could not be sharded
+        const std::string why = g_last_error;
+        (void)sert_comm_destroy(m);
+        g_last_error = why;
+    }
+    return rc;
 }
 
 int sert_comm_init_host(sert_model* m, int rank, int world, sert_allreduce_fn fn, void* user) {
@@ -2755,7 +2789,13 @@ int sert_comm_init_host(sert_model* m, int rank, int world, sert_allreduce_fn fn
     m->world = world;
     invalidate_speculation(m);
     m->ar_chunks = exchange_slabs();
-    return shard_setup(m);
+    const int rc = shard_setup(m);
+    if (rc != 0) {
+        const std::string why = g_last_error;
+        (void)sert_comm_destroy(m);
+        g_last_error = why;
+    }
+    return rc;
 }
 
 // After this call the model keeps its parameters (identical on every rank) but can no longer
@@ -2823,9 +2863,13 @@ int sert_bench_gemm(int device, int ta, int tb, int epi, int M, int N, int K, in
     };
     SERT_HIP(fill(A, na)); SERT_HIP(fill(B, nb)); SERT_HIP(fill(bias, (size_t)N));
     const int lda = ta ? M : K, ldb = tb ? K : N;
+#ifdef SERT_VARIANTS
     const int big = (getenv("SERT_GEMM_BIG") && !ta && tb && gemm_big_ok(K, lda, ldb) && splits == 1) ? atoi(getenv("SERT_GEMM_BIG")) : 0;
+#endif
     auto run = [&]() {
+#ifdef SERT_VARIANTS
         if (big) { launch_gemm_big_nt(s, A, B, C, M, N, K, lda, ldb, N, big == 2); return; }
+#endif
 #define SERT_BG(TA, TB, E) launch_gemm<TA, TB, E>(s, A, B, C, bias, M, N, K, lda, ldb, N, splits, kper, (size_t)M * N)
         if (!ta && !tb) { if (epi == 2) SERT_BG(false, false, EPI_BIAS_TANH); else if (epi == 1) SERT_BG(false, false, EPI_BIAS); else SERT_BG(false, false, EPI_STORE); }
         else if (ta && !tb) SERT_BG(true, false, EPI_STORE);
@@ -2849,7 +2893,90 @@ int sert_bench_gemm(int device, int ta, int tb, int epi, int M, int N, int K, in
     return 0;
 }
 
+int sert_bench_memory(int device, int kind, size_t bytes, size_t table_bytes, int row_bytes, int window,
+                      size_t gap_bytes, int blocks, int iters, double* avg_us) {
+    if (!avg_us || iters <= 0 || bytes < 4096) SERT_FAIL("bad argument");
+    SERT_HIP(hipSetDevice(device));
+    hipStream_t s;
+    SERT_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    std::vector<void*> owned;
+    auto alloc = [&](size_t b, void** out) -> int {
+        SERT_HIP(hipMalloc(out, b));
+        owned.push_back(*out);
+        return 0;
+    };
+    auto cleanup = [&]() {
+        for (void* p : owned) (void)hipFree(p);
+        (void)hipStreamDestroy(s);
+    };
+    const size_t n = (bytes / 16) * 4;   // floats per array (multiple of 4)
+    std::function<void()> run;
+    int rc = 0;
+    if (kind == SERT_MEMBENCH_COPY || kind == SERT_MEMBENCH_READ) {
+        float *a = nullptr, *b = nullptr;
+        if ((rc = alloc(n * 4, (void**)&a)) || (rc = alloc(kind == SERT_MEMBENCH_COPY ? n * 4 : 65536 * 4, (void**)&b))) { cleanup(); return rc; }
+        hipLaunchKernelGGL(mb_fill_f32, dim3(2048), dim3(256), 0, s, a, n, 1.0f);
+        const int nb = blocks > 0 ? blocks : 4096;
+        if (kind == SERT_MEMBENCH_COPY)
+            run = [=]() { hipLaunchKernelGGL(mb_stream_copy, dim3(nb), dim3(256), 0, s, (const float4*)a, (float4*)b, n / 4); };
+        else
+            run = [=]() { hipLaunchKernelGGL(mb_stream_read, dim3(nb), dim3(256), 0, s, (const float4*)a, n / 4, b); };
+    } else if (kind == SERT_MEMBENCH_GATHER) {
+        if (row_bytes < 16 || row_bytes % 16 || window < 1 || table_bytes < (size_t)row_bytes) { cleanup(); SERT_FAIL("bad gather shape"); }
+        const int d = row_bytes / 4;
+        const size_t rows = table_bytes / (size_t)row_bytes;
+        const size_t B = std::max<size_t>(1, n / d);
+        if (rows >= ((size_t)1 << 32) || B >= ((size_t)1 << 31)) { cleanup(); SERT_FAIL("gather shape too large"); }
+        float *tab = nullptr, *out = nullptr; uint32_t* ids = nullptr;
+        if ((rc = alloc(rows * row_bytes, (void**)&tab)) || (rc = alloc(B * row_bytes, (void**)&out)) ||
+            (rc = alloc(B * window * 4, (void**)&ids))) { cleanup(); return rc; }
+        hipLaunchKernelGGL(mb_fill_f32, dim3(2048), dim3(256), 0, s, tab, rows * d, 1.0f);
+        hipLaunchKernelGGL(mb_fill_ids, dim3(2048), dim3(256), 0, s, ids, B * window, (uint32_t)rows, 17u);
+        const int grid = grid_for((int64_t)B * d / 4, 256, 1 << 20);
+        run = [=]() { hipLaunchKernelGGL((vs_gather_mean<uint32_t, 4>), dim3(grid), dim3(256), 0, s, (const uint32_t*)ids, (const float*)tab, out, (int)B, window, d); };
+    } else if (kind == SERT_MEMBENCH_OPTIMIZER) {
+        float* arr[4] = {nullptr, nullptr, nullptr, nullptr};
+        if (gap_bytes == (size_t)-1) {   // four allocations of their own, as the model holds them
+            for (int k = 0; k < 4; ++k) if ((rc = alloc(n * 4, (void**)&arr[k]))) { cleanup(); return rc; }
+        } else {
+            if (gap_bytes % 16) { cleanup(); SERT_FAIL("gap must be a multiple of 16 bytes"); }
+            char* base = nullptr;
+            if ((rc = alloc(4 * (n * 4 + gap_bytes), (void**)&base))) { cleanup(); return rc; }
+            for (int k = 0; k < 4; ++k) arr[k] = (float*)(base + (size_t)k * (n * 4 + gap_bytes));
+        }
+        float* sq = nullptr;
+        if ((rc = alloc((size_t)8 * kOptBlocks * 4, (void**)&sq))) { cleanup(); return rc; }
+        hipLaunchKernelGGL(mb_fill_f32, dim3(2048), dim3(256), 0, s, arr[0], n, 0.01f);
+        hipLaunchKernelGGL(mb_fill_f32, dim3(2048), dim3(256), 0, s, arr[1], n, 1e-4f);
+        SERT_HIP(hipMemsetAsync(arr[2], 0, n * 4, s));
+        SERT_HIP(hipMemsetAsync(arr[3], 0, n * 4, s));
+        const int nb = blocks > 0 ? std::min(blocks, 8 * kOptBlocks) : 2 * kOptBlocks;
+        const AdamArgs aa{1e-7f, 1e-3f, 0.9f, 0.999f, 1e-8f};
+        float *p = arr[0], *g = arr[1], *m1 = arr[2], *v1 = arr[3];
+        run = [=]() { hipLaunchKernelGGL((adam_l2<false>), dim3(nb), dim3(256), 0, s, p, g, m1, v1, n, aa, sq, (const uint32_t*)nullptr, 1u, (int)kRowsAll); };
+    } else {
+        cleanup();
+        SERT_FAIL("unknown membench kind");
+    }
+    hipEvent_t e0, e1;
+    SERT_HIP(hipEventCreate(&e0)); SERT_HIP(hipEventCreate(&e1));
+    run(); run();
+    SERT_HIP(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) run();
+    SERT_HIP(hipEventRecord(e1, s));
+    const hipError_t se = hipStreamSynchronize(s);
+    float ms = 0.f;
+    if (se == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);
+    *avg_us = 1000.0 * ms / iters;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    cleanup();
+    SERT_HIP(se);
+    SERT_HIP(hipGetLastError());
+    return 0;
+}
+
 }  // extern "C"
+
 
 #ifdef SR_TIMELINE
 extern "C" int sert_debug_read(void* out, size_t bytes) {

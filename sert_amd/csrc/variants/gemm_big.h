@@ -13,7 +13,7 @@
 //   a lane's fragment read = float4 = k-quad (lane/16) of row (lane%16) of a 16-row block;
 //   MFMA step j of the slab contracts the k's {4g + j}: any partition of k is a valid order
 #pragma once
-#include "common.h"
+#include "../common.h"
 
 namespace sert {
 

@@ -22,7 +22,7 @@
 // half-waves -- a fixed permutation of k (any order is a valid fp32 summation; it is the same
 // in every launch, so the results are run-to-run identical).
 #pragma once
-#include "gemm.h"
+#include "../gemm.h"
 
 namespace sert {
 

@@ -93,17 +93,20 @@ class FileStore(object):
 
     def exchange(self, tag, data):
         """Every rank contributes `data` (bytes); returns the list of all contributions in
-        rank order.  A rank's file of generation g-1 is removed once generation g is complete
-        (every rank has then finished reading g-1)."""
+        rank order.  This rank's file of its PREVIOUS exchange is removed once the current one is
+        complete: every rank has then published its current contribution, which it does only after
+        it finished reading the previous exchange (broadcasts in between do not matter: the file is
+        tracked by name, not by generation arithmetic)."""
         g = self.next_generation()
-        self.set('%s.%d.%d' % (tag, g, self.rank), data)
+        mine = '%s.%d.%d' % (tag, g, self.rank)
+        self.set(mine, data)
         out = [data if r == self.rank else self.get('%s.%d.%d' % (tag, g, r)) for r in range(self.world)]
-        if g > 1:
-            self.drop('%s.%d.%d' % (self._last_tag, g - 1, self.rank))
-        self._last_tag = tag
+        if self._last_exchange_file is not None:
+            self.drop(self._last_exchange_file)
+        self._last_exchange_file = mine
         return out
 
-    _last_tag = 'x'
+    _last_exchange_file = None
 
 
 _context = Context()
@@ -114,19 +117,35 @@ def get_context():
     return _context
 
 
+def _process_start_time(pid):
+    """Field 22 of /proc/<pid>/stat (clock ticks since boot): with the pid, unique per process."""
+    try:
+        with open('/proc/%d/stat' % pid) as f:
+            return f.read().rsplit(')', 1)[1].split()[19]
+    except (OSError, IndexError):
+        return ''
+
+
+def _shared_tmp_base():
+    return '/dev/shm' if os.path.isdir('/dev/shm') and os.access('/dev/shm', os.W_OK) else tempfile.gettempdir()
+
+
 def _rendezvous_dir():
     explicit = os.environ.get('SERT_RDZV_DIR')
     if explicit:
         return explicit
     # ranks started by a foreign launcher share its pid as parent and its MASTER_PORT;
     # torch's elastic agent also hands every worker a path inside one per-launch directory
-    parts = [os.environ.get('MASTER_ADDR', ''), os.environ.get('MASTER_PORT', ''), str(os.getppid())]
+    # ... and that launcher's START TIME: a crashed earlier run with the same port and (in a container,
+    # easily) the same parent pid leaves its files behind -- rank 0's cleanup does not run on SIGKILL --
+    # and a new run must never see them (stale barrier files, a stale ncclUniqueId)
+    parts = [os.environ.get('MASTER_ADDR', ''), os.environ.get('MASTER_PORT', ''), str(os.getppid()),
+             _process_start_time(os.getppid())]
     err_file = os.environ.get('TORCHELASTIC_ERROR_FILE')
     if err_file:
         parts.append(os.path.dirname(os.path.dirname(os.path.dirname(err_file))))
     tag = hashlib.sha1('|'.join(parts).encode()).hexdigest()[:16]
-    base = '/dev/shm' if os.path.isdir('/dev/shm') and os.access('/dev/shm', os.W_OK) else tempfile.gettempdir()
-    return os.path.join(base, 'sert_rdzv_' + tag)
+    return os.path.join(_shared_tmp_base(), 'sert_rdzv_' + tag)
 
 
 def init_from_env():
@@ -270,7 +289,7 @@ def launch(argv, nproc, env=None, timeout=None):
     """Start `nproc` ranks of `argv` (a command line) on this node, one per GPU, and wait.
     Rank 0 inherits stdout; every rank inherits stderr.  Returns the first non-zero exit
     code (0 if all ranks succeeded); a rank that fails takes the others down."""
-    rdzv = tempfile.mkdtemp(prefix='sert_rdzv_', dir='/dev/shm' if os.path.isdir('/dev/shm') else None)
+    rdzv = tempfile.mkdtemp(prefix='sert_rdzv_', dir=_shared_tmp_base())
     procs = []
     try:
         for rank in range(nproc):

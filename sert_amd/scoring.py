@@ -131,7 +131,8 @@ class VectorSpaceCallback(Callback):
         queries = self.scorer.query_buffer(len(payloads))
         np.copyto(queries, self._as_queries(projections, len(payloads)))
         for kw, q in zip(kwargs_list, queries):
-            self._remember(kw['topic_id'], q)
+            # (a copy: `queries` is the scorer's reusable page-locked block, overwritten by the next call)
+            self._remember(kw['topic_id'], q.copy())
         idx, score = self.scorer.rank(queries, self.n_neighbors)
         for row, kw in enumerate(kwargs_list):
             self.rank_callback(kw['topic_id'], idx[row].astype(np.int64), score[row])

@@ -20,6 +20,13 @@ pytestmark = pytest.mark.gpu
 LOSS_TOL, ACT_TOL, GRAD_TOL, PARAM_TOL = 1e-5, 2e-5, 1e-4, 1e-4
 
 
+
+# The GEMM variants that lost their A/B (csrc/variants/) are not part of the product library: their
+# test ids exist only when the suite runs against a library built with them
+# (tools/build_variant.sh variants -DSERT_VARIANTS; SERT_LIB=sert_amd/variants/libsert_variants.so pytest ...).
+VARIANTS_BUILD = 'variants' in os.path.basename(os.environ.get('SERT_LIB', ''))
+
+
 @pytest.mark.parametrize('dims', [
     dict(B=64, n=5, z=4, Vw=500, Ve=37, dw=32, de=48),      # vector path, NPL=1
     dict(B=96, n=3, z=7, Vw=200, Ve=11, dw=30, de=70),      # scalar path, NPL=2, ragged tiles
@@ -32,7 +39,7 @@ LOSS_TOL, ACT_TOL, GRAD_TOL, PARAM_TOL = 1e-5, 2e-5, 1e-4, 1e-4
     dict(B=1100, n=3, z=4, Vw=2000, Ve=50, dw=128, de=128),     # strip GEMMs (gemm_strip.h), ragged last strip
     dict(B=1030, n=2, z=3, Vw=500, Ve=40, dw=96, de=64),        # strip GEMMs with idle waves (N = 64 / 96), K = 96 / 64
 ])
-@pytest.mark.parametrize('egrad', ['default', 'sorted', 'strip_gemm', 'roles_gemm'])
+@pytest.mark.parametrize('egrad', ['default', 'sorted'] + (['strip_gemm', 'roles_gemm'] if VARIANTS_BUILD else []))
 def test_vectorspace_steps(hip_lib, dims, egrad, monkeypatch):
     # entity gradient: V_e <= 2048 takes the sort-free bucket + register-accumulator path by default;
     # 'sorted' forces the counting-sort + chunked-reduce path every vocabulary size can take;
@@ -318,9 +325,10 @@ def test_score_topk_bf16_prefilter_no_gap_falls_back(hip_lib):
     _check_topk_against_oracle(E, Pj, idx, val, k)
 
 
-@pytest.mark.parametrize('mode', ['1', '2'])
+@pytest.mark.skipif(not VARIANTS_BUILD, reason='opt-in 256x256-tile scoring GEMM: not in the product build')
+@pytest.mark.parametrize('mode', ['1', '2'] if VARIANTS_BUILD else ['-'])
 def test_score_topk_big_tile_variant(hip_lib, mode):
-    """SERT_SCORE_BIG_TILE=1|2 (gemm_big.h, ragged M and N): fused == materialised, both == oracle."""
+    """SERT_SCORE_BIG_TILE=1|2 (variants/gemm_big.h, ragged M and N): fused == materialised, both == oracle."""
     rng = np.random.RandomState(17)
     V, d, Q, k = 70001, 32, 300, 100
     E = rng.randn(V, d).astype(np.float32)

@@ -1,6 +1,8 @@
 #!/bin/bash
 # Build an experimental variant of libsert_hip.so:  tools/build_variant.sh <name> [-DFOO=1 ...]
-# -> gpurun_out/variants/libsert_<name>.so ; run with SERT_LIB=<that path>
+# -> sert_amd/variants/libsert_<name>.so ; run with SERT_LIB=<that path>
+# The opt-in GEMM variants of csrc/variants/ (strip / role-specialised / 256x256-tile kernels that lost
+# their A/B) are compiled in with:  tools/build_variant.sh variants -DSERT_VARIANTS
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 NAME=$1; shift

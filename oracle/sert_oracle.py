@@ -23,6 +23,44 @@ import numpy as np
 
 EPS = 1e-7  # sert/models.py:200, :290, :900, :1067-1068
 
+# The semantics of Theano 0.8.2 / Lasagne 0.1 this restatement takes FROM MEMORY (neither library is
+# importable here; every use is tagged [upstream] below).  Each entry can be flipped to its plausible
+# alternative -- tools/semantics_drift.py and tests/test_semantics_cpu.py measure how far a wrong guess
+# could move the parameters and the ranking.  The defaults are the restatement.
+UPSTREAM = {
+    'clip_grad_inclusive': True,    # Clip.grad mask (x >= lo) & (x <= hi); alternative: strict inequalities
+    'sigmoid_cutoffs': True,        # ScalarSigmoid float32 c_code: x < -88 -> 0, x > 15 -> 1; alternative: exact
+    'sum_acc_float64': True,        # Sum of float32 accumulates in float64; alternative: float32 accumulation
+    'adam_eps_outside_sqrt': True,  # m / (sqrt(v) + eps); alternative: m / sqrt(v + eps)
+    'adam_folded_bias_correction': True,   # a_t = lr sqrt(1-b2^t)/(1-b1^t) applied to m / (sqrt(v) + eps);
+                                           # alternative (Kingma & Ba alg. 1): lr m_hat / (sqrt(v_hat) + eps)
+    'bias_regularised': False,      # DenseLayer b has regularizable=False; alternative: b is in the L2 term
+    'adadelta_eps_inside_sqrt': True,      # sqrt(delta + eps) / sqrt(accu + eps); alternative: eps outside
+}
+
+
+class upstream_choice(object):
+    """with upstream_choice(clip_grad_inclusive=False): ...   -- flip semantics for a block."""
+
+    def __init__(self, **kw):
+        unknown = set(kw) - set(UPSTREAM)
+        assert not unknown, unknown
+        self.kw = kw
+
+    def __enter__(self):
+        self.saved = {k: UPSTREAM[k] for k in self.kw}
+        UPSTREAM.update(self.kw)
+
+    def __exit__(self, *exc):
+        UPSTREAM.update(self.saved)
+
+
+def _clip_mask(x, lo, hi):
+    """Gradient mask of T.clip [upstream: Clip.grad -- inclusive bounds]."""
+    if UPSTREAM['clip_grad_inclusive']:
+        return (x >= lo) & (x <= hi)
+    return (x > lo) & (x < hi)
+
 
 # --------------------------------------------------------------------------- #
 # helpers
@@ -40,7 +78,8 @@ def glorot_uniform(rng, shape, dtype=np.float32):
 def _sum(x, axis=None, dtype=np.float32):
     """Theano's Sum accumulates float32 inputs in float64 and casts back
     [upstream: CAReduceDtype acc_dtype]."""
-    return np.sum(x, axis=axis, dtype=np.float64).astype(dtype)
+    acc = np.float64 if UPSTREAM['sum_acc_float64'] else dtype
+    return np.sum(x, axis=axis, dtype=acc).astype(dtype)
 
 
 def theano_sigmoid(x):
@@ -55,6 +94,8 @@ def theano_sigmoid(x):
     one = x.dtype.type(1.0)
     with np.errstate(over='ignore'):
         mid = one / (one + np.exp(-x))
+    if not UPSTREAM['sigmoid_cutoffs']:
+        return mid.astype(x.dtype)
     return np.where(x < lo, x.dtype.type(0.0),
                     np.where(x > hi, one, mid)).astype(x.dtype)
 
@@ -102,10 +143,19 @@ class Adam(object):
         T = dt.type
         a_t = self.step_size(self.t, self.lr, self.beta1, self.beta2, dt)
         b1, b2, eps = T(self.beta1), T(self.beta2), T(self.eps)
+        folded = UPSTREAM['adam_folded_bias_correction']
+        eps_out = UPSTREAM['adam_eps_outside_sqrt']
         for i, (p, g) in enumerate(zip(params, grads)):
             self.m[i] = b1 * self.m[i] + (T(1) - b1) * g
             self.v[i] = b2 * self.v[i] + (T(1) - b2) * g * g
-            p -= a_t * self.m[i] / (np.sqrt(self.v[i]) + eps)
+            if folded:
+                den = (np.sqrt(self.v[i]) + eps) if eps_out else np.sqrt(self.v[i] + eps)
+                p -= a_t * self.m[i] / den
+            else:
+                m_hat = self.m[i] / (T(1) - b1 ** T(self.t))
+                v_hat = self.v[i] / (T(1) - b2 ** T(self.t))
+                den = (np.sqrt(v_hat) + eps) if eps_out else np.sqrt(v_hat + eps)
+                p -= T(self.lr) * m_hat / den
 
 
 class Adadelta(object):
@@ -122,7 +172,10 @@ class Adadelta(object):
         rho, eps, lr = T(self.rho), T(self.eps), T(self.lr)
         for i, (p, g) in enumerate(zip(params, grads)):
             self.accu[i] = rho * self.accu[i] + (T(1) - rho) * g * g
-            upd = g * np.sqrt(self.delta[i] + eps) / np.sqrt(self.accu[i] + eps)
+            if UPSTREAM['adadelta_eps_inside_sqrt']:
+                upd = g * np.sqrt(self.delta[i] + eps) / np.sqrt(self.accu[i] + eps)
+            else:
+                upd = g * (np.sqrt(self.delta[i]) + eps) / (np.sqrt(self.accu[i]) + eps)
             p -= lr * upd
             self.delta[i] = rho * self.delta[i] + (T(1) - rho) * upd * upd
 
@@ -192,6 +245,8 @@ class VectorSpaceOracle(object):
         r1 = T(self.lam) * _sum(self.W * self.W, dtype=self.dtype) / (T(2) * m)
         r2 = T(self.lam) * (_sum(self.R_w * self.R_w, dtype=self.dtype) +
                             _sum(self.R_e * self.R_e, dtype=self.dtype)) / (T(2) * m)
+        if UPSTREAM['bias_regularised']:
+            r1 = r1 + T(self.lam) * _sum(self.b * self.b, dtype=self.dtype) / (T(2) * m)
         return T(r1 + r2)
 
     # -- loss + gradients -------------------------------------------------- #
@@ -206,7 +261,7 @@ class VectorSpaceOracle(object):
 
         g = (w / T(B)).astype(dt)                          # per-sample scale
         sig, s = f['sig'], f['s']
-        mask = ((sig >= lo) & (sig <= hi)).astype(dt)      # Clip.grad inclusive [upstream]
+        mask = _clip_mask(sig, lo, hi).astype(dt)          # Clip.grad inclusive [upstream]
         du = np.empty_like(s)
         # d/du -log(clip(sigma)) = -(1/s) * mask * sigma(1-sigma)
         du[:, 0] = -(g / s[:, 0]) * mask[:, 0] * sig[:, 0] * (T(1) - sig[:, 0])
@@ -219,7 +274,7 @@ class VectorSpaceOracle(object):
         np.add.at(dR_e, f['cand'].ravel(),
                   (du[:, :, None] * f['p'][:, None, :]).reshape(-1, self.R_e.shape[1]))
         t = f['t']
-        da = (dp * ((t >= -hi) & (t <= hi)).astype(dt) * (T(1) - t * t)).astype(dt)
+        da = (dp * _clip_mask(t, -hi, hi).astype(dt) * (T(1) - t * t)).astype(dt)
         dW = (f['h'].T @ da).astype(dt)
         db = _sum(da, axis=0, dtype=dt)
         dh = (da @ self.W.T).astype(dt)
@@ -232,6 +287,8 @@ class VectorSpaceOracle(object):
             dW += k * self.W
             dR_w += k * self.R_w
             dR_e += k * self.R_e
+            if UPSTREAM['bias_regularised']:
+                db = db + k * self.b
         f.update(du=du, dp=dp, da=da, dh=dh)
         return loss_train, [dR_e, dR_w, dW, db], f
 
@@ -371,8 +428,11 @@ class LogLinearOracle(object):
         if not self.lam > 0.0:
             return T(0)
         m = T(self.B)
-        return T(T(self.lam) * _sum(self.W * self.W, dtype=self.dtype) / (T(2) * m) +
-                 T(self.lam) * _sum(self.R_w * self.R_w, dtype=self.dtype) / (T(2) * m))
+        r = T(T(self.lam) * _sum(self.W * self.W, dtype=self.dtype) / (T(2) * m) +
+              T(self.lam) * _sum(self.R_w * self.R_w, dtype=self.dtype) / (T(2) * m))
+        if UPSTREAM['bias_regularised']:
+            r = T(r + T(self.lam) * _sum(self.b * self.b, dtype=self.dtype) / (T(2) * m))
+        return r
 
     def loss_and_grads(self, X, y, w):
         dt = self.dtype
@@ -391,9 +451,9 @@ class LogLinearOracle(object):
         else:
             Y = y.astype(dt)
         dQc = -(g[:, None] * Y) / Qc
-        dQ = dQc * ((Q >= lo) & (Q <= hi)).astype(dt)
+        dQ = dQc * _clip_mask(Q, lo, hi).astype(dt)
         dJ = Q * (dQ - _sum(dQ * Q, axis=1, dtype=dt)[:, None])
-        Pmask = ((P3 >= lo) & (P3 <= hi)).astype(dt)
+        Pmask = _clip_mask(P3, lo, hi).astype(dt)
         dP = dJ[:, None, :] * Pmask / np.clip(P3, lo, hi)
         dZ = (P3 * (dP - _sum(dP * P3, axis=2, dtype=dt)[:, :, None])).astype(dt)
         dZ2 = dZ.reshape(B * n, -1)
@@ -406,6 +466,8 @@ class LogLinearOracle(object):
             k = T(self.lam) / T(self.B)
             dW += k * self.W
             dR_w += k * self.R_w
+            if UPSTREAM['bias_regularised']:
+                db = db + k * self.b
         f.update(dJ=dJ, dZ=dZ2, dG=dG)
         return loss_train, [dR_w, dW, db], f
 

@@ -335,4 +335,116 @@ __global__ __launch_bounds__(256) void finalize_loss(const float* __restrict__ l
     }
 }
 
+// ---- the tail of a single-GPU vectorspace step in ONE launch ---------------------------------------
+// split-K combine of dW / db (gemm.h: reduce_partials_g<16>, same association) -> Adam on W and b ->
+// loss finalisation (finalize_loss above).  Three dependent launches of 4-13 us each were ~28 us of a
+// 330 us step, most of it launch and drain latency.  Every workgroup also pre-reduces a slice of the
+// loss and sum-of-squares partials (fp64) and publishes its two sums; the workgroup with the HIGHEST
+// index (dispatched last) collects them in workgroup order and publishes the loss -- a fixed
+// association.  No fence anywhere: a published value is ONE 64-bit agent-scope store that carries the
+// launch's sequence number in its upper half, so value and "ready" flag arrive together (a release
+// fence per workgroup -- an L2 write-back on this multi-XCD part -- made the first version of this
+// kernel take 23 us; nothing but these words has to be visible inside the launch).  The collector
+// never blocks anyone: every other workgroup runs to completion without waiting.
+struct TailArgs {
+    const float* part;            // [splits][stride]: dW (n_w) then db (n_b) partial slabs
+    int splits;
+    unsigned long long stride;
+    float *W, *b, *s0_w, *s1_w, *s0_b, *s1_b, *g_w, *g_b;
+    unsigned n_w, n_b;
+    AdamArgs aa;                  // l2k applies to W only (the bias is not regularised)
+    const float* loss_partials; int n_loss;
+    const float* sq_partials; int n_sq;    // sums of squares of the tensors updated before this launch
+    float inv_batch, reg_scale;
+    float* out;                   // [3] loss, data term, reg term (device or pinned host)
+    unsigned* host_flag; unsigned seq;
+    unsigned long long* blk;      // [2 * gridDim.x] (launch sequence number << 32) | float bits
+    unsigned launch_seq;          // != 0, different from the previous launch's
+};
+
+template <bool STORE_G>
+__global__ __launch_bounds__(1024) void vs_tail(const TailArgs t) {
+    __shared__ float red[16][64];
+    __shared__ double dred[2][16];
+    const int l = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const unsigned count = t.n_w + t.n_b;
+    const unsigned i = blockIdx.x * 64u + (unsigned)l;
+    float a = 0.f;
+    if (i < count) {
+#pragma unroll 8
+        for (int s = g; s < t.splits; s += 16) a += t.part[(size_t)s * t.stride + i];
+    }
+    red[g][l] = a;
+    double ls = 0.0, sq = 0.0;
+    for (int k = blockIdx.x * 1024 + threadIdx.x; k < t.n_loss; k += gridDim.x * 1024) ls += (double)t.loss_partials[k];
+    for (int k = blockIdx.x * 1024 + threadIdx.x; k < t.n_sq; k += gridDim.x * 1024) sq += (double)t.sq_partials[k];
+    __syncthreads();
+    if (g == 0 && i < count) {
+        float q[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[k] = (red[4 * k][l] + red[4 * k + 1][l]) + (red[4 * k + 2][l] + red[4 * k + 3][l]);
+        float gg = ((q[0] + q[1]) + q[2]) + q[3];   // (= reduce_partials_g<16>)
+        AdamArgs aa = t.aa;
+        const float omb1 = 1.0f - aa.b1, omb2 = 1.0f - aa.b2;
+        float ssf = 0.f;
+        if (i < t.n_w) {
+            float pp = t.W[i], m = t.s0_w[i], v = t.s1_w[i];
+            adam_elem(pp, gg, m, v, aa, omb1, omb2, ssf);
+            t.W[i] = pp; t.s0_w[i] = m; t.s1_w[i] = v;
+            if (STORE_G) t.g_w[i] = gg;
+            sq += (double)ssf;
+        } else {
+            const unsigned j = i - t.n_w;
+            aa.l2k = 0.f;
+            float pp = t.b[j], m = t.s0_b[j], v = t.s1_b[j];
+            adam_elem(pp, gg, m, v, aa, omb1, omb2, ssf);
+            t.b[j] = pp; t.s0_b[j] = m; t.s1_b[j] = v;
+            if (STORE_G) t.g_b[j] = gg;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        ls += __shfl_xor(ls, off);
+        sq += __shfl_xor(sq, off);
+    }
+    if (l == 0) { dred[0][g] = ls; dred[1][g] = sq; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        double x = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) x += dred[threadIdx.x][w];
+        const unsigned long long word = ((unsigned long long)t.launch_seq << 32) | (unsigned long long)__float_as_uint((float)x);
+        __hip_atomic_store(t.blk + 2 * blockIdx.x + threadIdx.x, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (blockIdx.x != gridDim.x - 1) return;
+    // ---- the collector: wait for every workgroup's two words, add them in workgroup order ----
+    __syncthreads();
+    double c0 = 0.0, c1 = 0.0;
+    for (unsigned k = threadIdx.x; k < gridDim.x; k += 1024) {
+        unsigned long long w0, w1;
+        do { w0 = __hip_atomic_load(t.blk + 2 * k + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((unsigned)(w0 >> 32) != t.launch_seq);
+        do { w1 = __hip_atomic_load(t.blk + 2 * k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((unsigned)(w1 >> 32) != t.launch_seq);
+        c0 += (double)__uint_as_float((unsigned)w0);
+        c1 += (double)__uint_as_float((unsigned)w1);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        c0 += __shfl_xor(c0, off);
+        c1 += __shfl_xor(c1, off);
+    }
+    if (l == 0) { dred[0][g] = c0; dred[1][g] = c1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double loss_sum = 0.0, sq_sum = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { loss_sum += dred[0][w]; sq_sum += dred[1][w]; }
+        const float data = (float)loss_sum * t.inv_batch;
+        const float reg = t.reg_scale * (float)sq_sum;
+        t.out[0] = data + reg;
+        t.out[1] = data;
+        t.out[2] = reg;
+        if (t.host_flag) __hip_atomic_store(t.host_flag, t.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 }  // namespace sert

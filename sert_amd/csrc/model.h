@@ -166,6 +166,13 @@ struct sert_model {
     int ll_U = 0;
     float* skbuf = nullptr;       // split-K partials of the long-K dX GEMMs (grown on demand)
     size_t skbuf_count = 0;
+    // single-GPU vectorspace step: split-K combine + W, b update + loss finalisation as one launch
+    // (kernels_opt.h: vs_tail).  tail_splits > 0: this step's dW / db still sit in `part` as that
+    // many partial slabs, tail_stride elements apart
+    unsigned long long* tail_blk = nullptr;
+    unsigned tail_launch_seq = 0;
+    int tail_splits = 0;
+    size_t tail_stride = 0;
     float* red_loss = nullptr;    // loss partials [kOptBlocks]
     float* red_sq = nullptr;      // sumsq partials [3 * kOptBlocks]
     float* d_loss = nullptr;      // [3] loss, data term, reg term (device)

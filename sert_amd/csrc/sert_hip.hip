@@ -822,7 +822,15 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
             launch_gemm<true, false, EPI_STORE, true>(sd, m->H, m->DA, m->part, nullptr, dw, de,
                                                       B, dw, de, de, splits, kper, stride);
         }
-        {
+        // single GPU: the combine rides in the step's tail launch (vs_tail) with the W, b update and
+        // the loss finalisation
+        static const bool no_tail = getenv("SERT_NO_TAIL") != nullptr;   // cross-check knob
+        m->tail_splits = 0;
+        if (!no_tail && !is_dp(m) && sd == m->stream && m->cfg.kind == SERT_KIND_VECTORSPACE && !m->pt_big[2] &&
+            mn + de < ((size_t)1 << 31)) {
+            m->tail_splits = splits;
+            m->tail_stride = stride;
+        } else {
             ScopedTimer t(m, TG_SPLITK);
             launch_reduce_partials(sd, m->part,
                                splits, stride, stride, m->g_w, mn, m->g_b);
@@ -1353,7 +1361,11 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
         }
         n_sq += blocks;
     };
-    if (split_small && dw_third_queue(m)) {
+    const int tail_splits = m->tail_splits;
+    m->tail_splits = 0;
+    if (tail_splits > 0) {
+        small_tensors(ss, 0x2u);          // R_e; W and b are updated by the tail launch below
+    } else if (split_small && dw_third_queue(m)) {
         small_tensors(m->stream3, 0xCu);  // W, b: behind dW and its combine on the third queue
         SERT_HIP(hipEventRecord(m->ev_join3, m->stream3));
         SERT_HIP(hipStreamWaitEvent(m->stream, m->ev_join3, 0));
@@ -1381,6 +1393,24 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
         const float* lp = is_dp(m) ? m->g_loss : m->red_loss;
         const int nl = is_dp(m) ? 1 : n_loss_partials;
         unsigned* flag = publish ? reinterpret_cast<unsigned*>(loss_dst + 4) : nullptr;
+        if (tail_splits > 0) {
+            TailArgs ta;
+            ta.part = m->part; ta.splits = tail_splits; ta.stride = m->tail_stride;
+            ta.W = m->W; ta.b = m->b; ta.s0_w = m->s0_w; ta.s1_w = m->s1_w; ta.s0_b = m->s0_b; ta.s1_b = m->s1_b;
+            ta.g_w = m->g_w; ta.g_b = m->g_b;
+            ta.n_w = (unsigned)m->n_w; ta.n_b = (unsigned)m->n_b;
+            ta.aa = aa;
+            ta.loss_partials = lp; ta.n_loss = nl;
+            ta.sq_partials = m->red_sq; ta.n_sq = n_sq;
+            ta.inv_batch = inv_batch; ta.reg_scale = reg_scale;
+            ta.out = loss_dst; ta.host_flag = flag; ta.seq = publish ? ++m->loss_seq : 0u;
+            ta.blk = m->tail_blk;
+            if (++m->tail_launch_seq == 0) ++m->tail_launch_seq;   // (0 = "never written")
+            ta.launch_seq = m->tail_launch_seq;
+            const int nb = cdiv((int64_t)(m->n_w + m->n_b), 64);
+            if (c.keep_grads) hipLaunchKernelGGL((vs_tail<true>), dim3(nb), dim3(1024), 0, m->stream, ta);
+            else              hipLaunchKernelGGL((vs_tail<false>), dim3(nb), dim3(1024), 0, m->stream, ta);
+        } else
         hipLaunchKernelGGL(finalize_loss, dim3(1), dim3(256), 0, m->stream, lp, nl, m->red_sq,
                            n_sq, inv_batch, reg_scale, loss_dst, flag, publish ? ++m->loss_seq : 0u,
                            is_dp(m) ? (const float*)m->g_sq : (const float*)nullptr);
@@ -1829,6 +1859,9 @@ static int create_resources(sert_model* m) {
         SERT_TRY(dzalloc(&m->red_sq, (size_t)8 * kOptBlocks, s));  // partials of up to 4 tensors (<= 2 kOptBlocks each)
         SERT_TRY(dzalloc(&m->sq_scratch, (size_t)8 * kOptBlocks, s));
         SERT_TRY(dzalloc(&m->d_loss, (size_t)4, s));
+        if (vs) {
+            SERT_TRY(dzalloc(&m->tail_blk, (size_t)2 * (cdiv((int64_t)(m->n_w + m->n_b), 64) + 1), s));
+        }
     }
     // pinned, device-mapped: [loss, data, reg, -, seq]; the step's last kernel writes it directly
     SERT_HIP(hipHostMalloc((void**)&m->h_loss, 8 * sizeof(float), hipHostMallocMapped | hipHostMallocCoherent));
@@ -1877,6 +1910,7 @@ int sert_destroy(sert_model* m) {
         }
     }
     (void)hipFree(m->sq_scratch);
+    (void)hipFree(m->tail_blk);
     if (m->comm_stream) (void)hipStreamDestroy(m->comm_stream);
     float* bufs[] = {m->rw, m->re, m->W, m->b, m->s0_rw, m->s0_re, m->s0_w, m->s0_b, m->s1_rw,
                      m->s1_re, m->s1_w, m->s1_b, m->gflat, m->H, m->T, m->DA, m->DH, m->rowloss,

@@ -56,46 +56,67 @@ def glorot(rng, shape):
 
 
 def group_work(kind, B, n, s, dw, de, Ve, Vw, z, distinct_words=None):
-    """Algorithmic bytes / flops per timed kernel group (SURVEY 8(d) per-pair figures x the pairs
-    one step processes; per-step optimiser term 32 B per parameter).  Keys = timing group names
-    of libsert_hip.so (sert_timing_name).  Loglinear: the GEMMs and the gather run on the
-    batch's DISTINCT words (duplicate tokens share a logit row), so their EXECUTED work is
-    counted with U = distinct_words rows instead of B n."""
+    """Per timed kernel group: what it is priced against and how much work one launch does.
+
+      kind 'mfma'   : flops (executed)                              -> fp32 MFMA peak
+      kind 'stream' : bytes streamed once (32 B per parameter and step for the optimiser)
+                      -> HBM spec peak and the MEASURED achievable rate of the same access shape
+      kind 'rows'   : data-dependent row fetches out of a table that fits the caches (L2 / Infinity
+                      Cache): `fetch` = bytes of rows actually fetched per launch, priced against the
+                      MEASURED row-fetch ceilings (bench.memory_ceilings) -- `alg` keeps SURVEY 8(d)'s
+                      per-pair figure, which also counts the read-modify-write of gradient rows that
+                      the order-fixed reductions keep in registers
+    Keys = timing group names of libsert_hip.so (sert_timing_name).  Loglinear: the GEMMs and the
+    gather run on the batch's DISTINCT words (duplicate tokens share a logit row), so their
+    EXECUTED work is counted with U = distinct_words rows instead of B n."""
+    def mfma(fl): return dict(kind='mfma', flops=fl)
+    def stream(by, **kw): return dict(kind='stream', alg=by, **kw)
+    def rows(alg, fetch, row_bytes, table_bytes, resident=None): return dict(
+        kind='rows', alg=alg, fetch=fetch, row_bytes=row_bytes, table_bytes=table_bytes, resident=resident)
+    P_w = 32.0 * Vw * dw
     if kind in ('vectorspace', 'vectorspace_softmax'):
         w = {
-            'gather':               ('hbm', B * (n * s + 4 * n * dw)),          # vs_gather_mean
-            'gemm_fwd':             ('mfma', 2.0 * B * dw * de),               # gemm_f32_mfma NN+tanh
-            'gemm_dW':              ('mfma', 2.0 * B * dw * de),               # gemm_f32_mfma TN split-K
-            'splitk_combine':       ('hbm', 4.0 * 1024 * (dw * de + de)),      # reduce_partials
-            'gemm_dX':              ('mfma', 2.0 * B * dw * de),               # gemm_f32_mfma NT
-            'word_grad_segsum':     ('hbm', B * (8 * n * dw)),                 # segsum_rows
-            'optimizer_word_table': ('hbm', 32.0 * Vw * dw),                   # adam_l2 (R_w)
-            'optimizer_other':      ('hbm', 32.0 * (Ve * de + dw * de + de)),  # adam_l2 (R_e, W, b)
+            'gather':               rows(B * (n * s + 4 * n * dw), B * 4.0 * n * dw, 4 * dw, 4.0 * Vw * dw),   # vs_gather_mean
+            'gemm_fwd':             mfma(2.0 * B * dw * de),               # gemm_f32_mfma NN+tanh
+            'gemm_dW':              mfma(2.0 * B * dw * de),               # gemm_f32_mfma TN split-K
+            'splitk_combine':       stream(4.0 * 1024 * (dw * de + de)),   # reduce_partials
+            'gemm_dX':              mfma(2.0 * B * dw * de),               # gemm_f32_mfma NT
+            'word_grad_segsum':     rows(B * (8.0 * n * dw), B * 4.0 * n * dw, 4 * dw, 4.0 * B * dw),   # segsum_rows: rows of dh
+            'optimizer_word_table': stream(P_w, optimizer_elems=Vw * dw),  # adam_l2 (R_w)
+            # adam_l2 over R_e where it is a big table (C4), else one optimizer_small launch: launch latency
+            'optimizer_other':      (stream(32.0 * (Ve * de + dw * de + de), optimizer_elems=Ve * de) if Ve * de > (1 << 22)
+                                     else dict(kind='latency', alg=32.0 * (Ve * de + dw * de + de))),
         }
         if kind == 'vectorspace':
             w.update({
-                'loss':               ('hbm', B * (8 + 4 * (1 + z) * de)),     # vs_nce
-                'entity_sort':        ('hbm', B * (1 + z) * 16.0),             # csort_* (keys+values r/w)
-                'entity_grad_reduce': ('hbm', B * (8 * (1 + z) * de)),         # egrad_chunk_reduce
-                'entity_grad_fixup':  ('hbm', 8.0 * Ve * de),                  # egrad_fixup
+                # vs_nce(_regs): (1+z) entity rows per pair out of R_e (+ the pair's own t row)
+                'loss':               rows(B * (8 + 4.0 * (1 + z) * de), B * 4.0 * (2 + z) * de, 4 * de, 4.0 * Ve * de),
+                'entity_sort':        dict(kind='latency', alg=B * (1 + z) * 16.0),            # egrad_bucket / csort_*
+                # egrad_acc / egrad_chunk_reduce: one row of clip(t) per (pair, candidate); row groups of
+                # <= 2 MB stay in one XCD's L2 on the sort-free path
+                'entity_grad_reduce': rows(B * (8.0 * (1 + z) * de), B * 4.0 * (1 + z) * de, 4 * de, 4.0 * B * de,
+                                           resident='l2' if Ve <= 2048 else None),
+                'entity_grad_fixup':  stream(8.0 * Ve * de),                                   # egrad_fixup
             })
         else:   # full softmax over the entity vocabulary: logits / dR_e / dp GEMMs dominate
-            w['gemm_fwd'] = ('mfma', 2.0 * B * dw * de + 2.0 * B * de * Ve)
-            w['entity_grad_reduce'] = ('mfma', 2.0 * B * de * Ve)
-            w['gemm_dX'] = ('mfma', 2.0 * B * dw * de + 2.0 * B * de * Ve)
-            w['loss'] = ('hbm', B * 8.0 * Ve)
+            w['gemm_fwd'] = mfma(2.0 * B * dw * de + 2.0 * B * de * Ve)
+            w['entity_grad_reduce'] = mfma(2.0 * B * de * Ve)
+            w['gemm_dX'] = mfma(2.0 * B * dw * de + 2.0 * B * de * Ve)
+            w['loss'] = stream(B * 8.0 * Ve)
         return w
     U = distinct_words if distinct_words else B * n
     return {
-        'gather':               ('hbm', U * (s + 4.0 * dw)),
-        'gemm_fwd':             ('mfma', 2.0 * U * dw * Ve),
-        'loss':                 ('hbm', B * (4.0 * n * Ve + 4.0 * Ve)),          # n table rows read, dJ written
-        'per_word_dz_sums':     ('hbm', B * n * 4.0 * Ve + U * 4.0 * Ve),
-        'gemm_dW':              ('mfma', 2.0 * U * dw * Ve),
-        'gemm_dX':              ('mfma', 2.0 * U * dw * Ve),
-        'word_grad_segsum':     ('hbm', U * (8.0 * dw)),
-        'optimizer_word_table': ('hbm', 32.0 * Vw * dw),
-        'optimizer_other':      ('hbm', 32.0 * (dw * Ve + Ve)),
+        'gather':               rows(U * (s + 4.0 * dw), U * 4.0 * dw, 4 * dw, 4.0 * Vw * dw),
+        'gemm_fwd':             mfma(2.0 * U * dw * Ve),
+        # ll_row_from_table: n rows of the (U, V_e) log-probability table per batch row, dJ written
+        'loss':                 rows(B * (4.0 * n * Ve + 4.0 * Ve), B * 4.0 * n * Ve, 4 * Ve, 4.0 * U * Ve),
+        'per_word_dz_sums':     rows(B * n * 4.0 * Ve + U * 4.0 * Ve, B * n * 4.0 * Ve, 4 * Ve, 4.0 * B * Ve),
+        'gemm_dW':              mfma(2.0 * U * dw * Ve),
+        'gemm_dX':              mfma(2.0 * U * dw * Ve),
+        'word_grad_segsum':     rows(U * (8.0 * dw), U * 4.0 * dw, 4 * dw, 4.0 * U * dw),
+        'optimizer_word_table': stream(P_w, optimizer_elems=Vw * dw),
+        'optimizer_other':      (stream(32.0 * (dw * Ve + Ve), optimizer_elems=dw * Ve) if dw * Ve > (1 << 22)
+                                 else dict(kind='latency', alg=32.0 * (dw * Ve + Ve))),
     }
 
 
@@ -105,7 +126,7 @@ def group_work(kind, B, n, s, dw, de, Ve, Vw, z, distinct_words=None):
 _COMMON_KERNELS = {
     'gemm_dW': ('gemm_f32_mfma<true, false, 0',), 'splitk_combine': ('reduce_partials',),
     'gemm_dX': ('gemm_f32_mfma<false, true, 0',), 'word_grad_segsum': ('segsum_rows<',),
-    'optimizer_other': ('optimizer_small',), 'finalize': ('finalize_loss',),
+    'optimizer_other': ('optimizer_small',), 'finalize': ('vs_tail', 'finalize_loss'),
 }
 KERNELS_OF_GROUP = {
     'vectorspace': dict(_COMMON_KERNELS, **{
@@ -184,46 +205,158 @@ def timed_steps(model, dist, num_batches, steps, warmup, timing=True):
     return dist.all_reduce_max(dt), timings, float(last)
 
 
-def kernel_table(timings, work):
-    """Per timing group: HIP-event average, algorithmic work, achieved rate and its fraction of
-    the bounding peak.  A memory-bound group whose ALGORITHMIC byte rate exceeds the HBM peak is
-    served from the Infinity Cache / L2 (its tables fit the 256 MB die cache): labelled
-    bound = 'cache' -- its fraction says how far above an HBM-only execution it runs, not how
-    well it uses HBM."""
+_CEIL_CACHE = {}
+
+
+def memory_ceilings(_capi, row_bytes, table_bytes_list, optimizer_elems=()):
+    """What this box's memory system delivers (sert_bench_memory, HIP events, run in this process):
+    float4 stream copy and read (achievable HBM), the step's own window gather over uniformly random
+    rows of `row_bytes` out of tables of the given sizes (the L2-resident one is the row-fetch PEAK, the
+    others the Infinity-Cache / HBM rates a table of that size sustains), and the dense optimiser's
+    seven streams over tensors of the given element counts."""
+    MB = 1 << 20
+    out = _CEIL_CACHE.setdefault('stream', {})
+    if not out:
+        us = _capi.bench_memory(_capi.MEMBENCH_COPY, 1200 * MB, blocks=4096, iters=10)
+        out['copy_GBps'] = 2 * 1200 * MB / (us * 1e-6) / 1e9
+        us = _capi.bench_memory(_capi.MEMBENCH_READ, 1200 * MB, blocks=4096, iters=10)
+        out['read_GBps'] = 1200 * MB / (us * 1e-6) / 1e9
+    res = dict(out)
+    rows = _CEIL_CACHE.setdefault('rows', {})
+    want = [(row_bytes, 512 * 1024)] + [(row_bytes, int(t)) for t in table_bytes_list]
+    for rb, tb in want:
+        rb16 = max(16, (int(rb) + 15) // 16 * 16)
+        key = (rb16, max(tb, rb16))
+        if key not in rows:
+            out_bytes = 65536 * rb16
+            us = _capi.bench_memory(_capi.MEMBENCH_GATHER, out_bytes, table_bytes=key[1], row_bytes=rb16, window=10, iters=10)
+            rows[key] = out_bytes * 10 / (us * 1e-6) / 1e9
+    res['row_fetch_GBps'] = {'%dB_rows_of_%.1fMB' % (k[0], k[1] / 1e6): round(v, 1) for k, v in rows.items() if k[0] == max(16, (int(row_bytes) + 15) // 16 * 16)}
+    opt = _CEIL_CACHE.setdefault('opt', {})
+    for n in optimizer_elems:
+        n = int(n)
+        if n >= (1 << 16) and n not in opt:
+            us = _capi.bench_memory(_capi.MEMBENCH_OPTIMIZER, n * 4, gap_bytes=_capi.SEPARATE_ALLOCATIONS,
+                                    blocks=4096 if n >= (1 << 24) else 2048, iters=10)
+            opt[n] = 28.0 * n / (us * 1e-6) / 1e9
+    res['optimizer_stream_GBps'] = {str(n): round(v, 1) for n, v in opt.items() if n in [int(x) for x in optimizer_elems]}
+    return res
+
+
+def ceilings_for(_capi, work):
+    """memory_ceilings for every row width / table size / optimiser tensor a work table names."""
+    merged = {}
+    opt = [w_.get('optimizer_elems', 0) for w_ in work.values() if w_['kind'] == 'stream']
+    widths = sorted(set(w_['row_bytes'] for w_ in work.values() if w_['kind'] == 'rows')) or [512]
+    for rb in widths:
+        c = memory_ceilings(_capi, rb, [w_['table_bytes'] for w_ in work.values() if w_['kind'] == 'rows' and w_['row_bytes'] == rb], opt)
+        rf = dict(merged.get('row_fetch_GBps', {}))
+        rf.update(c['row_fetch_GBps'])
+        merged.update(c)
+        merged['row_fetch_GBps'] = rf
+    return merged
+
+
+def _row_ceiling(row_bytes, table_bytes):
+    rows = _CEIL_CACHE.get('rows', {})
+    rb16 = max(16, (int(row_bytes) + 15) // 16 * 16)
+    l2 = rows.get((rb16, max(512 * 1024, rb16)))
+    same = [(abs(k[1] - table_bytes), v) for k, v in rows.items() if k[0] == rb16]
+    return l2, (min(same)[1] if same else None)
+
+
+def kernel_table(timings, work, traffic=None):
+    """Per timing group: HIP-event average, work per launch, achieved rate and its fraction of the
+    bound it is priced against.  No fraction is taken against a peak the kernel does not run on:
+
+      mfma   : executed flops / time / fp32 MFMA dense peak
+      hbm    : streamed bytes / time / 8 TB/s spec, plus frac_of_achievable against the MEASURED rate of
+               the same access shape on this box (stream copy, or the optimiser's seven streams over a
+               tensor of the same size) -- with the PMC-counted bytes as numerator where a counter
+               pass ran.  A streaming group whose counters show < 0.7 of its algorithmic bytes crossing
+               the fabric is not HBM-bound: relabelled 'cache'
+      cache  : row-fetch bytes / time / the MEASURED L2 row-fetch peak (uniformly random rows of the same
+               width out of an L2-resident table, the gather kernel's own access shape); the rate a
+               table of the kernel's real source size sustains under uniformly random ids is given
+               beside it (`table_ceiling_GBps`; a Zipfian id stream can beat that one, never the peak)
+    """
     kernels = {}
+    traffic = traffic or {}
+    stream_ceil = _CEIL_CACHE.get('stream', {})
     for name, us in timings.items():
         if us <= 0:
             continue
-        if name not in work:
-            kernels[name] = dict(us=round(us, 2))
+        wk = work.get(name)
+        if wk is None or wk['kind'] == 'latency':
+            kernels[name] = dict(us=round(us, 2), bound='latency')
             continue
-        bound, amount = work[name]
-        if bound == 'hbm':
-            ach = amount / (us * 1e-6) / 1e9
-            kernels[name] = dict(us=round(us, 2), bound='cache' if ach > HBM_PEAK_GBS else 'hbm',
-                                 achieved=round(ach, 1), unit='GB/s', frac=round(ach / HBM_PEAK_GBS, 4),
-                                 algorithmic_bytes=amount)
-        else:
-            ach = amount / (us * 1e-6) / 1e12
+        t = us * 1e-6
+        counted = traffic.get(name, {}).get('hbm_bytes')
+        if wk['kind'] == 'mfma':
+            ach = wk['flops'] / t / 1e12
             kernels[name] = dict(us=round(us, 2), bound='mfma', achieved=round(ach, 2), unit='TFLOP/s',
-                                 frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), algorithmic_flops=amount)
+                                 frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), algorithmic_flops=wk['flops'])
+            continue
+        kind = wk['kind']
+        if kind == 'stream' and counted is not None and counted < 0.7 * wk['alg']:
+            kind = 'rows'     # (served by the caches: price the bytes it asks for as row fetches)
+            wk = dict(wk, fetch=wk['alg'], row_bytes=512, table_bytes=0, resident=None)
+        if kind == 'stream':
+            ach = wk['alg'] / t / 1e9
+            rec = dict(us=round(us, 2), bound='hbm', achieved=round(ach, 1), unit='GB/s', frac=round(ach / HBM_PEAK_GBS, 4),
+                       algorithmic_bytes=wk['alg'])
+            # achievable = the best streaming rate measured on this box for this shape: the read-only stream
+            # bounds every read/write mix from above; the optimiser's own seven streams over a tensor of the
+            # same size can beat it where the Infinity Cache holds part of the tensor
+            opt_rate = _CEIL_CACHE.get('opt', {}).get(int(wk.get('optimizer_elems') or 0))
+            achievable = max([x for x in (opt_rate, stream_ceil.get('read_GBps'), stream_ceil.get('copy_GBps')) if x] or [0])
+            if achievable:
+                moved = counted if counted is not None else wk.get('executed', wk['alg'])
+                rec['achievable_GBps'] = round(achievable, 1)
+                rec['frac_of_achievable'] = round(min(moved, wk['alg']) / t / 1e9 / achievable, 4)
+                rec['achievable_is'] = ('adam_l2 over a tensor of the same size' if opt_rate and opt_rate >= achievable
+                                        else 'float4 read stream over 1.2 GB')
+            kernels[name] = rec
+        else:
+            ach = wk['fetch'] / t / 1e9
+            l2, same = _row_ceiling(wk['row_bytes'], wk['table_bytes'])
+            rec = dict(us=round(us, 2), bound='cache', achieved=round(ach, 1), unit='GB/s', row_fetch_bytes=wk['fetch'],
+                       algorithmic_bytes=wk['alg'])
+            if l2:
+                rec['peak'] = round(l2, 1)
+                rec['peak_is'] = 'measured L2 row-fetch rate (uniformly random %d-byte rows of an L2-resident table)' % wk['row_bytes']
+                rec['frac'] = round(ach / l2, 4)
+            if same and not wk.get('resident'):
+                rec['table_ceiling_GBps'] = round(same, 1)
+            kernels[name] = rec
+        if counted is not None:
+            kernels[name]['hbm_bytes_pmc'] = counted
     return kernels
 
 
 def roofline_of(kernels, traffic_by_group=None, traffic_source=None, kind='vectorspace'):
     """The LONGEST kernel group (whatever it is).  frac = achieved / peak with achieved =
     algorithmic work / measured time (the contract's definition); frac_counter = the same with
-    the PMC-counted bytes (what the memory system really moved)."""
-    cand = [k for k in kernels if 'bound' in kernels[k]]
+    the PMC-counted bytes (what the memory system really moved); achievable_peak / frac_of_achievable:
+    against the rate this box's memory system was measured to deliver for the same access shape."""
+    cand = [k for k in kernels if kernels[k].get('bound') in ('hbm', 'mfma', 'cache')]
     dom = max(cand, key=lambda k: kernels[k]['us'])
     kd = kernels[dom]
     mem = kd['bound'] != 'mfma'
     names = kernels_of_group(kind, dom)
-    out = dict(kernel=dom, hip_kernel=names[0] if names else None, bound='hbm' if mem else 'mfma',
-               achieved=kd['achieved'], peak=HBM_PEAK_GBS if mem else MFMA_F32_PEAK_TFLOPS,
-               unit=kd['unit'], frac=kd['frac'], avg_us=kd['us'], traffic=None)
     if kd['bound'] == 'cache':
-        out['served_from'] = 'Infinity Cache / L2 (the algorithmic byte rate exceeds the HBM peak)'
+        out = dict(kernel=dom, hip_kernel=names[0] if names else None, bound='hbm',
+                   achieved=kd['achieved'], peak=kd.get('peak'), unit='GB/s', frac=kd.get('frac'), avg_us=kd['us'], traffic=None,
+                   served_from='L2 / Infinity Cache: priced against the measured L2 row-fetch peak, not the HBM peak',
+                   table_ceiling_GBps=kd.get('table_ceiling_GBps'))
+    else:
+        out = dict(kernel=dom, hip_kernel=names[0] if names else None, bound='hbm' if mem else 'mfma',
+                   achieved=kd['achieved'], peak=HBM_PEAK_GBS if mem else MFMA_F32_PEAK_TFLOPS,
+                   unit=kd['unit'], frac=kd['frac'], avg_us=kd['us'], traffic=None)
+        if 'achievable_GBps' in kd:
+            out['achievable_peak'] = kd['achievable_GBps']
+            out['achievable_is'] = kd.get('achievable_is')
+            out['frac_of_achievable'] = kd['frac_of_achievable']
     tr = (traffic_by_group or {}).get(dom)
     if tr:
         if tr.get('hip_kernel'):
@@ -231,18 +364,19 @@ def roofline_of(kernels, traffic_by_group=None, traffic_source=None, kind='vecto
         out['traffic'] = tr['hbm_bytes']
         out['traffic_source'] = traffic_source
         out['avg_us_profiled'] = tr['avg_us_profiled']
-        if mem:
+        if mem and kd.get('algorithmic_bytes'):
             out['frac_counter'] = round(tr['hbm_bytes'] / (kd['us'] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
             out['traffic_over_algorithmic'] = round(tr['hbm_bytes'] / kd['algorithmic_bytes'], 3)
     return out
 
 
 # ---- live PMC passes --------------------------------------------------------------------
-def pmc_traffic_live(args, timeout=240):
-    """HBM bytes per launch of every kernel of the C2 step: two rocprofv3 passes (FETCH_SIZE and
+def pmc_traffic_live(inner_args, timeout=300, steps=12):
+    """HBM bytes per launch of every kernel of a step: two rocprofv3 passes (FETCH_SIZE and
     WRITE_SIZE do not fit one TCC pass; --kernel-trace only beside them, as
-    MI355X_MICROARCH.md prescribes) over a short run of THIS script's headline workload, read
-    back with tools/rocpd_pmc.py's corrections (FETCH_SIZE x 2 on gfx950)."""
+    MI355X_MICROARCH.md prescribes) over a short run of THIS script's inner loop on the workload
+    `inner_args` describes (--model / --batch / --vocab / ...), read back with tools/rocpd_pmc.py's
+    corrections (FETCH_SIZE x 2 on gfx950)."""
     if shutil.which('rocprofv3') is None:
         return None, 'rocprofv3 not found'
     sys.path.insert(0, os.path.join(ROOT, 'tools'))
@@ -253,9 +387,8 @@ def pmc_traffic_live(args, timeout=240):
         for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
             out = os.path.join(tmp, counter)
             cmd = ['rocprofv3', '--kernel-trace', '--pmc', counter, '-d', out, '-o', 'p', '--',
-                   sys.executable, os.path.abspath(__file__), '--profile-inner', '--steps', '12', '--warmup', '3',
-                   '--batch', str(args.batch or 65536), '--vocab', str(args.vocab), '--entities', str(args.entities),
-                   '--dim', str(args.dim), '--window', str(args.window), '--negatives', str(args.negatives)]
+                   sys.executable, os.path.abspath(__file__), '--profile-inner', '--steps', str(steps), '--warmup', '3'] + \
+                  [str(a) for a in inner_args]
             env = dict(os.environ, TMPDIR='/tmp')
             for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
                 env.pop(k, None)
@@ -273,18 +406,19 @@ def pmc_traffic_live(args, timeout=240):
             per[k] = dict(hbm_bytes=2 * f + w, fetch_bytes_corrected=2 * f, write_bytes=w,
                           avg_us_profiled=fetch.get(k, write.get(k, {})).get('us', 0.0),
                           calls=fetch.get(k, write.get(k, {})).get('calls', 0))
-        return per, 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run by this bench (12 steps each)'
+        return per, 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run by this bench (%d steps each)' % steps
     except Exception as e:   # noqa: BLE001 -- profiling is best effort, the bench line must still appear
         return None, 'live PMC passes failed: %r' % (e,)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def traffic_by_group(per_kernel, kernels, kind='vectorspace'):
+def traffic_by_group(per_kernel, timings, kind='vectorspace'):
     """Match the profiled kernels ('name @grid') to the timing groups: the launch of the group's
     dominant kernel whose profiled duration is closest to the live HIP-event average."""
     out = {}
-    for group, kd in kernels.items():
+    for group, us in timings.items():
+        kd = {'us': us}
         prefixes = kernels_of_group(kind, group)
         if not prefixes or not per_kernel:
             continue
@@ -367,6 +501,16 @@ print('RESULT ' + json.dumps(dict(value=steps * B / dt, steps=steps, seconds=dt,
 '''
 
 
+def _cgroup_quota():
+    """CPUs the container may use according to its cgroup (cpu.max), or None."""
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:
+            q, per = f.read().split()[:2]
+        return None if q == 'max' else round(float(q) / float(per), 2)
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline_mt(B, n, Vw, Ve, dw, de, z, budget_s):
     """oracle/sert_cpu.c (OpenMP) in its own process, pinned to the physical cores of socket 0."""
     tmp = tempfile.mkdtemp(prefix='sert_cpu_')
@@ -391,9 +535,13 @@ def cpu_baseline_mt(B, n, Vw, Ve, dw, de, z, budget_s):
         return dict(value=res['value'], unit='pairs/s', cores=res['cores'], kind='port',
                     ms_per_step=res['ms_per_step'], phases_ms_fastest_step=res.get('phases_ms'),
                     sample='%d steps of B=%d (%.1f s) of the same workload: multithreaded C restatement of the reference '
-                           'graph (oracle/sert_cpu.c, %s; OpenMP, %d threads pinned to the %d physical cores of socket 0; '
-                           'order-fixed segmented sums, fused L2 + Adam) -- not Theano, which cannot run here'
-                           % (res['steps'], B, res['seconds'], res['build'], res['threads'], res['cores']))
+                           'graph (oracle/sert_cpu.c, %s; OpenMP, %d threads on the %d CPUs this process may use -- the '
+                           'container\'s cgroup quota (cpu.max) on a host that shows %d hardware threads, not a whole '
+                           'socket; the fastest unthrottled 64-thread step measured on such a host was 13.5 ms = 4.9 M '
+                           'pairs/s, DESIGN.md section 4; order-fixed segmented sums, fused L2 + Adam) -- not Theano, '
+                           'which cannot run here'
+                           % (res['steps'], B, res['seconds'], res['build'], res['threads'], res['cores'], os.cpu_count() or 0),
+                    cgroup_cpu_quota=_cgroup_quota(), unthrottled_64_thread_pairs_per_s_measured_earlier=4.9e6)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
@@ -472,29 +620,62 @@ def query_bench(_capi, Q=10000, V=100000, d=128, k=100, reps=3, cpu_budget=8.0, 
     return out
 
 
-def c4_record(models, dist, steps):
-    """BASELINE configs[3]: V_w=500k, V_e=100k, d=300 with the reference's LSE model at the full
-    batch.  The dense L2 + dense Adam of sert/models.py:764-795, :548-549 make every row of both
-    tables live every step: 32 B x 180 M parameters = 5.8 GB per step is the HBM wall."""
-    Vw, Ve, d, n, z, B = 500000, 100000, 300, 10, 10, 65536
-    rng = np.random.RandomState(4)
-    X, y, w = synth_data(rng, 2 * B, n, Vw, Ve)
-    m = build_model('vectorspace', models, B, n, Vw, Ve, d, d, z, X, y, w, seed=4)
-    dt, _, loss = timed_steps(m, dist, 2, steps, 2, timing=False)
-    _, tm, _ = timed_steps(m, dist, 2, steps, 1, timing=True)
-    work = group_work('vectorspace', B, n, X.dtype.itemsize, d, d, Ve, Vw, z)
-    work['optimizer_other'] = ('hbm', 32.0 * (Ve * d + d * d + d))
-    kernels = kernel_table(tm, work)
-    total_bytes = sum(v for k, (b, v) in work.items() if b == 'hbm' and k in tm)
+def _step_bytes(work, present):
+    """Sum of the algorithmic bytes of the memory-side groups that ran."""
+    return sum(w.get('alg', 0.0) for k, w in work.items() if w['kind'] in ('stream', 'rows', 'latency') and k in present)
+
+
+def measure_record(kind, models, _capi, dist, dims, steps, warmup, seed, live_pmc, num_batches=2, data=None, label=''):
+    """One secondary record (loglinear / additive full softmax / C4): K untimed steps for the rate, the same
+    steps with HIP events for the per-kernel table, the memory ceilings of its table shapes, and --
+    live_pmc -- the two counter passes over the same workload for `traffic`."""
+    B, n, Vw, Ve, d, de, z = dims['B'], dims['n'], dims['Vw'], dims['Ve'], dims['d'], dims['de'], dims['z']
+    if data is None:
+        rng = np.random.RandomState(seed)
+        data = synth_data(rng, num_batches * B, n, Vw, Ve)
+    X, y, w = data
+    m = build_model(kind, models, B, n, Vw, Ve, d, de, z, X, y, w, seed=seed)
+    dt, _, loss = timed_steps(m, dist, num_batches, steps, warmup, timing=False)
+    _, tm, _ = timed_steps(m, dist, num_batches, steps, 1, timing=True)
+    del m
+    U = None
+    if kind == 'loglinear':
+        U = float(np.mean([len(np.unique(X[j * B:(j + 1) * B])) for j in range(num_batches)]))
+    work = group_work(kind, B, n, X.dtype.itemsize, d, de, Ve, Vw, z, U)
+    ceil = ceilings_for(_capi, work)
+    per_kernel, source, tbg = None, None, {}
+    if live_pmc:
+        inner = ['--model', kind, '--batch', B, '--vocab', Vw, '--entities', Ve, '--dim', d, '--entity-dim', de,
+                 '--window', n, '--negatives', z, '--num-batches', num_batches, '--seed', seed]
+        per_kernel, source = pmc_traffic_live(inner, steps=6 if Vw * d > 5e7 else 12)
+        if per_kernel:
+            tbg = traffic_by_group(per_kernel, tm, kind)
+    kernels = kernel_table(tm, work, tbg)
+    roof = roofline_of(kernels, tbg, source, kind=kind)
+    if not tbg:
+        roof['traffic_note'] = source or 'counter passes not requested (--no-live-pmc)'
+    total_bytes = _step_bytes(work, tm)
     rec = {
-        'workload': 'C4 LSE: VectorSpaceLanguageModel (NCE z=%d, Adam) V_w=%d V_e=%d d=%d window=%d batch=%d' % (z, Vw, Ve, d, n, B),
-        'value': steps * B / dt, 'unit': 'pairs/s', 'ms_per_step': 1000 * dt / steps, 'last_loss': loss,
-        'kernels': kernels, 'roofline': roofline_of(kernels),
+        'workload': label, 'value': steps * B / dt, 'unit': 'pairs/s', 'ms_per_step': 1000 * dt / steps, 'last_loss': loss,
+        'kernels': kernels, 'roofline': roof,
+        'memory_ceilings': ceil,
         'whole_step': {'algorithmic_bytes': total_bytes,
                        'achieved_GBps': round(total_bytes / (dt / steps) / 1e9, 1),
                        'frac_of_hbm_peak': round(total_bytes / (dt / steps) / 1e9 / HBM_PEAK_GBS, 4)},
     }
-    del m
+    if U is not None:
+        rec['distinct_words_per_batch'] = U
+    return rec, work, tm, dt
+
+
+def c4_record(models, _capi, dist, steps, live_pmc):
+    """BASELINE configs[3]: V_w=500k, V_e=100k, d=300 with the reference's LSE model at the full
+    batch.  The dense L2 + dense Adam of sert/models.py:764-795, :548-549 make every row of both
+    tables live every step: 32 B x 180 M parameters = 5.8 GB per step is the HBM wall."""
+    dims = dict(B=65536, n=10, Vw=500000, Ve=100000, d=300, de=300, z=10)
+    rec, _, _, _ = measure_record(
+        'vectorspace', models, _capi, dist, dims, steps, 2, 4, live_pmc,
+        label='C4 LSE: VectorSpaceLanguageModel (NCE z=10, Adam) V_w=500000 V_e=100000 d=300 window=10 batch=65536')
     return rec
 
 
@@ -503,7 +684,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--model', choices=['vectorspace', 'loglinear'], default='vectorspace')
+    ap.add_argument('--model', choices=['vectorspace', 'loglinear', 'vectorspace_softmax'], default='vectorspace')
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default 65536)')
     ap.add_argument('--vocab', type=int, default=100000)
     ap.add_argument('--entities', type=int, default=1000)
@@ -512,11 +693,15 @@ def main():
     ap.add_argument('--window', type=int, default=10)
     ap.add_argument('--negatives', type=int, default=10)
     ap.add_argument('--num-batches', type=int, default=8)
+    ap.add_argument('--seed', type=int, default=0, help='seed of the synthetic data set (SURVEY 8-d: seeds 0..2)')
+    ap.add_argument('--weights', choices=['ones', 'uniform'], default='ones',
+                    help='instance weights: 1 (LSE, --no_instance_weights) or U[0.5, 2] (SURVEY 8-d second run)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-budget', type=float, default=12.0)
     ap.add_argument('--no-loglinear-extra', action='store_true')
     ap.add_argument('--no-query-extra', action='store_true')
     ap.add_argument('--no-c4-extra', action='store_true')
+    ap.add_argument('--no-seed-extra', action='store_true', help='skip the seeds 1, 2 and U[0.5, 2]-weights runs')
     ap.add_argument('--no-live-pmc', action='store_true')
     ap.add_argument('--profile-inner', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -546,9 +731,16 @@ def main():
     Bg = Bl * N
     n, Vw, Ve, d, z = args.window, args.vocab, args.entities, args.dim, args.negatives
     de = args.entity_dim or d
-    rng = np.random.RandomState(0)
-    X, y, w = synth_data(rng, args.num_batches * Bg, n, Vw, Ve)
-    model = build_model(kind, models, Bg, n, Vw, Ve, d, de, z, X, y, w, seed=0)
+
+    def dataset(seed, weights):
+        rng = np.random.RandomState(seed)
+        X_, y_, w_ = synth_data(rng, args.num_batches * Bg, n, Vw, Ve)
+        if weights == 'uniform':
+            w_ = rng.uniform(0.5, 2.0, len(w_)).astype(np.float32)
+        return X_, y_, w_
+
+    X, y, w = dataset(args.seed, args.weights)
+    model = build_model(kind, models, Bg, n, Vw, Ve, d, de, z, X, y, w, seed=args.seed)
 
     if args.profile_inner:     # the workload of the rocprofv3 --pmc passes: the steps and nothing else
         timed_steps(model, dist, args.num_batches, args.steps, args.warmup, timing=False)
@@ -576,13 +768,26 @@ def main():
     dist.barrier()
     dt_async = dist.all_reduce_max(time.perf_counter() - t0)
     device_info = _capi.device_info(model._engine.cfg.device)
+    comm = getattr(model, 'comm_info', lambda: None)()
     del model, eng
+
+    # seeds 0..2 and a second run with instance weights w ~ U[0.5, 2] (same K steps each)
+    seed_runs = None
+    if N == 1 and not args.no_seed_extra:
+        seed_runs = {'seed_%d' % args.seed: {'value': value, 'ms_per_step': 1000.0 * dt / args.steps}}
+        for sd, wt in ((1, 'ones'), (2, 'ones'), (args.seed, 'uniform')):
+            Xs, ys, ws = dataset(sd, wt)
+            ms_ = build_model(kind, models, Bg, n, Vw, Ve, d, de, z, Xs, ys, ws, seed=sd)
+            dts, _, _ = timed_steps(ms_, dist, args.num_batches, args.steps, args.warmup, timing=False)
+            seed_runs['seed_%d%s' % (sd, '_w_uniform_0.5_2' if wt == 'uniform' else '')] = {
+                'value': args.steps * Bg / dts, 'ms_per_step': 1000.0 * dts / args.steps}
+            del ms_
 
     # N > 1: the same total work split over the ranks (global batch fixed at 65536)
     strong = None
     if N > 1 and Bl % N == 0:
         ms = build_model(kind, models, Bl, n, Vw, Ve, d, de, z, X[:args.num_batches * Bl], y[:args.num_batches * Bl],
-                         w[:args.num_batches * Bl], seed=0)
+                         w[:args.num_batches * Bl], seed=args.seed)
         dts, _, _ = timed_steps(ms, dist, args.num_batches, args.steps, args.warmup, timing=False)
         strong = {'value': args.steps * Bl / dts, 'unit': 'pairs/s', 'ms_per_step': 1000.0 * dts / args.steps,
                   'global_batch': Bl, 'per_gpu_batch': Bl // N,
@@ -592,28 +797,32 @@ def main():
 
     out = None
     s = X.dtype.itemsize
+    live = not args.no_live_pmc
     if ctx.rank == 0:
         distinct = None
         if kind == 'loglinear':
             distinct = float(np.mean([len(np.unique(X[j * Bg:j * Bg + Bl])) for j in range(args.num_batches)]))
         work = group_work(kind, Bl, n, s, d, de, Ve, Vw, z, distinct)
-        kernels = kernel_table(timings, work)
+        ceilings = ceilings_for(_capi, work)
         per_kernel, traffic_source = (None, None)
-        if N == 1 and kind == 'vectorspace' and not args.no_live_pmc:
-            per_kernel, traffic_source = pmc_traffic_live(args)
-        if per_kernel is None and os.path.exists(os.path.join(ROOT, COMMITTED_PMC)):
+        if N == 1 and live:
+            inner = ['--model', kind, '--batch', Bl, '--vocab', Vw, '--entities', Ve, '--dim', d, '--entity-dim', de,
+                     '--window', n, '--negatives', z, '--num-batches', args.num_batches, '--seed', args.seed,
+                     '--weights', args.weights]
+            per_kernel, traffic_source = pmc_traffic_live(inner)
+        if per_kernel is None and kind == 'vectorspace' and Bl == 65536 and os.path.exists(os.path.join(ROOT, COMMITTED_PMC)):
             why = traffic_source
             with open(os.path.join(ROOT, COMMITTED_PMC)) as f:
                 per_kernel = json.load(f)
             traffic_source = COMMITTED_PMC + ' (committed earlier; live passes unavailable: %s)' % why
-        tbg = traffic_by_group(per_kernel, kernels) if (kind == 'vectorspace' and Bl == 65536) else {}
-        for g, rec in tbg.items():
-            kernels[g]['hbm_bytes_pmc'] = rec['hbm_bytes']
+        tbg = traffic_by_group(per_kernel, timings, kind) if per_kernel else {}
+        kernels = kernel_table(timings, work, tbg)
         roofline = roofline_of(kernels, tbg, traffic_source, kind=kind)
         if per_kernel is None or not tbg:
             roofline['traffic_note'] = traffic_source
-        step_bytes = sum(v for k, (b, v) in work.items() if b == 'hbm' and k in kernels)
-        step_flops = sum(v for k, (b, v) in work.items() if b == 'mfma' and k in kernels)
+        step_bytes = _step_bytes(work, kernels)
+        step_flops = sum(w_['flops'] for k, w_ in work.items() if w_['kind'] == 'mfma' and k in kernels)
+        kernel_sum_us = sum(v['us'] for v in kernels.values())
         out = {
             'metric': 'training_pairs_per_sec', 'value': value, 'unit': 'pairs/s',
             'n_gpus': N, 'steps': args.steps, 'warmup': args.warmup,
@@ -621,18 +830,25 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {
                 'workload': ('C2 LSE: %s V_w=%d V_e=%d d=%d window=%d batch/GPU=%d%s' % (
-                    'VectorSpaceLanguageModel (NCE z=%d, Adam)' % z if kind == 'vectorspace'
-                    else 'LanguageModel (full softmax, Adadelta)',
+                    {'vectorspace': 'VectorSpaceLanguageModel (NCE z=%d, Adam)' % z,
+                     'loglinear': 'LanguageModel (full softmax, Adadelta)',
+                     'vectorspace_softmax': 'VectorSpaceSoftmaxLanguageModel (additive full softmax, Adam)'}[kind],
                     Vw, Ve, d, n, Bl, ('' if de == d else ' d_e=%d' % de) + ('' if N == 1 else ' global_batch=%d' % Bg))),
-                'global_batch': Bg, 'parallelism': 'dp%d' % N if N == 1 else 'dp%d, ZeRO-1 word table (reduce-scatter + sharded Adam + all-gather)' % N,
-                'id_dtype': str(X.dtype), 'lambda': 0.01,
+                'global_batch': Bg,
+                'parallelism': 'dp%d' % N if N == 1 else 'dp%d, %s' % (N, (comm or {}).get('exchange', 'data parallel')),
+                'id_dtype': str(X.dtype), 'lambda': 0.01, 'seed': args.seed,
+                'instance_weights': '1' if args.weights == 'ones' else 'U[0.5, 2]',
             },
             'roofline': roofline,
+            'memory_ceilings': dict(ceilings, note='measured in this process on this box (sert_bench_memory): float4 stream copy / '
+                                    'read over 1.2 GB, vs_gather_mean over uniformly random rows (window 10), adam_l2 over '
+                                    'four separately allocated arrays; spec HBM peak %.0f GB/s' % HBM_PEAK_GBS),
             'whole_step': {
                 'algorithmic_bytes': step_bytes, 'algorithmic_flops': step_flops,
                 'achieved_GBps': round(step_bytes / (dt / args.steps) / 1e9, 1),
                 'frac_of_hbm_peak': round(step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
-                'note': 'sum of the groups\' algorithmic bytes / ms_per_step; much of it is served by the Infinity '
+                'kernel_us_sum_serial': round(kernel_sum_us, 1),
+                'note': 'sum of the groups\' algorithmic bytes / ms_per_step; much of it is served by L2 and the Infinity '
                         'Cache (tables of 51 MB + 33 MB activations), so this is not an HBM utilisation',
             },
             'ms_per_step_instrumented': 1000.0 * dt_instr / args.steps,
@@ -644,54 +860,41 @@ def main():
             'last_loss': last_loss,
             'device': device_info,
         }
+        if seed_runs is not None:
+            vals = [v['value'] for k, v in seed_runs.items() if 'uniform' not in k]
+            out['seeds'] = dict(seed_runs, mean_value_seeds_0_1_2=float(np.mean(vals)),
+                                spread_rel=float((max(vals) - min(vals)) / np.mean(vals)))
+        if comm:
+            out['rccl_ranks'] = comm.get('rccl_ranks')
+            out['comm_bytes_per_step'] = comm.get('comm_bytes_per_step')
+            out['comm'] = comm
         if strong is not None:
             out['strong_scaling'] = strong
 
     # extra: the reference's full-softmax model (loglinear) at the C2 dims AND the C2 batch
-    if N == 1 and kind == 'vectorspace' and not args.no_loglinear_extra:
-        Bll = 65536
-        rng2 = np.random.RandomState(1)
-        nb2 = 2
-        X2, y2, w2 = synth_data(rng2, nb2 * Bll, n, Vw, Ve)
-        m2 = build_model('loglinear', models, Bll, n, Vw, Ve, d, d, z, X2, y2, w2, seed=1)
+    if ctx.rank == 0 and N == 1 and kind == 'vectorspace' and not args.no_loglinear_extra:
         st = max(5, min(20, args.steps))
-        dt2, _, _ = timed_steps(m2, dist, nb2, st, 3, timing=False)
-        _, tm2, _ = timed_steps(m2, dist, nb2, st, 1, timing=True)
-        U = float(np.mean([len(np.unique(X2[j * Bll:(j + 1) * Bll])) for j in range(nb2)]))
-        work2 = group_work('loglinear', Bll, n, X2.dtype.itemsize, d, d, Ve, Vw, z, U)
-        k2 = kernel_table(tm2, work2)
-        fl_exec = sum(v for k, (b, v) in work2.items() if b == 'mfma')
-        out['loglinear'] = {
-            'workload': 'LanguageModel (full softmax over V_e, Adadelta) V_w=%d V_e=%d d=%d window=%d batch=%d' % (Vw, Ve, d, n, Bll),
-            'value': st * Bll / dt2, 'unit': 'pairs/s', 'ms_per_step': 1000 * dt2 / st,
-            'kernels': k2, 'roofline': roofline_of(k2, kind='loglinear'),
-            'distinct_words_per_batch': U,
-            'mfma_tflops_executed': fl_exec / (dt2 / st) / 1e12,
-            'note': 'the three GEMMs run on the %.0f distinct words of a batch of %d tokens (duplicate tokens share '
-                    'their logit row); mfma_tflops_executed counts those flops only' % (U, Bll * n),
-        }
-        del m2
+        dims = dict(B=65536, n=n, Vw=Vw, Ve=Ve, d=d, de=d, z=z)
+        rec, work2, _, dt2 = measure_record(
+            'loglinear', models, _capi, dist, dims, st, 3, 1, live,
+            label='LanguageModel (full softmax over V_e, Adadelta) V_w=%d V_e=%d d=%d window=%d batch=65536' % (Vw, Ve, d, n))
+        fl_exec = sum(w_['flops'] for w_ in work2.values() if w_['kind'] == 'mfma')
+        rec['mfma_tflops_executed'] = fl_exec / (dt2 / st) / 1e12
+        rec['note'] = ('the three GEMMs run on the %.0f distinct words of a batch of %d tokens (duplicate tokens share '
+                       'their logit row); mfma_tflops_executed counts those flops only' % (rec['distinct_words_per_batch'], 65536 * n))
+        out['loglinear'] = rec
         # extra: the ADDITIVE full-softmax LSE variant (BASELINE.json configs[1] wording:
         # "embed gather + MFMA projection + full softmax"), same dims and batch as the headline
-        m3 = build_model('vectorspace_softmax', models, Bl, n, Vw, Ve, d, d, z, X[:4 * Bl], y[:4 * Bl],
-                         w[:4 * Bl], seed=2)
-        dt3, _, _ = timed_steps(m3, dist, 4, st, 3, timing=False)
-        _, tm3, _ = timed_steps(m3, dist, 4, st, 1, timing=True)
-        work3 = group_work('vectorspace_softmax', Bl, n, s, d, d, Ve, Vw, z)
-        k3 = kernel_table(tm3, work3)
-        fl3 = 6.0 * Bl * d * d + 6.0 * Bl * d * Ve
-        out['lse_full_softmax'] = {
-            'workload': 'VectorSpaceSoftmaxLanguageModel (additive, not in the reference): gather + mean-pool + '
-                        'tanh projection + full softmax over V_e=%d, Adam; V_w=%d d=%d window=%d batch=%d' % (
-                            Ve, Vw, d, n, Bl),
-            'value': st * Bl / dt3, 'unit': 'pairs/s', 'ms_per_step': 1000 * dt3 / st,
-            'kernels': k3, 'roofline': roofline_of(k3, kind='vectorspace_softmax'),
-            'mfma_tflops_whole_step': fl3 / (dt3 / st) / 1e12,
-        }
-        del m3
+        dims = dict(B=Bl, n=n, Vw=Vw, Ve=Ve, d=d, de=d, z=z)
+        rec, _, _, dt3 = measure_record(
+            'vectorspace_softmax', models, _capi, dist, dims, st, 3, 2, live, num_batches=4,
+            label='VectorSpaceSoftmaxLanguageModel (additive, not in the reference): gather + mean-pool + tanh projection + '
+                  'full softmax over V_e=%d, Adam; V_w=%d d=%d window=%d batch=%d' % (Ve, Vw, d, n, Bl))
+        rec['mfma_tflops_whole_step'] = (6.0 * Bl * d * d + 6.0 * Bl * d * Ve) / (dt3 / st) / 1e12
+        out['lse_full_softmax'] = rec
 
     if ctx.rank == 0 and N == 1 and kind == 'vectorspace' and not args.no_c4_extra:
-        out['c4'] = c4_record(models, dist, max(5, min(10, args.steps)))
+        out['c4'] = c4_record(models, _capi, dist, max(5, min(10, args.steps)), live)
 
     if ctx.rank == 0 and N == 1 and not args.no_query_extra:
         out['query'] = query_bench(_capi, cpu=not args.no_cpu_baseline)

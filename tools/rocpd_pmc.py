@@ -22,12 +22,30 @@ def short(name):
 
 def per_kernel(path, counter):
     """Keyed by 'kernel @grid': the same kernel launched at different sizes (e.g. the
-    optimiser over a 12.8 M-element table and over a 128-element bias) stays apart."""
+    optimiser over a 12.8 M-element table and over a 128-element bias) stays apart.  Launches of
+    one kernel with ONE grid size but clearly different durations (the C4 step runs adam_l2 over
+    the 150 M-element word table and the 30 M-element entity table with the same 4096 workgroups)
+    are split into duration clusters, keyed 'kernel @grid #k' in ascending duration."""
     db = sqlite3.connect(path)
-    rows = db.execute("select kernel_name, grid_size, count(*), avg(value), avg(duration) from "
-                      "counters_collection where counter_name = ? group by kernel_name, grid_size",
-                      (counter,)).fetchall()
-    return {'%s @%d' % (short(r[0]), r[1]): dict(calls=r[2], kib=r[3], us=r[4] / 1e3) for r in rows}
+    rows = db.execute("select kernel_name, grid_size, value, duration from counters_collection "
+                      "where counter_name = ?", (counter,)).fetchall()
+    groups = {}
+    for name, grid, value, dur in rows:
+        groups.setdefault((short(name), grid), []).append((dur, value))
+    out = {}
+    for (name, grid), items in groups.items():
+        items.sort()
+        clusters, cur = [], [items[0]]
+        for it in items[1:]:
+            if it[0] > 1.5 * cur[-1][0] and it[0] - cur[-1][0] > 5000:   # (ns) a gap of > 50 % and > 5 us
+                clusters.append(cur)
+                cur = []
+            cur.append(it)
+        clusters.append(cur)
+        for k, cl in enumerate(clusters):
+            key = '%s @%d' % (name, grid) + ('' if len(clusters) == 1 else ' #%d' % k)
+            out[key] = dict(calls=len(cl), kib=sum(v for _, v in cl) / len(cl), us=sum(d for d, _ in cl) / len(cl) / 1e3)
+    return out
 
 
 def main(argv):

@@ -245,26 +245,58 @@ int sert_score_topk(int device, const float* entities, int64_t num_entities, int
 /* ncclGetUniqueId; rank 0 calls it and ships the bytes to the other ranks. */
 int sert_comm_unique_id(char id[SERT_COMM_ID_BYTES]);
 /* ncclCommInitRank on this handle's device.  From here on the model is data parallel
- * (SURVEY 8-e, 8-f4): rank r trains rows [r*B_l, (r+1)*B_l) of every global batch; the word
- * table (and any other tensor beyond 4 M elements) is owned ZeRO-1 style -- its gradient is
- * reduce-scattered, each rank runs the dense optimiser (sert/models.py:548-549: every element,
- * every step) on the 1/world of the rows it owns, keeping only that share of the optimiser
- * state, and the updated rows are all-gathered; the small tensors' gradients and the loss sum
- * are all-reduced and those tensors updated identically everywhere.  SERT_AR_CHUNKS=k pipelines
- * the exchange of a big tensor in k slabs.  sert_get_tensor of a SERT_T_STATE* tensor is then a
- * COLLECTIVE call (every rank, same order). */
+ * (SURVEY 8-e, 8-f4): rank r trains rows [r*B_l, (r+1)*B_l) of every global batch.  Every rank
+ * OWNS 1/world of the word table (and of any other tensor beyond 4 M elements): the dense
+ * optimiser (sert/models.py:548-549: every element, every step) runs on the owned share only and
+ * only that share of the optimiser state exists.
+ *   word table, default: owned BY ROWS; per step two all-to-alls over static per-batch lists --
+ *     the parameter rows a rank's batch touches come from their owners before the forward, their
+ *     gradient rows go back after the backward (csrc/kernels_xchg.h).  Rows nobody touches do not
+ *     travel.  Until the next collective read, a rank's copy of R_w is current only where it owns
+ *     or has fetched: sert_get_tensor(SERT_T_RW), the evaluation calls and sert_predict_tokens then
+ *     first all-gather the table and are therefore COLLECTIVE (every rank, same order).
+ *   SERT_DP_EXCHANGE=zero1 (or a word dim that is no multiple of 4, keep_grads, SERT_AR_CHUNKS > 1)
+ *     and every other big tensor: gradient reduce-scattered, owned slabs updated, all-gathered.
+ * The small tensors' gradients and the loss sum are all-reduced and those tensors updated
+ * identically everywhere.  sert_get_tensor of a SERT_T_STATE* tensor is a COLLECTIVE call. */
 int sert_comm_init(sert_model* m, const char id[SERT_COMM_ID_BYTES], int rank, int world);
-/* Host-mediated exchange: every gradient/loss all-reduce becomes device -> pinned host
- * -> fn (in-place SUM over ranks of host_buf[count]; returns 0 on success) -> device,
- * synchronously.  A verification transport, not a fast path: it lets several ranks
- * share ONE GPU (RCCL refuses duplicate devices), so the data-parallel step -- row
- * sharding, global 1/B scaling, rank-invariant negatives, L2 applied once, loss
- * reduction -- can be checked against a single-process run on a 1-GPU box. */
-typedef int (*sert_allreduce_fn)(void* user, float* host_buf, size_t count);
-int sert_comm_init_host(sert_model* m, int rank, int world, sert_allreduce_fn fn, void* user);
+/* Host-mediated exchange: every collective of the data-parallel step becomes device -> pinned host
+ * -> fn -> device, synchronously.  fn is an ALL-TO-ALL of float segments: on entry `send` holds, for
+ * every rank q (this rank included), send_counts[q] floats at send_offsets[q]; on return `recv` must
+ * hold, at recv_offsets[q], the recv_counts[q] floats rank q addressed to this rank.  Offsets and
+ * counts are in floats; fn moves bits and never does arithmetic on them.  Returns 0 on success.
+ * Reduce-scatter, all-gather, all-reduce and the row exchange are all expressed through it, every
+ * rank receiving exactly its pieces (sums are formed in rank order on the host).  A verification
+ * transport, not a fast path: it lets several ranks share ONE GPU (RCCL refuses duplicate devices),
+ * so the data-parallel step -- row sharding, global 1/B scaling, rank-invariant negatives, piece and
+ * slab indexing of the owned tensors, L2 applied once, loss reduction -- can be checked against a
+ * single-process run on a 1-GPU box. */
+typedef int (*sert_alltoall_fn)(void* user, const float* send, const int64_t* send_offsets,
+                                const int64_t* send_counts, float* recv, const int64_t* recv_offsets,
+                                const int64_t* recv_counts);
+int sert_comm_init_host(sert_model* m, int rank, int world, sert_alltoall_fn fn, void* user);
+/* Exchange statistics of a data-parallel model, out[0..n) (n <= 8):
+ *   [0] world  [1] exchange of the word table: 0 none, 1 ZeRO-1 (reduce-scatter + all-gather), 2 by rows
+ *   [2] bytes this rank sent + received per training step (mean over the steps run so far)
+ *   [3] the same figure ZeRO-1 would move: 2 x 2 (N-1)/N x padded table bytes
+ *   [4] transport: 1 RCCL, 2 host-mediated  [5] training steps counted
+ *   [6] mean rows per batch this rank fetches from peers  [7] mean rows per batch it serves */
+int sert_comm_stats(sert_model* m, double* out, int n);
 int sert_comm_destroy(sert_model* m);
 
 /* ---- diagnostics -------------------------------------------------------- */
+
+/* Host-only (no device is touched): the row-exchange lists rank `rank` of `world` derives for batch
+ * `batch` from the touched-row bitmaps of ALL ranks, allbits[world][num_batches][bit_words] -- the
+ * function sert_upload_dataset runs on the gathered bitmaps (csrc/kernels_xchg.h).  Lets the
+ * multi-rank algebra of the exchange be checked without any GPU: serve_cnt / fetch_cnt [world];
+ * serve_rows / fetch_rows peer-major; union_rows with their contributions ptr / ent in rank order
+ * (ent < 0: this rank's own row); sizes[5] = {serve, fetch, union, entries, largest transfer in rows}.
+ * Every output array must hold `capacity` entries. */
+int sert_debug_row_lists(const uint32_t* allbits, int world, int rank, int64_t num_batches, int64_t bit_words,
+                         int64_t rows_per_rank, int64_t vocab, int64_t batch, int32_t* serve_cnt,
+                         int32_t* fetch_cnt, int32_t* serve_rows, int32_t* fetch_rows, int32_t* union_rows,
+                         int32_t* ptr, int32_t* ent, int64_t capacity, int64_t* sizes);
 
 /* hipStreamSynchronize on the handle's stream. */
 int sert_synchronize(sert_model* m);

@@ -33,15 +33,16 @@ EXPORTS = [
     'sert_predict_project', 'sert_predict_tokens', 'sert_score_topk',
     'sert_scorer_create', 'sert_scorer_destroy', 'sert_scorer_topk', 'sert_scorer_scores',
     'sert_host_alloc', 'sert_host_free',
-    'sert_comm_unique_id', 'sert_comm_init', 'sert_comm_init_host', 'sert_comm_destroy',
+    'sert_comm_unique_id', 'sert_comm_init', 'sert_comm_init_host', 'sert_comm_destroy', 'sert_comm_stats',
     'sert_synchronize', 'sert_timing_enable', 'sert_timing_reset', 'sert_timing_count',
-    'sert_timing_name', 'sert_timing_avg_us', 'sert_bench_gemm', 'sert_bench_memory',
+    'sert_timing_name', 'sert_timing_avg_us', 'sert_bench_gemm', 'sert_bench_memory', 'sert_debug_row_lists',
 ]
 
 
-# int (*sert_allreduce_fn)(void* user, float* host_buf, size_t count)
-ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float),
-                                ctypes.c_size_t)
+# int (*sert_alltoall_fn)(void* user, const float* send, const int64_t* send_offsets, const int64_t* send_counts,
+#                         float* recv, const int64_t* recv_offsets, const int64_t* recv_counts)
+_F32P, _I64P = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int64)
+ALLTOALL_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, _F32P, _I64P, _I64P, _F32P, _I64P, _I64P)
 
 
 class SertConfig(ctypes.Structure):
@@ -123,7 +124,9 @@ def load():
     lib.sert_comm_unique_id.argtypes = [ctypes.c_char_p]
     lib.sert_comm_init.argtypes = [vp, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
     lib.sert_comm_destroy.argtypes = [vp]
-    lib.sert_comm_init_host.argtypes = [vp, ctypes.c_int, ctypes.c_int, ALLREDUCE_FN, vp]
+    lib.sert_comm_init_host.argtypes = [vp, ctypes.c_int, ctypes.c_int, ALLTOALL_FN, vp]
+    lib.sert_comm_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.c_int]
+    lib.sert_debug_row_lists.argtypes = [fp, ctypes.c_int, ctypes.c_int, i64, i64, i64, i64, i64] + [fp] * 7 + [i64, fp]
     lib.sert_synchronize.argtypes = [vp]
     lib.sert_timing_enable.argtypes = [vp, ctypes.c_int]
     lib.sert_timing_reset.argtypes = [vp]
@@ -306,19 +309,38 @@ class Engine(object):
         assert len(unique_id) == COMM_ID_BYTES
         check(self._lib.sert_comm_init(self._h, unique_id, rank, world))
 
-    def comm_init_host(self, rank, world, allreduce):
+    def comm_init_host(self, rank, world, alltoall):
         """Host-mediated exchange (verification transport, sert_comm_init_host):
-        ``allreduce(array)`` sums a float32 numpy array over the ranks IN PLACE."""
-        def trampoline(_user, buf, count):
+        ``alltoall(send, send_offsets, send_counts, recv, recv_offsets, recv_counts)`` moves float32
+        segments between the ranks (numpy views of the engine's pinned buffers; offsets and counts are
+        int64 arrays of length world, in floats) -- see sert_amd.distributed.host_alltoall."""
+        def trampoline(_user, send, soff, scnt, recv, roff, rcnt):
             try:
-                allreduce(np.ctypeslib.as_array(buf, shape=(count,)))
+                so = np.ctypeslib.as_array(soff, shape=(world,))
+                sc = np.ctypeslib.as_array(scnt, shape=(world,))
+                ro = np.ctypeslib.as_array(roff, shape=(world,))
+                rc = np.ctypeslib.as_array(rcnt, shape=(world,))
+                ns = int((so + sc).max()) if world else 0
+                nr = int((ro + rc).max()) if world else 0
+                sbuf = np.ctypeslib.as_array(send, shape=(max(ns, 1),))
+                rbuf = np.ctypeslib.as_array(recv, shape=(max(nr, 1),))
+                alltoall(sbuf, so, sc, rbuf, ro, rc)
                 return 0
             except Exception:  # noqa: BLE001 - reported through the C error path
                 import traceback
                 traceback.print_exc()
                 return 1
-        self._host_allreduce = ALLREDUCE_FN(trampoline)   # keep the thunk alive
-        check(self._lib.sert_comm_init_host(self._h, rank, world, self._host_allreduce, None))
+        self._host_alltoall = ALLTOALL_FN(trampoline)   # keep the thunk alive
+        check(self._lib.sert_comm_init_host(self._h, rank, world, self._host_alltoall, None))
+
+    def comm_stats(self):
+        """sert_comm_stats as a dict (world 1 / no communicator: exchange 'none')."""
+        v = (ctypes.c_double * 8)()
+        check(self._lib.sert_comm_stats(self._h, v, 8))
+        return {'world': int(v[0]), 'exchange': {0: 'none', 1: 'zero1', 2: 'rows'}[int(v[1])],
+                'bytes_per_step': float(v[2]), 'zero1_bytes_per_step': float(v[3]),
+                'transport': {0: 'none', 1: 'rccl', 2: 'host'}[int(v[4])], 'steps': int(v[5]),
+                'rows_fetched_per_batch': float(v[6]), 'rows_served_per_batch': float(v[7])}
 
     # diagnostics
     def synchronize(self):
@@ -505,3 +527,20 @@ def bench_memory(kind, nbytes, table_bytes=0, row_bytes=512, window=10, gap_byte
     check(load().sert_bench_memory(device, kind, nbytes, table_bytes, row_bytes, window, gap_bytes, blocks, iters,
                                    ctypes.byref(us)))
     return us.value
+
+
+def debug_row_lists(allbits, rank, rows_per_rank, vocab, batch):
+    """sert_debug_row_lists (host only): the exchange lists of one rank and batch as numpy arrays."""
+    allbits = np.ascontiguousarray(allbits, dtype=np.uint32)
+    world, nb, bw = allbits.shape
+    cap = int(vocab) + 2
+    i32 = lambda n: np.zeros(n, dtype=np.int32)
+    scnt, fcnt = i32(world), i32(world)
+    srows, frows, urows, ptr, ent = (i32(cap * world) for _ in range(5))
+    sizes = np.zeros(5, dtype=np.int64)
+    check(load().sert_debug_row_lists(allbits.ctypes.data, world, rank, nb, bw, rows_per_rank, vocab, batch,
+                                      scnt.ctypes.data, fcnt.ctypes.data, srows.ctypes.data, frows.ctypes.data,
+                                      urows.ctypes.data, ptr.ctypes.data, ent.ctypes.data, cap * world, sizes.ctypes.data))
+    ns, nf, nu, ne = (int(x) for x in sizes[:4])
+    return dict(serve_cnt=scnt, fetch_cnt=fcnt, serve_rows=srows[:ns], fetch_rows=frows[:nf], union_rows=urows[:nu],
+                ptr=ptr[:nu + 1], ent=ent[:ne], max_xfer_rows=int(sizes[4]))

@@ -4,6 +4,7 @@
 #include <string>
 #include "common.h"
 #include "word_index.h"
+#include "kernels_xchg.h"
 #include "../../include/sert_hip.h"
 
 namespace sert {
@@ -212,11 +213,30 @@ struct sert_model {
     int rank = 0, world = 1;
     void* comm = nullptr;         // ncclComm_t
     bool comm_dead = false;       // communicator destroyed: the (sharded) model can no longer train
-    // host-mediated exchange (sert_comm_init_host): verification transport
-    int (*host_ar)(void*, float*, size_t) = nullptr;
+    // host-mediated exchange (sert_comm_init_host): verification transport.  ONE primitive -- an
+    // all-to-all of float segments between the ranks -- carries every collective the step needs, each
+    // rank receiving exactly its pieces (reduce-scatter, all-gather, the all-to-alls of the row exchange,
+    // the small all-reduce), so the piece / padding / slab indexing is what a multi-rank test exercises
+    sert_alltoall_fn host_ar = nullptr;
     void* host_ar_user = nullptr;
-    float* host_ar_buf = nullptr;   // pinned staging
-    size_t host_ar_cap = 0;
+    float *host_send = nullptr, *host_recv = nullptr;   // pinned staging
+    size_t host_send_cap = 0, host_recv_cap = 0;
+
+    // ---- the word table exchanged BY ROWS (kernels_xchg.h) ----
+    bool xr_mode = false;            // R_w is owned by rows (decided when the communicator is attached)
+    bool xr_on = false;              // ... and the exchange lists of the uploaded training split exist
+    int64_t xr_rows_per_rank = 0;
+    sert::RowExchangeLists* xr = nullptr;      // host copy: per batch and peer counts, offsets
+    int32_t *xr_serve = nullptr, *xr_fetch = nullptr, *xr_union = nullptr, *xr_ent = nullptr, *xr_ptr = nullptr;
+    uint32_t* xr_ubits = nullptr;
+    float *xr_send = nullptr, *xr_recv = nullptr;      // (max rows any batch moves) x d_w
+    bool rw_full = true;             // every row of R_w held by this rank is current
+    int64_t xr_fetched_batch = -1;   // rw_full == false: the rows this batch touches are current
+    int64_t xr_batch = -1;           // batch of the training step in flight
+    hipEvent_t ev_params_ready = nullptr, ev_word_updated = nullptr;
+    // bytes this rank sent + received through collectives, and steps counted (sert_comm_stats)
+    double comm_bytes_moved = 0.0;
+    int64_t comm_steps = 0;
     hipStream_t comm_stream = nullptr;          // all collectives are issued here, in one fixed order
     hipEvent_t ev_rest_ready = nullptr, ev_ar_done = nullptr;
     // the exchange of a big tensor is cut into ar_chunks slabs so that the optimiser of

@@ -80,6 +80,10 @@ struct Rccl {
     int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*ReduceScatter)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 };
 static Rccl g_rccl;
@@ -100,11 +104,16 @@ static int rccl_load() {
     g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(lib, "ncclAllReduce");
     g_rccl.ReduceScatter = (decltype(g_rccl.ReduceScatter))dlsym(lib, "ncclReduceScatter");
     g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(lib, "ncclAllGather");
+    g_rccl.Send = (decltype(g_rccl.Send))dlsym(lib, "ncclSend");
+    g_rccl.Recv = (decltype(g_rccl.Recv))dlsym(lib, "ncclRecv");
+    g_rccl.GroupStart = (decltype(g_rccl.GroupStart))dlsym(lib, "ncclGroupStart");
+    g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))dlsym(lib, "ncclGroupEnd");
     g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(lib, "ncclGetErrorString");
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllReduce ||
-        !g_rccl.ReduceScatter || !g_rccl.AllGather)
+        !g_rccl.ReduceScatter || !g_rccl.AllGather || !g_rccl.Send || !g_rccl.Recv || !g_rccl.GroupStart ||
+        !g_rccl.GroupEnd)
         SERT_FAIL("librccl is missing ncclGetUniqueId/ncclCommInitRank/ncclCommDestroy/ncclAllReduce/"
-                  "ncclReduceScatter/ncclAllGather");
+                  "ncclReduceScatter/ncclAllGather/ncclSend/ncclRecv/ncclGroupStart/ncclGroupEnd");
     g_rccl.lib = lib;
     return 0;
 }
@@ -375,28 +384,262 @@ static inline size_t piece_off(const sert_model* m, int i, int c) {
     return (size_t)c * slab_elems(m, i) + (size_t)m->rank * m->pt_sc[i];
 }
 
-// device -> pinned host -> callback (sum over ranks) -> device, synchronously on `st`.
-// own_only: everything outside this rank's pieces of sharded tensor `own_tensor` is zeroed on
-// the host first, so that the sum is an all-gather.
-static int host_allreduce(sert_model* m, float* dev, size_t count, hipStream_t st, int own_tensor = -1) {
+// ---- host-mediated transport: every collective through ONE all-to-all callback ------------------
+static int host_reserve(sert_model* m, size_t send_floats, size_t recv_floats) {
+    if (m->host_send_cap < send_floats) {
+        if (m->host_send) (void)hipHostFree(m->host_send);
+        m->host_send = nullptr; m->host_send_cap = 0;
+        SERT_HIP(hipHostMalloc((void**)&m->host_send, std::max<size_t>(send_floats, 64) * sizeof(float), hipHostMallocDefault));
+        m->host_send_cap = std::max<size_t>(send_floats, 64);
+    }
+    if (m->host_recv_cap < recv_floats) {
+        if (m->host_recv) (void)hipHostFree(m->host_recv);
+        m->host_recv = nullptr; m->host_recv_cap = 0;
+        SERT_HIP(hipHostMalloc((void**)&m->host_recv, std::max<size_t>(recv_floats, 64) * sizeof(float), hipHostMallocDefault));
+        m->host_recv_cap = std::max<size_t>(recv_floats, 64);
+    }
+    return 0;
+}
+static int host_call(sert_model* m, const std::vector<int64_t>& soff, const std::vector<int64_t>& scnt,
+                     const std::vector<int64_t>& roff, const std::vector<int64_t>& rcnt) {
+    if (m->host_ar(m->host_ar_user, m->host_send, soff.data(), scnt.data(), m->host_recv, roff.data(), rcnt.data()) != 0)
+        SERT_FAIL("host all-to-all callback failed");
+    for (int q = 0; q < m->world; ++q)
+        if (q != m->rank) m->comm_bytes_moved += 4.0 * (double)(scnt[(size_t)q] + rcnt[(size_t)q]);
+    return 0;
+}
+// In-place SUM of dev[0, count) over the ranks (every rank sends the whole buffer to every rank and
+// adds the copies in rank order: identical bits everywhere).  For the small replicated remainder.
+static int host_allreduce(sert_model* m, float* dev, size_t count, hipStream_t st) {
     if (count == 0) return 0;
-    if (m->host_ar_cap < count) {
-        if (m->host_ar_buf) (void)hipHostFree(m->host_ar_buf);
-        m->host_ar_buf = nullptr; m->host_ar_cap = 0;
-        SERT_HIP(hipHostMalloc((void**)&m->host_ar_buf, count * sizeof(float), hipHostMallocDefault));
-        m->host_ar_cap = count;
-    }
-    SERT_HIP(hipMemcpyAsync(m->host_ar_buf, dev, count * sizeof(float), hipMemcpyDeviceToHost, st));
+    const size_t W = (size_t)m->world;
+    SERT_TRY(host_reserve(m, count, count * W));
+    SERT_HIP(hipMemcpyAsync(m->host_send, dev, count * sizeof(float), hipMemcpyDeviceToHost, st));
     SERT_HIP(hipStreamSynchronize(st));
-    if (own_tensor >= 0) {
-        const size_t sc = m->pt_sc[own_tensor], slab = slab_elems(m, own_tensor);
-        for (size_t o = 0; o < count; o += slab)
-            for (int r = 0; r < m->world; ++r)
-                if (r != m->rank) memset(m->host_ar_buf + o + (size_t)r * sc, 0, sc * sizeof(float));
+    std::vector<int64_t> soff(W, 0), scnt(W, (int64_t)count), roff(W), rcnt(W, (int64_t)count);
+    for (size_t q = 0; q < W; ++q) roff[q] = (int64_t)(q * count);
+    SERT_TRY(host_call(m, soff, scnt, roff, rcnt));
+    float* acc = m->host_send;
+    for (size_t k = 0; k < count; ++k) acc[k] = m->host_recv[k];
+    for (size_t q = 1; q < W; ++q) {
+        const float* src = m->host_recv + q * count;
+        for (size_t k = 0; k < count; ++k) acc[k] += src[k];
     }
-    if (m->host_ar(m->host_ar_user, m->host_ar_buf, count) != 0) SERT_FAIL("host all-reduce callback failed");
-    SERT_HIP(hipMemcpyAsync(dev, m->host_ar_buf, count * sizeof(float), hipMemcpyHostToDevice, st));
+    SERT_HIP(hipMemcpyAsync(dev, acc, count * sizeof(float), hipMemcpyHostToDevice, st));
     SERT_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+// Reduce-scatter of one slab (world pieces of sc floats at `slab`): piece q goes to rank q, this rank
+// adds the world copies of ITS piece in rank order and stores the sum over its piece -- only there.
+static int host_reduce_scatter(sert_model* m, float* slab, size_t sc, hipStream_t st) {
+    const size_t W = (size_t)m->world;
+    SERT_TRY(host_reserve(m, sc * W, sc * W));
+    SERT_HIP(hipMemcpyAsync(m->host_send, slab, sc * W * sizeof(float), hipMemcpyDeviceToHost, st));
+    SERT_HIP(hipStreamSynchronize(st));
+    std::vector<int64_t> soff(W), scnt(W, (int64_t)sc), roff(W), rcnt(W, (int64_t)sc);
+    for (size_t q = 0; q < W; ++q) { soff[q] = (int64_t)(q * sc); roff[q] = (int64_t)(q * sc); }
+    SERT_TRY(host_call(m, soff, scnt, roff, rcnt));
+    float* acc = m->host_send;
+    for (size_t k = 0; k < sc; ++k) acc[k] = m->host_recv[k];
+    for (size_t q = 1; q < W; ++q) {
+        const float* src = m->host_recv + q * sc;
+        for (size_t k = 0; k < sc; ++k) acc[k] += src[k];
+    }
+    SERT_HIP(hipMemcpyAsync(slab + (size_t)m->rank * sc, acc, sc * sizeof(float), hipMemcpyHostToDevice, st));
+    SERT_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+// All-gather of one slab: this rank's piece goes to everyone, piece q arrives from rank q.
+static int host_allgather(sert_model* m, float* slab, size_t sc, hipStream_t st) {
+    const size_t W = (size_t)m->world;
+    SERT_TRY(host_reserve(m, sc, sc * W));
+    SERT_HIP(hipMemcpyAsync(m->host_send, slab + (size_t)m->rank * sc, sc * sizeof(float), hipMemcpyDeviceToHost, st));
+    SERT_HIP(hipStreamSynchronize(st));
+    std::vector<int64_t> soff(W, 0), scnt(W, (int64_t)sc), roff(W), rcnt(W, (int64_t)sc);
+    for (size_t q = 0; q < W; ++q) roff[q] = (int64_t)(q * sc);
+    SERT_TRY(host_call(m, soff, scnt, roff, rcnt));
+    SERT_HIP(hipMemcpyAsync(slab, m->host_recv, sc * W * sizeof(float), hipMemcpyHostToDevice, st));
+    SERT_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+// All-to-all of float segments between device buffers (offsets / counts in floats, peers only).
+static int host_alltoallv(sert_model* m, const float* dsend, size_t stotal, const std::vector<int64_t>& soff,
+                          const std::vector<int64_t>& scnt, float* drecv, size_t rtotal, const std::vector<int64_t>& roff,
+                          const std::vector<int64_t>& rcnt, hipStream_t st) {
+    SERT_TRY(host_reserve(m, stotal, rtotal));
+    if (stotal) SERT_HIP(hipMemcpyAsync(m->host_send, dsend, stotal * sizeof(float), hipMemcpyDeviceToHost, st));
+    SERT_HIP(hipStreamSynchronize(st));
+    SERT_TRY(host_call(m, soff, scnt, roff, rcnt));
+    if (rtotal) SERT_HIP(hipMemcpyAsync(drecv, m->host_recv, rtotal * sizeof(float), hipMemcpyHostToDevice, st));
+    SERT_HIP(hipStreamSynchronize(st));
+    return 0;
+}
+static int rccl_alltoallv(sert_model* m, const float* dsend, const std::vector<int64_t>& soff, const std::vector<int64_t>& scnt,
+                          float* drecv, const std::vector<int64_t>& roff, const std::vector<int64_t>& rcnt, hipStream_t st) {
+    SERT_NCCL(g_rccl.GroupStart());
+    for (int q = 0; q < m->world; ++q) {
+        if (q == m->rank) continue;
+        if (scnt[(size_t)q]) SERT_NCCL(g_rccl.Send(dsend + soff[(size_t)q], (size_t)scnt[(size_t)q], /*ncclFloat32*/ 7, q, m->comm, st));
+        if (rcnt[(size_t)q]) SERT_NCCL(g_rccl.Recv(drecv + roff[(size_t)q], (size_t)rcnt[(size_t)q], 7, q, m->comm, st));
+        m->comm_bytes_moved += 4.0 * (double)(scnt[(size_t)q] + rcnt[(size_t)q]);
+    }
+    SERT_NCCL(g_rccl.GroupEnd());
+    return 0;
+}
+
+// ---- the word table exchanged by rows (kernels_xchg.h) -------------------------------------------
+static inline bool xr_async(const sert_model* m) { return m->comm && !m->timing.enabled; }
+
+// One all-to-all of rows: `send_cnt[q]` rows to rank q out of xr_send (peer-major), `recv_cnt[q]` rows
+// from rank q into xr_recv (peer-major), d_w floats each.
+static int xr_alltoall(sert_model* m, const std::vector<int32_t>& send_cnt, const std::vector<int32_t>& recv_cnt, hipStream_t st) {
+    const size_t W = (size_t)m->world;
+    const int64_t d = m->cfg.word_dim;
+    std::vector<int64_t> soff(W), scnt(W), roff(W), rcnt(W);
+    int64_t so = 0, ro = 0;
+    for (size_t q = 0; q < W; ++q) {
+        soff[q] = so; scnt[q] = (int64_t)send_cnt[q] * d; so += scnt[q];
+        roff[q] = ro; rcnt[q] = (int64_t)recv_cnt[q] * d; ro += rcnt[q];
+    }
+    if (m->host_ar) return host_alltoallv(m, m->xr_send, (size_t)so, soff, scnt, m->xr_recv, (size_t)ro, roff, rcnt, st);
+    return rccl_alltoallv(m, m->xr_send, soff, scnt, m->xr_recv, roff, rcnt, st);
+}
+
+// PARAMETERS of the rows batch `b` touches: the owners pack and send them, this rank scatters what
+// it receives into its copy of R_w.  Runs on the communication stream behind the word table's update.
+static int xr_fetch_params(sert_model* m, int64_t b) {
+    if (!m->xr_on || m->rw_full || m->xr_fetched_batch == b) return 0;
+    if ((size_t)b >= m->xr->batches.size()) SERT_FAIL("batch has no row-exchange lists");
+    const RowExchangeBatch& xb = m->xr->batches[(size_t)b];
+    const int d4 = m->cfg.word_dim / 4;
+    const bool async = xr_async(m);
+    hipStream_t st = async ? m->comm_stream : m->stream;
+    ScopedTimer tm(m, TG_ALLGATHER);
+    if (async) SERT_HIP(hipStreamWaitEvent(st, m->ev_word_updated, 0));   // (the owners' rows are final)
+    if (xb.serve_total)
+        hipLaunchKernelGGL(xchg_pack_rows, dim3(grid_for((int64_t)xb.serve_total * d4)), dim3(256), 0, st, (const float*)m->rw,
+                           (const int32_t*)m->xr_serve + xb.serve_off, xb.serve_total, d4, reinterpret_cast<float4*>(m->xr_send));
+    SERT_TRY(xr_alltoall(m, xb.serve_cnt, xb.fetch_cnt, st));
+    if (xb.fetch_total)
+        hipLaunchKernelGGL(xchg_unpack_rows, dim3(grid_for((int64_t)xb.fetch_total * d4)), dim3(256), 0, st, m->rw,
+                           (const int32_t*)m->xr_fetch + xb.fetch_off, xb.fetch_total, d4, reinterpret_cast<const float4*>(m->xr_recv));
+    if (async) {
+        SERT_HIP(hipEventRecord(m->ev_params_ready, st));
+        SERT_HIP(hipStreamWaitEvent(m->stream, m->ev_params_ready, 0));
+    }
+    m->xr_fetched_batch = b;
+    return 0;
+}
+
+// GRADIENT rows of batch `b`: packed from this rank's dR_w, sent to their owners; the rows received
+// are added to this rank's own in rank order into dR_w[owned rows].
+static int xr_return_grads(sert_model* m, int64_t b) {
+    const RowExchangeBatch& xb = m->xr->batches[(size_t)b];
+    const int d4 = m->cfg.word_dim / 4;
+    const bool async = xr_async(m);
+    hipStream_t st = async ? m->comm_stream : m->stream;
+    ScopedTimer tm(m, TG_REDUCE_SCATTER);
+    if (async) {
+        SERT_HIP(hipEventRecord(m->ev_grad_ready[0], m->stream));
+        SERT_HIP(hipStreamWaitEvent(st, m->ev_grad_ready[0], 0));
+    }
+    if (xb.fetch_total)
+        hipLaunchKernelGGL(xchg_pack_rows, dim3(grid_for((int64_t)xb.fetch_total * d4)), dim3(256), 0, st, (const float*)m->g_rw,
+                           (const int32_t*)m->xr_fetch + xb.fetch_off, xb.fetch_total, d4, reinterpret_cast<float4*>(m->xr_send));
+    SERT_TRY(xr_alltoall(m, xb.fetch_cnt, xb.serve_cnt, st));
+    if (xb.nunion)
+        hipLaunchKernelGGL(xchg_reduce_rows, dim3(grid_for((int64_t)xb.nunion * d4)), dim3(256), 0, st,
+                           reinterpret_cast<const float4*>(m->xr_recv), (const int32_t*)m->xr_ptr + xb.ptr_off,
+                           (const int32_t*)m->xr_ent + xb.ent_off, (const int32_t*)m->xr_union + xb.union_off, xb.nunion, d4, m->g_rw);
+    if (async) {
+        SERT_HIP(hipEventRecord(m->ev_rs_done[0][0], st));
+        m->rs_issued[0] = true;
+    }
+    return 0;
+}
+
+static void xr_free_lists(sert_model* m) {
+    m->xr_on = false;
+    (void)hipFree(m->xr_serve); (void)hipFree(m->xr_fetch); (void)hipFree(m->xr_union); (void)hipFree(m->xr_ent);
+    (void)hipFree(m->xr_ptr); (void)hipFree(m->xr_ubits); (void)hipFree(m->xr_send); (void)hipFree(m->xr_recv);
+    m->xr_serve = m->xr_fetch = m->xr_union = m->xr_ent = m->xr_ptr = nullptr;
+    m->xr_ubits = nullptr; m->xr_send = m->xr_recv = nullptr;
+    delete m->xr;
+    m->xr = nullptr;
+}
+
+// The exchange lists of a freshly uploaded training split: every rank's per-batch touched bitmaps are
+// all-gathered (in groups of batches: at most 64 MB of bitmaps at a time), the lists derived from
+// them on the host (kernels_xchg.h) and uploaded.  COLLECTIVE: every rank uploads its split.
+static int xr_build_lists(sert_model* m, const std::vector<uint32_t>& bits, int64_t nb, int64_t bit_words) {
+    xr_free_lists(m);
+    if (nb == 0 || !m->xr_mode || !m->pt_sharded[0]) return 0;
+    m->xr = new RowExchangeLists();
+    const size_t W = (size_t)m->world;
+    const int64_t group = std::max<int64_t>(1, std::min<int64_t>(nb, ((int64_t)64 << 20) / (bit_words * 4 * (int64_t)W)));
+    std::vector<uint32_t> all;
+    hipStream_t s = m->stream;
+    for (int64_t b0 = 0; b0 < nb; b0 += group) {
+        const int64_t gb = std::min(group, nb - b0);
+        const size_t cnt = (size_t)(gb * bit_words);
+        all.resize(W * cnt);
+        const uint32_t* mine = bits.data() + (size_t)(b0 * bit_words);
+        if (m->host_ar) {
+            SERT_TRY(host_reserve(m, cnt, cnt * W));
+            memcpy(m->host_send, mine, cnt * 4);
+            std::vector<int64_t> soff(W, 0), scnt(W, (int64_t)cnt), roff(W), rcnt(W, (int64_t)cnt);
+            for (size_t q = 0; q < W; ++q) roff[q] = (int64_t)(q * cnt);
+            const double moved = m->comm_bytes_moved;
+            SERT_TRY(host_call(m, soff, scnt, roff, rcnt));
+            m->comm_bytes_moved = moved;   // (set-up traffic is not part of a step)
+            memcpy(all.data(), m->host_recv, W * cnt * 4);
+        } else {
+            float *src = nullptr, *dst = nullptr;
+            SERT_TRY(dmalloc(&src, cnt));
+            SERT_TRY(dmalloc(&dst, cnt * W));
+            SERT_HIP(hipMemcpyAsync(src, mine, cnt * 4, hipMemcpyHostToDevice, s));
+            const int rc = g_rccl.AllGather(src, dst, cnt, /*ncclFloat32: bits only*/ 7, m->comm, s);
+            hipError_t he = hipMemcpyAsync(all.data(), dst, W * cnt * 4, hipMemcpyDeviceToHost, s);
+            if (he == hipSuccess) he = hipStreamSynchronize(s);
+            (void)hipFree(src); (void)hipFree(dst);
+            if (rc != 0) SERT_FAIL("ncclAllGather of the touched-row bitmaps failed");
+            SERT_HIP(he);
+        }
+        build_row_exchange(all.data(), m->world, m->rank, gb, bit_words, m->xr_rows_per_rank, m->cfg.vocab_size, *m->xr);
+    }
+    const RowExchangeLists& L = *m->xr;
+    auto up = [&](int32_t** d, const std::vector<int32_t>& h) -> int {
+        SERT_TRY(dmalloc(d, std::max<size_t>(1, h.size())));
+        if (!h.empty()) SERT_HIP(hipMemcpyAsync(*d, h.data(), h.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        return 0;
+    };
+    SERT_TRY(up(&m->xr_serve, L.serve_rows)); SERT_TRY(up(&m->xr_fetch, L.fetch_rows));
+    SERT_TRY(up(&m->xr_union, L.union_rows)); SERT_TRY(up(&m->xr_ent, L.ent)); SERT_TRY(up(&m->xr_ptr, L.ptr));
+    SERT_TRY(dmalloc(&m->xr_ubits, std::max<size_t>(1, L.union_bits.size())));
+    if (!L.union_bits.empty())
+        SERT_HIP(hipMemcpyAsync(m->xr_ubits, L.union_bits.data(), L.union_bits.size() * 4, hipMemcpyHostToDevice, s));
+    const size_t buf = (size_t)std::max<int32_t>(1, L.max_xfer_rows) * (size_t)m->cfg.word_dim;
+    SERT_TRY(dmalloc(&m->xr_send, buf));
+    SERT_TRY(dmalloc(&m->xr_recv, buf));
+    SERT_HIP(hipStreamSynchronize(s));
+    m->xr_on = true;
+    return 0;
+}
+
+// Make every row of R_w on this rank current (all-gather of the owned slabs).  COLLECTIVE.
+static int ensure_full_rw(sert_model* m) {
+    if (m->rw_full || !m->pt_sharded[0] || !is_dp(m)) { m->rw_full = true; return 0; }
+    if (m->comm_dead) SERT_FAIL("the communicator of this data-parallel model was destroyed");
+    const size_t sc = m->pt_sc[0], slab = sc * (size_t)m->world;
+    if (m->comm_stream) SERT_HIP(hipStreamSynchronize(m->comm_stream));
+    SERT_HIP(hipStreamSynchronize(m->stream));
+    for (int c = 0; c < m->ar_chunks; ++c) {
+        if (m->host_ar) SERT_TRY(host_allgather(m, m->rw + (size_t)c * slab, sc, m->stream));
+        else SERT_NCCL(g_rccl.AllGather(m->rw + (size_t)c * slab + (size_t)m->rank * sc, m->rw + (size_t)c * slab, sc, 7, m->comm, m->stream));
+    }
+    SERT_HIP(hipStreamSynchronize(m->stream));
+    m->rw_full = true;
+    m->xr_fetched_batch = -1;
     return 0;
 }
 
@@ -407,9 +650,13 @@ static int exchange_grad(sert_model* m, int i) {
     const ParamTensor t = param_tensor(m, i);
     const size_t sc = m->pt_sc[i];
     m->rs_issued[i] = false;
-    // verification transport: the whole padded gradient is summed through the host (every rank
-    // then holds the full sum; only the owned pieces are read)
-    if (m->host_ar) return host_allreduce(m, t.g, m->pt_pad[i], m->stream);
+    if (i == 0 && m->xr_on) return xr_return_grads(m, m->xr_batch);
+    // verification transport: slab by slab, this rank receives and sums ITS piece only
+    if (m->host_ar) {
+        ScopedTimer tm(m, TG_REDUCE_SCATTER);
+        for (int c = 0; c < m->ar_chunks; ++c) SERT_TRY(host_reduce_scatter(m, t.g + (size_t)c * slab_elems(m, i), sc, m->stream));
+        return 0;
+    }
     if (m->timing.enabled) {   // timing mode: serial, on the main stream
         ScopedTimer tm(m, TG_REDUCE_SCATTER);
         for (int c = 0; c < m->ar_chunks; ++c)
@@ -419,6 +666,7 @@ static int exchange_grad(sert_model* m, int i) {
     }
     SERT_HIP(hipEventRecord(m->ev_grad_ready[i], m->stream));
     SERT_HIP(hipStreamWaitEvent(m->comm_stream, m->ev_grad_ready[i], 0));
+    m->comm_bytes_moved += 8.0 * (double)sc * (double)(m->world - 1) * m->ar_chunks;   // (N-1) pieces out, (N-1) in per slab
     for (int c = 0; c < m->ar_chunks; ++c) {
         SERT_NCCL(g_rccl.ReduceScatter(t.g + (size_t)c * slab_elems(m, i), t.g + piece_off(m, i, c), sc, 7, 0,
                                        m->comm, m->comm_stream));
@@ -436,7 +684,8 @@ static int allreduce_rest(sert_model* m) {
     for (int i = 1; i < 4; ++i) SERT_TRY(exchange_grad(m, i));
     float* rest = m->gflat + m->rest_off;
     const size_t count = m->gflat_count - m->rest_off;
-    if (m->host_ar) return host_allreduce(m, rest, count, m->stream);
+    if (m->host_ar) { ScopedTimer t(m, TG_ALLREDUCE); return host_allreduce(m, rest, count, m->stream); }
+    m->comm_bytes_moved += 16.0 * (double)count * (double)(m->world - 1) / (double)m->world;   // ring all-reduce: 2 (N-1)/N out + in
     if (m->timing.enabled) {
         ScopedTimer t(m, TG_ALLREDUCE);
         SERT_NCCL(g_rccl.AllReduce(rest, rest, count, 7, 0, m->comm, m->stream));
@@ -1288,15 +1537,27 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
         }
         const size_t sc = m->pt_sc[i];
         const int nch = m->ar_chunks;
+        // word table owned by rows: the gradient rows were returned to their owners (xr_return_grads);
+        // rows of the owned range no rank touched take a zero gradient without reading it, and nothing
+        // is gathered -- the next forward fetches the rows it needs (xr_fetch_params)
+        const bool by_rows = (i == 0) && m->xr_on;
         {
             ScopedTimer tm(m, tg);
             for (int ch = 0; ch < nch; ++ch) {
-                if (exchanged && m->rs_issued[i]) SERT_HIP(hipStreamWaitEvent(m->stream, m->ev_rs_done[i][ch], 0));
+                if (exchanged && m->rs_issued[i]) SERT_HIP(hipStreamWaitEvent(m->stream, m->ev_rs_done[i][by_rows ? 0 : ch], 0));
                 const size_t off = piece_off(m, i, ch);
                 const int nb = (int)std::min<int64_t>(std::max(1, kOptBlocks / nch), cdiv(cdiv(sc, 4), 256));
                 // (the padding behind the tensor's last element is zero with a zero gradient: it stays zero)
+                const uint32_t* ub = by_rows ? m->xr_ubits + (size_t)m->xr_batch * (size_t)m->xr->owned_bit_words : nullptr;
                 launch_stream_opt(m, m->stream, t.p + off, t.g + off, t.s0 + (size_t)ch * sc, t.s1 + (size_t)ch * sc, sc,
-                                  nb, aa, da, m->sq_scratch, nullptr, 1u);
+                                  nb, aa, da, m->sq_scratch, ub, by_rows ? (unsigned)c.word_dim : 1u);
+                if (by_rows) {
+                    if (exchanged) SERT_HIP(hipEventRecord(m->ev_word_updated, m->stream));
+                    m->rw_full = false;
+                    m->xr_fetched_batch = -1;
+                    continue;
+                }
+                m->comm_bytes_moved += 8.0 * (double)sc * (double)(m->world - 1);   // all-gather: (N-1) pieces out, (N-1) in
                 if (exchanged) {
                     SERT_HIP(hipEventRecord(m->ev_opt_done[i][ch], m->stream));
                     SERT_HIP(hipStreamWaitEvent(m->comm_stream, m->ev_opt_done[i][ch], 0));
@@ -1307,8 +1568,11 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
             }
         }
         m->rs_issued[i] = false;
-        if (m->host_ar) {
-            SERT_TRY(host_allreduce(m, t.p, m->pt_pad[i], m->stream, i));
+        if (by_rows) {
+            // (nothing to gather)
+        } else if (m->host_ar) {
+            ScopedTimer tm(m, TG_ALLGATHER);
+            for (int ch = 0; ch < nch; ++ch) SERT_TRY(host_allgather(m, t.p + (size_t)ch * slab_elems(m, i), sc, m->stream));
         } else if (m->comm && m->timing.enabled) {
             ScopedTimer tm(m, TG_ALLGATHER);
             for (int ch = 0; ch < nch; ++ch)
@@ -1479,6 +1743,11 @@ static int step_forward_backward(sert_model* m, const DataSplit& ds, int64_t bat
         SERT_HIP(hipEventRecord(m->ev_step_done, m->stream));
         m->step_done_pending = false;
     }
+    // data parallel, word table owned by rows: the rows this batch touches arrive from their owners
+    if (m->xr_on) {
+        m->xr_batch = batch_index;
+        SERT_TRY(xr_fetch_params(m, batch_index));
+    }
     // the main stream's first kernels go out BEFORE the prologue's host calls: the GPU
     // starts on gather + projection while the host is still enqueueing
     if (is_vs(m) && !is_fs(m)) {
@@ -1492,7 +1761,9 @@ static int step_forward_backward(sert_model* m, const DataSplit& ds, int64_t bat
     } else {
         // (the previous step's optimiser and loss kernels read what the prologue overwrites)
         if (pre != m->stream) SERT_HIP(hipStreamWaitEvent(pre, m->ev_step_done, 0));
-        if (m->use_touched) {
+        if (m->use_touched || m->xr_on) {
+            // (by rows: dR_w is written where this rank's batch touches, read where the lists say, and
+            //  the owned rows nobody touched are never read -- the table needs no zeroing)
             SERT_HIP(hipMemsetAsync(m->gflat + m->ar_split, 0, (m->gflat_alloc - m->ar_split) * sizeof(float), pre));
         } else {
             SERT_HIP(hipMemsetAsync(m->gflat, 0, m->gflat_alloc * sizeof(float), pre));
@@ -1550,6 +1821,7 @@ static int train_step_async(sert_model* m, int64_t batch_index, const int64_t* n
     if (!have_fb) SERT_TRY(step_forward_backward(m, ds, batch_index, negatives, &fused_pre));
     SERT_TRY(allreduce_rest(m));
     SERT_TRY(optimizer_and_loss(m, loss_dst, publish, bits));
+    if (is_dp(m)) m->comm_steps += 1;
     SERT_HIP(hipGetLastError());   // a rejected launch (bad configuration) surfaces here, not as a hang
     // (an event record stalls its queue for ~6 us: steps with the fused prologue skip it)
     if (fused_pre) m->step_done_pending = true;
@@ -1596,7 +1868,7 @@ static int shard_setup(sert_model* m) {
     hipStream_t s = m->stream;
     SERT_HIP(hipStreamSynchronize(s));
     SERT_HIP(hipStreamSynchronize(m->stream2));
-    SERT_HIP(hipStreamSynchronize(m->stream3));
+    if (m->stream3) SERT_HIP(hipStreamSynchronize(m->stream3));
     float** P[4] = {&m->rw, &m->re, &m->W, &m->b};
     float** S0[4] = {&m->s0_rw, &m->s0_re, &m->s0_w, &m->s0_b};
     float** S1[4] = {&m->s1_rw, &m->s1_re, &m->s1_w, &m->s1_b};
@@ -1604,7 +1876,13 @@ static int shard_setup(sert_model* m) {
     for (int i = 0; i < 4; ++i) {
         if (!m->pt_big[i]) continue;
         const size_t unit = (size_t)m->world * (size_t)m->ar_chunks;
-        const size_t sc = round_up((n[i] + unit - 1) / unit, 64);
+        size_t sc = round_up((n[i] + unit - 1) / unit, 64);
+        if (i == 0 && m->xr_mode) {
+            // owned by rows: a piece is a whole number of rows (a multiple of 16, so that it stays a
+            // multiple of 64 elements)
+            m->xr_rows_per_rank = (int64_t)round_up(cdiv((int64_t)m->cfg.vocab_size, m->world), 16);
+            sc = (size_t)m->xr_rows_per_rank * (size_t)m->cfg.word_dim;
+        }
         const size_t pad = sc * unit;
         float *np = nullptr, *ns0 = nullptr, *ns1 = nullptr;
         SERT_TRY(dzalloc(&np, pad, s));
@@ -1653,7 +1931,7 @@ static int sharded_state_io(sert_model* m, int i, int k, float* host_out, const 
         SERT_HIP(hipMemcpyAsync(full + piece_off(m, i, c), st + (size_t)c * sc, sc * sizeof(float), hipMemcpyDeviceToDevice, s));
     int rc = 0;
     if (m->host_ar) {
-        rc = host_allreduce(m, full, pad, s);   // everything not owned is zero: the sum is the gather
+        for (int c = 0; c < m->ar_chunks && rc == 0; ++c) rc = host_allgather(m, full + (size_t)c * slab_elems(m, i), sc, s);
     } else {
         for (int c = 0; c < m->ar_chunks && rc == 0; ++c)
             if (g_rccl.AllGather(full + piece_off(m, i, c), full + (size_t)c * slab_elems(m, i), sc, 7, m->comm, s) != 0)
@@ -1738,8 +2016,17 @@ static int create_resources(sert_model* m) {
     const auto& c = m->cfg;
     SERT_HIP(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
     SERT_HIP(hipStreamCreateWithFlags(&m->stream2, hipStreamNonBlocking));
-    SERT_HIP(hipStreamCreateWithFlags(&m->stream3, hipStreamNonBlocking));
-    SERT_HIP(hipStreamCreateWithFlags(&m->stream4, hipStreamNonBlocking));
+    // The opt-in schedules that need a third / fourth queue create them; by default they do not exist:
+    // HIP maps streams onto FOUR hardware queues, and a fifth stream -- the communication stream of a
+    // data-parallel model -- would share one with the main stream (its kernels then queue behind the
+    // main stream's, and every cross-stream event costs 10-30 us instead of ~6)
+    {
+        const char* e3 = getenv("SERT_STREAMS");
+        const bool want3 = (e3 && atoi(e3) >= 3) || (getenv("SERT_DW_THIRD") && atoi(getenv("SERT_DW_THIRD")) != 0);
+        const bool want4 = getenv("SERT_ADAM_SPLIT") && atoi(getenv("SERT_ADAM_SPLIT")) != 0;
+        if (want3) SERT_HIP(hipStreamCreateWithFlags(&m->stream3, hipStreamNonBlocking));
+        if (want4) SERT_HIP(hipStreamCreateWithFlags(&m->stream4, hipStreamNonBlocking));
+    }
     SERT_HIP(hipEventCreateWithFlags(&m->ev_word_opt, hipEventDisableTiming));
     SERT_HIP(hipEventCreateWithFlags(&m->ev_early, hipEventDisableTiming));
     SERT_HIP(hipEventCreateWithFlags(&m->ev_join3, hipEventDisableTiming));
@@ -1911,6 +2198,9 @@ int sert_destroy(sert_model* m) {
     }
     (void)hipFree(m->sq_scratch);
     (void)hipFree(m->tail_blk);
+    xr_free_lists(m);
+    if (m->ev_params_ready) (void)hipEventDestroy(m->ev_params_ready);
+    if (m->ev_word_updated) (void)hipEventDestroy(m->ev_word_updated);
     if (m->comm_stream) (void)hipStreamDestroy(m->comm_stream);
     float* bufs[] = {m->rw, m->re, m->W, m->b, m->s0_rw, m->s0_re, m->s0_w, m->s0_b, m->s1_rw,
                      m->s1_re, m->s1_w, m->s1_b, m->gflat, m->H, m->T, m->DA, m->DH, m->rowloss,
@@ -1927,7 +2217,8 @@ int sert_destroy(sert_model* m) {
     (void)hipFree(m->etail); (void)hipFree(m->epart); (void)hipFree(m->eg_entries); (void)hipFree(m->eg_offs); (void)hipFree(m->sort_hist); (void)hipFree(m->sort_bin_total);
     (void)hipFree(m->sort_k_tmp); (void)hipFree(m->sort_v_tmp);
     if (m->h_loss) (void)hipHostFree(m->h_loss);
-    if (m->host_ar_buf) (void)hipHostFree(m->host_ar_buf);
+    if (m->host_send) (void)hipHostFree(m->host_send);
+    if (m->host_recv) (void)hipHostFree(m->host_recv);
     free_split(m->split[0]); free_split(m->split[1]);
     if (m->timing.created)
         for (int g = 0; g < TG_COUNT; ++g)
@@ -1961,8 +2252,10 @@ int sert_set_tensor(sert_model* m, int which, const float* host, size_t count) {
     if (t.count != count) SERT_FAIL("element count mismatch");
     if (which >= SERT_T_STATE0_RW && which <= SERT_T_STATE1_B && m->pt_sharded[(which - SERT_T_STATE0_RW) % 4])
         return sharded_state_io(m, (which - SERT_T_STATE0_RW) % 4, (which - SERT_T_STATE0_RW) / 4, nullptr, host);
+    if (m->comm_stream) SERT_HIP(hipStreamSynchronize(m->comm_stream));
     SERT_HIP(hipMemcpyAsync(t.ptr, host, count * sizeof(float), hipMemcpyHostToDevice, m->stream));
     SERT_HIP(hipStreamSynchronize(m->stream));
+    if (which == SERT_T_RW) { m->rw_full = true; m->xr_fetched_batch = -1; }   // (every rank sets the whole table)
     return 0;
 }
 
@@ -1979,6 +2272,9 @@ int sert_get_tensor(sert_model* m, int which, float* host, size_t count) {
         SERT_FAIL("gradients and activations are only readable from a model created with keep_grads = 1");
     if (which >= SERT_T_STATE0_RW && which <= SERT_T_STATE1_B && m->pt_sharded[(which - SERT_T_STATE0_RW) % 4])
         return sharded_state_io(m, (which - SERT_T_STATE0_RW) % 4, (which - SERT_T_STATE0_RW) / 4, host, nullptr);
+    if (which == SERT_T_RW) SERT_TRY(ensure_full_rw(m));   // (owned by rows: collective while stale)
+    if (m->comm_stream) SERT_HIP(hipStreamSynchronize(m->comm_stream));
+    if (m->stream2) SERT_HIP(hipStreamSynchronize(m->stream2));
     SERT_HIP(hipMemcpyAsync(host, t.ptr, count * sizeof(float), hipMemcpyDeviceToHost, m->stream));
     SERT_HIP(hipStreamSynchronize(m->stream));
     return 0;
@@ -2126,6 +2422,8 @@ int sert_upload_dataset(sert_model* m, int split, const void* x, const int32_t* 
             SERT_HIP(hipStreamSynchronize(s));
             d.bit_words = wi.bit_words;
         }
+        // data parallel, word table owned by rows: the per-batch exchange lists (collective)
+        if (is_dp(m)) SERT_TRY(xr_build_lists(m, wi.touched_bits, nb, wi.bit_words));
         d.idx_batches = wi.batches;
         if ((size_t)wi.max_part_rows + 1 > m->wpart_rows) {
             (void)hipFree(m->wpart);
@@ -2160,8 +2458,12 @@ int sert_train_batch(sert_model* m, int64_t batch_index, const int64_t* negative
             m->spec_fb_batch = hint;
             m->spec_fb_step = m->step;
         } else if (is_vs(m) && !is_fs(m)) {
-            SERT_TRY(vs_project(m, ds, hint));   // data parallel: the parameter-only part
+            // data parallel: the parameter-only part (by rows: behind the fetch of the rows it reads)
+            if (m->xr_on) SERT_TRY(xr_fetch_params(m, hint));
+            SERT_TRY(vs_project(m, ds, hint));
             m->projected_batch = hint;
+        } else if (m->xr_on) {
+            SERT_TRY(xr_fetch_params(m, hint));
         }
         return 0;
     };
@@ -2268,6 +2570,7 @@ int sert_eval_batch(sert_model* m, int split, int64_t batch_index, const int64_t
     SERT_TRY(eval_check_args(m, split));
     invalidate_speculation(m);   // evaluation reuses the activation buffers and the negatives
     SERT_HIP(hipSetDevice(m->cfg.device));
+    SERT_TRY(ensure_full_rw(m));
     const DataSplit& ds = m->split[split];
     const int B = m->cfg.batch_size;
     if (batch_index < 0 || (batch_index + 1) * (int64_t)B > ds.N) SERT_FAIL("batch_index out of range");
@@ -2296,6 +2599,7 @@ int sert_eval_batches(sert_model* m, int split, const int64_t* batch_indices, in
     if (count == 0) return 0;
     invalidate_speculation(m);
     SERT_HIP(hipSetDevice(m->cfg.device));
+    SERT_TRY(ensure_full_rw(m));
     const DataSplit& ds = m->split[split];
     const int B = m->cfg.batch_size;
     for (int64_t i = 0; i < count; ++i)
@@ -2358,6 +2662,7 @@ int sert_predict_tokens(sert_model* m, const void* ids, int64_t rows, float* out
     if (is_vs(m)) SERT_FAIL("sert_predict_tokens is the loglinear predict_fn");
     if (rows <= 0) return 0;
     SERT_HIP(hipSetDevice(m->cfg.device));
+    SERT_TRY(ensure_full_rw(m));
     const auto& c = m->cfg;
     const int n = c.window_size, d = c.word_dim, V = c.num_entities;
     const int64_t toks = rows * n;
@@ -2759,6 +3064,15 @@ int sert_score_topk(int device, const float* entities, int64_t V, int32_t dim, c
 // latency to the exchange, which on a world of one costs more than the overlap of slab c's
 // optimiser with slab c+1's reduce-scatter returns; SERT_AR_CHUNKS=k is there to be tuned on a
 // multi-GPU node.
+// The word table is exchanged by rows (kernels_xchg.h) unless SERT_DP_EXCHANGE=zero1 asks for the
+// reduce-scatter / all-gather of whole slabs, or the model cannot take it: rows that are no multiple of
+// 16 bytes, gradients the caller wants to read back (keep_grads), several slabs per tensor.
+static bool row_exchange_wanted(const sert_model* m) {
+    const char* e = getenv("SERT_DP_EXCHANGE");
+    if (e && !strcmp(e, "zero1")) return false;
+    return m->cfg.word_dim % 4 == 0 && !m->cfg.keep_grads && m->ar_chunks == 1 && !m->cfg.inference_only;
+}
+
 static int exchange_slabs() {
     const char* e = getenv("SERT_AR_CHUNKS");
     const int want = e ? atoi(e) : 1;
@@ -2800,6 +3114,11 @@ int sert_comm_init(sert_model* m, const char id[SERT_COMM_ID_BYTES], int rank, i
         }
     }
     m->ar_chunks = exchange_slabs();
+    m->xr_mode = row_exchange_wanted(m);
+    if (!m->ev_params_ready) {
+        SERT_HIP(hipEventCreateWithFlags(&m->ev_params_ready, hipEventDisableTiming));
+        SERT_HIP(hipEventCreateWithFlags(&m->ev_word_updated, hipEventDisableTiming));
+    }
     const int rc = shard_setup(m);
     if (rc != 0) {   // never leave a communicator behind a model that could not be sharded
         const std::string why = g_last_error;
@@ -2809,7 +3128,7 @@ int sert_comm_init(sert_model* m, const char id[SERT_COMM_ID_BYTES], int rank, i
     return rc;
 }
 
-int sert_comm_init_host(sert_model* m, int rank, int world, sert_allreduce_fn fn, void* user) {
+int sert_comm_init_host(sert_model* m, int rank, int world, sert_alltoall_fn fn, void* user) {
     if (!m || !fn) SERT_FAIL("null argument");
     if (world < 1 || rank < 0 || rank >= world) SERT_FAIL("bad rank/world");
     if ((int64_t)m->cfg.batch_size * world != m->cfg.global_batch_size)
@@ -2823,6 +3142,7 @@ int sert_comm_init_host(sert_model* m, int rank, int world, sert_allreduce_fn fn
     m->world = world;
     invalidate_speculation(m);
     m->ar_chunks = exchange_slabs();
+    m->xr_mode = row_exchange_wanted(m);
     const int rc = shard_setup(m);
     if (rc != 0) {
         const std::string why = g_last_error;
@@ -2839,6 +3159,7 @@ int sert_comm_destroy(sert_model* m) {
     (void)hipSetDevice(m->cfg.device);
     if (m->comm_stream) (void)hipStreamSynchronize(m->comm_stream);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
+    if (!m->comm_dead && is_dp(m) && !m->rw_full) (void)ensure_full_rw(m);   // (collective: every rank destroys)
     if (m->host_ar || m->comm) m->comm_dead = true;
     m->host_ar = nullptr;
     m->host_ar_user = nullptr;
@@ -2850,13 +3171,57 @@ int sert_comm_destroy(sert_model* m) {
     return 0;
 }
 
+int sert_comm_stats(sert_model* m, double* out, int n) {
+    if (!m || !out || n < 1 || n > 8) SERT_FAIL("bad argument");
+    double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    v[0] = (double)m->world;
+    if (is_dp(m) || m->comm_dead) {
+        v[1] = m->pt_sharded[0] ? (m->xr_mode ? 2.0 : 1.0) : 0.0;
+        v[2] = m->comm_steps > 0 ? m->comm_bytes_moved / (double)m->comm_steps : 0.0;
+        const double W = (double)m->world;
+        v[3] = 2.0 * 2.0 * (W - 1.0) / W * 4.0 * (double)m->pt_pad[0];
+        v[4] = m->host_ar ? 2.0 : 1.0;
+        v[5] = (double)m->comm_steps;
+        if (m->xr && !m->xr->batches.empty()) {
+            double f = 0.0, sv = 0.0;
+            for (const RowExchangeBatch& b : m->xr->batches) { f += b.fetch_total; sv += b.serve_total; }
+            v[6] = f / (double)m->xr->batches.size();
+            v[7] = sv / (double)m->xr->batches.size();
+        }
+    }
+    for (int i = 0; i < n; ++i) out[i] = v[i];
+    return 0;
+}
+
+int sert_debug_row_lists(const uint32_t* allbits, int world, int rank, int64_t num_batches, int64_t bit_words,
+                         int64_t rows_per_rank, int64_t vocab, int64_t batch, int32_t* serve_cnt, int32_t* fetch_cnt,
+                         int32_t* serve_rows, int32_t* fetch_rows, int32_t* union_rows, int32_t* ptr, int32_t* ent,
+                         int64_t capacity, int64_t* sizes) {
+    if (!allbits || world < 1 || rank < 0 || rank >= world || batch < 0 || batch >= num_batches || !sizes)
+        SERT_FAIL("bad argument");
+    RowExchangeLists L;
+    build_row_exchange(allbits, world, rank, num_batches, bit_words, rows_per_rank, vocab, L);
+    const RowExchangeBatch& xb = L.batches[(size_t)batch];
+    sizes[0] = xb.serve_total; sizes[1] = xb.fetch_total; sizes[2] = xb.nunion; sizes[3] = xb.nent; sizes[4] = L.max_xfer_rows;
+    if (std::max<int64_t>(std::max(xb.serve_total, xb.fetch_total), std::max(xb.nunion + 1, xb.nent)) > capacity)
+        SERT_FAIL("capacity too small");
+    for (int q = 0; q < world; ++q) { serve_cnt[q] = xb.serve_cnt[(size_t)q]; fetch_cnt[q] = xb.fetch_cnt[(size_t)q]; }
+    std::copy_n(L.serve_rows.begin() + xb.serve_off, xb.serve_total, serve_rows);
+    std::copy_n(L.fetch_rows.begin() + xb.fetch_off, xb.fetch_total, fetch_rows);
+    std::copy_n(L.union_rows.begin() + xb.union_off, xb.nunion, union_rows);
+    std::copy_n(L.ptr.begin() + xb.ptr_off, xb.nunion + 1, ptr);
+    std::copy_n(L.ent.begin() + xb.ent_off, xb.nent, ent);
+    return 0;
+}
+
 int sert_synchronize(sert_model* m) {
     if (!m) SERT_FAIL("null model");
     SERT_HIP(hipSetDevice(m->cfg.device));
     SERT_HIP(hipStreamSynchronize(m->stream));
     SERT_HIP(hipStreamSynchronize(m->stream2));
-    SERT_HIP(hipStreamSynchronize(m->stream3));
-    SERT_HIP(hipStreamSynchronize(m->stream4));
+    if (m->stream3) SERT_HIP(hipStreamSynchronize(m->stream3));
+    if (m->stream4) SERT_HIP(hipStreamSynchronize(m->stream4));
+    if (m->comm_stream) SERT_HIP(hipStreamSynchronize(m->comm_stream));
     return 0;
 }
 

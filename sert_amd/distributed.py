@@ -16,8 +16,8 @@ What the host needs beyond that is tiny -- the 128-byte ncclUniqueId, the initia
 parameters, barriers, a max over ranks of a wall time -- and goes through a
 rendezvous DIRECTORY on the node's shared memory file system (atomic renames, polling):
 no sockets, no port beyond the one the launcher already owns, no third-party package.
-``host_allreduce`` (the verification transport behind SERT_COMM=host, several ranks on
-one GPU) sums through the same directory.
+``host_alltoall`` (the verification transport behind SERT_COMM=host, several ranks on
+one GPU) moves its float segments through the same directory.
 """
 import atexit
 import hashlib
@@ -81,6 +81,19 @@ class FileStore(object):
                 time.sleep(delay)
                 delay = min(0.01, delay * 1.5)
 
+    def wait(self, key, timeout=None):
+        """Block until `key` is published; returns its path (large values are read by the caller)."""
+        path = self._file(key)
+        deadline = time.time() + (timeout or _TIMEOUT_S)
+        delay = _POLL_S
+        while not os.path.exists(path):
+            if time.time() > deadline:
+                raise RuntimeError('rendezvous timed out waiting for %r in %s (rank %d of %d)'
+                                   % (key, self.path, self.rank, self.world))
+            time.sleep(delay)
+            delay = min(0.01, delay * 1.5)
+        return path
+
     def drop(self, key):
         try:
             os.unlink(self._file(key))
@@ -107,6 +120,7 @@ class FileStore(object):
         return out
 
     _last_exchange_file = None
+    _last_a2a = None
 
 
 _context = Context()
@@ -237,18 +251,47 @@ def _all_gather_bytes(tag, data):
     return _need_store().exchange(tag, data)
 
 
-def host_allreduce(array):
-    """In-place sum of a float32 numpy array over the ranks, in rank order on every rank
-    (identical bits everywhere) -- the callback of the host-mediated exchange
-    (SERT_COMM=host: several ranks on one GPU, for verification; RCCL refuses duplicate
-    devices)."""
-    if _context.world_size <= 1:
+def host_alltoall(send, send_offsets, send_counts, recv, recv_offsets, recv_counts):
+    """The callback of the host-mediated exchange (SERT_COMM=host: several ranks on one GPU, for
+    verification; RCCL refuses duplicate devices): rank r's `send` holds send_counts[q] float32 at
+    send_offsets[q] for every rank q; on return recv[recv_offsets[q] : + recv_counts[q]] holds what
+    rank q addressed to this rank.  Bits are moved, never interpreted.  One file per rank and call
+    (the whole send buffer, with its offset table in front); every reader maps the slice addressed to it."""
+    world, rank = _context.world_size, _context.rank
+    so = np.asarray(send_offsets, dtype=np.int64)
+    sc = np.asarray(send_counts, dtype=np.int64)
+    ro = np.asarray(recv_offsets, dtype=np.int64)
+    rc = np.asarray(recv_counts, dtype=np.int64)
+    if world <= 1:
+        if rc[0]:
+            recv[ro[0]:ro[0] + rc[0]] = send[so[0]:so[0] + sc[0]]
         return
-    parts = _all_gather_bytes('ar', array.tobytes())
-    total = np.frombuffer(parts[0], dtype=array.dtype).copy()
-    for p in parts[1:]:
-        total += np.frombuffer(p, dtype=array.dtype)
-    array[...] = total.reshape(array.shape)
+    st = _need_store()
+    g = st.next_generation()
+    n = int((so + sc).max())
+    header = np.concatenate([so, sc]).astype(np.int64)
+    st.set('a2a.%d.%d' % (g, rank), header.tobytes() + np.ascontiguousarray(send[:n]).tobytes())
+    hbytes = header.nbytes
+    for q in range(world):
+        if q == rank:
+            if rc[q]:
+                assert rc[q] == sc[q]
+                recv[ro[q]:ro[q] + rc[q]] = send[so[q]:so[q] + sc[q]]
+            continue
+        path = st.wait('a2a.%d.%d' % (g, q))      # (published atomically: it exists = it is complete)
+        with open(path, 'rb') as f:
+            hdr = np.frombuffer(f.read(hbytes), dtype=np.int64)
+            off, cnt = int(hdr[rank]), int(hdr[world + rank])
+            if cnt != int(rc[q]):
+                raise RuntimeError('host all-to-all: rank %d sends %d floats to rank %d, which expects %d'
+                                   % (q, cnt, rank, int(rc[q])))
+            if cnt:
+                f.seek(hbytes + 4 * off)
+                recv[ro[q]:ro[q] + cnt] = np.frombuffer(f.read(4 * cnt), dtype=np.float32)
+    # this rank's file of the previous call can go once everybody has published the current one
+    if st._last_a2a is not None:
+        st.drop(st._last_a2a)
+    st._last_a2a = 'a2a.%d.%d' % (g, rank)
 
 
 def barrier():

@@ -257,13 +257,30 @@ class ModelBase(ModelInterface):
             # verification transport: the exchange goes through pinned host memory and
             # gloo, so that several ranks can share one GPU (tests on a 1-GPU box)
             self._engine.comm_init_host(ctx.rank, ctx.world_size,
-                                        distributed.host_allreduce)
+                                        distributed.host_alltoall)
         elif ctx.world_size > 1 or os.environ.get('SERT_FORCE_COMM') == '1':
             self._engine.comm_init(ctx.unique_id(), ctx.rank, ctx.world_size)
 
         self._upload(_capi.SPLIT_TRAIN, x_train, self.training_set[1],
                      self.training_set[2])
         self._upload(_capi.SPLIT_VALIDATE, x_val, self.validation_set[1], None)
+
+    def comm_info(self):
+        """Additive: what the data-parallel exchange of this model moves (None when single-process)."""
+        if self._engine is None or self._ctx.world_size <= 1:
+            return None
+        st = self._engine.comm_stats()
+        names = {'rows': 'word table owned by rows: all-to-all of the touched parameter rows before the forward and '
+                         'of their gradient rows after the backward (static per-batch lists), dense optimiser on the '
+                         'owned rows',
+                 'zero1': 'ZeRO-1 word table (reduce-scatter + sharded optimiser + all-gather)', 'none': 'replicated'}
+        return {'exchange': names[st['exchange']], 'exchange_kind': st['exchange'],
+                'rccl_ranks': st['world'] if st['transport'] == 'rccl' else 0, 'transport': st['transport'],
+                'comm_bytes_per_step': st['bytes_per_step'], 'zero1_comm_bytes_per_step': st['zero1_bytes_per_step'],
+                'steps_counted': st['steps'], 'rows_fetched_per_batch': st['rows_fetched_per_batch'],
+                'rows_served_per_batch': st['rows_served_per_batch'],
+                'note': 'bytes this rank sends + receives per training step through collectives (word-table exchange + '
+                        'the small all-reduce), mean over the steps run so far'}
 
     def _shard_rows(self, num_instances):
         """Row indices this rank owns (None when single-process)."""

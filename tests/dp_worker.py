@@ -14,12 +14,44 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def run_c2(kind):
+    """Three steps at the headline size (C2), evaluation of one batch, the tables and the word table's
+    optimiser state -- for any world size (batch_size is the GLOBAL batch)."""
+    import bench
+    from sert_amd import models, _capi as C
+    B, n, z, Vw, Ve, d = 65536, 10, 10, 100000, 1000, 128
+    rng = np.random.RandomState(0)
+    X, y, w = bench.synth_data(rng, 2 * B, n, Vw, Ve)
+    w = rng.uniform(0.5, 2.0, len(w)).astype(np.float32)
+    models.VectorSpaceLanguageModel.sampler_seed = 1234
+    m = bench.build_model('vectorspace', models, B, n, Vw, Ve, d, d, z, X, y, w, seed=0)
+    out = {}
+    m._engine.hint_next_batch(1)
+    out['loss0'] = np.float64(m.train_fn(0))
+    m._engine.hint_next_batch(0)
+    out['loss1'] = np.float64(m.train_fn(1))
+    out['loss2'] = np.float64(m.train_fn(0))
+    out['eval0'] = np.float64(m.test_fn(0))
+    for name, which in (('Rw', C.T_RW), ('Re', C.T_RE), ('W', C.T_W), ('b', C.T_B),
+                        ('opt_state0_rw', C.T_STATE0_RW), ('opt_state1_rw', C.T_STATE1_RW)):
+        out[name] = m._engine.get_tensor(which).copy()
+    info = m.comm_info()
+    out['exchange'] = np.str_(info['exchange_kind'] if info else 'none')
+    out['comm_bytes_per_step'] = np.float64(info['comm_bytes_per_step'] if info else 0.0)
+    out['zero1_bytes_per_step'] = np.float64(info['zero1_comm_bytes_per_step'] if info else 0.0)
+    return out
+
+
 def run(kind):
     """Train two epochs + evaluate; identical code for any world size (the model's
     batch_size is the GLOBAL batch).  Returns a dict of numpy results."""
+    if kind == 'c2':
+        return run_c2(kind)
     from sert_amd import models
     from tests import util as U
-    B, n, z, Vw, Ve, d = 64, 3, 4, 200, 20, 16
+    B, n, z, Vw, Ve, d = 96, 3, 4, 200, 20, 16          # 96 rows: 2, 3 and 4 ranks
+    if kind == 'loglinear_bigw':
+        Ve, d = 70000, 64                               # dense W: 4.48 M elements (> 2^22: a sharded tensor), no R_e
     if kind == 'vectorspace':
         p = U.make_vs_problem(61, B * 6 + 5, n, z, Vw, Ve, d, d)      # +5: an incomplete tail
         pv = U.make_vs_problem(62, B * 2, n, z, Vw, Ve, d, d)
@@ -51,6 +83,10 @@ def run(kind):
     out['step'] = np.int64(st.pop('step'))
     for name, value in st.items():
         out['opt_' + name] = value
+    info = m.comm_info()
+    out['exchange'] = np.str_(info['exchange_kind'] if info else 'none')
+    out['comm_world'] = np.int64(m._ctx.world_size)
+    out['comm_bytes_per_step'] = np.float64(info['comm_bytes_per_step'] if info else 0.0)
     return out
 
 

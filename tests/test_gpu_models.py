@@ -231,25 +231,30 @@ def test_device_sampler_is_uniform(hip_lib):
     eng.close()
 
 
-@pytest.mark.parametrize('chunks', [None, '1', '3', '16'])
-def test_rccl_single_rank_communicator(hip_lib, monkeypatch, chunks):
-    """ncclCommInitRank / ncclReduceScatter / ncclAllGather / ncclAllReduce through the C ABI
-    with world=1 (all a 1-GPU box can run): the data-parallel exchange -- the word table's
-    gradient reduce-scattered slab by slab, the optimiser on the owned pieces with the
-    piece-sized state, the updated slabs all-gathered, the small tensors all-reduced -- is
-    exercised and is the identity.  The communicator is attached AFTER the parameters were set
+@pytest.mark.parametrize('chunks,exchange', [(None, 'zero1'), ('1', 'zero1'), ('3', 'zero1'), ('16', 'zero1'), (None, 'rows')])
+def test_rccl_single_rank_communicator(hip_lib, monkeypatch, chunks, exchange):
+    """ncclCommInitRank / ncclReduceScatter / ncclAllGather / ncclAllReduce / grouped ncclSend-ncclRecv
+    through the C ABI with world=1 (all a 1-GPU box can run): the data-parallel exchange -- the word
+    table's gradient reduce-scattered slab by slab, the optimiser on the owned pieces with the
+    piece-sized state, the updated slabs all-gathered ('zero1'), or the word table owned by rows
+    with its pack / all-to-all / rank-ordered sum / row-filtered optimiser and the all-gather behind
+    the evaluation and the read-back ('rows': keep_grads off) -- and the small tensors all-reduced,
+    is exercised and is the identity.  The communicator is attached AFTER the parameters were set
     (they move into the padded allocation) and the optimiser state is read back through the
     collective gather."""
     if chunks is not None:
         monkeypatch.setenv('SERT_AR_CHUNKS', chunks)
+    monkeypatch.setenv('SERT_DP_EXCHANGE', exchange)
+    keep = 0 if exchange == 'rows' else 1
     B, n, z, Vw, Ve, dw, de = 64, 3, 4, 101, 12, 16, 16
     p = U.make_vs_problem(31, B * 2, n, z, Vw, Ve, dw, de)
     neg = p['rng'].randint(0, Ve, (B, z)).astype(np.int64)
     outs = []
     for use_comm in (False, True):
-        eng = U.vs_engine(p, B, n, z, 0.01)
+        eng = U.vs_engine(p, B, n, z, 0.01, keep_grads=keep)
         if use_comm:
             eng.comm_init(C.comm_unique_id(), 0, 1)
+            assert eng.comm_stats()['exchange'] == exchange
         eng.upload_dataset(C.SPLIT_TRAIN, p['X'], y_int=p['y'], w=p['w'])
         l0 = eng.train_batch(0, neg)
         l1 = eng.train_batch(1, neg)
@@ -531,43 +536,77 @@ def test_full_size_known_answers(hip_lib):
     eng.close()
 
 
-@pytest.mark.parametrize('kind,launcher,chunks', [('vectorspace', 'own', None), ('loglinear', 'own', None),
-                                                  ('vectorspace', 'own', '3'), ('vectorspace', 'torchrun', None)])
-def test_two_ranks_on_one_gpu_match_single_process(hip_lib, tmp_path, kind, launcher, chunks):
-    """The data-parallel step with TWO real ranks (one process each) on the one GPU of the test
-    box, through the host-mediated exchange (RCCL refuses duplicate devices): row sharding,
-    global 1/B scaling, rank-invariant negatives, L2 applied once, the ZeRO-1 word table
-    (gradient reduce-scatter, optimiser and its state on the owned pieces only, parameter
-    all-gather; one slab or three), the loss and eval-loss reductions, the collective read-back
-    of the sharded optimiser state -- against the same code run single-process.  Ranks are
-    started by the product's own launcher (sert_amd.distributed, no PyTorch) and, once, by
-    torch.distributed.run as the driver does.  Tolerance: fp32 reassociation of the sums."""
+@pytest.mark.parametrize('kind,launcher,world,exchange,chunks', [
+    ('vectorspace', 'own', 2, 'rows', None), ('loglinear', 'own', 2, 'rows', None),
+    ('vectorspace', 'own', 4, 'rows', None), ('loglinear', 'own', 3, 'rows', None),
+    ('vectorspace', 'own', 2, 'zero1', None), ('vectorspace', 'own', 4, 'zero1', '3'), ('loglinear', 'own', 2, 'zero1', '2'),
+    ('loglinear_bigw', 'own', 2, 'rows', None), ('loglinear_bigw', 'own', 2, 'zero1', None),
+    ('vectorspace', 'torchrun', 2, 'rows', None)])
+def test_ranks_on_one_gpu_match_single_process(hip_lib, tmp_path, kind, launcher, world, exchange, chunks):
+    """The data-parallel step with 2-4 real ranks (one process each) on the one GPU of the test box,
+    through the host-mediated exchange (RCCL refuses duplicate devices), every rank receiving exactly
+    its pieces: row sharding of the batch, global 1/B scaling, rank-invariant negatives, L2 applied
+    once; the word table owned BY ROWS (all-to-all of the touched parameter rows and of their gradient
+    rows over the static lists, rank-ordered sum at the owner, dense optimiser on the owned rows, the
+    collective all-gather behind the evaluation passes and the parameter read-back) or ZeRO-1 style
+    (piecewise reduce-scatter, optimiser and its state on the owned pieces, all-gather; one slab,
+    two or three); a dense W of more than 4 M elements beside an absent R_e (loglinear_bigw: sharded
+    W, small bias); the loss and eval-loss reductions; the collective read-back of the sharded
+    optimiser state -- against the same code run single-process.  Ranks are started by the product's
+    own launcher (sert_amd.distributed, no PyTorch) and, once, by torch.distributed.run as the driver
+    does.  Tolerance: fp32 reassociation of the sums."""
     import socket
     from tests import dp_worker
     out = str(tmp_path / 'dp.npz')
-    env = dict(os.environ, SERT_COMM='host', OMP_NUM_THREADS='1')
+    env = dict(os.environ, SERT_COMM='host', OMP_NUM_THREADS='1', SERT_DP_EXCHANGE=exchange)
     if chunks:
         env['SERT_AR_CHUNKS'] = chunks
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'SERT_RDZV_DIR'):
         env.pop(k, None)
     worker = [os.path.join(U.ROOT, 'tests', 'dp_worker.py'), kind, out]
     if launcher == 'own':
-        cmd = [sys.executable, '-m', 'sert_amd.distributed', '2'] + worker
+        cmd = [sys.executable, '-m', 'sert_amd.distributed', str(world)] + worker
     else:
         with socket.socket() as s:
             s.bind(('127.0.0.1', 0))
             port = s.getsockname()[1]
-        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world),
                '--master-addr', '127.0.0.1', '--master-port', str(port)] + worker
-    subprocess.run(cmd, check=True, env=env, cwd=U.ROOT, timeout=600)
+    subprocess.run(cmd, check=True, env=env, cwd=U.ROOT, timeout=900)
     two = np.load(out)
     one = dp_worker.run(kind)
+    assert str(two['exchange']) == (exchange if chunks is None else 'zero1')
+    assert int(two['comm_world']) == world and float(two['comm_bytes_per_step']) > 0
     scalars = ('epoch1', 'epoch2', 'train_error', 'validation_error')
     for key in scalars:
         assert abs(float(two[key]) - float(one[key])) <= 2e-5 * abs(float(one[key])), key
-    for key in [k for k in one if k not in scalars]:
+    for key in [k for k in one if k not in scalars and k not in ('exchange', 'comm_world', 'comm_bytes_per_step')]:
         assert U.rel_err(two[key], one[key]) < 2e-5, key
     assert int(two['step']) == int(one['step'])
+
+
+def test_two_ranks_at_c2_size_match_single_process(hip_lib, tmp_path):
+    """The same check ONCE at the headline size (V_w = 100k, V_e = 1k, d = 128, window 10, global
+    batch 65536 -> 32768 rows per rank): three steps, the evaluation of a batch and the full tables,
+    two ranks through the host-mediated exchange by rows against one process.  At this size a rank
+    serves and fetches ~20 k rows per step through lists of ~10 MB -- the offsets, counts and the
+    rank-ordered sums are exercised at their real extents, not on a 200-word toy."""
+    from tests import dp_worker
+    out = str(tmp_path / 'dp_c2.npz')
+    env = dict(os.environ, SERT_COMM='host', OMP_NUM_THREADS='1', SERT_DP_EXCHANGE='rows')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'SERT_RDZV_DIR'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'sert_amd.distributed', '2', os.path.join(U.ROOT, 'tests', 'dp_worker.py'), 'c2', out]
+    subprocess.run(cmd, check=True, env=env, cwd=U.ROOT, timeout=1200)
+    two = np.load(out)
+    one = dp_worker.run('c2')
+    assert str(two['exchange']) == 'rows'
+    # by rows a rank moves fewer bytes than ZeRO-1 would
+    assert float(two['comm_bytes_per_step']) < 0.8 * float(two['zero1_bytes_per_step'])
+    for key in ('loss0', 'loss1', 'loss2', 'eval0'):
+        assert abs(float(two[key]) - float(one[key])) <= 2e-5 * abs(float(one[key])), key
+    for key in ('Rw', 'Re', 'W', 'b', 'opt_state0_rw', 'opt_state1_rw'):
+        assert U.rel_err(two[key], one[key]) < 2e-5, key
 
 
 def test_bench_launches_its_own_ranks(hip_lib):

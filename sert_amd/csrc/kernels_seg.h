@@ -18,7 +18,14 @@ namespace sert {
 // LL_FINAL (loglinear distinct-word backward, with DST_SLOT): a final row is stored as
 //   mask(lp) * acc - exp(lp) * rsum[slot],  lp = logp[slot, :],  mask = eps <= P <= 1-eps
 // (kernels_ll.h: dZu = mask dJsum - P rsum) instead of acc / divisor.
-template <int LPI, bool DST_SLOT = false, bool LL_FINAL = false>
+// SKIP_DENSE (loglinear): items of the batch's dense heavy words are left out -- segsum_heavy computes
+// their rows; a chunk item of such a word carries slot = -1, a final item is recognised by its slot.
+struct DenseSlots {
+    int n;
+    int slot[kHeavyMax];
+};
+
+template <int LPI, bool DST_SLOT = false, bool LL_FINAL = false, bool SKIP_DENSE = false>
 __global__ __launch_bounds__(256) void segsum_rows(const float* __restrict__ src,
                                                    const int32_t* __restrict__ rows,
                                                    const int4* __restrict__ items, int nitems,
@@ -28,12 +35,19 @@ __global__ __launch_bounds__(256) void segsum_rows(const float* __restrict__ src
                                                    unsigned char* __restrict__ touched,
                                                    int rdiv = 1,
                                                    const float* __restrict__ logp = nullptr,
-                                                   const float* __restrict__ rsum = nullptr) {
+                                                   const float* __restrict__ rsum = nullptr,
+                                                   const DenseSlots dense = DenseSlots()) {
     constexpr int IPB = 256 / LPI;  // items per block
     const int sub = threadIdx.x / LPI, l = threadIdx.x % LPI;
     const int item = blockIdx.x * IPB + sub;
     if (item >= nitems) return;
     const int4 it = items[item];
+    if (SKIP_DENSE) {
+        bool skip = it.z < 0 && it.w < 0;
+        if (it.z >= 0)
+            for (int h = 0; h < dense.n; ++h) skip = skip || (dense.slot[h] == it.w);
+        if (skip) return;
+    }
     if (touched && l == 0 && it.z >= 0) touched[it.z] = 1;
     const int chunks = d >> 2;
     // gridDim.y > 1: wide rows (d/4 > LPI) are cut into gridDim.y column groups, one
@@ -214,6 +228,148 @@ __global__ __launch_bounds__(1024) void segsum_upper_fused(const float* __restri
         }
         s.x /= divisor; s.y /= divisor; s.z /= divisor; s.w /= divisor;
         *reinterpret_cast<float4*>(final_dst + (size_t)h.z * d + 4 * c) = s;
+    }
+}
+
+// ---- dense heavy words (word_index.h: kHeavyMax) -------------------------------------------------
+// part[block][h][cols] = sum over the block's kHeavyRowsPerBlock batch rows i of cnt[i][h] * src[i, cols],
+// for the batch's kHeavyMax heavy words at once: ONE coalesced streaming pass over src (B x d) instead of
+// one row fetch per occurrence.  1024 threads = 32 lane groups of 32 lanes; a group takes eight rows of
+// the block (all eight in flight), a lane one float4 column of the 128-column slab blockIdx.y.  The
+// groups are combined in a fixed order: the two halves of a wave by a lane exchange, then the sixteen
+// waves through FOUR LDS slots (32 KB: wave w adds into slot w % 4 in round w / 4), so that two
+// workgroups fit a CU and one's reduction overlaps the other's loads (one 128 KB slot per wave: 100 us
+// for the 262 MB of dJ at C2 dims -- a workgroup alone on its CU loads a third of the time).
+__global__ __launch_bounds__(1024) void segsum_heavy(const float* __restrict__ src, const uint4* __restrict__ cnt16,
+                                                     int B, int d, float* __restrict__ part) {
+    extern __shared__ float4 hv_lds[];   // [4 slots][kHeavyMax][32]
+    const int l = threadIdx.x & 31, g = threadIdx.x >> 5, wv = threadIdx.x >> 6;
+    const int d4 = d >> 2;
+    // 1-D grid, column slab FASTEST: the workgroups running at the same time cover whole rows of src (the
+    // slabs of a row block are neighbours in launch order), not one 512-byte piece of every row
+    const int nslab = (d4 + 31) / 32;
+    const int slab = blockIdx.x % nslab, rblk = blockIdx.x / nslab;
+    const int ch = slab * 32 + l;                  // this lane's float4 column
+    const bool on = ch < d4;
+    float4 acc[kHeavyMax];
+#pragma unroll
+    for (int h = 0; h < kHeavyMax; ++h) acc[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+    constexpr int RPG = kHeavyRowsPerBlock / 32;   // rows per lane group
+    const int row0 = rblk * kHeavyRowsPerBlock + g * RPG;
+    uint4 c[RPG];
+    float4 v[RPG];
+#pragma unroll
+    for (int q = 0; q < RPG; ++q) {
+        const int i = min(row0 + q, B - 1);
+        c[q] = cnt16[i];
+        if (row0 + q >= B) c[q] = make_uint4(0u, 0u, 0u, 0u);
+        v[q] = on ? *reinterpret_cast<const float4*>(src + (size_t)i * d + 4 * ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int q = 0; q < RPG; ++q) {
+        const unsigned cw[4] = {c[q].x, c[q].y, c[q].z, c[q].w};
+#pragma unroll
+        for (int h = 0; h < kHeavyMax; ++h) {
+            const float f = (float)((cw[h >> 2] >> (8 * (h & 3))) & 0xffu);
+            acc[h].x += f * v[q].x; acc[h].y += f * v[q].y; acc[h].z += f * v[q].z; acc[h].w += f * v[q].w;
+        }
+    }
+    // lower half of the wave += upper half (group 2w + group 2w+1), then one slot per wave in LDS
+#pragma unroll
+    for (int h = 0; h < kHeavyMax; ++h) {
+        acc[h].x += __shfl_xor(acc[h].x, 32); acc[h].y += __shfl_xor(acc[h].y, 32);
+        acc[h].z += __shfl_xor(acc[h].z, 32); acc[h].w += __shfl_xor(acc[h].w, 32);
+    }
+    for (int round = 0; round < 4; ++round) {
+        if ((wv >> 2) == round && (threadIdx.x & 63) < 32) {
+            float4* slot = hv_lds + (size_t)(wv & 3) * kHeavyMax * 32;
+#pragma unroll
+            for (int h = 0; h < kHeavyMax; ++h) {
+                if (round == 0) slot[h * 32 + l] = acc[h];
+                else { float4 o = slot[h * 32 + l]; o.x += acc[h].x; o.y += acc[h].y; o.z += acc[h].z; o.w += acc[h].w; slot[h * 32 + l] = o; }
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < kHeavyMax * 32) {
+        const int h = threadIdx.x >> 5;
+        float4 a = hv_lds[h * 32 + l];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float4 t = hv_lds[(w * kHeavyMax + h) * 32 + l];
+            a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+        }
+        if (on) reinterpret_cast<float4*>(part)[((size_t)rblk * kHeavyMax + h) * d4 + ch] = a;
+    }
+}
+
+// final[word[h], :] = (sum over the blocks, in block order within eight interleaved groups, then the
+// groups in order) / divisor.  One workgroup per heavy word.
+__global__ __launch_bounds__(256) void segsum_heavy_combine(const float* __restrict__ part, int nblocks, int d,
+                                                            const int32_t* __restrict__ words, int nheavy,
+                                                            float* __restrict__ final_dst, float divisor) {
+    __shared__ float4 hc_lds[8][32];
+    const int h = blockIdx.x;
+    if (h >= nheavy) return;
+    const int d4 = d >> 2;
+    const int l = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int ch = blockIdx.y * 32 + l;          // (gridDim.y slabs of 32 float4 columns)
+    const float4* p4 = reinterpret_cast<const float4*>(part);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ch < d4) {
+#pragma unroll 8
+        for (int b = g; b < nblocks; b += 8) {
+            const float4 v = p4[((size_t)b * kHeavyMax + h) * d4 + ch];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+    }
+    hc_lds[g][l] = a;
+    __syncthreads();
+    if (g == 0 && ch < d4) {
+        a = hc_lds[0][l];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) { const float4 v = hc_lds[q][l]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+        a.x /= divisor; a.y /= divisor; a.z /= divisor; a.w /= divisor;
+        reinterpret_cast<float4*>(final_dst)[(size_t)words[h] * d4 + ch] = a;
+    }
+}
+
+// Loglinear: row `slot[h]` of dZu = mask(lp) * (sum of the heavy word's dJ rows) - exp(lp) * rsum[slot]
+// (the LL_FINAL store of segsum_rows), from the per-block partials of segsum_heavy over dJ.
+__global__ __launch_bounds__(256) void segsum_heavy_combine_ll(const float* __restrict__ part, int nblocks, int d,
+                                                               const DenseSlots dense, float* __restrict__ final_dst,
+                                                               const float* __restrict__ logp, const float* __restrict__ rsum) {
+    __shared__ float4 hc_lds[8][32];
+    const int h = blockIdx.x;
+    if (h >= dense.n) return;
+    const int d4 = d >> 2;
+    const int l = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int ch = blockIdx.y * 32 + l;
+    const float4* p4 = reinterpret_cast<const float4*>(part);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ch < d4) {
+#pragma unroll 8
+        for (int b = g; b < nblocks; b += 8) {
+            const float4 v = p4[((size_t)b * kHeavyMax + h) * d4 + ch];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+    }
+    hc_lds[g][l] = a;
+    __syncthreads();
+    const int slot = dense.slot[h];
+    const float rs = rsum[slot];
+    const float LOGLO = logf(SERT_CLIP_LO), LOGHI = logf(SERT_CLIP_HI);
+    if (g == 0 && ch < d4) {
+        a = hc_lds[0][l];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) { const float4 v = hc_lds[q][l]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+        const size_t o = (size_t)slot * d + 4 * ch;
+        const float4 lp = *reinterpret_cast<const float4*>(logp + o);
+        a.x = ((lp.x >= LOGLO && lp.x <= LOGHI) ? a.x : 0.f) - __expf(lp.x) * rs;
+        a.y = ((lp.y >= LOGLO && lp.y <= LOGHI) ? a.y : 0.f) - __expf(lp.y) * rs;
+        a.z = ((lp.z >= LOGLO && lp.z <= LOGHI) ? a.z : 0.f) - __expf(lp.z) * rs;
+        a.w = ((lp.w >= LOGLO && lp.w <= LOGHI) ? a.w : 0.f) - __expf(lp.w) * rs;
+        *reinterpret_cast<float4*>(final_dst + o) = a;
     }
 }
 

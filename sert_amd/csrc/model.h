@@ -28,6 +28,8 @@ struct DataSplit {
     int32_t* idx_slots = nullptr;    // loglinear: per token position, rank of its word among them
     int32_t* idx_rows_div = nullptr; // loglinear: idx_rows / n (batch row of every level-0 entry)
     uint32_t* idx_touched_bits = nullptr;   // per batch: bit w set iff word w occurs in it (word_index.h)
+    uint4* idx_dense_counts = nullptr;      // per batch and row: occurrence counts of the batch's dense heavy words
+    int32_t* idx_dense_words = nullptr;     // per batch: their word ids (kHeavyMax slots)
     int64_t bit_words = 0;                  // 32-bit words per batch in idx_touched_bits
     std::vector<BatchIndex> idx_batches;
 };
@@ -138,6 +140,7 @@ struct sert_model {
 
     // scratch
     float* wpart = nullptr;       // segmented-reduce partial rows (word gradient tree)
+    float* hpart = nullptr;       // dense heavy words: per row-block partial rows [blocks][kHeavyMax][d_w]
     size_t wpart_rows = 0;
     float* part = nullptr;        // split-K partials
     size_t part_count = 0;

@@ -220,6 +220,17 @@ static int word_grad_segsum(sert_model* m, const DataSplit& ds, int64_t batch_in
     static const bool no_fused_upper = getenv("SERT_SEG_NO_FUSED_UPPER") != nullptr;   // cross-check knob
     const bool fused_upper = !no_fused_upper && bx.fused_upper_ok && ds.idx_heavy && d % 4 == 0 && d / 4 <= 32 &&
                              bx.nlevels == 3 && bx.item_cnt[1] > 0;
+    // the batch's heavy words: one streaming pass over src for all of them (kernels_seg.h: segsum_heavy)
+    if (bx.dense_cnt > 0) {
+        const int B = m->cfg.batch_size, d4 = d / 4;
+        const int nblk = cdiv(B, kHeavyRowsPerBlock);
+        const uint4* cnt = ds.idx_dense_counts + (size_t)batch_index * B;
+        const size_t lds = (size_t)4 * kHeavyMax * 32 * sizeof(float4);   // 32 KB
+        hipLaunchKernelGGL(segsum_heavy, dim3(nblk * cdiv(d4, 32)), dim3(1024), lds, m->stream, src, cnt, B, d, m->hpart);
+        hipLaunchKernelGGL(segsum_heavy_combine, dim3(bx.dense_cnt, cdiv(d4, 32)), dim3(256), 0, m->stream,
+                           (const float*)m->hpart, nblk, d, (const int32_t*)ds.idx_dense_words + (size_t)batch_index * kHeavyMax,
+                           bx.dense_cnt, m->g_rw, divisor);
+    }
     for (int l = 0; l < bx.nlevels; ++l) {
         const int nitems = bx.item_cnt[l];
         if (nitems == 0) continue;
@@ -283,7 +294,16 @@ static int dzu_from_dj(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         const int4* items = ds.idx_items + bx.item_off[l];
         const float* in = (l == 0) ? m->J : m->zpart + (size_t)bx.part_off[l - 1] * V;
         float* pout = m->zpart + (size_t)bx.part_off[l] * V;
-        if (V % 4 == 0) {
+        if (V % 4 == 0 && bx.dense_cnt > 0) {
+            // (the batch's heavy words are summed by segsum_heavy below: their items are skipped)
+            DenseSlots dsl;
+            dsl.n = bx.dense_cnt;
+            for (int h = 0; h < kHeavyMax; ++h) dsl.slot[h] = h < bx.dense_cnt ? bx.dense_slot[h] : -2;
+            hipLaunchKernelGGL((segsum_rows<64, true, true, true>), dim3(cdiv(nitems, 4), cdiv(V / 4, 64)), dim3(256), 0,
+                               m->stream, in, rows, items, nitems, m->dZu, pout, V, 1.0f,
+                               (unsigned char*)nullptr, 1, (const float*)m->Zu,
+                               (const float*)m->ll_rsum, dsl);
+        } else if (V % 4 == 0) {
             hipLaunchKernelGGL((segsum_rows<64, true, true>), dim3(cdiv(nitems, 4), cdiv(V / 4, 64)), dim3(256), 0,
                                m->stream, in, rows, items, nitems, m->dZu, pout, V, 1.0f,
                                (unsigned char*)nullptr, 1, (const float*)m->Zu,
@@ -292,6 +312,20 @@ static int dzu_from_dj(sert_model* m, const DataSplit& ds, int64_t batch_index) 
             hipLaunchKernelGGL((segsum_rows_scalar<true>), dim3(cdiv(nitems, 4), cdiv(V, 64)), dim3(256), 0, m->stream, in,
                                rows, items, nitems, m->dZu, pout, V, 1.0f, (unsigned char*)nullptr, 1);
         }
+    }
+    if (V % 4 == 0 && bx.dense_cnt > 0) {
+        // Heavy words: sum_i cnt[i][h] dJ[i, :] by ONE pass over dJ (262 MB at C2 dims) instead of one 4 kB
+        // row fetch per occurrence -- a dozen words hold over half of a Zipfian batch's tokens
+        const int B = m->cfg.batch_size, d4 = V / 4;
+        const int nblk = cdiv(B, kHeavyRowsPerBlock);
+        const uint4* cnt = ds.idx_dense_counts + (size_t)batch_index * B;
+        const size_t lds = (size_t)4 * kHeavyMax * 32 * sizeof(float4);   // 32 KB
+        hipLaunchKernelGGL(segsum_heavy, dim3(nblk * cdiv(d4, 32)), dim3(1024), lds, m->stream, (const float*)m->J, cnt, B, V, m->hpart);
+        DenseSlots dsl;
+        dsl.n = bx.dense_cnt;
+        for (int h = 0; h < kHeavyMax; ++h) dsl.slot[h] = h < bx.dense_cnt ? bx.dense_slot[h] : -2;
+        hipLaunchKernelGGL(segsum_heavy_combine_ll, dim3(bx.dense_cnt, cdiv(d4, 32)), dim3(256), 0, m->stream,
+                           (const float*)m->hpart, nblk, V, dsl, m->dZu, (const float*)m->Zu, (const float*)m->ll_rsum);
     }
     if (V % 4 != 0)   // (odd V_e: separate finishing pass)
         hipLaunchKernelGGL(ll_dzu_combine, dim3(grid_for((int64_t)m->ll_U * V)), dim3(256), 0, m->stream, m->dZu,
@@ -2174,6 +2208,7 @@ static void free_split(DataSplit& d) {
     (void)hipFree(d.idx_heavy); d.idx_heavy = nullptr;
     (void)hipFree(d.idx_uwords); (void)hipFree(d.idx_slots); (void)hipFree(d.idx_rows_div);
     (void)hipFree(d.idx_touched_bits);
+    (void)hipFree(d.idx_dense_counts); (void)hipFree(d.idx_dense_words);
     d.idx_uwords = nullptr; d.idx_slots = nullptr; d.idx_rows_div = nullptr;
     d = DataSplit();
 }
@@ -2205,7 +2240,7 @@ int sert_destroy(sert_model* m) {
     if (m->comm_stream) (void)hipStreamDestroy(m->comm_stream);
     float* bufs[] = {m->rw, m->re, m->W, m->b, m->s0_rw, m->s0_re, m->s0_w, m->s0_b, m->s1_rw,
                      m->s1_re, m->s1_w, m->s1_b, m->gflat, m->H, m->T, m->DA, m->DH, m->rowloss,
-                     m->G, m->Z, m->J, m->DG, m->DH2, m->part, m->skbuf, m->wpart, m->red_loss, m->red_sq, m->d_loss,
+                     m->G, m->Z, m->J, m->DG, m->DH2, m->part, m->skbuf, m->wpart, m->hpart, m->red_loss, m->red_sq, m->d_loss,
                      m->d_losses};
     for (float* p : bufs) (void)hipFree(p);
     (void)hipFree(m->ll_tokstat); (void)hipFree(m->ll_lse); (void)hipFree(m->ll_jstat);
@@ -2377,10 +2412,19 @@ int sert_upload_dataset(sert_model* m, int split, const void* x, const int32_t* 
         const int64_t nb = N / B;
         WordIndex wi;
         const bool row_is_pos = !is_vs(m);
+        // vectorspace models: the heavy words of a batch are summed by one dense pass (word_index.h);
+        // SERT_NO_DENSE_HEAVY=1 keeps them in the tree (cross-check knob)
+        // (vectorspace: opt-in, SERT_DENSE_HEAVY=1 -- measured a wash at C2 and C4: the tree's first level is
+        //  bound by its 44 k word items, not by the entries the heavy words take out of it.  loglinear: the
+        //  V_e-wide per-word sums are bandwidth-bound; on by default where V_e % 4 == 0)
+        const bool dense_heavy = !getenv("SERT_NO_DENSE_HEAVY") &&
+                                 (is_vs(m) ? (m->cfg.word_dim % 4 == 0 && m->cfg.word_dim <= 512 && getenv("SERT_DENSE_HEAVY") != nullptr &&
+                                              atoi(getenv("SERT_DENSE_HEAVY")) != 0)
+                                           : (m->cfg.num_entities % 4 == 0));
         bool ids_ok = true;
         SERT_ID_DISPATCH(m->cfg.id_bytes,
                          ids_ok = build_word_index<IdT>((const IdT*)x, nb, B, n, m->cfg.vocab_size, row_is_pos, wi,
-                                                        /*want_slots=*/!is_vs(m)));
+                                                        /*want_slots=*/!is_vs(m), /*dense_heavy=*/dense_heavy));
         if (!ids_ok) SERT_FAIL("token id >= vocab_size in x");
         if (!is_vs(m) && !wi.slots.empty()) {
             const size_t V = (size_t)m->cfg.num_entities;
@@ -2425,6 +2469,21 @@ int sert_upload_dataset(sert_model* m, int split, const void* x, const int32_t* 
         }
         // data parallel, word table owned by rows: the per-batch exchange lists (collective)
         if (is_dp(m)) SERT_TRY(xr_build_lists(m, wi.touched_bits, nb, wi.bit_words));
+        if (wi.any_dense) {
+            SERT_HIP(hipMalloc((void**)&d.idx_dense_counts, wi.dense_counts.size()));
+            SERT_HIP(hipMemcpyAsync(d.idx_dense_counts, wi.dense_counts.data(), wi.dense_counts.size(), hipMemcpyHostToDevice, s));
+            std::vector<int32_t> hw((size_t)nb * kHeavyMax, 0);
+            for (int64_t b = 0; b < nb; ++b)
+                for (int h = 0; h < wi.batches[(size_t)b].dense_cnt; ++h) hw[(size_t)b * kHeavyMax + h] = wi.batches[(size_t)b].dense_word[h];
+            SERT_TRY(dmalloc(&d.idx_dense_words, hw.size()));
+            SERT_HIP(hipMemcpyAsync(d.idx_dense_words, hw.data(), hw.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+            SERT_HIP(hipStreamSynchronize(s));
+            if (!m->hpart)
+                SERT_TRY(dmalloc(&m->hpart, (size_t)cdiv(B, kHeavyRowsPerBlock) * kHeavyMax *
+                                               (size_t)(is_vs(m) ? m->cfg.word_dim : m->cfg.num_entities)));
+        } else {
+            for (auto& bxx : wi.batches) bxx.dense_cnt = 0;
+        }
         d.idx_batches = wi.batches;
         if ((size_t)wi.max_part_rows + 1 > m->wpart_rows) {
             (void)hipFree(m->wpart);

@@ -19,6 +19,15 @@
 namespace sert {
 
 constexpr int kSegChunk = 64;
+// HEAVY words (vectorspace): a word with more than kHeavyMinCount occurrences in a batch leaves the
+// tree.  Its gradient row is a count-weighted sum over ALL batch rows, sum_i cnt[i][h] src[i, :],
+// which one streaming pass over src computes for up to kHeavyMax words at once (kernels_seg.h:
+// segsum_heavy) -- instead of fetching the same B rows once per occurrence through three tree levels.
+// Zipfian tokens put over half of a batch's tokens on a dozen words (stop words, the padding id, the
+// clipped tail of the synthetic stream): at C2 the tree then walks 280 k entries instead of 655 k.
+constexpr int kHeavyMax = 16;            // counts of one batch row: 16 bytes, one load
+constexpr int kHeavyMinCount = 4096;     // = kSegChunk^2: without its heavy words a tree has two levels
+constexpr int kHeavyRowsPerBlock = 256;
 constexpr int kSegMaxLevels = 6;
 constexpr int kFusedMaxChunks = 32;   // level-1 chunk items one workgroup of segsum_upper_fused combines: one per lane group
                                       // (64, two per group, measured SLOWER than the separate level-2 launch: 19 vs 13 us)
@@ -46,6 +55,10 @@ struct BatchIndex {
     int64_t heavy_off = 0;                // offset into heavy[] (in entries of four ints)
     int32_t heavy_cnt = 0;
     bool fused_upper_ok = false;          // nlevels == 3 and every heavy word has <= kFusedMaxChunks chunks
+    // words summed densely (kHeavyMax per batch at most), outside the tree
+    int32_t dense_cnt = 0;
+    int32_t dense_word[kHeavyMax] = {};
+    int32_t dense_slot[kHeavyMax] = {};   // (loglinear) their ranks among the batch's distinct words
 };
 
 struct WordIndex {
@@ -65,14 +78,29 @@ struct WordIndex {
     // rows no token of the batch points to can be updated while the batch is still in flight.
     std::vector<uint32_t> touched_bits;
     int64_t bit_words = 0;
+    // dense heavy words: per batch and batch row, kHeavyMax occurrence counts (uint8); empty if no
+    // batch has any
+    std::vector<uint8_t> dense_counts;    // [num_batches][B][kHeavyMax]
+    bool any_dense = false;
 };
 
 // ids: (num_batches*B*n) token ids of the complete batches, IdT wide.
 // row_of_pos: entry value = pos / n (vectorspace: row of dh) or pos (loglinear: row of dG).
 template <typename IdT>
 bool build_word_index(const IdT* ids, int64_t num_batches, int B, int n, int vocab,
-                      bool row_is_pos, WordIndex& out, bool want_slots = false) {
+                      bool row_is_pos, WordIndex& out, bool want_slots = false, bool dense_heavy = false) {
     const int64_t T = (int64_t)B * n;
+    // vectorspace (rows = batch rows): the heavy words LEAVE the tree.  loglinear (want_slots: the tree
+    // also carries per-position scalars and, in the per-token cross-check mode, the word gradient): they
+    // stay in it, FLAGGED -- chunk items get slot = -1, and the V_e-wide per-word sums skip every item of
+    // a flagged word (kernels_seg.h: SKIP_DENSE) because segsum_heavy computes those rows densely
+    const bool flag_only = want_slots;
+    dense_heavy = dense_heavy && (want_slots || !row_is_pos) && n <= 255;
+    std::vector<int8_t> heavy_slot;       // word -> its slot among the batch's dense words, or -1
+    if (dense_heavy) {
+        heavy_slot.assign((size_t)vocab, (int8_t)-1);
+        out.dense_counts.assign((size_t)(num_batches * B) * kHeavyMax, (uint8_t)0);
+    }
     out.rows.resize((size_t)(num_batches * T));
     out.batches.resize((size_t)num_batches);
     if (want_slots) out.slots.resize((size_t)(num_batches * T));
@@ -99,6 +127,34 @@ bool build_word_index(const IdT* ids, int64_t num_batches, int B, int n, int voc
         {
             uint32_t* bits = out.touched_bits.data() + bi * out.bit_words;
             for (int32_t wid : touched) bits[wid >> 5] |= 1u << (wid & 31);
+        }
+        // dense heavy words: the (at most kHeavyMax) words with more than kHeavyMinCount occurrences,
+        // heaviest first; only worth a pass over all rows if they hold a good share of the tokens
+        bx.dense_cnt = 0;
+        if (dense_heavy) {
+            std::vector<std::pair<int32_t, int32_t>> cand;   // (count, word)
+            for (int32_t wid : touched)
+                if (count[wid] > kHeavyMinCount) cand.push_back({count[wid], wid});
+            std::sort(cand.begin(), cand.end(), [](const std::pair<int32_t, int32_t>& a, const std::pair<int32_t, int32_t>& b) {
+                return a.first != b.first ? a.first > b.first : a.second < b.second;
+            });
+            if ((int)cand.size() > kHeavyMax) cand.resize(kHeavyMax);
+            int64_t held = 0;
+            for (const auto& c : cand) held += c.first;
+            if (!cand.empty() && held * 8 >= T) {   // >= 1/8 of the batch's tokens
+                for (size_t h = 0; h < cand.size(); ++h) {
+                    bx.dense_word[h] = cand[h].second;
+                    bx.dense_slot[h] = (int32_t)(std::lower_bound(touched.begin(), touched.end(), cand[h].second) - touched.begin());
+                    heavy_slot[(size_t)cand[h].second] = (int8_t)h;
+                }
+                bx.dense_cnt = (int32_t)cand.size();
+                uint8_t* dc = out.dense_counts.data() + (size_t)(bi * B) * kHeavyMax;
+                for (int64_t p = 0; p < T; ++p) {
+                    const int8_t h = heavy_slot[(size_t)x[p]];
+                    if (h >= 0) ++dc[(size_t)(p / n) * kHeavyMax + h];
+                }
+                out.any_dense = true;
+            }
         }
         bx.uw_off = (int64_t)out.uwords.size();
         bx.num_distinct = (int32_t)touched.size();
@@ -132,9 +188,15 @@ bool build_word_index(const IdT* ids, int64_t num_batches, int B, int n, int voc
         }
 
         // level 0 items
-        struct Seg { int32_t begin, end, word, slot; };
-        std::vector<Seg> segs(touched.size());
-        for (size_t t = 0; t < touched.size(); ++t) segs[t] = {start[t], start[t + 1], touched[t], (int32_t)t};
+        struct Seg { int32_t begin, end, word, slot; bool dense; };
+        std::vector<Seg> segs;
+        segs.reserve(touched.size());
+        for (size_t t = 0; t < touched.size(); ++t) {
+            const bool dense = bx.dense_cnt > 0 && heavy_slot[(size_t)touched[t]] >= 0;
+            if (dense && !flag_only) continue;   // summed densely, not by the tree
+            segs.push_back({start[t], start[t + 1], touched[t], (int32_t)t, dense});
+        }
+        for (int h = 0; h < bx.dense_cnt; ++h) heavy_slot[(size_t)bx.dense_word[h]] = (int8_t)-1;
         int level = 0;
         int64_t part_base = 0;
         while (!segs.empty() && level < kSegMaxLevels) {
@@ -150,10 +212,10 @@ bool build_word_index(const IdT* ids, int64_t num_batches, int B, int n, int voc
                     const int32_t first = nparts;
                     for (int32_t b = s.begin; b < s.end; b += kSegChunk) {
                         const int32_t e = std::min(s.end, b + kSegChunk);
-                        out.items.push_back({b, e, -(nparts + 1), 0});
+                        out.items.push_back({b, e, -(nparts + 1), s.dense ? -1 : 0});
                         ++nparts;
                     }
-                    next.push_back({first, nparts, s.word, s.slot});
+                    next.push_back({first, nparts, s.word, s.slot, s.dense});
                 }
             }
             bx.item_cnt[level] = (int32_t)((int64_t)out.items.size() - bx.item_off[level]);

@@ -38,6 +38,8 @@ VARIANTS_BUILD = 'variants' in os.path.basename(os.environ.get('SERT_LIB', ''))
     dict(B=4100, n=2, z=3, Vw=300, Ve=2048, dw=16, de=64),      # largest vocabulary of the LDS path, ragged last row group
     dict(B=1100, n=3, z=4, Vw=2000, Ve=50, dw=128, de=128),     # strip GEMMs (gemm_strip.h), ragged last strip
     dict(B=1030, n=2, z=3, Vw=500, Ve=40, dw=96, de=64),        # strip GEMMs with idle waves (N = 64 / 96), K = 96 / 64
+    dict(B=20000, n=5, z=3, Vw=300, Ve=40, dw=32, de=16),       # three dense heavy words (> 4096 occurrences each: segsum_heavy), the rest through the tree
+    dict(B=6000, n=5, z=2, Vw=300, Ve=30, dw=300, de=32),       # one dense heavy word at d_w = 300 (64 lanes x 2 chunks)
 ])
 @pytest.mark.parametrize('egrad', ['default', 'sorted'] + (['strip_gemm', 'roles_gemm'] if VARIANTS_BUILD else []))
 def test_vectorspace_steps(hip_lib, dims, egrad, monkeypatch):
@@ -46,6 +48,8 @@ def test_vectorspace_steps(hip_lib, dims, egrad, monkeypatch):
     # 'strip_gemm' switches the opt-in strip-streaming projection GEMMs on (gemm_strip.h)
     if egrad == 'sorted':
         monkeypatch.setenv('SERT_EGRAD_SORT', '1')
+    if dims['B'] >= 6000:
+        monkeypatch.setenv('SERT_DENSE_HEAVY', '1')    # (opt-in for vectorspace: the dense heavy-word pass)
     if egrad in ('strip_gemm', 'roles_gemm'):
         if dims['B'] < 1024:
             pytest.skip('strip GEMMs take M >= 1024 only')
@@ -159,6 +163,36 @@ def test_loglinear_steps(hip_lib, dims, labels):
     P = eng.predict_tokens(p['X'][:7])
     _, Pref = ora.token_distributions(p['X'][:7])
     assert U.rel_err(P, Pref) < 1e-5
+    eng.close()
+
+
+def test_loglinear_dense_heavy_words(hip_lib):
+    """Words with more than 4096 occurrences in a batch: their rows of the per-word dZ sums come from the
+    dense pass over dJ (segsum_heavy over V_e-wide rows + segsum_heavy_combine_ll), the other words' from
+    the tree with the heavy words' items skipped.  Zipfian ids clipped to a small vocabulary put two such
+    words into a batch of 9000 x 5 tokens; two steps against the oracle."""
+    B, n, Vw, Ve, d, steps = 9000, 5, 300, 24, 16, 2
+    rng = np.random.RandomState(3)
+    p = U.make_ll_problem(3, B * steps, n, Vw, Ve, d, 'int')
+    p['X'] = rng.permutation(Vw)[np.minimum(rng.zipf(1.1, size=(B * steps, n)) - 1, Vw - 1)].astype(p['X'].dtype)
+    counts = np.bincount(p['X'][:B].ravel(), minlength=Vw)
+    assert (counts > 4096).sum() >= 2
+    lam = 0.01
+    eng = U.ll_engine(p, B, n, lam)
+    eng.upload_dataset(C.SPLIT_TRAIN, p['X'], y_int=p['y'], w=p['w'])
+    ora = O.LogLinearOracle(B, n, p['Rw'], p['W'], p['b'], lam)
+    for s in range(steps):
+        sl = slice(s * B, (s + 1) * B)
+        loss_ref, grads_ref, _ = ora.loss_and_grads(p['X'][sl], p['ydense'][sl], p['w'][sl])
+        ora.opt.update(ora.params(), grads_ref)
+        loss = eng.train_batch(s)
+        assert abs(loss - loss_ref) <= LOSS_TOL * abs(loss_ref), (s, loss, loss_ref)
+        dRw, dW, db = grads_ref
+        assert U.rel_err(eng.get_tensor(C.T_GRAD_W), dW.ravel()) < GRAD_TOL
+        assert U.rel_err(eng.get_tensor(C.T_GRAD_B), db.ravel()) < GRAD_TOL
+        assert U.rel_err(eng.get_tensor(C.T_GRAD_RW), dRw.ravel()) < GRAD_TOL
+    assert U.rel_err(eng.get_tensor(C.T_RW), ora.R_w.ravel()) < PARAM_TOL
+    assert U.rel_err(eng.get_tensor(C.T_W), ora.W.ravel()) < PARAM_TOL
     eng.close()
 
 

@@ -389,6 +389,52 @@ __global__ __launch_bounds__(NT) void ll_row_from_table(const float* __restrict_
     // 1. J and its max; clipped-token bits
     float mx = -INFINITY;
     unsigned long long oob = 0ull;
+    if ((V & 3) == 0) {
+        // 16-byte loads, the rows of five window positions for TWO column chunks of the thread in
+        // flight at once: the scalar loop below walks V / NT dependent trips of n four-byte loads (eight
+        // round trips to the Infinity Cache per batch row at V_e = 1000 -- the kernel was bound by
+        // that chain, 27 us of residency per workgroup, not by bytes).  Additions in window order per
+        // element, as below: same bits.
+        const int V4 = V >> 2;
+#ifndef SERT_LL_ROW_GC
+#define SERT_LL_ROW_GC 5    // (10: 80 staging registers, 317 us against 248 at C2 dims)
+#endif
+        constexpr int GC = SERT_LL_ROW_GC;
+        for (int e0 = tid; e0 < V4; e0 += 2 * NT) {
+            const int e1 = e0 + NT;
+            const bool two = e1 < V4;
+            float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+            for (int k0 = 0; k0 < n; k0 += GC) {
+                float4 v0[GC], v1[GC];
+#pragma unroll
+                for (int q = 0; q < GC; ++q) {
+                    const float4* row = reinterpret_cast<const float4*>(Zu + (size_t)s_slot[min(k0 + q, n - 1)] * V);
+                    v0[q] = row[e0];
+                    v1[q] = row[two ? e1 : e0];
+                }
+#pragma unroll
+                for (int q = 0; q < GC; ++q) {
+                    if (k0 + q >= n) continue;
+                    const float x[8] = {v0[q].x, v0[q].y, v0[q].z, v0[q].w, v1[q].x, v1[q].y, v1[q].z, v1[q].w};
+                    bool bad = false;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) bad = bad || (!(x[c] >= LOGLO && x[c] <= LOGHI) && (c < 4 || two));
+                    if (bad) oob |= 1ull << (k0 + q);
+                    a0.x += fminf(fmaxf(x[0], LOGLO), LOGHI); a0.y += fminf(fmaxf(x[1], LOGLO), LOGHI);
+                    a0.z += fminf(fmaxf(x[2], LOGLO), LOGHI); a0.w += fminf(fmaxf(x[3], LOGLO), LOGHI);
+                    a1.x += fminf(fmaxf(x[4], LOGLO), LOGHI); a1.y += fminf(fmaxf(x[5], LOGLO), LOGHI);
+                    a1.z += fminf(fmaxf(x[6], LOGLO), LOGHI); a1.w += fminf(fmaxf(x[7], LOGLO), LOGHI);
+                }
+            }
+            reinterpret_cast<float4*>(Jl)[e0] = a0;
+            mx = fmaxf(mx, fmaxf(fmaxf(a0.x, a0.y), fmaxf(a0.z, a0.w)));
+            if (two) {
+                reinterpret_cast<float4*>(Jl)[e1] = a1;
+                mx = fmaxf(mx, fmaxf(fmaxf(a1.x, a1.y), fmaxf(a1.z, a1.w)));
+            }
+        }
+        __syncthreads();   // (the passes below read Jl element-strided: other threads' float4 stores)
+    } else
     for (int e = tid; e < V; e += NT) {
         float a = 0.f;
         for (int k = 0; k < n; ++k) {
@@ -434,6 +480,15 @@ __global__ __launch_bounds__(NT) void ll_row_from_table(const float* __restrict_
     __syncthreads();
     float tot = 0.f;
     float* dj_out = dJ_out + (size_t)i * V;
+    if ((V & 3) == 0) {
+        // (same per-thread element sets as the strided loop would give? no: so the partial sums are
+        //  grouped per float4 here -- `tot` only feeds r_k, to fp32 rounding)
+        for (int e4 = tid; e4 < (V >> 2); e4 += NT) {
+            const float4 dj = reinterpret_cast<const float4*>(Jl)[e4];
+            reinterpret_cast<float4*>(dj_out)[e4] = dj;
+            tot += (dj.x + dj.y) + (dj.z + dj.w);
+        }
+    } else
     for (int e = tid; e < V; e += NT) {
         const float dj = Jl[e];
         dj_out[e] = dj;

@@ -251,9 +251,12 @@ __global__ __launch_bounds__(1024) void segsum_heavy(const float* __restrict__ s
     const int slab = blockIdx.x % nslab, rblk = blockIdx.x / nslab;
     const int ch = slab * 32 + l;                  // this lane's float4 column
     const bool on = ch < d4;
-    float4 acc[kHeavyMax];
+    // (two-wide vector type: the 4 x 16 x 8 multiply-adds per thread compile to v_pk_fma_f32, two per
+    //  instruction -- the pass is VALU-bound otherwise: 2.1 GFLOP on the scalar FMA rate is 35 us)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 acc2[kHeavyMax][2];
 #pragma unroll
-    for (int h = 0; h < kHeavyMax; ++h) acc[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int h = 0; h < kHeavyMax; ++h) { acc2[h][0] = (f32x2)(0.f); acc2[h][1] = (f32x2)(0.f); }
     constexpr int RPG = kHeavyRowsPerBlock / 32;   // rows per lane group
     const int row0 = rblk * kHeavyRowsPerBlock + g * RPG;
     uint4 c[RPG];
@@ -268,12 +271,19 @@ __global__ __launch_bounds__(1024) void segsum_heavy(const float* __restrict__ s
 #pragma unroll
     for (int q = 0; q < RPG; ++q) {
         const unsigned cw[4] = {c[q].x, c[q].y, c[q].z, c[q].w};
+        f32x2 lo, hi;
+        lo.x = v[q].x; lo.y = v[q].y; hi.x = v[q].z; hi.y = v[q].w;
 #pragma unroll
         for (int h = 0; h < kHeavyMax; ++h) {
             const float f = (float)((cw[h >> 2] >> (8 * (h & 3))) & 0xffu);
-            acc[h].x += f * v[q].x; acc[h].y += f * v[q].y; acc[h].z += f * v[q].z; acc[h].w += f * v[q].w;
+            const f32x2 ff = (f32x2)(f);
+            acc2[h][0] = __builtin_elementwise_fma(ff, lo, acc2[h][0]);
+            acc2[h][1] = __builtin_elementwise_fma(ff, hi, acc2[h][1]);
         }
     }
+    float4 acc[kHeavyMax];
+#pragma unroll
+    for (int h = 0; h < kHeavyMax; ++h) acc[h] = make_float4(acc2[h][0].x, acc2[h][0].y, acc2[h][1].x, acc2[h][1].y);
     // lower half of the wave += upper half (group 2w + group 2w+1), then one slot per wave in LDS
 #pragma unroll
     for (int h = 0; h < kHeavyMax; ++h) {

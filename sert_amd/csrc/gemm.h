@@ -423,6 +423,215 @@ __global__ __launch_bounds__(256, SERT_GEMM_WAVES) void gemm_f32_mfma(const Gemm
     }
 }
 
+// ---- 128 x 160 tiles: N just above a multiple of 128 ------------------------------------------------
+// d = 300 (C4, the reference's default --word_representation_size): three 128-column tiles cover 384
+// columns for 300 -- 22 % of the MFMA work of the projection GEMMs and 39 % of dW's is padding.  Two
+// 160-column tiles cover 320.  Four waves stacked along M, each a 32 x 160 strip = five 32x32x2
+// accumulators (80 VGPRs); A side as above (128 rows), B side 160 columns (leading dimension 164).
+// Same k order per output element as gemm_f32_mfma (one fmaf chain over k): bit-identical results.
+// EPI_STORE / EPI_BIAS / EPI_BIAS_TANH, split-K and the column sums of op(B) (CSB); 16-byte loads only.
+constexpr int GN2 = 160, GLD2 = 164;
+
+__device__ __forceinline__ void gload_kmajor160(const float* __restrict__ base, int ld, int krem, int crem,
+                                                float4 (&r)[3], unsigned& mask) {
+    mask = 0x7u;
+    const int t = threadIdx.x;
+    const int kr = t / GTPR, cq = (t % GTPR) * 4;
+    const bool kok = kr < krem;
+    const unsigned roff = kok ? (unsigned)kr * (unsigned)ld : 0u;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int c = cq + j * (GTPR * 4);
+        const bool ok = kok && c < GN2 && c < crem;
+        if (!ok) mask &= ~(1u << j);
+        r[j] = *reinterpret_cast<const float4*>(base + (ok ? roff + (unsigned)c : 0u));
+    }
+}
+__device__ __forceinline__ void lstore_kmajor160(float (*dst)[GLD2], const float4 (&r)[3], unsigned mask) {
+    const int t = threadIdx.x;
+    const int kr = t / GTPR, cq = (t % GTPR) * 4;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int c = cq + j * (GTPR * 4);
+        if (c >= GN2) continue;
+        const bool ok = (mask >> j) & 1u;
+        *reinterpret_cast<float4*>(&dst[kr][c]) =
+            make_float4(ok ? r[j].x : 0.f, ok ? r[j].y : 0.f, ok ? r[j].z : 0.f, ok ? r[j].w : 0.f);
+    }
+}
+// source stored [c][k]: rows c = t / 2 (0..127) and, for the first 64 threads, 128 + t / 2
+__device__ __forceinline__ void gload_cmajor160(const float* __restrict__ base, int ld, int krem, int crem,
+                                                float4 (&r)[4], unsigned& mask) {
+    mask = 0xfu;
+    const int t = threadIdx.x;
+    const int kh = (t & 1) * (GK / 2);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int c = p * 128 + (t >> 1);
+        const bool cok = c < GN2 && c < crem && (p == 0 || t < 64);
+        const unsigned roff = cok ? (unsigned)c * (unsigned)ld : 0u;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = kh + j * 4;
+            const bool ok = cok && k < krem;
+            if (!ok) mask &= ~(1u << (2 * p + j));
+            r[2 * p + j] = *reinterpret_cast<const float4*>(base + (ok ? roff + (unsigned)k : 0u));
+        }
+    }
+}
+__device__ __forceinline__ void lstore_cmajor160(float (*dst)[GLD2], const float4 (&r)[4], unsigned mask) {
+    const int t = threadIdx.x;
+    const int kh = (t & 1) * (GK / 2);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        if (p == 1 && t >= 64) continue;
+        const int c = p * 128 + (t >> 1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int kl = kh + j * 4;
+            const bool ok = (mask >> (2 * p + j)) & 1u;
+            const float4 v = r[2 * p + j];
+            dst[kl + 0][c] = ok ? v.x : 0.f;
+            dst[kl + 1][c] = ok ? v.y : 0.f;
+            dst[kl + 2][c] = ok ? v.z : 0.f;
+            dst[kl + 3][c] = ok ? v.w : 0.f;
+        }
+    }
+}
+
+template <bool TA, bool TB, int EPI, bool CSB>
+__global__ __launch_bounds__(256, 3) void gemm_f32_mfma_n160(const GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float As[2][GK][GLD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GK][GLD2];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int tiles_mn = g.tiles_m * g.tiles_n;
+    const int total = tiles_mn * g.splits;
+    int item = blockIdx.x;
+    if (item >= total) return;
+    int m0, n0, kbeg, kend, z, tm_idx;
+    auto decode = [&](int it) {
+        z = it / tiles_mn;
+        const int t = it - z * tiles_mn;
+        tm_idx = t / g.tiles_n;
+        m0 = tm_idx * GM;
+        n0 = (t - tm_idx * g.tiles_n) * GN2;
+        kbeg = z * g.kper;
+        kend = min(g.K, kbeg + g.kper);
+    };
+    unsigned mka = 0xffffffffu, mkb = 0xffffffffu;
+    float4 ra[GNV];
+    float4 rbk[3];
+    float4 rbc[4];
+    auto gload = [&](int mm0, int nn0, int k0, int ke) {
+        int lda_ = g.lda, ldb_ = g.ldb;
+        asm volatile("" : "+s"(lda_), "+s"(ldb_));
+        if (TA) gload_kmajor<true>(g.A + (size_t)k0 * lda_ + mm0, lda_, ke - k0, g.M - mm0, ra, mka);
+        else    gload_cmajor<true>(g.A + (size_t)mm0 * lda_ + k0, lda_, ke - k0, g.M - mm0, ra, mka);
+        if (TB) gload_cmajor160(g.B + (size_t)nn0 * ldb_ + k0, ldb_, ke - k0, g.N - nn0, rbc, mkb);
+        else    gload_kmajor160(g.B + (size_t)k0 * ldb_ + nn0, ldb_, ke - k0, g.N - nn0, rbk, mkb);
+    };
+    auto lstore = [&](int buf) {
+        if (TA) lstore_kmajor(As[buf], ra, mka); else lstore_cmajor(As[buf], ra, mka);
+        if (TB) lstore_cmajor160(Bs[buf], rbc, mkb); else lstore_kmajor160(Bs[buf], rbk, mkb);
+    };
+    float bias_v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    auto load_bias = [&]() {
+        if (EPI == EPI_BIAS || EPI == EPI_BIAS_TANH) {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int col = n0 + j * 32 + li;
+                bias_v[j] = (col < g.N) ? g.bias[col] : 0.f;
+            }
+        }
+    };
+    decode(item);
+    load_bias();
+    gload(m0, n0, kbeg, kend);
+    lstore(0);
+    __syncthreads();
+    int buf = 0;
+    f32x16 acc[5];
+    float csum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    while (true) {
+        const int next_item = item + gridDim.x;
+        const bool has_next_item = next_item < total;
+        for (int k0 = kbeg; k0 < kend; k0 += GK) {
+            const bool next_k = (k0 + GK) < kend;
+            bool staged = false;
+            if (next_k) {
+                gload(m0, n0, k0 + GK, kend);
+                staged = true;
+            } else if (has_next_item) {
+                const int zz = next_item / tiles_mn;
+                const int t = next_item - zz * tiles_mn;
+                const int tmi = t / g.tiles_n;
+                const int kb = zz * g.kper;
+                gload(tmi * GM, (t - tmi * g.tiles_n) * GN2, kb, min(g.K, kb + g.kper));
+                staged = true;
+            }
+            if (CSB && tm_idx == 0 && threadIdx.x < GN2) {
+                float cs = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < GK; ++kk) cs += Bs[buf][kk][threadIdx.x];
+                csum += cs;
+            }
+#pragma unroll
+            for (int kk = 0; kk < GK; kk += 2) {
+                const int k = kk + lh;
+                const float a = As[buf][k][w * 32 + li];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    const float b = Bs[buf][k][j * 32 + li];
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
+                }
+            }
+            if (staged) lstore(buf ^ 1);
+            if (!next_k) {
+                float* Cz = g.C + (size_t)z * g.c_split_stride;
+                if (CSB && tm_idx == 0 && threadIdx.x < GN2) {
+                    if (n0 + (int)threadIdx.x < g.N) Cz[(size_t)g.M * g.N + n0 + threadIdx.x] = csum;
+                    csum = 0.f;
+                }
+                float* Ct = Cz + (size_t)m0 * g.ldc + n0;
+                const int mrem = g.M - m0, nrem = g.N - n0;
+                unsigned uld = (unsigned)g.ldc;
+                asm volatile("" : "+s"(uld));
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    const int col = j * 32 + li;
+                    const int row0 = w * 32 + 4 * lh;
+                    float bv = bias_v[j];
+                    if (EPI == EPI_BIAS || EPI == EPI_BIAS_TANH) asm volatile("" : "+v"(bv));
+                    unsigned off = (unsigned)row0 * uld + (unsigned)col;
+                    const bool cok = col < nrem;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = row0 + (r & 3) + 8 * (r >> 2);
+                        float v = acc[j][r];
+                        if (EPI == EPI_BIAS) v = v + bv;
+                        if (EPI == EPI_BIAS_TANH) v = fast_tanh(v + bv);
+                        if (cok && row < mrem) Ct[off] = v;
+                        acc[j][r] = 0.f;
+                        off += ((r & 3) == 3) ? 5u * uld : uld;
+                    }
+                }
+            }
+            __syncthreads();
+            buf ^= 1;
+        }
+        if (!has_next_item) break;
+        item = next_item;
+        decode(item);
+        load_bias();
+    }
+}
+
 // ---- 64x64-tile variant for SMALL problems -------------------------------------------
 // A GEMM with fewer 128x128 tiles than CUs (the projection and its backward at batch 4096:
 // 32 x 3 tiles at d = 300) leaves most of the chip idle and every tile latency-bound: 35-40 us
@@ -559,6 +768,15 @@ inline void launch_gemm(hipStream_t s, const float* A, const float* B, float* C,
     const bool vec = (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A) % 16 == 0) &&
                      (((uintptr_t)B) % 16 == 0) && (K % 4 == 0) && (kper % 4 == 0) &&
                      (TA ? (M % 4 == 0) : true) && (TB ? true : (N % 4 == 0));
+    // N just above a multiple of 128 (d = 300): 160-column tiles pad less (gemm_f32_mfma_n160)
+    static const bool no_n160 = getenv("SERT_GEMM_NO_N160") != nullptr;   // cross-check knob
+    if (!no_n160 && vec && EPI != EPI_FILTER && (long long)cdiv(N, GN2) * GN2 * 11 <= (long long)cdiv(N, GN) * GN * 10) {   // >= 10 % less padding
+        g.tiles_n = cdiv(N, GN2);
+        const long long total160 = (long long)g.tiles_m * g.tiles_n * splits;
+        const int grid160 = (int)std::min<long long>(total160, 256 * 3);
+        SERT_LAUNCH((gemm_f32_mfma_n160<TA, TB, EPI == EPI_FILTER ? EPI_STORE : EPI, CSB>), dim3(grid160), dim3(256), 0, s, g);
+        return;
+    }
     const long long total = (long long)g.tiles_m * g.tiles_n * splits;
     // persistent: at most 2 workgroups per CU (256 CUs), each walks items w, w+grid, ...
     static const int max_grid = [] {

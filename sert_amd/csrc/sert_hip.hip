@@ -371,6 +371,8 @@ static int gemm_long_k(sert_model* m, hipStream_t s, const float* A, const float
     int splits = 1;
     if (tiles < 512 && K >= 4096) splits = std::min(cdiv(1024, tiles), K / 1024);
     else if (tiles < 256 && K >= 512) splits = std::min(cdiv(1024, tiles), K / 128);   // few tiles, medium K
+    // (between one and two tiles per CU -- the loglinear dG at C2 dims, 347 tiles -- a three-way split was
+    //  tried: 162 -> 175 us with its combine; co-resident workgroups share the matrix pipe without loss)
     if (splits <= 1) {
         launch_gemm<TA, TB, EPI_STORE>(s, A, Bm, C, nullptr, M, N, K, lda, ldb, N);
         return 0;

@@ -1589,7 +1589,9 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
                 launch_stream_opt(m, m->stream, t.p + off, t.g + off, t.s0 + (size_t)ch * sc, t.s1 + (size_t)ch * sc, sc,
                                   nb, aa, da, m->sq_scratch, ub, by_rows ? (unsigned)c.word_dim : 1u);
                 if (by_rows) {
-                    if (exchanged) SERT_HIP(hipEventRecord(m->ev_word_updated, m->stream));
+                    // (recorded in every mode: a later step on the communication stream waits for it whatever
+                    //  mode THIS step ran in)
+                    if (m->ev_word_updated) SERT_HIP(hipEventRecord(m->ev_word_updated, m->stream));
                     m->rw_full = false;
                     m->xr_fetched_batch = -1;
                     continue;

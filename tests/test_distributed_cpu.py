@@ -142,3 +142,85 @@ def test_two_ranks_equal_single_process(tmp_path, transport):
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, out
         assert 'rank %d ok' % rank in out
+
+
+ROWS_WORKER = textwrap.dedent('''
+    import os, sys
+    import numpy as np
+    sys.path.insert(0, %(root)r)
+    from sert_amd import _capi, distributed as D
+
+    ctx = D.init_from_env()
+    W, me = ctx.world_size, ctx.rank
+    rng = np.random.RandomState(123)                 # same bitmaps and data on every rank
+    vocab, d, nb = 1000, 8, 3
+    R = (-(-vocab // W) + 15) // 16 * 16
+    bw = (((vocab + 31) // 32) + 3) // 4 * 4
+    touched = rng.rand(W, nb, vocab) < 0.35
+    bits = np.zeros((W, nb, bw), dtype=np.uint32)
+    for r in range(W):
+        for b in range(nb):
+            w = np.nonzero(touched[r, b])[0]
+            np.bitwise_or.at(bits[r, b], w >> 5, (np.uint32(1) << (w & 31).astype(np.uint32)))
+    lo, hi = min(vocab, me * R), min(vocab, me * R + R)
+    table = rng.randn(vocab, d).astype(np.float32)   # the "true" parameters; this rank holds its rows only
+    for b in range(nb):
+        L = _capi.debug_row_lists(bits, me, R, vocab, b)
+        scnt, fcnt = L['serve_cnt'].astype(np.int64) * d, L['fetch_cnt'].astype(np.int64) * d
+        soff = np.concatenate([[0], np.cumsum(scnt)[:-1]]); foff = np.concatenate([[0], np.cumsum(fcnt)[:-1]])
+        # ---- phase P: owners pack and send, this rank unpacks ----
+        mine = np.full((vocab, d), np.nan, np.float32)
+        mine[lo:hi] = table[lo:hi]
+        send = np.ascontiguousarray(mine[L['serve_rows']].ravel()) if len(L['serve_rows']) else np.zeros(1, np.float32)
+        recv = np.zeros(max(1, int(fcnt.sum())), np.float32)
+        D.host_alltoall(send, soff, scnt, recv, foff, fcnt)
+        if len(L['fetch_rows']):
+            mine[L['fetch_rows']] = recv[:fcnt.sum()].reshape(-1, d)
+        need = np.nonzero(touched[me, b])[0]
+        assert np.array_equal(mine[need], table[need]), ('params', me, b)
+        # ---- phase G: gradient rows go back, rank-ordered sum at the owner ----
+        grads = [np.where(touched[r, b][:, None], np.random.RandomState(1000 * b + r).randn(vocab, d), 0).astype(np.float32)
+                 for r in range(W)]
+        g = grads[me].copy()
+        send = np.ascontiguousarray(g[L['fetch_rows']].ravel()) if len(L['fetch_rows']) else np.zeros(1, np.float32)
+        recv = np.zeros(max(1, int(scnt.sum())), np.float32)
+        D.host_alltoall(send, foff, fcnt, recv, soff, scnt)
+        rows = recv[:scnt.sum()].reshape(-1, d)
+        for u, wrow in enumerate(L['union_rows']):
+            acc = np.zeros(d, np.float32)
+            for e in L['ent'][L['ptr'][u]:L['ptr'][u + 1]]:
+                acc = acc + (g[wrow] if e < 0 else rows[e])
+            g[wrow] = acc
+        dense = np.zeros((vocab, d), np.float32)
+        for r in range(W):
+            dense = np.where(touched[r, b][:, None], dense + grads[r], dense)
+        assert np.array_equal(g[lo:hi], dense[lo:hi]), ('grads', me, b)
+    D.barrier()
+    D.shutdown()
+    print('rank %%d ok' %% me)
+''')
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_row_exchange_over_the_store_transport(tmp_path, world):
+    """World 2 and 3, one process per rank, CPU only: the row exchange of the data-parallel word table
+    (the lists of sert_debug_row_lists = the upload's own builder) carried by the product's host
+    transport, sert_amd.distributed.host_alltoall -- every rank ends up with the current value of
+    exactly the rows its batch touches, and every owner with the rank-ordered sum of the gradient rows."""
+    script = tmp_path / 'rows_worker.py'
+    script.write_text(ROWS_WORKER % {'root': ROOT})
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for rank, p in enumerate(procs):
+        try:
+            out, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, _ = p.communicate()
+        assert p.returncode == 0, out.decode()
+        assert 'rank %d ok' % rank in out.decode()

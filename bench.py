@@ -81,6 +81,7 @@ def group_work(kind, B, n, s, dw, de, Ve, Vw, z, distinct_words=None):
             'gemm_dW':              mfma(2.0 * B * dw * de),               # gemm_f32_mfma TN split-K
             'splitk_combine':       stream(4.0 * 1024 * (dw * de + de)),   # reduce_partials
             'gemm_dX':              mfma(2.0 * B * dw * de),               # gemm_f32_mfma NT
+            'gemm_bwd_fused':       mfma(4.0 * B * dw * de),               # vs_bwd_fused: dh and dW in one launch (opt-in)
             'word_grad_segsum':     rows(B * (8.0 * n * dw), B * 4.0 * n * dw, 4 * dw, 4.0 * B * dw),   # segsum_rows: rows of dh
             'optimizer_word_table': stream(P_w, optimizer_elems=Vw * dw),  # adam_l2 (R_w)
             # adam_l2 over R_e where it is a big table (C4), else one optimizer_small launch: launch latency
@@ -125,7 +126,7 @@ def group_work(kind, B, n, s, dw, de, Ve, Vw, z, distinct_words=None):
 # egrad_acc up to 2048 entities and egrad_chunk_reduce above)
 _COMMON_KERNELS = {
     'gemm_dW': ('gemm_f32_mfma<true, false, 0',), 'splitk_combine': ('reduce_partials',),
-    'gemm_dX': ('gemm_f32_mfma<false, true, 0',), 'word_grad_segsum': ('segsum_rows<',),
+    'gemm_dX': ('gemm_f32_mfma<false, true, 0',), 'gemm_bwd_fused': ('vs_bwd_fused',), 'word_grad_segsum': ('segsum_rows<',),
     'optimizer_other': ('optimizer_small',), 'finalize': ('vs_tail', 'finalize_loss'),
 }
 KERNELS_OF_GROUP = {
@@ -199,6 +200,9 @@ def timed_steps(model, dist, num_batches, steps, warmup, timing=True):
     if not np.isfinite(last):
         raise RuntimeError('non-finite loss in the timed region')
     timings = eng.timings()
+    if model._engine.cfg.kind == 1 and timings.get('gemm_dX', 0) > 0 and not timings.get('gemm_dW', 0) > 0:
+        # SERT_BWD_FUSED=1: dh and dW came out of one launch (vs_bwd_fused), timed under gemm_dX
+        timings['gemm_bwd_fused'] = timings.pop('gemm_dX')
     if model._engine.cfg.kind == 0 and 'entity_grad_reduce' in timings:
         # loglinear reuses this timing slot for the per-distinct-word sums of dJ / r
         timings['per_word_dz_sums'] = timings.pop('entity_grad_reduce')

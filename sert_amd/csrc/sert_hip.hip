@@ -13,6 +13,7 @@
 
 #include "common.h"
 #include "gemm.h"
+#include "gemm_bwd_fused.h"
 #ifdef SERT_VARIANTS   // opt-in GEMM variants that lost their A/B (csrc/variants/; tools/build_variant.sh -DSERT_VARIANTS)
 #include "variants/gemm_big.h"
 #include "variants/gemm_strip.h"
@@ -931,12 +932,24 @@ static int vs_loss(sert_model* m, const DataSplit& ds, int64_t batch_index) {
     return 0;
 }
 
+// dh and dW (+ db) of the projection in one launch (gemm_bwd_fused.h) where the shape allows it
+static bool bwd_fused_applies(const sert_model* m) {
+    // opt-in (SERT_BWD_FUSED=1): measured EQUAL to the two gemm.h launches at C2 (57.5 us against 29.3 + 29.2;
+    // step 0.3030 against 0.3046 ms, inside the run-to-run spread) -- the fused kernel keeps the matrix pipe as
+    // busy as they do (48 %), it only saves a launch and half of the partial slabs
+    static const bool on = getenv("SERT_BWD_FUSED") && atoi(getenv("SERT_BWD_FUSED")) != 0;
+    return on && m->cfg.kind == SERT_KIND_VECTORSPACE && m->cfg.word_dim == FB_D && m->cfg.entity_dim == FB_D &&
+           m->cfg.batch_size >= 1024 && m->nstreams < 3 && (size_t)256 * (FB_D * FB_D + FB_D) <= m->part_count;
+}
+
 static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) {
     const auto& c = m->cfg;
     const int B = c.batch_size, n = c.window_size, dw = c.word_dim, de = c.entity_dim;
     const size_t row0 = (size_t)batch_index * B;
     const bool fork_late = fork_late_mode(m);
     const bool fork_nce = fork_late && fork_at_nce(m);
+    const bool fused_bwd = bwd_fused_applies(m);
+    const int fused_grid = std::min(256, cdiv(B, FB_ROWS));   // one workgroup per CU, or per strip if there are fewer
     auto entity_grad = [&]() -> int {
         // fork: this chain only depends on the NCE kernel and is independent of the
         // GEMMs / word-table reduction below, so it runs on the side stream
@@ -1039,6 +1052,16 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
             // (ev_dense below: the completion signal of this GEMM, not a barrier packet behind it)
             dense_bound = m->lazy_join && ext_events() && !strip && !fork_nce;
             if (dense_bound) set_stop_event(fork_late ? m->ev_fork : m->ev_dense);
+            if (fused_bwd) {
+                // dh, the per-workgroup partial slabs of dW and their column sums (db): one launch
+                static const bool attr_set = hipFuncSetAttribute((const void*)vs_bwd_fused, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                                 (int)vs_bwd_fused_lds_bytes()) == hipSuccess;
+                if (!attr_set) { set_stop_event(nullptr); SERT_FAIL("cannot reserve the LDS of vs_bwd_fused"); }
+                BwdFusedArgs fa;
+                fa.DA = m->DA; fa.H = m->H; fa.W = m->W; fa.DH = m->DH; fa.part = m->part; fa.B = B;
+                fa.stride = (size_t)FB_D * FB_D + FB_D;
+                SERT_LAUNCH(vs_bwd_fused, dim3(fused_grid), dim3(FB_THREADS), vs_bwd_fused_lds_bytes(), m->stream, fa);
+            } else
 #ifdef SERT_VARIANTS
             if (strip)
                 launch_gemm_strip<true, EPI_STORE>(m->stream, m->DA, m->W, m->DH, nullptr, B, dw, de, de, de, dw);
@@ -1090,6 +1113,11 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         splits = cdiv(B, kper);
         const size_t mn = (size_t)dw * de;
         const size_t stride = mn + de;
+        if (fused_bwd) {
+            // (the partial slabs were written by vs_bwd_fused, behind which this runs)
+            splits = fused_grid;
+            if (sd != m->stream) SERT_FAIL("internal: the fused backward needs dW's combine on the main stream");
+        } else
 #ifdef SERT_VARIANTS
         if (gemm_strip_ok(B, de, dw, dw, de, false, m->H, m->DA) && dw % 32 == 0 && de % 4 == 0) {
             // strip kernel: every workgroup accumulates its contiguous strips' h^T.da (+ column sums)
@@ -1148,6 +1176,11 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         SERT_TRY(dh_gemm());
         SERT_TRY(word_table_sum());
         SERT_TRY(dense_grad());
+    } else if (fused_bwd) {
+        SERT_TRY(entity_grad());
+        SERT_TRY(dh_gemm());           // (dh and the dW partials in one launch)
+        SERT_TRY(dense_grad());
+        SERT_TRY(word_table_sum());
     } else {
         // single GPU: the MFMA-bound dW beside the latency-bound sort of the side stream
         SERT_TRY(entity_grad());

@@ -112,6 +112,15 @@ def test_vectorspace_known_answers(hip_lib):
     eng.close()
 
 
+@pytest.mark.parametrize('B', [1100, 4096 + 37])
+def test_vectorspace_fused_backward(hip_lib, monkeypatch, B):
+    """SERT_BWD_FUSED=1 (opt-in, gemm_bwd_fused.h): dh = da.W^T and dW = h^T.da (+ db) out of ONE launch, for
+    d_w = d_e = 128 -- a ragged last 64-row strip, fewer strips than workgroups / several strips per
+    workgroup; three steps against the oracle (loss, activations, every gradient, parameters)."""
+    monkeypatch.setenv('SERT_BWD_FUSED', '1')
+    test_vectorspace_steps(hip_lib, dict(B=B, n=3, z=4, Vw=2000, Ve=50, dw=128, de=128), 'default', monkeypatch)
+
+
 def test_vectorspace_predict(hip_lib):
     p = U.make_vs_problem(5, 8, 3, 2, 40, 9, 24, 40)
     eng = U.vs_engine(p, 8, 3, 2, 0.0)

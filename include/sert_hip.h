@@ -298,6 +298,13 @@ int sert_debug_row_lists(const uint32_t* allbits, int world, int rank, int64_t n
                          int32_t* fetch_cnt, int32_t* serve_rows, int32_t* fetch_rows, int32_t* union_rows,
                          int32_t* ptr, int32_t* ent, int64_t capacity, int64_t* sizes);
 
+/* roctx ranges around host-side phases (no reference counterpart): forwarded to
+ * roctxRangePushA / roctxRangePop of the ROCm tools library when it can be loaded, no-ops otherwise.
+ * With SERT_ROCTX=1 in the environment the library itself wraps every kernel group of a step (the
+ * sert_timing_name groups) in a range. */
+int sert_profile_range_push(const char* name);
+int sert_profile_range_pop(void);
+
 /* hipStreamSynchronize on the handle's stream. */
 int sert_synchronize(sert_model* m);
 /* Average duration in microseconds of the named kernel group over the steps

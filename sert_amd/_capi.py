@@ -36,6 +36,7 @@ EXPORTS = [
     'sert_comm_unique_id', 'sert_comm_init', 'sert_comm_init_host', 'sert_comm_destroy', 'sert_comm_stats',
     'sert_synchronize', 'sert_timing_enable', 'sert_timing_reset', 'sert_timing_count',
     'sert_timing_name', 'sert_timing_avg_us', 'sert_bench_gemm', 'sert_bench_memory', 'sert_debug_row_lists',
+    'sert_profile_range_push', 'sert_profile_range_pop',
 ]
 
 
@@ -128,6 +129,8 @@ def load():
     lib.sert_comm_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.c_int]
     lib.sert_debug_row_lists.argtypes = [fp, ctypes.c_int, ctypes.c_int, i64, i64, i64, i64, i64] + [fp] * 7 + [i64, fp]
     lib.sert_synchronize.argtypes = [vp]
+    lib.sert_profile_range_push.argtypes = [ctypes.c_char_p]
+    lib.sert_profile_range_pop.argtypes = []
     lib.sert_timing_enable.argtypes = [vp, ctypes.c_int]
     lib.sert_timing_reset.argtypes = [vp]
     lib.sert_timing_count.argtypes = [vp]
@@ -544,3 +547,17 @@ def debug_row_lists(allbits, rank, rows_per_rank, vocab, batch):
     ns, nf, nu, ne = (int(x) for x in sizes[:4])
     return dict(serve_cnt=scnt, fetch_cnt=fcnt, serve_rows=srows[:ns], fetch_rows=frows[:nf], union_rows=urows[:nu],
                 ptr=ptr[:nu + 1], ent=ent[:ne], max_xfer_rows=int(sizes[4]))
+
+
+class profile_range(object):
+    """with profile_range('epoch 3'): ...   -- a roctx range (sert_profile_range_push / pop)."""
+
+    def __init__(self, name):
+        self.name = name.encode() if isinstance(name, str) else name
+
+    def __enter__(self):
+        check(load().sert_profile_range_push(self.name))
+        return self
+
+    def __exit__(self, *exc):
+        check(load().sert_profile_range_pop())

@@ -37,12 +37,44 @@ static const char* kTimingNames[TG_COUNT] = {
     "entity_grad_fixup", "gemm_dW", "splitk_combine", "gemm_dX",      "word_grad_segsum",
     "allreduce",     "reduce_scatter", "all_gather", "optimizer_word_table",  "optimizer_other",      "finalize"};
 
+// ---- roctx ranges (sert_profile_range_push / pop) ------------------------------------
+// Loaded lazily from the ROCm tools library; SERT_ROCTX=1 additionally wraps every kernel group of a step
+// (the timing groups below) in a range, so that a rocprofv3 --marker-trace shows the step's structure on
+// the host timeline.  Without the library the calls are no-ops.
+struct Roctx {
+    bool tried = false;
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+};
+static Roctx g_roctx;
+static void roctx_load() {
+    if (g_roctx.tried) return;
+    g_roctx.tried = true;
+    for (const char* n : {"libroctx64.so.4", "libroctx64.so", "librocprofiler-sdk-roctx.so.1", "/opt/rocm/lib/libroctx64.so"}) {
+        void* lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) continue;
+        g_roctx.push = (decltype(g_roctx.push))dlsym(lib, "roctxRangePushA");
+        g_roctx.pop = (decltype(g_roctx.pop))dlsym(lib, "roctxRangePop");
+        if (g_roctx.push && g_roctx.pop) return;
+        g_roctx.push = nullptr; g_roctx.pop = nullptr;
+    }
+}
+static bool roctx_groups() {
+    static const bool on = [] {
+        const bool want = getenv("SERT_ROCTX") && atoi(getenv("SERT_ROCTX")) != 0;
+        if (want) roctx_load();
+        return want && g_roctx.push != nullptr;
+    }();
+    return on;
+}
+
 // ---- timing ----------------------------------------------------------------
 struct ScopedTimer {
     sert_model* m;
     int g;
     hipStream_t s;
     ScopedTimer(sert_model* m_, int g_, hipStream_t s_ = nullptr) : m(m_), g(g_), s(s_ ? s_ : m_->stream) {
+        if (roctx_groups()) (void)g_roctx.push(kTimingNames[g]);
         // a group bracketed several times in one step spans first start .. last end
         if (m->timing.enabled && !m->timing.used[g]) {
             (void)hipEventRecord(m->timing.ev[g][0], s);
@@ -53,6 +85,7 @@ struct ScopedTimer {
             (void)hipEventRecord(m->timing.ev[g][1], s);
             m->timing.used[g] = true;
         }
+        if (roctx_groups()) (void)g_roctx.pop();
     }
 };
 
@@ -3309,6 +3342,16 @@ int sert_debug_row_lists(const uint32_t* allbits, int world, int rank, int64_t n
     std::copy_n(L.ptr.begin() + xb.ptr_off, xb.nunion + 1, ptr);
     std::copy_n(L.ent.begin() + xb.ent_off, xb.nent, ent);
     return 0;
+}
+
+int sert_profile_range_push(const char* name) {
+    roctx_load();
+    if (!name) SERT_FAIL("null range name");
+    return g_roctx.push ? (g_roctx.push(name) < 0 ? 1 : 0) : 0;
+}
+int sert_profile_range_pop(void) {
+    roctx_load();
+    return g_roctx.pop ? (g_roctx.pop() < 0 ? 1 : 0) : 0;
 }
 
 int sert_synchronize(sert_model* m) {

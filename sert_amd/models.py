@@ -342,25 +342,27 @@ class ModelBase(ModelInterface):
         count = self.training_num_instances
         logging.info('Training on %d training instances (%d batches).',
                      count, self._number_of_batches(count))
-        if self.steps_per_sync > 1 and self.negative_sampler is None:
-            num_batches, losses = self._iterate_chunks(
-                self._engine.train_batches, count, int(self.steps_per_sync),
-                report_interval=1000, shuffle=True)
-        else:
-            num_batches, losses = self._iterate_batches(
-                self.train_fn, count, report_interval=1000, shuffle=True)
+        with _capi.profile_range('sert train pass'):      # (a roctx range; a no-op without the tools library)
+            if self.steps_per_sync > 1 and self.negative_sampler is None:
+                num_batches, losses = self._iterate_chunks(
+                    self._engine.train_batches, count, int(self.steps_per_sync),
+                    report_interval=1000, shuffle=True)
+            else:
+                num_batches, losses = self._iterate_batches(
+                    self.train_fn, count, report_interval=1000, shuffle=True)
         return num_batches, np.mean(losses)
 
     def _error_pass(self, fn, split, count):
         """(mean, std) of the per-batch evaluation losses of a split."""
         chunk = int(self.eval_batches_per_sync)
-        if chunk > 1 and self.eval_negative_sampler is None:
-            _, losses = self._iterate_chunks(
-                lambda batches: self._engine.eval_batches(
-                    split, np.asarray(batches, dtype=np.int64)),
-                count, chunk, report_interval=10000, shuffle=False)
-        else:
-            _, losses = self._iterate_batches(fn, count)
+        with _capi.profile_range('sert error pass'):
+            if chunk > 1 and self.eval_negative_sampler is None:
+                _, losses = self._iterate_chunks(
+                    lambda batches: self._engine.eval_batches(
+                        split, np.asarray(batches, dtype=np.int64)),
+                    count, chunk, report_interval=10000, shuffle=False)
+            else:
+                _, losses = self._iterate_batches(fn, count)
         return np.mean(losses), np.std(losses)
 
     def train_error(self):

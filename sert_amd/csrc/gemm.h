@@ -41,7 +41,8 @@ constexpr int GM = 128, GN = 128, GK = SERT_GK, GLD = 132;
 constexpr int GNV = GK / 8;          // float4 pieces per thread per operand slab
 constexpr int GTPR = 256 / GK;       // threads per k-row in the k-major loader
 
-enum { EPI_STORE = 0, EPI_BIAS = 1, EPI_BIAS_TANH = 2, EPI_FILTER = 3 };
+enum { EPI_STORE = 0, EPI_BIAS = 1, EPI_BIAS_TANH = 2, EPI_FILTER = 3, EPI_ACCUM = 4 };
+// EPI_ACCUM: C += op(A).op(B) (read-modify-write of C; the caller orders the launches that add to one C)
 // EPI_FILTER (query scoring): nothing is stored to C.  The elements of row r that reach
 // the row's threshold (bias[r]) are written, as (order-preserving key, column), to small
 // per-(row, 64-column group) lists: the 32 lanes of a half-wave hold the same row, so the
@@ -393,6 +394,7 @@ __global__ __launch_bounds__(256, SERT_GEMM_WAVES) void gemm_f32_mfma(const Gemm
                                 float v = acc[tm][tn][r];
                                 if (EPI == EPI_BIAS) v = v + bv;
                                 if (EPI == EPI_BIAS_TANH) v = fast_tanh(v + bv);
+                                if (EPI == EPI_ACCUM) v = v + Ct[off];
                                 Ct[off] = v;
                                 acc[tm][tn][r] = 0.f;
                                 off += ((r & 3) == 3) ? 5u * uld : uld;
@@ -405,7 +407,7 @@ __global__ __launch_bounds__(256, SERT_GEMM_WAVES) void gemm_f32_mfma(const Gemm
                                 float v = acc[tm][tn][r];
                                 if (EPI == EPI_BIAS) v = v + bv;
                                 if (EPI == EPI_BIAS_TANH) v = fast_tanh(v + bv);
-                                if (cok && row < mrem) Ct[off] = v;
+                                if (cok && row < mrem) Ct[off] = (EPI == EPI_ACCUM) ? v + Ct[off] : v;
                                 acc[tm][tn][r] = 0.f;
                                 off += ((r & 3) == 3) ? 5u * uld : uld;
                             }
@@ -616,7 +618,7 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_mfma_n160(const GemmArgs g) {
                         float v = acc[j][r];
                         if (EPI == EPI_BIAS) v = v + bv;
                         if (EPI == EPI_BIAS_TANH) v = fast_tanh(v + bv);
-                        if (cok && row < mrem) Ct[off] = v;
+                        if (cok && row < mrem) Ct[off] = (EPI == EPI_ACCUM) ? v + Ct[off] : v;
                         acc[j][r] = 0.f;
                         off += ((r & 3) == 3) ? 5u * uld : uld;
                     }
@@ -743,7 +745,7 @@ inline void launch_gemm(hipStream_t s, const float* A, const float* B, float* C,
     // small problem (less than 3/4 of a 128x128 tile per CU): 64x64 tiles, one workgroup each
     static const bool no_small = getenv("SERT_GEMM_NO_SMALL") != nullptr;
     static const long long small_below = getenv("SERT_GEMM_SMALL_BELOW") ? atoll(getenv("SERT_GEMM_SMALL_BELOW")) : 192;   // tuning knob
-    if (!TA && !CSB && EPI != EPI_FILTER && splits == 1 && !no_small &&
+    if (!TA && !CSB && EPI != EPI_FILTER && EPI != EPI_ACCUM && splits == 1 && !no_small &&
         (long long)cdiv(M, GM) * cdiv(N, GN) < small_below && (long long)M * N >= 4 * SM * SM) {
         g.cand = nullptr; g.cnt = nullptr; g.cap = 0;
         g.A = A; g.B = B; g.C = C; g.bias = bias;
@@ -752,8 +754,8 @@ inline void launch_gemm(hipStream_t s, const float* A, const float* B, float* C,
         g.tiles_m = cdiv(M, SM); g.tiles_n = cdiv(N, SM);
         const bool vecs = (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A) % 16 == 0) &&
                           (((uintptr_t)B) % 16 == 0) && (K % 4 == 0) && (TB ? true : (N % 4 == 0));
-        if (vecs) SERT_LAUNCH((gemm_f32_mfma_small<TB, EPI == EPI_FILTER ? EPI_STORE : EPI, true>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, s, g);
-        else      SERT_LAUNCH((gemm_f32_mfma_small<TB, EPI == EPI_FILTER ? EPI_STORE : EPI, false>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, s, g);
+        if (vecs) SERT_LAUNCH((gemm_f32_mfma_small<TB, (EPI == EPI_FILTER || EPI == EPI_ACCUM) ? EPI_STORE : EPI, true>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, s, g);
+        else      SERT_LAUNCH((gemm_f32_mfma_small<TB, (EPI == EPI_FILTER || EPI == EPI_ACCUM) ? EPI_STORE : EPI, false>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, s, g);
         return;
     }
     g.cand = cand; g.cnt = cnt; g.cap = cap;

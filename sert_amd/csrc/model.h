@@ -115,6 +115,8 @@ struct sert_model {
     // per-batch activations
     float *H = nullptr, *T = nullptr, *DA = nullptr, *DH = nullptr, *rowloss = nullptr;
     float* DH2 = nullptr;         // full-softmax variant: p = clip(t)  (B, d_e)
+    // full-softmax variant: the logits exist for fs_tile rows at a time (== batch_size: the whole batch)
+    int fs_tile = 0;
     int32_t* neg = nullptr;       // (B, z) device negatives
     // the NEXT training step's negatives, drawn at the end of this step on the side stream (they
     // depend on (seed, step, row) only): the sampler leaves the next step's critical path

@@ -1255,19 +1255,41 @@ static int fs_forward(sert_model* m, const DataSplit& ds, int64_t batch_index) {
         // p = clip(t) ; logits = p.R_e^T   (B, V)
         hipLaunchKernelGGL(vs_clip, dim3(grid_for((int64_t)B * de)), dim3(256), 0, m->stream, m->T, m->DH2,
                            (size_t)B * de);
-        launch_gemm<false, true, EPI_STORE>(m->stream, m->DH2, m->re, m->Z, nullptr, B, V, de, de, de, V);
     }
-    {
-        ScopedTimer t(m, TG_LOSS);
-        const float inv_batch = 1.0f / (float)c.global_batch_size;
-        // rows up to 2048 entities stay in registers (one read, one write)
+    const float inv_batch = 1.0f / (float)c.global_batch_size;
+    const int tile = m->fs_tile > 0 ? m->fs_tile : B;
+    for (int r0 = 0; r0 < B; r0 += tile) {
+        const int rows = std::min(tile, B - r0);
+        {
+            ScopedTimer t(m, TG_GEMM_FWD);
+            launch_gemm<false, true, EPI_STORE>(m->stream, m->DH2 + (size_t)r0 * de, m->re, m->Z, nullptr, rows, V, de, de, de, V);
+        }
+        {
+            ScopedTimer t(m, TG_LOSS);
+            // rows up to 2048 entities stay in registers (one read, one write)
 #define SERT_FS_CE(EPL)                                                                                   \
-    hipLaunchKernelGGL((fs_softmax_ce<TRAIN, EPL>), dim3(cdiv(B, 4)), dim3(256), 0, m->stream, m->Z, \
-                       ds.y + row0, TRAIN ? ds.w + row0 : nullptr, m->rowloss, B, V, inv_batch)
-        if (V <= 64 * 16)      SERT_FS_CE(16);
-        else if (V <= 64 * 32) SERT_FS_CE(32);
-        else                   SERT_FS_CE(0);
+    hipLaunchKernelGGL((fs_softmax_ce<TRAIN, EPL>), dim3(cdiv(rows, 4)), dim3(256), 0, m->stream, m->Z, \
+                       ds.y + row0 + r0, TRAIN ? ds.w + row0 + r0 : nullptr, m->rowloss + r0, rows, V, inv_batch)
+            if (V <= 64 * 16)      SERT_FS_CE(16);
+            else if (V <= 64 * 32) SERT_FS_CE(32);
+            else                   SERT_FS_CE(0);
 #undef SERT_FS_CE
+        }
+        if (TRAIN && tile < B) {
+            // row tiles: this tile's share of the backward that needs its dZ, before the next tile's
+            // logits overwrite it -- dR_e += dZ_t^T.p_t (the first tile stores), dp_t = dZ_t.R_e
+            {
+                ScopedTimer t(m, TG_EGRAD);
+                if (r0 == 0)
+                    launch_gemm<true, false, EPI_STORE>(m->stream, m->Z, m->DH2, m->g_re, nullptr, V, de, rows, V, de, de);
+                else
+                    launch_gemm<true, false, EPI_ACCUM>(m->stream, m->Z, m->DH2 + (size_t)r0 * de, m->g_re, nullptr, V, de, rows, V, de, de);
+            }
+            {
+                ScopedTimer t(m, TG_GEMM_DX);
+                SERT_TRY((gemm_long_k<false, false>(m, m->stream, m->Z, m->re, m->DA + (size_t)r0 * de, rows, de, V, V, de)));
+            }
+        }
     }
     return 0;
 }
@@ -1275,7 +1297,8 @@ static int fs_forward(sert_model* m, const DataSplit& ds, int64_t batch_index) {
 static int fs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) {
     const auto& c = m->cfg;
     const int B = c.batch_size, n = c.window_size, dw = c.word_dim, de = c.entity_dim, V = c.num_entities;
-    {
+    const bool tiled = m->fs_tile > 0 && m->fs_tile < B;   // (fs_forward already consumed every tile's dZ)
+    if (!tiled) {
         // dR_e (V, d_e) = dZ^T.p : reduction over the batch, split-K, order-fixed combine
         ScopedTimer t(m, TG_EGRAD);
         const int tiles = cdiv(de, GN) * cdiv(V, GM);
@@ -1291,7 +1314,7 @@ static int fs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
     {
         // dp = dZ.R_e (B, d_e) ; da = dp * clip'(t) * tanh'(a)
         ScopedTimer t(m, TG_GEMM_DX);
-        SERT_TRY((gemm_long_k<false, false>(m, m->stream, m->Z, m->re, m->DA, B, de, V, V, de)));
+        if (!tiled) SERT_TRY((gemm_long_k<false, false>(m, m->stream, m->Z, m->re, m->DA, B, de, V, V, de)));
         hipLaunchKernelGGL(vs_tanh_backward, dim3(grid_for((int64_t)B * de)), dim3(256), 0, m->stream, m->DA,
                            m->T, (size_t)B * de);
     }
@@ -2178,7 +2201,20 @@ static int create_resources(sert_model* m) {
             SERT_TRY(dzalloc(&m->neg_stage, std::max<size_t>(4, B * c.num_negatives), s));
             part = (size_t)1024 * (dw * de + de);
             if (c.kind == SERT_KIND_VECTORSPACE_SOFTMAX) {
-                SERT_TRY(dzalloc(&m->Z, B * V, s));       // logits -> dL/dlogits
+                // The logit matrix is never larger than ~1.7 GB (SERT_FS_TILE_MB): beyond that the step walks
+                // row tiles -- logits, softmax cross-entropy, dR_e += dZ^T.p and dp = dZ.R_e per tile -- so the
+                // C4 configuration (65536 x 100 000 logits = 26 GB as one matrix) needs 1.6 GB of scratch.
+                // SERT_FS_TILE_ROWS forces a tile height (tests).
+                {
+                    const char* em = getenv("SERT_FS_TILE_MB");
+                    const size_t cap = (size_t)(em && atoi(em) > 0 ? atoi(em) : 1700) << 20;
+                    size_t tile = B;
+                    if (B * V * sizeof(float) > cap) tile = std::max<size_t>(256, (cap / (V * sizeof(float))) / 256 * 256);
+                    const char* er = getenv("SERT_FS_TILE_ROWS");
+                    if (er && atoi(er) > 0) tile = (size_t)atoi(er);
+                    m->fs_tile = (int)std::min<size_t>(B, tile);
+                }
+                SERT_TRY(dzalloc(&m->Z, (size_t)m->fs_tile * V, s));       // logits -> dL/dlogits, one row tile
                 SERT_TRY(dzalloc(&m->DH2, B * de, s));    // p = clip(t)
                 const size_t tiles = (size_t)cdiv(de, GN) * cdiv(V, GM);
                 const size_t sp = std::max<size_t>(1, cdiv(1024, tiles)) + 1;

@@ -485,8 +485,14 @@ def test_model_with_empty_validation_and_short_data(hip_lib):
     dict(B=96, n=3, Vw=200, Ve=1000, dw=30, de=68),
     dict(B=256, n=10, Vw=3000, Ve=1000, dw=128, de=128),     # C2-shaped
 ])
-def test_vectorspace_softmax_variant_steps(hip_lib, dims):
-    """Additive full-softmax variant (SERT_KIND_VECTORSPACE_SOFTMAX) vs its oracle."""
+@pytest.mark.parametrize('tile', [None, 40])
+def test_vectorspace_softmax_variant_steps(hip_lib, dims, tile, monkeypatch):
+    """Additive full-softmax variant (SERT_KIND_VECTORSPACE_SOFTMAX) vs its oracle; tile = 40: the logits
+    exist for 40 rows at a time (the path that keeps the C4 configuration's 26 GB logit matrix at 1.6 GB:
+    per row tile logits, cross-entropy, dR_e += dZ^T.p through the accumulating GEMM epilogue, dp = dZ.R_e;
+    ragged last tile)."""
+    if tile:
+        monkeypatch.setenv('SERT_FS_TILE_ROWS', str(tile))
     B, n = dims['B'], dims['n']
     steps = 3
     p = U.make_vs_problem(8, B * steps, n, 0, dims['Vw'], dims['Ve'], dims['dw'], dims['de'], zipf=True)

@@ -291,15 +291,19 @@ def kernel_table(timings, work, traffic=None):
         if us <= 0:
             continue
         wk = work.get(name)
+        counted = traffic.get(name, {}).get('hbm_bytes')
         if wk is None or wk['kind'] == 'latency':
             kernels[name] = dict(us=round(us, 2), bound='latency')
+            if counted is not None:
+                kernels[name]['hbm_bytes_pmc'] = counted
             continue
         t = us * 1e-6
-        counted = traffic.get(name, {}).get('hbm_bytes')
         if wk['kind'] == 'mfma':
             ach = wk['flops'] / t / 1e12
             kernels[name] = dict(us=round(us, 2), bound='mfma', achieved=round(ach, 2), unit='TFLOP/s',
                                  frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), algorithmic_flops=wk['flops'])
+            if counted is not None:
+                kernels[name]['hbm_bytes_pmc'] = counted
             continue
         kind = wk['kind']
         if kind == 'stream' and counted is not None and counted < 0.7 * wk['alg']:
@@ -624,6 +628,24 @@ def query_bench(_capi, Q=10000, V=100000, d=128, k=100, reps=3, cpu_budget=8.0, 
     return out
 
 
+def whole_step_record(work, kernels, seconds_per_step, extra=None):
+    """Whole-step rates.  `algorithmic_GBps` = sum of the memory-side groups' SURVEY 8(d) bytes / step time --
+    a rate of REQUESTED bytes, most of them served by L2 and the Infinity Cache, so it may exceed the HBM
+    peak and is not reported as a fraction of it.  `counted_hbm_GBps` / `frac_of_hbm_peak` = what the PMC
+    passes counted crossing the fabric for the same groups / step time (null without counters)."""
+    alg = _step_bytes(work, kernels)
+    counted = [v.get('hbm_bytes_pmc') for k, v in kernels.items()]
+    have = [c for c in counted if c is not None]
+    rec = {'algorithmic_bytes': alg, 'algorithmic_GBps': round(alg / seconds_per_step / 1e9, 1),
+           'counted_hbm_bytes': (sum(have) if have else None),
+           'counted_hbm_GBps': (round(sum(have) / seconds_per_step / 1e9, 1) if have else None),
+           'frac_of_hbm_peak': (round(sum(have) / seconds_per_step / 1e9 / HBM_PEAK_GBS, 4) if have else None),
+           'groups_with_counters': '%d of %d' % (len(have), len(counted))}
+    if extra:
+        rec.update(extra)
+    return rec
+
+
 def _step_bytes(work, present):
     """Sum of the algorithmic bytes of the memory-side groups that ran."""
     return sum(w.get('alg', 0.0) for k, w in work.items() if w['kind'] in ('stream', 'rows', 'latency') and k in present)
@@ -658,14 +680,11 @@ def measure_record(kind, models, _capi, dist, dims, steps, warmup, seed, live_pm
     roof = roofline_of(kernels, tbg, source, kind=kind)
     if not tbg:
         roof['traffic_note'] = source or 'counter passes not requested (--no-live-pmc)'
-    total_bytes = _step_bytes(work, tm)
     rec = {
         'workload': label, 'value': steps * B / dt, 'unit': 'pairs/s', 'ms_per_step': 1000 * dt / steps, 'last_loss': loss,
         'kernels': kernels, 'roofline': roof,
         'memory_ceilings': ceil,
-        'whole_step': {'algorithmic_bytes': total_bytes,
-                       'achieved_GBps': round(total_bytes / (dt / steps) / 1e9, 1),
-                       'frac_of_hbm_peak': round(total_bytes / (dt / steps) / 1e9 / HBM_PEAK_GBS, 4)},
+        'whole_step': whole_step_record(work, kernels, dt / steps),
     }
     if U is not None:
         rec['distinct_words_per_batch'] = U
@@ -824,7 +843,6 @@ def main():
         roofline = roofline_of(kernels, tbg, traffic_source, kind=kind)
         if per_kernel is None or not tbg:
             roofline['traffic_note'] = traffic_source
-        step_bytes = _step_bytes(work, kernels)
         step_flops = sum(w_['flops'] for k, w_ in work.items() if w_['kind'] == 'mfma' and k in kernels)
         kernel_sum_us = sum(v['us'] for v in kernels.values())
         out = {
@@ -847,14 +865,8 @@ def main():
             'memory_ceilings': dict(ceilings, note='measured in this process on this box (sert_bench_memory): float4 stream copy / '
                                     'read over 1.2 GB, vs_gather_mean over uniformly random rows (window 10), adam_l2 over '
                                     'four separately allocated arrays; spec HBM peak %.0f GB/s' % HBM_PEAK_GBS),
-            'whole_step': {
-                'algorithmic_bytes': step_bytes, 'algorithmic_flops': step_flops,
-                'achieved_GBps': round(step_bytes / (dt / args.steps) / 1e9, 1),
-                'frac_of_hbm_peak': round(step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
-                'kernel_us_sum_serial': round(kernel_sum_us, 1),
-                'note': 'sum of the groups\' algorithmic bytes / ms_per_step; much of it is served by L2 and the Infinity '
-                        'Cache (tables of 51 MB + 33 MB activations), so this is not an HBM utilisation',
-            },
+            'whole_step': whole_step_record(work, kernels, dt / args.steps, {
+                'algorithmic_flops': step_flops, 'kernel_us_sum_serial': round(kernel_sum_us, 1)}),
             'ms_per_step_instrumented': 1000.0 * dt_instr / args.steps,
             'deferred_loss_readback': {'value': args.steps * Bg / dt_async, 'unit': 'pairs/s',
                                        'ms_per_step': 1000.0 * dt_async / args.steps,

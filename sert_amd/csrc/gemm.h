@@ -742,9 +742,12 @@ inline void launch_gemm(hipStream_t s, const float* A, const float* B, float* C,
                         unsigned char* cnt = nullptr, int cap = 0) {
     if (splits <= 1) { splits = 1; kper = K; }
     GemmArgs g;
-    // small problem (less than 3/4 of a 128x128 tile per CU): 64x64 tiles, one workgroup each
+    // small problem (fewer than two 128x128 tiles per CU): 64x64 tiles, one workgroup each
     static const bool no_small = getenv("SERT_GEMM_NO_SMALL") != nullptr;
-    static const long long small_below = getenv("SERT_GEMM_SMALL_BELOW") ? atoll(getenv("SERT_GEMM_SMALL_BELOW")) : 192;   // tuning knob
+    // below TWO 128x128 tiles per CU the 64x64 tiles win or draw (round 3 sweep at d = 128: 384 tiles
+    // 30.5 -> 26.3 us, the loglinear dG with 347 tiles and K = 1000 162 -> 126 us; 256 and 512 tiles: equal):
+    // a CU that gets a second big tile sets the time of the launch, four times as many small ones spread evenly
+    static const long long small_below = getenv("SERT_GEMM_SMALL_BELOW") ? atoll(getenv("SERT_GEMM_SMALL_BELOW")) : 512;   // tuning knob
     if (!TA && !CSB && EPI != EPI_FILTER && EPI != EPI_ACCUM && splits == 1 && !no_small &&
         (long long)cdiv(M, GM) * cdiv(N, GN) < small_below && (long long)M * N >= 4 * SM * SM) {
         g.cand = nullptr; g.cnt = nullptr; g.cap = 0;

@@ -512,6 +512,157 @@ __global__ __launch_bounds__(NT) void ll_row_from_table(const float* __restrict_
     }
 }
 
+// The same row, ONE WAVE per batch row, everything in registers: no LDS, no workgroup barrier.
+// ll_row_from_table spends a workgroup and five barrier-separated block reductions on a row whose whole
+// state is V_e floats; with V_e <= 64 * 4 * E4PL a lane holds its E4PL float4 chunks of J (chunk c of
+// the row lives on lane c % 64), the reductions are wave reductions, and four times as many rows are in
+// flight per CU.  Same arithmetic per element (window order of the additions, clamp, expf, the label
+// fix-up); the cross-lane sums are grouped differently -- fp32 reassociation of loss_i, s and r.
+// V % 4 == 0, n <= 64, TRAIN only.
+template <int E4PL>
+__global__ __launch_bounds__(256) void ll_row_wave(const float* __restrict__ Zu, const int32_t* __restrict__ slot,
+                                                   const int32_t* __restrict__ y_int, const int64_t* __restrict__ indptr,
+                                                   const int32_t* __restrict__ indices, const float* __restrict__ data,
+                                                   const float* __restrict__ w, float* __restrict__ rowloss, int B, int n,
+                                                   int V, float inv_batch, float* __restrict__ dJ_out,
+                                                   float* __restrict__ r_out) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= B) return;
+    const int V4 = V >> 2;
+    const float LOGLO = logf(SERT_CLIP_LO), LOGHI = logf(SERT_CLIP_HI);
+    const int my_slot = slot[(size_t)i * n + min(lane, n - 1)];
+    float4 J[E4PL];
+#pragma unroll
+    for (int j = 0; j < E4PL; ++j) J[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned long long oob = 0ull;
+#ifndef SERT_LL_WAVE_GC
+#define SERT_LL_WAVE_GC 3   // (5: 269 us, 3: 261, 10: 356 for the loss group at C2 dims -- registers against rows in flight)
+#endif
+    constexpr int GC = (E4PL <= 4) ? SERT_LL_WAVE_GC : 2;      // window rows in flight: GC * E4PL float4 per lane
+    for (int k0 = 0; k0 < n; k0 += GC) {
+        float4 v[GC][E4PL];
+#pragma unroll
+        for (int q = 0; q < GC; ++q) {
+            const int sl = __shfl(my_slot, min(k0 + q, n - 1));
+            const float4* row = reinterpret_cast<const float4*>(Zu + (size_t)sl * V);
+#pragma unroll
+            for (int j = 0; j < E4PL; ++j) {
+                const int c = lane + 64 * j;
+                v[q][j] = row[c < V4 ? c : 0];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < GC; ++q) {
+            if (k0 + q >= n) continue;
+            bool bad = false;
+#pragma unroll
+            for (int j = 0; j < E4PL; ++j) {
+                const bool in = lane + 64 * j < V4;
+                const float x[4] = {v[q][j].x, v[q][j].y, v[q][j].z, v[q][j].w};
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) bad = bad || (in && !(x[cc] >= LOGLO && x[cc] <= LOGHI));
+                J[j].x += fminf(fmaxf(x[0], LOGLO), LOGHI); J[j].y += fminf(fmaxf(x[1], LOGLO), LOGHI);
+                J[j].z += fminf(fmaxf(x[2], LOGLO), LOGHI); J[j].w += fminf(fmaxf(x[3], LOGLO), LOGHI);
+            }
+            if (bad) oob |= 1ull << (k0 + q);
+        }
+    }
+    // 1. max, sum of exponentials
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < E4PL; ++j)
+        if (lane + 64 * j < V4) mx = fmaxf(mx, fmaxf(fmaxf(J[j].x, J[j].y), fmaxf(J[j].z, J[j].w)));
+    mx = wave_max(mx);
+    float4 E[E4PL];
+    float se = 0.f;
+#pragma unroll
+    for (int j = 0; j < E4PL; ++j) {
+        const bool in = lane + 64 * j < V4;
+        E[j].x = in ? expf(J[j].x - mx) : 0.f; E[j].y = in ? expf(J[j].y - mx) : 0.f;
+        E[j].z = in ? expf(J[j].z - mx) : 0.f; E[j].w = in ? expf(J[j].w - mx) : 0.f;
+        se += (E[j].x + E[j].y) + (E[j].z + E[j].w);
+    }
+    se = wave_sum(se);
+    // 2. loss and s = sum_e dQ_e Q_e over the label entries  models.py:289-292; the entry's owner lane
+    //    keeps its fix-up (dQ_e Q_e) for step 3
+    const float wi = w[i];
+    const float g = wi * inv_batch;
+    float loss = 0.f, sdq = 0.f;
+    float4 fix[E4PL];
+#pragma unroll
+    for (int j = 0; j < E4PL; ++j) fix[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int64_t l0 = 0, l1 = 1;
+    if (y_int == nullptr) { l0 = indptr[i]; l1 = indptr[i + 1]; }
+    for (int64_t l = l0; l < l1; ++l) {
+        const int e = y_int ? y_int[i] : indices[l];
+        const float yv = y_int ? 1.f : data[l];
+        const int c = e >> 2, comp = e & 3;
+        if ((c & 63) == lane) {                  // (one lane per entry: the sums below are wave sums of one term)
+            const int j = c >> 6;
+            float ev = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < E4PL; ++jj)
+                if (jj == j) ev = comp == 0 ? E[jj].x : comp == 1 ? E[jj].y : comp == 2 ? E[jj].z : E[jj].w;
+            const float q = ev / se;
+            const float qc = fminf(fmaxf(q, SERT_CLIP_LO), SERT_CLIP_HI);
+            loss -= yv * logf(qc);
+            const bool inside = (q >= SERT_CLIP_LO) && (q <= SERT_CLIP_HI);
+            const float qdq = q * (inside ? -(g * yv) / qc : 0.f);
+            sdq += qdq;
+#pragma unroll
+            for (int jj = 0; jj < E4PL; ++jj)
+                if (jj == j) {
+                    if (comp == 0) fix[jj].x += qdq; else if (comp == 1) fix[jj].y += qdq;
+                    else if (comp == 2) fix[jj].z += qdq; else fix[jj].w += qdq;
+                }
+        }
+    }
+    loss = wave_sum(loss);
+    sdq = wave_sum(sdq);
+    if (lane == 0) rowloss[i] = wi * loss;
+    // 3. dJ_e = Q_e (dQ_e - s) = -Q_e s + [label entries]
+    float tot = 0.f;
+    float4* dj_out = reinterpret_cast<float4*>(dJ_out + (size_t)i * V);
+#pragma unroll
+    for (int j = 0; j < E4PL; ++j) {
+        const int c = lane + 64 * j;
+        if (c >= V4) continue;
+        float4 dj;
+        dj.x = -(E[j].x / se) * sdq + fix[j].x; dj.y = -(E[j].y / se) * sdq + fix[j].y;
+        dj.z = -(E[j].z / se) * sdq + fix[j].z; dj.w = -(E[j].w / se) * sdq + fix[j].w;
+        J[j] = dj;
+        dj_out[c] = dj;
+        tot += (dj.x + dj.y) + (dj.z + dj.w);
+    }
+    tot = wave_sum(tot);
+    // 4. r_k: the plain total unless a probability of token k is clipped (then the masked sum, from its row)
+    unsigned lo = (unsigned)oob, hi = (unsigned)(oob >> 32);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { lo |= __shfl_xor(lo, off); hi |= __shfl_xor(hi, off); }
+    const unsigned long long any = ((unsigned long long)hi << 32) | lo;
+    float my_r = tot;
+    if (any) {
+        for (int k = 0; k < n; ++k) {
+            if (!((any >> k) & 1ull)) continue;
+            const int sl = __shfl(my_slot, k);
+            const float4* row = reinterpret_cast<const float4*>(Zu + (size_t)sl * V);
+            float r = 0.f;
+#pragma unroll
+            for (int j = 0; j < E4PL; ++j) {
+                const int c = lane + 64 * j;
+                if (c >= V4) continue;
+                const float4 lp = row[c];
+                r += ((lp.x >= LOGLO && lp.x <= LOGHI) ? J[j].x : 0.f) + ((lp.y >= LOGLO && lp.y <= LOGHI) ? J[j].y : 0.f) +
+                     ((lp.z >= LOGLO && lp.z <= LOGHI) ? J[j].z : 0.f) + ((lp.w >= LOGLO && lp.w <= LOGHI) ? J[j].w : 0.f);
+            }
+            r = wave_sum(r);
+            if (lane == k) my_r = r;
+        }
+    }
+    if (lane < n) r_out[(size_t)i * n + lane] = my_r;
+}
+
 // dZu[u, e] = mask_ue DJsum[u, e] - P_ue Rsum[u]   (in place over DJsum; logp = the word's
 // log-probability row, mask = eps <= P <= 1-eps)
 __global__ __launch_bounds__(256) void ll_dzu_combine(float* __restrict__ dZu, const float* __restrict__ logp,

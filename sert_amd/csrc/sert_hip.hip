@@ -1458,6 +1458,19 @@ static int ll_forward(sert_model* m, const DataSplit& ds, int64_t batch_index) {
             // put four times as many rows on a CU -- loss kernel 307 -> 111 us at batch 65536, V_e = 100;
             // 86 -> 75 us at V_e = 1000, 139 -> 134 us at 2000 (batch 8192)
             static const int nt128_below = getenv("SERT_LL_NT128_BELOW") ? atoi(getenv("SERT_LL_NT128_BELOW")) : 2048;   // tuning knob
+            // up to 2048 entities (V_e % 4 == 0): one WAVE per row, the row in registers, no LDS and no barrier
+            static const bool no_wave = getenv("SERT_LL_NO_ROW_WAVE") != nullptr;   // cross-check knob
+#define SERT_LL_WAVE(E)                                                                                        \
+    hipLaunchKernelGGL((ll_row_wave<E>), dim3(cdiv(B, 4)), dim3(256), 0, m->stream, (const float*)m->Zu, slot, y, \
+                       indptr, ds.csr_indices, ds.csr_data, w, m->rowloss, B, n, V, inv_batch, m->J, m->ll_r)
+            if (!no_wave && V % 4 == 0 && V <= 2048) {
+                const int e4 = cdiv(V / 4, 64);
+                if (e4 <= 1) SERT_LL_WAVE(1);
+                else if (e4 <= 2) SERT_LL_WAVE(2);
+                else if (e4 <= 4) SERT_LL_WAVE(4);
+                else SERT_LL_WAVE(8);
+            } else
+#undef SERT_LL_WAVE
             if (V <= nt128_below)
                 hipLaunchKernelGGL((ll_row_from_table<128>), dim3(B), dim3(128), lds, m->stream, (const float*)m->Zu,
                                    slot, y, indptr, ds.csr_indices, ds.csr_data, w, m->rowloss, n, V, inv_batch,

@@ -1515,7 +1515,8 @@ static int ll_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
     {
         // dW (d, V) = G^T.dZ, reduction over the tokens (distinct words); db = column sums of dZ
         const int tiles = cdiv(V, GN) * cdiv(d, GM);
-        int splits = std::max(1, std::min(cdiv(rows, GK), cdiv(1024, tiles)));
+        static const int want_items = getenv("SERT_LL_DW_ITEMS") ? std::max(1, atoi(getenv("SERT_LL_DW_ITEMS"))) : 1024;   // tuning knob
+        int splits = std::max(1, std::min(cdiv(rows, GK), cdiv(want_items, tiles)));
         int kper = (int)round_up(cdiv(rows, splits), GK);
         splits = cdiv(rows, kper);
         const size_t mn = (size_t)d * V;

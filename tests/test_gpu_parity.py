@@ -136,6 +136,8 @@ def test_vectorspace_predict(hip_lib):
     dict(B=32, n=4, Vw=300, Ve=53, d=24),
     dict(B=64, n=5, Vw=10000, Ve=100, d=64),     # C1-shaped
     dict(B=40, n=3, Vw=500, Ve=1000, d=30),
+    dict(B=33, n=6, Vw=400, Ve=400, d=20),        # one wave per row, two float4 chunks per lane (ll_row_wave<2>)
+    dict(B=21, n=7, Vw=300, Ve=2048, d=12),       # ... eight chunks per lane: the largest row the wave kernel takes
     dict(B=8, n=10, Vw=300, Ve=3500, d=16),       # 154 KB slab: fused kernel
     dict(B=8, n=12, Vw=300, Ve=4000, d=16),       # > LDS: streaming path, one segment
     dict(B=5, n=5, Vw=300, Ve=12000, d=16),       # streaming path, 3 segments, 16-byte rows

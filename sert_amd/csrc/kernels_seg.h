@@ -172,6 +172,30 @@ __global__ __launch_bounds__(256) void segsum_rows_scalar(const float* __restric
     }
 }
 
+// d = 1 (the per-position scalars r_ik of the loglinear backward, summed per word): one wave per item,
+// one ENTRY PER LANE (an item has at most kSegChunk = 64 entries), a wave reduction in a fixed lane order.
+// segsum_rows_scalar walked the entries four at a time on ONE active lane -- sixteen dependent trips for a
+// full chunk: 39 us for the 44 k items of a C2-dims batch, two dependent loads here.
+__global__ __launch_bounds__(256) void segsum_scalar_wave(const float* __restrict__ src, const int32_t* __restrict__ rows,
+                                                          const int4* __restrict__ items, int nitems,
+                                                          float* __restrict__ final_dst, float* __restrict__ partial_dst) {
+    const int lane = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= nitems) return;
+    const int4 it = items[item];
+    float a = 0.f;
+    for (int e0 = it.x; e0 < it.y; e0 += 64) {      // (one trip: chunks hold <= 64 entries)
+        const int e = e0 + lane;
+        float v = 0.f;
+        if (e < it.y) v = src[rows ? rows[e] : e];
+        a += wave_sum(v);
+    }
+    if (lane == 0) {
+        if (it.z >= 0) final_dst[it.w] = a;        // (DST_SLOT: the word's rank among the batch's distinct words)
+        else partial_dst[-(it.z + 1)] = a;
+    }
+}
+
 // Levels 1 and 2 of a three-level tree in ONE launch (word_index.h: heavy_off).  Workgroups
 // [0, nb_normal) take 32 level-1 items each and store the final ones (a chunk item -- dst < 0 -- is
 // left to its word's workgroup); workgroup nb_normal + h sums the <= 32 chunk items of heavy word h,
@@ -310,6 +334,87 @@ __global__ __launch_bounds__(1024) void segsum_heavy(const float* __restrict__ s
             a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
         }
         if (on) reinterpret_cast<float4*>(part)[((size_t)rblk * kHeavyMax + h) * d4 + ch] = a;
+    }
+}
+
+// Wide rows (the loglinear dJ: V_e floats): one WAVE per batch row and 512-column slab, so that a row's
+// counts are wave-uniform -- most of a row's sixteen counts are zero (ten tokens, three to four distinct
+// heavy words), and a uniform branch skips their multiply-adds: the pass was VALU-bound on 16 x V_e x B
+// products of which under a quarter are non-zero.  512 threads = 8 waves x 32 rows (four trips of eight
+// rows in flight); waves combined through two LDS slots in four rounds (fixed order).
+__global__ __launch_bounds__(512) void segsum_heavy_wide(const float* __restrict__ src, const uint4* __restrict__ cnt16,
+                                                         int B, int d, float* __restrict__ part) {
+    extern __shared__ float4 hv_lds[];   // [2 slots][kHeavyMax][128]
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int d4 = d >> 2;
+    const int nslab = (d4 + 127) / 128;
+    const int slab = blockIdx.x % nslab, rblk = blockIdx.x / nslab;
+    const int ch0 = slab * 128 + lane, ch1 = ch0 + 64;
+    const bool on0 = ch0 < d4, on1 = ch1 < d4;
+    f32x2 acc[kHeavyMax][4];
+#pragma unroll
+    for (int h = 0; h < kHeavyMax; ++h)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[h][q] = (f32x2)(0.f);
+    constexpr int RPW = kHeavyRowsPerBlock / 8;    // rows per wave
+    const int row0 = rblk * kHeavyRowsPerBlock + wv * RPW;
+    for (int t0 = 0; t0 < RPW; t0 += 8) {
+        uint4 c[8];
+        float4 v0[8], v1[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int i = __builtin_amdgcn_readfirstlane(min(row0 + t0 + q, B - 1));
+            c[q] = cnt16[i];
+            if (row0 + t0 + q >= B) c[q] = make_uint4(0u, 0u, 0u, 0u);
+            v0[q] = on0 ? *reinterpret_cast<const float4*>(src + (size_t)i * d + 4 * ch0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            v1[q] = on1 ? *reinterpret_cast<const float4*>(src + (size_t)i * d + 4 * ch1) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const unsigned cw[4] = {(unsigned)__builtin_amdgcn_readfirstlane((int)c[q].x), (unsigned)__builtin_amdgcn_readfirstlane((int)c[q].y),
+                                    (unsigned)__builtin_amdgcn_readfirstlane((int)c[q].z), (unsigned)__builtin_amdgcn_readfirstlane((int)c[q].w)};
+            f32x2 a, b, cc, dd;
+            a.x = v0[q].x; a.y = v0[q].y; b.x = v0[q].z; b.y = v0[q].w;
+            cc.x = v1[q].x; cc.y = v1[q].y; dd.x = v1[q].z; dd.y = v1[q].w;
+#pragma unroll
+            for (int h = 0; h < kHeavyMax; ++h) {
+                const unsigned byte = (cw[h >> 2] >> (8 * (h & 3))) & 0xffu;
+                if (byte != 0u) {                       // (wave-uniform)
+                    const f32x2 ff = (f32x2)((float)byte);
+                    acc[h][0] = __builtin_elementwise_fma(ff, a, acc[h][0]);
+                    acc[h][1] = __builtin_elementwise_fma(ff, b, acc[h][1]);
+                    acc[h][2] = __builtin_elementwise_fma(ff, cc, acc[h][2]);
+                    acc[h][3] = __builtin_elementwise_fma(ff, dd, acc[h][3]);
+                }
+            }
+        }
+    }
+    for (int round = 0; round < 4; ++round) {
+        if ((wv >> 1) == round) {
+            float4* slot = hv_lds + (size_t)(wv & 1) * kHeavyMax * 128;
+#pragma unroll
+            for (int h = 0; h < kHeavyMax; ++h) {
+                float4 x0 = make_float4(acc[h][0].x, acc[h][0].y, acc[h][1].x, acc[h][1].y);
+                float4 x1 = make_float4(acc[h][2].x, acc[h][2].y, acc[h][3].x, acc[h][3].y);
+                if (round != 0) {
+                    const float4 o0 = slot[h * 128 + lane], o1 = slot[h * 128 + 64 + lane];
+                    x0.x += o0.x; x0.y += o0.y; x0.z += o0.z; x0.w += o0.w;
+                    x1.x += o1.x; x1.y += o1.y; x1.z += o1.z; x1.w += o1.w;
+                }
+                slot[h * 128 + lane] = x0;
+                slot[h * 128 + 64 + lane] = x1;
+            }
+        }
+        __syncthreads();
+    }
+    for (int k = threadIdx.x; k < kHeavyMax * 128; k += 512) {
+        const int h = k >> 7, cl = k & 127;
+        const int ch = slab * 128 + cl;
+        if (ch >= d4) continue;
+        const float4 p0 = hv_lds[k], p1 = hv_lds[kHeavyMax * 128 + k];
+        reinterpret_cast<float4*>(part)[((size_t)rblk * kHeavyMax + h) * d4 + ch] =
+            make_float4(p0.x + p1.x, p0.y + p1.y, p0.z + p1.z, p0.w + p1.w);
     }
 }
 

@@ -318,8 +318,8 @@ static int dzu_from_dj(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         const int4* items = ds.idx_items + bx.item_off[l];
         const float* in = (l == 0) ? m->ll_r : m->ll_rpart + (size_t)bx.part_off[l - 1];
         float* pout = m->ll_rpart + (size_t)bx.part_off[l];
-        hipLaunchKernelGGL((segsum_rows_scalar<true>), dim3(cdiv(nitems, 4)), dim3(256), 0, m->stream, in,
-                           rows, items, nitems, m->ll_rsum, pout, 1, 1.0f, (unsigned char*)nullptr, 1);
+        hipLaunchKernelGGL(segsum_scalar_wave, dim3(cdiv(nitems, 4)), dim3(256), 0, m->stream, in, rows, items, nitems,
+                           m->ll_rsum, pout);
     }
     for (int l = 0; l < bx.nlevels; ++l) {
         const int nitems = bx.item_cnt[l];
@@ -353,8 +353,11 @@ static int dzu_from_dj(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         const int B = m->cfg.batch_size, d4 = V / 4;
         const int nblk = cdiv(B, kHeavyRowsPerBlock);
         const uint4* cnt = ds.idx_dense_counts + (size_t)batch_index * B;
-        const size_t lds = (size_t)4 * kHeavyMax * 32 * sizeof(float4);   // 32 KB
-        hipLaunchKernelGGL(segsum_heavy, dim3(nblk * cdiv(d4, 32)), dim3(1024), lds, m->stream, (const float*)m->J, cnt, B, V, m->hpart);
+        static const bool attr_set = hipFuncSetAttribute((const void*)segsum_heavy_wide, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                         2 * kHeavyMax * 128 * (int)sizeof(float4)) == hipSuccess;
+        if (!attr_set) SERT_FAIL("cannot reserve the LDS of segsum_heavy_wide");
+        hipLaunchKernelGGL(segsum_heavy_wide, dim3(nblk * cdiv(d4, 128)), dim3(512), (size_t)2 * kHeavyMax * 128 * sizeof(float4), m->stream,
+                           (const float*)m->J, cnt, B, V, m->hpart);
         DenseSlots dsl;
         dsl.n = bx.dense_cnt;
         for (int h = 0; h < kHeavyMax; ++h) dsl.slot[h] = h < bx.dense_cnt ? bx.dense_slot[h] : -2;

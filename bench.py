@@ -320,10 +320,16 @@ def kernel_table(timings, work, traffic=None):
             achievable = max([x for x in (opt_rate, stream_ceil.get('read_GBps'), stream_ceil.get('copy_GBps')) if x] or [0])
             if achievable:
                 moved = counted if counted is not None else wk.get('executed', wk['alg'])
-                rec['achievable_GBps'] = round(achievable, 1)
-                rec['frac_of_achievable'] = round(min(moved, wk['alg']) / t / 1e9 / achievable, 4)
+                own = min(moved, wk['alg']) / t / 1e9
                 rec['achievable_is'] = ('adam_l2 over a tensor of the same size' if opt_rate and opt_rate >= achievable
                                         else 'float4 read stream over 1.2 GB')
+                if own > achievable:
+                    # the kernel outran every stream measured beside it: the box's ceiling is at least its own
+                    # rate, and that is what the fraction is taken against
+                    rec['achievable_is'] = 'this kernel (the %s reached %.1f GB/s)' % (rec['achievable_is'], achievable)
+                    achievable = own
+                rec['achievable_GBps'] = round(achievable, 1)
+                rec['frac_of_achievable'] = round(own / achievable, 4)
             kernels[name] = rec
         else:
             ach = wk['fetch'] / t / 1e9

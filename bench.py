@@ -667,14 +667,15 @@ def measure_record(kind, models, _capi, dist, dims, steps, warmup, seed, live_pm
         data = synth_data(rng, num_batches * B, n, Vw, Ve)
     X, y, w = data
     m = build_model(kind, models, B, n, Vw, Ve, d, de, z, X, y, w, seed=seed)
-    dt, _, loss = timed_steps(m, dist, num_batches, steps, warmup, timing=False)
-    _, tm, _ = timed_steps(m, dist, num_batches, steps, 1, timing=True)
-    del m
     U = None
     if kind == 'loglinear':
         U = float(np.mean([len(np.unique(X[j * B:(j + 1) * B])) for j in range(num_batches)]))
     work = group_work(kind, B, n, X.dtype.itemsize, d, de, Ve, Vw, z, U)
+    # (same order as the headline: ceilings, per-kernel pass, then the number -- see main)
     ceil = ceilings_for(_capi, work)
+    _, tm, _ = timed_steps(m, dist, num_batches, steps, 1, timing=True)
+    dt, _, loss = timed_steps(m, dist, num_batches, steps, warmup, timing=False)
+    del m
     per_kernel, source, tbg = None, None, {}
     if live_pmc:
         inner = ['--model', kind, '--batch', B, '--vocab', Vw, '--entities', Ve, '--dim', d, '--entity-dim', de,
@@ -775,11 +776,21 @@ def main():
         timed_steps(model, dist, args.num_batches, args.steps, args.warmup, timing=False)
         return
 
-    # pass 1 (the number): K untimed steps.  pass 2: the same K steps again with HIP
-    # events around every kernel (serialised, slower) for the per-kernel table.
+    # Order of the measurements.  A GPU that sat idle while the host generated the data set and built the
+    # inverted index needs some tens of milliseconds of load to reach its operating clocks: the same 20 steps
+    # read 319 us/step straight after the build, 304 in a second region and 295 from the third on
+    # (tools/experiments/r03_step_times.py).  The bench therefore does its other GPU
+    # work FIRST -- the memory ceilings of this box, then the K steps with HIP events around every
+    # kernel (serialised, slower: the per-kernel table) -- and takes the number last: W untimed warm-up
+    # steps, barrier + synchronise, EXACTLY K steps, synchronise + barrier.
+    distinct = None
+    if kind == 'loglinear':
+        distinct = float(np.mean([len(np.unique(X[j * Bg:j * Bg + Bl])) for j in range(args.num_batches)]))
+    work = group_work(kind, Bl, n, X.dtype.itemsize, d, de, Ve, Vw, z, distinct)
+    ceilings = ceilings_for(_capi, work)      # (every rank: each has its own GPU to bring up to speed)
+    dt_instr, timings, _ = timed_steps(model, dist, args.num_batches, args.steps, 2, timing=True)
     dt, _, last_loss = timed_steps(model, dist, args.num_batches, args.steps, args.warmup, timing=False)
     value = args.steps * Bg / dt
-    dt_instr, timings, _ = timed_steps(model, dist, args.num_batches, args.steps, 2, timing=True)
 
     # pass 3 (extra, not the headline): the same steps with the loss read-back deferred
     # (sert_train_batches: 25 batches per host synchronisation) -- what the per-step
@@ -807,6 +818,7 @@ def main():
         for sd, wt in ((1, 'ones'), (2, 'ones'), (args.seed, 'uniform')):
             Xs, ys, ws = dataset(sd, wt)
             ms_ = build_model(kind, models, Bg, n, Vw, Ve, d, de, z, Xs, ys, ws, seed=sd)
+            timed_steps(ms_, dist, args.num_batches, args.steps, 2, timing=True)     # (GPU idle during the build: as above)
             dts, _, _ = timed_steps(ms_, dist, args.num_batches, args.steps, args.warmup, timing=False)
             seed_runs['seed_%d%s' % (sd, '_w_uniform_0.5_2' if wt == 'uniform' else '')] = {
                 'value': args.steps * Bg / dts, 'ms_per_step': 1000.0 * dts / args.steps}
@@ -817,6 +829,7 @@ def main():
     if N > 1 and Bl % N == 0:
         ms = build_model(kind, models, Bl, n, Vw, Ve, d, de, z, X[:args.num_batches * Bl], y[:args.num_batches * Bl],
                          w[:args.num_batches * Bl], seed=args.seed)
+        timed_steps(ms, dist, args.num_batches, args.steps, 2, timing=True)
         dts, _, _ = timed_steps(ms, dist, args.num_batches, args.steps, args.warmup, timing=False)
         strong = {'value': args.steps * Bl / dts, 'unit': 'pairs/s', 'ms_per_step': 1000.0 * dts / args.steps,
                   'global_batch': Bl, 'per_gpu_batch': Bl // N,
@@ -828,11 +841,6 @@ def main():
     s = X.dtype.itemsize
     live = not args.no_live_pmc
     if ctx.rank == 0:
-        distinct = None
-        if kind == 'loglinear':
-            distinct = float(np.mean([len(np.unique(X[j * Bg:j * Bg + Bl])) for j in range(args.num_batches)]))
-        work = group_work(kind, Bl, n, s, d, de, Ve, Vw, z, distinct)
-        ceilings = ceilings_for(_capi, work)
         per_kernel, traffic_source = (None, None)
         if N == 1 and live:
             inner = ['--model', kind, '--batch', Bl, '--vocab', Vw, '--entities', Ve, '--dim', d, '--entity-dim', de,
@@ -874,6 +882,9 @@ def main():
             'whole_step': whole_step_record(work, kernels, dt / args.steps, {
                 'algorithmic_flops': step_flops, 'kernel_us_sum_serial': round(kernel_sum_us, 1)}),
             'ms_per_step_instrumented': 1000.0 * dt_instr / args.steps,
+            'measurement_order': 'memory ceilings, then the K steps with per-kernel HIP events, then the number '
+                                 '(W untimed warm-up steps + exactly K timed steps): the GPU is at operating clocks '
+                                 'when the timed region starts',
             'deferred_loss_readback': {'value': args.steps * Bg / dt_async, 'unit': 'pairs/s',
                                        'ms_per_step': 1000.0 * dt_async / args.steps,
                                        'note': '25 batches per host synchronisation (additive mode; the headline '

@@ -128,10 +128,16 @@ __global__ __launch_bounds__(256) void egrad_fixup(const int32_t* __restrict__ r
     const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (e >= V) return;
     const int s = run_start[e], t = run_end[e];
-    if (t <= s) return;                      // entity not in this batch (arrays are zeroed)
+    const int pieces = de / VEC;
+    if (t <= s) {                            // entity not in this batch (the bounds are zeroed): a zero row
+        if (g == 0)                          // (dR_e itself is NOT zeroed per step: every row is written)
+            for (int c = l; c < pieces; c += 16)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) GRe[(size_t)e * de + VEC * c + v] = 0.f;
+        return;
+    }
     const int cs = s / kEChunk, cl = (t - 1) / kEChunk;
     if (cs == cl) return;                    // run inside one chunk: written directly
-    const int pieces = de / VEC;
     for (int c = l; c < pieces; c += 16) {
         float a[VEC];
 #pragma unroll
@@ -174,10 +180,13 @@ __global__ __launch_bounds__(256) void egrad_fixup_wg(const int32_t* __restrict_
     const int e = blockIdx.x;
     if (e >= V) return;
     const int s = run_start[e], t = run_end[e];
-    if (t <= s) return;                      // workgroup-uniform
+    const int pieces = de / VEC;
+    if (t <= s) {                            // workgroup-uniform; entity not in this batch: a zero row
+        for (int c = threadIdx.x; c < de; c += 256) GRe[(size_t)e * de + c] = 0.f;
+        return;
+    }
     const int cs = s / kEChunk, cl = (t - 1) / kEChunk;
     if (cs == cl) return;
-    const int pieces = de / VEC;
     for (int c = l; c < pieces; c += 16) {
         float a[VEC];
 #pragma unroll

@@ -26,7 +26,7 @@ struct AdamArgs {
 // Lasagne 0.1 adam [upstream]:
 //   m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g^2 ; p = p - a_t*m/(sqrt(v)+eps)
 __device__ __forceinline__ void adam_elem(float& p, float& g, float& m, float& v, const AdamArgs& a,
-                                          float omb1, float omb2, float& ss) {
+                                          float omb1, float omb2, float& ss, float& ss_new) {
     const float pv = p;
     const float gv = g + a.l2k * pv;
     ss += pv * pv;
@@ -34,7 +34,9 @@ __device__ __forceinline__ void adam_elem(float& p, float& g, float& m, float& v
     const float vv = a.b2 * v + omb2 * gv * gv;
     m = mv;
     v = vv;
-    p = pv - a.a_t * mv / (sqrtf(vv) + a.eps);
+    const float pn = pv - a.a_t * mv / (sqrtf(vv) + a.eps);
+    p = pn;
+    ss_new += pn * pn;    // (the same expression, in the same element order, as `ss` of the NEXT step's launch)
     g = gv;
 }
 
@@ -58,9 +60,13 @@ __global__ __launch_bounds__(256) void adam_l2(float* __restrict__ p, float* __r
                                                size_t count, AdamArgs a,
                                                float* __restrict__ sumsq_partial,
                                                const uint32_t* __restrict__ bits = nullptr,
-                                               unsigned row_len = 1, int rows_mode = kRowsAll) {
+                                               unsigned row_len = 1, int rows_mode = kRowsAll,
+                                               float* __restrict__ sumsq_new_partial = nullptr) {
+    // sumsq_new_partial: also leave the sums of squares of the UPDATED values, partitioned exactly as
+    // sumsq_partial is -- what the next step's launch over the same tensor would compute as its pre-update
+    // sums, bit for bit (the deferred entity-table update of the side-heavy schedule, sert_hip.hip)
     __shared__ float red[4];
-    float ss = 0.f;
+    float ss = 0.f, ssn = 0.f;
     const float omb1 = 1.0f - a.b1, omb2 = 1.0f - a.b2;
     const size_t n4 = count >> 2;
     float4* p4 = reinterpret_cast<float4*>(p);
@@ -88,10 +94,10 @@ __global__ __launch_bounds__(256) void adam_l2(float* __restrict__ p, float* __r
 #endif
         float4 gg = make_float4(0.f, 0.f, 0.f, 0.f);
         if (hit) gg = g4[i];
-        adam_elem(pp.x, gg.x, mm.x, vv.x, a, omb1, omb2, ss);
-        adam_elem(pp.y, gg.y, mm.y, vv.y, a, omb1, omb2, ss);
-        adam_elem(pp.z, gg.z, mm.z, vv.z, a, omb1, omb2, ss);
-        adam_elem(pp.w, gg.w, mm.w, vv.w, a, omb1, omb2, ss);
+        adam_elem(pp.x, gg.x, mm.x, vv.x, a, omb1, omb2, ss, ssn);
+        adam_elem(pp.y, gg.y, mm.y, vv.y, a, omb1, omb2, ss, ssn);
+        adam_elem(pp.z, gg.z, mm.z, vv.z, a, omb1, omb2, ss, ssn);
+        adam_elem(pp.w, gg.w, mm.w, vv.w, a, omb1, omb2, ss, ssn);
 #ifndef SERT_ADAM_NO_NT
         p4[i] = pp;
         { nt_f4 t; t.x = mm.x; t.y = mm.y; t.z = mm.z; t.w = mm.w; __builtin_nontemporal_store(t, reinterpret_cast<nt_f4*>(m) + i); }
@@ -105,10 +111,42 @@ __global__ __launch_bounds__(256) void adam_l2(float* __restrict__ p, float* __r
         const size_t i = (n4 << 2) + threadIdx.x;
         if (i < count) {
             float pp = p[i], gg = g[i], mm = m[i], vv = v[i];
-            adam_elem(pp, gg, mm, vv, a, omb1, omb2, ss);
+            adam_elem(pp, gg, mm, vv, a, omb1, omb2, ss, ssn);
             p[i] = pp; m[i] = mm; v[i] = vv;
             if (STORE_G) g[i] = gg;
         }
+    }
+    const float tot = block_sum_256(ss, red);
+    if (threadIdx.x == 0) sumsq_partial[blockIdx.x] = tot;
+    if (sumsq_new_partial) {      // (kernel-uniform)
+        __syncthreads();
+        const float tn = block_sum_256(ssn, red);
+        if (threadIdx.x == 0) sumsq_new_partial[blockIdx.x] = tn;
+    }
+}
+
+// The pre-update sums of squares of adam_l2 WITHOUT the update: same slices, same element order, same
+// block reduction -- partial[b] equals what adam_l2<...>(p, ..., sumsq_partial) with the same grid leaves
+// in sumsq_partial[b] (first step of a deferred entity-table update, or after the host replaced the table).
+__global__ __launch_bounds__(256) void sumsq_like_adam(const float* __restrict__ p, size_t count,
+                                                       float* __restrict__ sumsq_partial) {
+    __shared__ float red[4];
+    float ss = 0.f;
+    const size_t n4 = count >> 2;
+    const float4* p4 = reinterpret_cast<const float4*>(p);
+    const size_t per = (n4 + gridDim.x - 1) / gridDim.x;
+    const size_t lo = (size_t)blockIdx.x * per;
+    const size_t hi = lo + per < n4 ? lo + per : n4;
+    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const float4 pp = p4[i];
+        ss += pp.x * pp.x;
+        ss += pp.y * pp.y;
+        ss += pp.z * pp.z;
+        ss += pp.w * pp.w;
+    }
+    if (blockIdx.x == 0) {
+        const size_t i = (n4 << 2) + threadIdx.x;
+        if (i < count) ss += p[i] * p[i];
     }
     const float tot = block_sum_256(ss, red);
     if (threadIdx.x == 0) sumsq_partial[blockIdx.x] = tot;
@@ -230,7 +268,7 @@ __global__ __launch_bounds__(256) void optimizer_small(SmallTensors t, AdamArgs 
         } else {
             gg = g[k];
         }
-        if (ADAM) adam_elem(pp, gg, a0, a1, aa, omb1, omb2, ss);
+        if (ADAM) { float unused = 0.f; adam_elem(pp, gg, a0, a1, aa, omb1, omb2, ss, unused); }
         else adadelta_elem(pp, gg, a0, a1, da, omr, ss);
         p[k] = pp; s0[k] = a0; s1[k] = a1;
         if (STORE_G) g[k] = gg;
@@ -355,6 +393,7 @@ struct TailArgs {
     AdamArgs aa;                  // l2k applies to W only (the bias is not regularised)
     const float* loss_partials; int n_loss;
     const float* sq_partials; int n_sq;    // sums of squares of the tensors updated before this launch
+    const float* sq_alt; int sq_alt_lo, sq_alt_hi;   // partials [sq_alt_lo, sq_alt_hi) live in sq_alt[0..) instead (empty range: none)
     float inv_batch, reg_scale;
     float* out;                   // [3] loss, data term, reg term (device or pinned host)
     unsigned* host_flag; unsigned seq;
@@ -377,7 +416,8 @@ __global__ __launch_bounds__(1024) void vs_tail(const TailArgs t) {
     red[g][l] = a;
     double ls = 0.0, sq = 0.0;
     for (int k = blockIdx.x * 1024 + threadIdx.x; k < t.n_loss; k += gridDim.x * 1024) ls += (double)t.loss_partials[k];
-    for (int k = blockIdx.x * 1024 + threadIdx.x; k < t.n_sq; k += gridDim.x * 1024) sq += (double)t.sq_partials[k];
+    for (int k = blockIdx.x * 1024 + threadIdx.x; k < t.n_sq; k += gridDim.x * 1024)
+        sq += (double)((k >= t.sq_alt_lo && k < t.sq_alt_hi) ? t.sq_alt[k - t.sq_alt_lo] : t.sq_partials[k]);
     __syncthreads();
     if (g == 0 && i < count) {
         float q[4];
@@ -389,7 +429,7 @@ __global__ __launch_bounds__(1024) void vs_tail(const TailArgs t) {
         float ssf = 0.f;
         if (i < t.n_w) {
             float pp = t.W[i], m = t.s0_w[i], v = t.s1_w[i];
-            adam_elem(pp, gg, m, v, aa, omb1, omb2, ssf);
+            { float unused = 0.f; adam_elem(pp, gg, m, v, aa, omb1, omb2, ssf, unused); }
             t.W[i] = pp; t.s0_w[i] = m; t.s1_w[i] = v;
             if (STORE_G) t.g_w[i] = gg;
             sq += (double)ssf;
@@ -397,7 +437,7 @@ __global__ __launch_bounds__(1024) void vs_tail(const TailArgs t) {
             const unsigned j = i - t.n_w;
             aa.l2k = 0.f;
             float pp = t.b[j], m = t.s0_b[j], v = t.s1_b[j];
-            adam_elem(pp, gg, m, v, aa, omb1, omb2, ssf);
+            { float unused = 0.f; adam_elem(pp, gg, m, v, aa, omb1, omb2, ssf, unused); }
             t.b[j] = pp; t.s0_b[j] = m; t.s1_b[j] = v;
             if (STORE_G) t.g_b[j] = gg;
         }

@@ -81,6 +81,14 @@ struct sert_model {
     bool re_in_parts = false;        // this step: dR_e is still the row groups' partial tables (summed by the optimiser)
     bool fork_bound = false;         // ev_fork rides on the NCE kernel's completion signal (no record needed)
     bool lazy_join = false;          // this step: the main stream never waits for the entity chain
+    bool side_heavy = false;         // this step: entity chain, entity-table optimiser and dW on the side stream (big R_e)
+    // side-heavy schedule: the entity table's update is DEFERRED past the step's tail -- it only has to land
+    // before the next reader of R_e (the next loss kernel); the sums of squares the tail needs were left by
+    // the previous step's launch (re_sq[k]: partials of the updated table, for optimiser step re_sq_for[k])
+    hipEvent_t ev_re = nullptr;
+    bool re_pending = false;
+    float* re_sq = nullptr;          // [2][2 * kOptBlocks]
+    int64_t re_sq_for[2] = {-1, -1};
     int n_loss_partials = 0;
     int nce_loss_partials = 0;       // > 0: vs_nce wrote this many per-workgroup loss partials into red_loss
     // SERT_STREAMS: 1 = everything on the main stream (0.423 ms/step at C2), 2 = + the entity

@@ -198,8 +198,23 @@ static void discard_run_ahead(sert_model* m) {
 }
 static void invalidate_speculation(sert_model* m) {
     discard_run_ahead(m);
+    if (m->re_pending) {       // (a deferred entity-table update: see settle_entity_update)
+        (void)hipStreamWaitEvent(m->stream, m->ev_re, 0);
+        m->re_pending = false;
+    }
+    m->re_sq_for[0] = m->re_sq_for[1] = -1;
     m->projected_batch = -1;
     m->neg_alt_step = -1;      // (step counter, seed-relevant state or data may change)
+}
+
+// A deferred entity-table update (side-heavy schedule) must have landed before the main stream reads R_e,
+// its optimiser state or dR_e again.
+static int settle_entity_update(sert_model* m) {
+    if (m->re_pending) {
+        SERT_HIP(hipStreamWaitEvent(m->stream, m->ev_re, 0));
+        m->re_pending = false;
+    }
+    return 0;
 }
 
 struct TensorRef {
@@ -886,6 +901,21 @@ static bool dw_third_queue(const sert_model* m) {
     return on && fork_late_mode(m) && !fork_at_nce(m);   // (the W update must stay behind the dh GEMM)
 }
 
+// Single GPU, BIG entity table (more than 2^22 elements: the sorted entity-gradient chain and a streaming
+// optimiser launch of its own -- C4): the main stream keeps nothing but the critical chain
+//   loss -> dh GEMM -> segmented sum -> word-table optimiser -> tail,
+// the side stream takes, forked on the loss kernel,
+//   entity chain -> entity-table optimiser -> dW GEMM,
+// and is joined in front of the tail.  The MFMA-bound dW (off the critical path: it only feeds the tail)
+// and the 0.96 GB of the entity table's optimiser then run BESIDE the 750 us the word table streams,
+// instead of in front of and behind it.  SERT_SIDE_HEAVY=0 restores dW in front of dh on the main stream
+// and both optimiser launches behind the join.
+static bool side_heavy_mode(const sert_model* m) {
+    static const bool off = getenv("SERT_SIDE_HEAVY") && atoi(getenv("SERT_SIDE_HEAVY")) == 0;
+    return !off && ext_events() && !is_dp(m) && !m->timing.enabled && m->nstreams == 2 && m->pt_big[1] && !m->pt_big[2] &&
+           m->cfg.kind == SERT_KIND_VECTORSPACE && !m->cfg.keep_grads;
+}
+
 // NCE score / loss / gradient coefficients
 template <bool TRAIN>
 static int vs_loss(sert_model* m, const DataSplit& ds, int64_t batch_index) {
@@ -984,7 +1014,8 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
     const size_t row0 = (size_t)batch_index * B;
     const bool fork_late = fork_late_mode(m);
     const bool fork_nce = fork_late && fork_at_nce(m);
-    const bool fused_bwd = bwd_fused_applies(m);
+    const bool side_heavy = side_heavy_mode(m);
+    const bool fused_bwd = bwd_fused_applies(m) && !side_heavy;
     const int fused_grid = std::min(256, cdiv(B, FB_ROWS));   // one workgroup per CU, or per strip if there are fewer
     auto entity_grad = [&]() -> int {
         // fork: this chain only depends on the NCE kernel and is independent of the
@@ -1134,7 +1165,7 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         // the dependency chain loss -> dh -> segmented sum -> word-table optimiser.
         // (measured: 0.376 -> 0.386 ms at C2 -- off by default, SERT_DW_SIDE=1 to try it)
         static const bool dw_side = getenv("SERT_DW_SIDE") && atoi(getenv("SERT_DW_SIDE")) != 0;
-        if (dw_side && m->lazy_join) sd = m->stream2;
+        if ((dw_side || side_heavy) && m->lazy_join) sd = m->stream2;
         if (fork_late && m->lazy_join && dw_third_queue(m)) sd = m->stream3;
         if (sd != m->stream && sd != m->stream2 && !fork_late) SERT_HIP(hipStreamWaitEvent(sd, m->ev_fork, 0));
         // ~1024 workgroup items in all, at most 512 slabs (the optimum at one output tile: 512 slabs
@@ -1175,7 +1206,9 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         // the loss finalisation
         static const bool no_tail = getenv("SERT_NO_TAIL") != nullptr;   // cross-check knob
         m->tail_splits = 0;
-        if (!no_tail && !is_dp(m) && sd == m->stream && m->cfg.kind == SERT_KIND_VECTORSPACE && !m->pt_big[2] &&
+        // (side_heavy: the partial slabs come from the side stream, which is joined in front of the tail)
+        if (!no_tail && !is_dp(m) && (sd == m->stream || (side_heavy && sd == m->stream2)) &&
+            m->cfg.kind == SERT_KIND_VECTORSPACE && !m->pt_big[2] &&
             mn + de < ((size_t)1 << 31)) {
             m->tail_splits = splits;
             m->tail_stride = stride;
@@ -1193,8 +1226,14 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
     // the side stream right behind the entity chain: the main stream then never waits for
     // that chain, and the word-table optimiser starts straight after segsum instead of
     // idling ~12 us on a cross-queue dependency.
-    m->lazy_join = !is_dp(m) && !m->timing.enabled && m->nstreams == 2 && m->n_re <= ((size_t)1 << 22);
-    if (fork_nce) {
+    m->lazy_join = !is_dp(m) && !m->timing.enabled && m->nstreams == 2 && (m->n_re <= ((size_t)1 << 22) || side_heavy);
+    m->side_heavy = side_heavy;
+    if (side_heavy) {
+        SERT_TRY(entity_grad());       // side, forked on the loss kernel's completion
+        SERT_TRY(dh_gemm());           // main (its completion is ev_dense)
+        SERT_TRY(word_table_sum());    // main
+        SERT_TRY(dense_grad());        // side, behind the entity chain
+    } else if (fork_nce) {
         SERT_TRY(entity_grad());       // side, forked on the NCE kernel's completion
         SERT_TRY(dh_gemm());
         SERT_TRY(dense_grad());
@@ -1576,11 +1615,11 @@ static int reduce_rowloss(sert_model* m, hipStream_t st) {
 // One streaming optimiser launch over `count` elements (kernels_opt.h).
 static void launch_stream_opt(sert_model* m, hipStream_t st, float* p, float* g, float* s0, float* s1, size_t count,
                               int nb, const AdamArgs& aa, const AdadeltaArgs& da, float* sq,
-                              const uint32_t* bits, unsigned row_len, int rows_mode = kRowsAll) {
+                              const uint32_t* bits, unsigned row_len, int rows_mode = kRowsAll, float* sq_new = nullptr) {
     const bool keep = m->cfg.keep_grads != 0;
     if (is_vs(m)) {
-        if (keep) hipLaunchKernelGGL((adam_l2<true>), dim3(nb), dim3(256), 0, st, p, g, s0, s1, count, aa, sq, bits, row_len, rows_mode);
-        else      hipLaunchKernelGGL((adam_l2<false>), dim3(nb), dim3(256), 0, st, p, g, s0, s1, count, aa, sq, bits, row_len, rows_mode);
+        if (keep) hipLaunchKernelGGL((adam_l2<true>), dim3(nb), dim3(256), 0, st, p, g, s0, s1, count, aa, sq, bits, row_len, rows_mode, sq_new);
+        else      hipLaunchKernelGGL((adam_l2<false>), dim3(nb), dim3(256), 0, st, p, g, s0, s1, count, aa, sq, bits, row_len, rows_mode, sq_new);
     } else {
         if (keep) hipLaunchKernelGGL((adadelta_l2<true>), dim3(nb), dim3(256), 0, st, p, g, s0, s1, count, da, sq, bits, row_len, rows_mode);
         else      hipLaunchKernelGGL((adadelta_l2<false>), dim3(nb), dim3(256), 0, st, p, g, s0, s1, count, da, sq, bits, row_len, rows_mode);
@@ -1659,11 +1698,25 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
     // owned piece as soon as its gradient slab has been reduce-scattered, the all-gather of the
     // updated slab right behind it
     bool any_ag = false;
+    const int tail_splits = m->tail_splits;
+    m->tail_splits = 0;
+    // side-heavy schedule: the entity table is updated BEHIND the join of the tail (see below)
+    static const bool no_defer = getenv("SERT_RE_DEFER") && atoi(getenv("SERT_RE_DEFER")) == 0;
+    const bool defer_re = !no_defer && m->side_heavy && side_small && tail_splits > 0 && m->pt_big[1] && is_vs(m) && !c.keep_grads;
+    int re_sq_lo = 0, re_nb = 0;
     for (int i = 0; i < 4; ++i) {
         if (!m->pt_big[i]) continue;
         const ParamTensor t = param_tensor(m, i);
         if (t.n == 0) continue;
         const int tg = i == 0 ? TG_OPT_WORD : TG_OPTIMIZER;
+        if (i == 1 && defer_re) {
+            // (its slots in the partial array stay where they are: the tail reads them from re_sq)
+            const int64_t max_nb = t.n >= ((size_t)1 << 24) ? 2 * kOptBlocks : kOptBlocks;
+            re_nb = (int)std::min<int64_t>(max_nb, cdiv(cdiv(t.n, 4), 256));
+            re_sq_lo = n_sq;
+            n_sq += re_nb;
+            continue;
+        }
         if (!(is_dp(m) && m->pt_sharded[i])) {
             ScopedTimer tm(m, tg);
             // (tables of 2^24 elements and more -- C4: 150 M and 30 M -- stream faster over twice the
@@ -1672,7 +1725,9 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
             const int64_t max_nb = t.n >= ((size_t)1 << 24) ? 2 * kOptBlocks : kOptBlocks;
             const int nb = (int)std::min<int64_t>(max_nb, cdiv(cdiv(t.n, 4), 256));
             const uint32_t* tf = (i == 0 && m->use_touched) ? bits : nullptr;
-            launch_stream_opt(m, m->stream, t.p, t.g, t.s0, t.s1, t.n, nb, aa, da, m->red_sq + n_sq, tf,
+            // (side_heavy: the entity table streams on the side stream, behind its gradient chain)
+            launch_stream_opt(m, (i == 1 && m->side_heavy && side_small) ? ss : m->stream, t.p, t.g, t.s0, t.s1, t.n, nb, aa, da,
+                              m->red_sq + n_sq, tf,
                               i == 0 ? (unsigned)c.word_dim : 1u,
                               (i == 0 && tf && m->early_issued) ? kRowsTouched : kRowsAll);
             n_sq += nb;
@@ -1770,8 +1825,6 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
         }
         n_sq += blocks;
     };
-    const int tail_splits = m->tail_splits;
-    m->tail_splits = 0;
     if (tail_splits > 0) {
         small_tensors(ss, 0x2u);          // R_e; W and b are updated by the tail launch below
     } else if (split_small && dw_third_queue(m)) {
@@ -1785,9 +1838,29 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
     } else {
         small_tensors(ss, 0xEu);
     }
+    const int re_cur = (int)(m->step & 1), re_nxt = re_cur ^ 1;
+    const size_t re_cap = (size_t)2 * kOptBlocks;
+    if (defer_re && m->re_sq_for[re_cur] != m->step) {
+        // no previous deferred launch left this step's sums (first step, another schedule in between, the
+        // host replaced the table): the same partials from a read-only pass, in front of the join
+        hipLaunchKernelGGL(sumsq_like_adam, dim3(re_nb), dim3(256), 0, ss, (const float*)m->re, m->n_re, m->re_sq + re_cur * re_cap);
+        m->re_sq_for[re_cur] = m->step;
+    }
     if (side_small) {
         SERT_HIP(hipEventRecord(m->ev_small, ss));
         SERT_HIP(hipStreamWaitEvent(m->stream, m->ev_small, 0));
+    }
+    if (defer_re) {
+        // The entity table's L2 + Adam, behind the join: the tail does not wait for it.  Nothing reads R_e,
+        // its state or dR_e before the next loss kernel (settle_entity_update), so its 0.96 GB stream beside
+        // the tail and the next step's gather and projection GEMM.  It also leaves the sums of squares of the
+        // UPDATED table: the next step's regularisation term.
+        const ParamTensor t = param_tensor(m, 1);
+        launch_stream_opt(m, ss, t.p, t.g, t.s0, t.s1, t.n, re_nb, aa, da, m->red_sq + re_sq_lo, nullptr, 1u, kRowsAll,
+                          m->re_sq + re_nxt * re_cap);
+        m->re_sq_for[re_nxt] = m->step + 1;
+        SERT_HIP(hipEventRecord(m->ev_re, ss));
+        m->re_pending = true;
     }
     if (m->early_issued) {   // the untouched rows' sum of squares (and their update) must have landed
         SERT_HIP(hipStreamWaitEvent(m->stream, m->ev_early, 0));
@@ -1811,6 +1884,9 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
             ta.aa = aa;
             ta.loss_partials = lp; ta.n_loss = nl;
             ta.sq_partials = m->red_sq; ta.n_sq = n_sq;
+            ta.sq_alt = defer_re ? m->re_sq + re_cur * re_cap : nullptr;
+            ta.sq_alt_lo = defer_re ? re_sq_lo : 0;
+            ta.sq_alt_hi = defer_re ? re_sq_lo + re_nb : 0;
             ta.inv_batch = inv_batch; ta.reg_scale = reg_scale;
             ta.out = loss_dst; ta.host_flag = flag; ta.seq = publish ? ++m->loss_seq : 0u;
             ta.blk = m->tail_blk;
@@ -1835,9 +1911,20 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
     return 0;
 }
 
+// First element of the gradient buffer the step's prologue has to zero when the word table needs no
+// zeroing: behind g_rw -- and behind g_re too where the sorted entity-gradient chain runs, which writes
+// EVERY row of dR_e (a run inside one chunk by the chunk, a longer one by the fix-up, an entity without a
+// pair as zeros by the fix-up): 120 MB less to write per step at C4.
+static size_t zero_from(const sert_model* m) {
+    static const bool all = getenv("SERT_ZERO_GRE") != nullptr;   // cross-check knob
+    if (!all && m->cfg.kind == SERT_KIND_VECTORSPACE && !m->epart && m->n_re > 0 && m->g_re == m->gflat + m->ar_split)
+        return m->ar_split + round_up(m->pt_pad[1], 4);
+    return m->ar_split;
+}
+
 static bool fused_prologue_applies_with(const sert_model* m, bool touched) {
     return is_vs(m) && !is_fs(m) && !m->timing.enabled && m->nstreams >= 2 && touched &&
-           m->cfg.num_negatives > 0 && (m->gflat_alloc - m->ar_split) % 4 == 0;
+           m->cfg.num_negatives > 0 && (m->gflat_alloc - zero_from(m)) % 4 == 0;
 }
 static bool fused_prologue_applies(const sert_model* m) { return fused_prologue_applies_with(m, m->use_touched); }
 // sampler of optimiser step m->step + zeroing of the small gradient buffers
@@ -1845,8 +1932,8 @@ static void launch_fused_prologue(sert_model* m) {
     const int64_t count = (int64_t)m->cfg.batch_size * m->cfg.num_negatives;
     hipLaunchKernelGGL(vs_sample_negatives, dim3(grid_for((count + 3) / 4)), dim3(256), 0, m->stream, m->neg,
                        count, (int64_t)m->rank * count, (uint32_t)m->cfg.num_entities, m->cfg.seed,
-                       (uint64_t)m->step * 2, reinterpret_cast<float4*>(m->gflat + m->ar_split),
-                       (m->gflat_alloc - m->ar_split) / 4, (uint4*)nullptr, (size_t)0);
+                       (uint64_t)m->step * 2, reinterpret_cast<float4*>(m->gflat + zero_from(m)),
+                       (m->gflat_alloc - zero_from(m)) / 4, (uint4*)nullptr, (size_t)0);
 }
 
 static bool use_touched_now(const sert_model* m) {
@@ -1867,6 +1954,7 @@ static int step_forward_backward(sert_model* m, const DataSplit& ds, int64_t bat
     // Prologue (zeroing, negative sampling): nothing before the loss kernel needs it, so
     // for the vectorspace step it runs on the side stream beside gather + projection.
     m->lazy_join = false;
+    m->side_heavy = false;
     const bool side_pre = is_vs(m) && !is_fs(m) && !m->timing.enabled && m->nstreams >= 2;
     // One fused prologue launch on the MAIN stream (sampler + zeroing of the small gradient
     // buffers and the row flags) when nothing big has to be zeroed and the device draws the
@@ -1899,6 +1987,7 @@ static int step_forward_backward(sert_model* m, const DataSplit& ds, int64_t bat
         if (m->projected_batch != batch_index) SERT_TRY(vs_project(m, ds, batch_index));
         m->projected_batch = -1;
     }
+    SERT_TRY(settle_entity_update(m));   // (the prologue zeroes dR_e, the loss kernel reads R_e)
     if (have_neg) {
         // (no prologue launch at all)
     } else if (fused_pre) {
@@ -1909,7 +1998,7 @@ static int step_forward_backward(sert_model* m, const DataSplit& ds, int64_t bat
         if (m->use_touched || m->xr_on) {
             // (by rows: dR_w is written where this rank's batch touches, read where the lists say, and
             //  the owned rows nobody touched are never read -- the table needs no zeroing)
-            SERT_HIP(hipMemsetAsync(m->gflat + m->ar_split, 0, (m->gflat_alloc - m->ar_split) * sizeof(float), pre));
+            SERT_HIP(hipMemsetAsync(m->gflat + zero_from(m), 0, (m->gflat_alloc - zero_from(m)) * sizeof(float), pre));
         } else {
             SERT_HIP(hipMemsetAsync(m->gflat, 0, m->gflat_alloc * sizeof(float), pre));
         }
@@ -2181,6 +2270,7 @@ static int create_resources(sert_model* m) {
     SERT_HIP(hipEventCreateWithFlags(&m->ev_dense, hipEventDisableTiming));
     SERT_HIP(hipEventCreateWithFlags(&m->ev_loss, hipEventDisableTiming));
     SERT_HIP(hipEventCreateWithFlags(&m->ev_small, hipEventDisableTiming));
+    SERT_HIP(hipEventCreateWithFlags(&m->ev_re, hipEventDisableTiming));
     SERT_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
     SERT_HIP(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
     const size_t B = c.batch_size, n = c.window_size, dw = c.word_dim, V = c.num_entities;
@@ -2302,6 +2392,7 @@ static int create_resources(sert_model* m) {
         SERT_TRY(dzalloc(&m->part, part, s));
         SERT_TRY(dzalloc(&m->red_loss, std::max<size_t>((size_t)kOptBlocks, (B + 15) / 16), s));
         SERT_TRY(dzalloc(&m->red_sq, (size_t)8 * kOptBlocks, s));  // partials of up to 4 tensors (<= 2 kOptBlocks each)
+        SERT_TRY(dzalloc(&m->re_sq, (size_t)4 * kOptBlocks, s));
         SERT_TRY(dzalloc(&m->sq_scratch, (size_t)8 * kOptBlocks, s));
         SERT_TRY(dzalloc(&m->d_loss, (size_t)4, s));
         if (vs) {
@@ -2363,7 +2454,7 @@ int sert_destroy(sert_model* m) {
     if (m->comm_stream) (void)hipStreamDestroy(m->comm_stream);
     float* bufs[] = {m->rw, m->re, m->W, m->b, m->s0_rw, m->s0_re, m->s0_w, m->s0_b, m->s1_rw,
                      m->s1_re, m->s1_w, m->s1_b, m->gflat, m->H, m->T, m->DA, m->DH, m->rowloss,
-                     m->G, m->Z, m->J, m->DG, m->DH2, m->part, m->skbuf, m->wpart, m->hpart, m->red_loss, m->red_sq, m->d_loss,
+                     m->G, m->Z, m->J, m->DG, m->DH2, m->part, m->skbuf, m->wpart, m->hpart, m->red_loss, m->red_sq, m->re_sq, m->d_loss,
                      m->d_losses};
     for (float* p : bufs) (void)hipFree(p);
     (void)hipFree(m->ll_tokstat); (void)hipFree(m->ll_lse); (void)hipFree(m->ll_jstat);
@@ -2386,7 +2477,7 @@ int sert_destroy(sert_model* m) {
     if (m->ev_join) (void)hipEventDestroy(m->ev_join);
     if (m->stream2) (void)hipStreamDestroy(m->stream2);
     if (m->ev_join3) (void)hipEventDestroy(m->ev_join3);
-    for (hipEvent_t e : {m->ev_step_done, m->ev_neg, m->ev_opt_fork, m->ev_small, m->ev_dense, m->ev_loss})
+    for (hipEvent_t e : {m->ev_step_done, m->ev_neg, m->ev_opt_fork, m->ev_small, m->ev_re, m->ev_dense, m->ev_loss})
         if (e) (void)hipEventDestroy(e);
     if (m->stream3) (void)hipStreamDestroy(m->stream3);
     if (m->stream4) (void)hipStreamDestroy(m->stream4);
@@ -2412,6 +2503,8 @@ int sert_set_tensor(sert_model* m, int which, const float* host, size_t count) {
     if (which >= SERT_T_STATE0_RW && which <= SERT_T_STATE1_B && m->pt_sharded[(which - SERT_T_STATE0_RW) % 4])
         return sharded_state_io(m, (which - SERT_T_STATE0_RW) % 4, (which - SERT_T_STATE0_RW) / 4, nullptr, host);
     if (m->comm_stream) SERT_HIP(hipStreamSynchronize(m->comm_stream));
+    SERT_TRY(settle_entity_update(m));
+    m->re_sq_for[0] = m->re_sq_for[1] = -1;
     SERT_HIP(hipMemcpyAsync(t.ptr, host, count * sizeof(float), hipMemcpyHostToDevice, m->stream));
     SERT_HIP(hipStreamSynchronize(m->stream));
     if (which == SERT_T_RW) { m->rw_full = true; m->xr_fetched_batch = -1; }   // (every rank sets the whole table)
@@ -2726,6 +2819,7 @@ int sert_train_batches(sert_model* m, const int64_t* batch_indices, int64_t coun
 static int eval_step_async(sert_model* m, const DataSplit& ds, int64_t batch_index, const int64_t* negatives,
                            float* dst) {
     const int B = m->cfg.batch_size;
+    SERT_TRY(settle_entity_update(m));
     if (is_fs(m)) {
         SERT_TRY(fs_forward<false>(m, ds, batch_index));
     } else if (is_vs(m)) {

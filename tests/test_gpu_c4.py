@@ -145,22 +145,27 @@ print('RESULT ' + json.dumps(out))
 
 
 def test_c4_vectorspace_full_batch_known_answer_determinism_untouched_rows(hip_lib):
-    """B = 65 536 over the full C4 tables, three times in fresh processes: twice as shipped
+    """B = 65 536 over the full C4 tables, five times in fresh processes: twice as shipped
     (bit-identical: order-fixed reductions everywhere, no float atomics) and once with
     SERT_NO_TOUCHED=1 (every gradient row zeroed and read: the plain dense update) -- the
     untouched-row shortcut must not change a bit over 500 000 rows."""
     import json
     code = FULL_BATCH_WORKER % dict(root=U.ROOT, VW=VW, VE=VE, D=D, n=N_WIN, z=Z)
     outs = []
-    for extra in ({}, {}, {'SERT_NO_TOUCHED': '1'}):
+    for extra in ({}, {}, {'SERT_NO_TOUCHED': '1'}, {'SERT_SIDE_HEAVY': '0'}, {'SERT_RE_DEFER': '0'}):
         r = subprocess.run([sys.executable, '-c', code], check=True, env=dict(os.environ, **extra),
                            cwd=U.ROOT, stdout=subprocess.PIPE, timeout=900)
         line = [l for l in r.stdout.decode().splitlines() if l.startswith('RESULT ')][-1]
         outs.append(json.loads(line[len('RESULT '):]))
-    a, b, dense = outs
+    a, b, dense, one_queue_opt, no_defer = outs
     assert abs(a['known'] - (1 + Z) * np.log(2.0)) < 2e-5
     assert a == b, 'two identical runs differ'
     assert a == dense, 'untouched-row path differs from the dense path'
+    # the shipped schedule for a big entity table (entity chain, dW and the DEFERRED entity-table update on the
+    # side stream, its sums of squares carried over from the previous step's launch) against both optimiser
+    # launches behind the join, and against the side stream without the deferral: not a bit may differ
+    assert a == one_queue_opt, 'side-heavy schedule differs from the plain one'
+    assert a == no_defer, 'deferred entity-table update differs from the in-step one'
     assert all(v for k, v in a.items() if k.startswith('finite_'))
     assert a['losses'][2] < a['losses'][0]          # the same batch again, two updates later
     assert a['absmax_m_Rw'] > 0 and a['absmax_v_Re'] > 0

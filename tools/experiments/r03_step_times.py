@@ -35,12 +35,16 @@ def region(model, steps, warmup, num_batches=2):
 
 def main():
     B, n, Vw, Ve, d, z = 65536, 10, 100000, 1000, 128, 10
+    if '--c4' in sys.argv:
+        Vw, Ve, d = 500000, 100000, 300
     rng = np.random.RandomState(0)
     X, y, w = bench.synth_data(rng, 2 * B, n, Vw, Ve)
     m = bench.build_model('vectorspace', models, B, n, Vw, Ve, d, d, z, X, y, w, seed=0)
     for steps, warmup in ((20, 5), (20, 5), (100, 10), (20, 50)):
         st, th, te = region(m, steps, warmup)
         d_ = np.diff(np.concatenate([[0.0], st]))
+        if '--all' in sys.argv:
+            print(np.round(d_, 0).astype(int).tolist())
         print('steps %3d warmup %2d: total %.1f us = %.2f us/step; first return %.1f, steps 2-5 %s, median of the rest %.1f, '
               'last return -> hint %.1f -> synchronised %.1f'
               % (steps, warmup, te, te / steps, d_[0], np.round(d_[1:5], 1).tolist(), float(np.median(d_[5:])), th - st[-1], te - th))

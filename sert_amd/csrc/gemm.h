@@ -770,8 +770,12 @@ inline void launch_gemm(hipStream_t s, const float* A, const float* B, float* C,
     g.c_split_stride = c_split_stride;
     g.vecA = g.vecB = 0;
     // vector path: every 16-byte piece aligned and wholly inside or outside
+    // (an operand stored k-major -- A of A^T.B, B of A.B -- is contiguous along the tile's M / N axis and its k
+    //  remainder is a per-row mask: only an operand that is contiguous along k needs K and kper in whole pieces.
+    //  The loglinear dW = G^T.dZ has K = the batch's distinct words, any number: 160 -> 117 us at C2 dims)
+    const bool k_pieces = (K % 4 == 0) && (kper % 4 == 0);
     const bool vec = (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A) % 16 == 0) &&
-                     (((uintptr_t)B) % 16 == 0) && (K % 4 == 0) && (kper % 4 == 0) &&
+                     (((uintptr_t)B) % 16 == 0) && (k_pieces || (TA && !TB)) &&
                      (TA ? (M % 4 == 0) : true) && (TB ? true : (N % 4 == 0));
     // N just above a multiple of 128 (d = 300): 160-column tiles pad less (gemm_f32_mfma_n160)
     static const bool no_n160 = getenv("SERT_GEMM_NO_N160") != nullptr;   // cross-check knob

@@ -877,9 +877,10 @@ static bool ext_events() {
 // Every cross-queue event costs its queue ~5-7 us (the kernel that carries a completion signal
 // ends with a cache write-back): two per step instead of three.  SERT_FORK_LATE=0 restores the
 // fork right behind the NCE kernel with dW on the main stream.
+static bool side_heavy_mode(const sert_model* m);
 static bool fork_late_mode(const sert_model* m) {
     static const bool on = !(getenv("SERT_FORK_LATE") && atoi(getenv("SERT_FORK_LATE")) == 0);
-    return on && ext_events() && !is_dp(m) && !m->timing.enabled && m->nstreams == 2 &&
+    return on && !side_heavy_mode(m) && ext_events() && !is_dp(m) && !m->timing.enabled && m->nstreams == 2 &&
            m->n_re <= ((size_t)1 << 22) && m->cfg.kind == SERT_KIND_VECTORSPACE;
 }
 
@@ -911,9 +912,9 @@ static bool dw_third_queue(const sert_model* m) {
 // instead of in front of and behind it.  SERT_SIDE_HEAVY=0 restores dW in front of dh on the main stream
 // and both optimiser launches behind the join.
 static bool side_heavy_mode(const sert_model* m) {
-    static const bool off = getenv("SERT_SIDE_HEAVY") && atoi(getenv("SERT_SIDE_HEAVY")) == 0;
-    return !off && ext_events() && !is_dp(m) && !m->timing.enabled && m->nstreams == 2 && m->pt_big[1] && !m->pt_big[2] &&
-           m->cfg.kind == SERT_KIND_VECTORSPACE && !m->cfg.keep_grads;
+    static const int level = getenv("SERT_SIDE_HEAVY") ? atoi(getenv("SERT_SIDE_HEAVY")) : 1;   // 2: small entity tables too
+    return level > 0 && ext_events() && !is_dp(m) && !m->timing.enabled && m->nstreams == 2 && (m->pt_big[1] || level > 1) &&
+           !m->pt_big[2] && m->cfg.kind == SERT_KIND_VECTORSPACE && !m->cfg.keep_grads;
 }
 
 // NCE score / loss / gradient coefficients
@@ -3538,7 +3539,9 @@ int sert_bench_gemm(int device, int ta, int tb, int epi, int M, int N, int K, in
     if (splits < 1) splits = 1;
     int kper = (int)round_up(cdiv(K, splits), GK);
     splits = cdiv(K, kper);
-    const size_t na = (size_t)M * K, nb = (size_t)K * N, nc = (size_t)M * N * splits;
+    // SERT_BENCH_GEMM_CSB=1 (A^T.B only): with the column sums of B riding along, as dW + db run in the step
+    const bool csb = ta && !tb && getenv("SERT_BENCH_GEMM_CSB") != nullptr;
+    const size_t na = (size_t)M * K, nb = (size_t)K * N, nc = ((size_t)M * N + (csb ? N : 0)) * splits;
     float *A = nullptr, *B = nullptr, *C = nullptr, *bias = nullptr;
     SERT_TRY(dmalloc(&A, na)); SERT_TRY(dmalloc(&B, nb)); SERT_TRY(dmalloc(&C, nc)); SERT_TRY(dmalloc(&bias, (size_t)N));
     std::vector<float> h(std::max(std::max(na, nb), (size_t)N));
@@ -3558,6 +3561,7 @@ int sert_bench_gemm(int device, int ta, int tb, int epi, int M, int N, int K, in
 #endif
 #define SERT_BG(TA, TB, E) launch_gemm<TA, TB, E>(s, A, B, C, bias, M, N, K, lda, ldb, N, splits, kper, (size_t)M * N)
         if (!ta && !tb) { if (epi == 2) SERT_BG(false, false, EPI_BIAS_TANH); else if (epi == 1) SERT_BG(false, false, EPI_BIAS); else SERT_BG(false, false, EPI_STORE); }
+        else if (csb) launch_gemm<true, false, EPI_STORE, true>(s, A, B, C, bias, M, N, K, lda, ldb, N, splits, kper, (size_t)M * N + N);
         else if (ta && !tb) SERT_BG(true, false, EPI_STORE);
         else if (!ta && tb) SERT_BG(false, true, EPI_STORE);
         else SERT_BG(true, true, EPI_STORE);

@@ -1564,14 +1564,25 @@ static int ll_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         splits = cdiv(rows, kper);
         const size_t mn = (size_t)d * V;
         const size_t stride = mn + V;
+        // Single GPU, a GEMM worth forking for: dW, its combine and (optimizer_and_loss) the W, b update only
+        // feed the loss finalisation -- they run on the side stream beside dG -> row scatter -> word-table
+        // update instead of in front of them.  SERT_LL_DW_SIDE=0 keeps the whole step on one stream.
+        static const bool dw_side_off = getenv("SERT_LL_DW_SIDE") && atoi(getenv("SERT_LL_DW_SIDE")) == 0;
+        const bool dw_side = !dw_side_off && !is_dp(m) && !m->timing.enabled && m->nstreams >= 2 && ext_events() &&
+                             2.0 * (double)rows * d * V >= 2e9;
+        hipStream_t sd = dw_side ? m->stream2 : m->stream;
+        if (dw_side) {
+            SERT_HIP(hipEventRecord(m->ev_fork, m->stream));
+            SERT_HIP(hipStreamWaitEvent(sd, m->ev_fork, 0));
+        }
         {
             ScopedTimer t(m, TG_GEMM_DW);
-            launch_gemm<true, false, EPI_STORE, true>(m->stream, m->G, dZ, m->part, nullptr, d, V,
+            launch_gemm<true, false, EPI_STORE, true>(sd, m->G, dZ, m->part, nullptr, d, V,
                                                       (int)rows, d, V, V, splits, kper, stride);
         }
         {
             ScopedTimer t(m, TG_SPLITK);
-            launch_reduce_partials(m->stream, m->part,
+            launch_reduce_partials(sd, m->part,
                                splits, stride, stride, m->g_w, mn, m->g_b);
         }
         {

@@ -142,6 +142,8 @@ def test_vectorspace_predict(hip_lib):
     dict(B=8, n=12, Vw=300, Ve=4000, d=16),       # > LDS: streaming path, one segment
     dict(B=5, n=5, Vw=300, Ve=12000, d=16),       # streaming path, 3 segments, 16-byte rows
     dict(B=4, n=4, Vw=200, Ve=9001, d=12),        # streaming path, ragged last segment, scalar rows
+    dict(B=512, n=8, Vw=3000, Ve=4096, d=128),    # dW = G^T.dZ of > 2 GFLOP: dW, combine and W, b update on the side stream;
+                                                  # an odd number of distinct words through the 16-byte k-major loaders
 ])
 def test_loglinear_steps(hip_lib, dims, labels):
     B, n = dims['B'], dims['n']
@@ -801,7 +803,52 @@ def test_schedule_variants_do_not_change_a_bit(hip_lib):
     import sys
     code = SCHEDULE_WORKER % dict(root=U.ROOT)
     variants = ({}, {'SERT_STREAMS': '1'}, {'SERT_FORK_LATE': '0'}, {'SERT_EXT_EVENTS': '0'},
-                {'SERT_EGRAD_GROUP_SUM': '1'}, {'SERT_FORK_AT': 'nce'}, {'SERT_SEG_NO_FUSED_UPPER': '1'})
+                {'SERT_EGRAD_GROUP_SUM': '1'}, {'SERT_FORK_AT': 'nce'}, {'SERT_SEG_NO_FUSED_UPPER': '1'},
+                {'SERT_SIDE_HEAVY': '2'})   # (entity chain, dW and the small-tensor update on the side stream)
+    outs = []
+    for extra in variants:
+        r = subprocess.run([sys.executable, '-c', code], check=True, env=dict(os.environ, **extra),
+                           cwd=U.ROOT, stdout=subprocess.PIPE, timeout=600)
+        line = [l for l in r.stdout.decode().splitlines() if l.startswith('RESULT ')][-1]
+        outs.append(json.loads(line[len('RESULT '):]))
+    for extra, o in zip(variants[1:], outs[1:]):
+        assert o == outs[0], 'schedule variant %r changed the results' % (extra,)
+    assert all(np.isfinite(outs[0]['losses']))
+
+
+LL_SCHEDULE_WORKER = r'''
+import sys, json, zlib
+sys.path.insert(0, %(root)r)
+import numpy as np
+from tests import util as U
+from sert_amd import _capi as C
+B, n, Vw, Ve, d = 4096, 8, 5000, 2000, 128
+p = U.make_ll_problem(5, 3 * B, n, Vw, Ve, d, 'int')
+eng = U.ll_engine(p, B, n, 0.01, keep_grads=0)
+eng.upload_dataset(C.SPLIT_TRAIN, p['X'], y_int=p['y'], w=p['w'])
+losses = []
+for s in range(6):
+    eng.hint_next_batch((s + 1) %% 3 if s < 5 else -1)     # (the next batch's forward + backward run ahead)
+    losses.append(float(eng.train_batch(s %% 3)))
+out = {'losses': losses}
+for name, which in (('Rw', C.T_RW), ('W', C.T_W), ('b', C.T_B), ('a_W', C.T_STATE0_W), ('d_b', C.T_STATE1_B)):
+    out['crc_' + name] = zlib.crc32(eng.get_tensor(which).tobytes())
+eng.close()
+print('RESULT ' + json.dumps(out))
+'''
+
+
+@pytest.mark.gpu
+def test_loglinear_side_stream_does_not_change_a_bit(hip_lib):
+    """Loglinear with a dW GEMM worth forking for (2 x 5000 x 128 x 2000 flop): dW, its combine and the W, b
+    update on the side stream, with the next batch running ahead, against the whole step on one stream
+    (SERT_LL_DW_SIDE=0, SERT_STREAMS=1): bit-identical losses, parameters and Adadelta state."""
+    import json
+    import os
+    import subprocess
+    import sys
+    code = LL_SCHEDULE_WORKER % dict(root=U.ROOT)
+    variants = ({}, {'SERT_LL_DW_SIDE': '0'}, {'SERT_STREAMS': '1'})
     outs = []
     for extra in variants:
         r = subprocess.run([sys.executable, '-c', code], check=True, env=dict(os.environ, **extra),

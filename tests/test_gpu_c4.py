@@ -169,3 +169,40 @@ def test_c4_vectorspace_full_batch_known_answer_determinism_untouched_rows(hip_l
     assert all(v for k, v in a.items() if k.startswith('finite_'))
     assert a['losses'][2] < a['losses'][0]          # the same batch again, two updates later
     assert a['absmax_m_Rw'] > 0 and a['absmax_v_Re'] > 0
+
+
+def test_deferred_entity_table_update_between_other_calls(hip_lib):
+    """An entity table of more than 2^22 elements takes the side-heavy schedule: its L2 + Adam launch runs
+    BEHIND the step's tail and the tail takes the table's sum of squares from the previous step's launch.
+    Every other entry point that reads R_e, its state or dR_e has to order itself behind that launch, and a
+    host write to the table has to invalidate the carried sums: train / evaluate / read / overwrite / train
+    again / several batches per call, each loss and the final tensors against the oracle."""
+    B, n, z, Vw, Ve, d, lam = 64, 4, 5, 500, 33000, 128, 0.01
+    p = U.make_vs_problem(9, 4 * B, n, z, Vw, Ve, d, d)
+    eng = U.vs_engine(p, B, n, z, lam, keep_grads=0)
+    eng.upload_dataset(C.SPLIT_TRAIN, p['X'], y_int=p['y'], w=p['w'])
+    ora = O.VectorSpaceOracle(B, n, z, p['Rw'], p['Re'], p['W'], p['b'], lam)
+    rng = p['rng']
+
+    def step(s):
+        sl = slice(s * B, (s + 1) * B)
+        neg = rng.randint(0, Ve, size=(B, z)).astype(np.int64)
+        ref = ora.train_step(p['X'][sl], p['y'][sl], p['w'][sl], neg)
+        got = eng.train_batch(s, neg)
+        assert abs(got - ref) <= LOSS_TOL * abs(ref), (s, got, ref)
+
+    step(0)
+    neg = rng.randint(0, Ve, size=(B, z)).astype(np.int64)          # evaluation reads R_e straight behind a step
+    ev, ev_ref = eng.eval_batch(C.SPLIT_TRAIN, 1, neg), ora.eval_loss(p['X'][B:2 * B], p['y'][B:2 * B], neg)
+    assert abs(ev - ev_ref) <= LOSS_TOL * abs(ev_ref)
+    step(1)
+    assert max_rel(eng.get_tensor(C.T_RE), ora.R_e) < PARAM_TOL
+    new_re = (ora.R_e * np.float32(1.5)).astype(np.float32)           # the host replaces the table: ||R_e||^2 changes
+    eng.set_tensor(C.T_RE, new_re)
+    ora.R_e[...] = new_re
+    step(2)
+    step(3)
+    assert max_rel(eng.get_tensor(C.T_STATE1_RE), ora.opt.v[0]) < PARAM_TOL
+    for name, which, ref in (('Re', C.T_RE, ora.R_e), ('Rw', C.T_RW, ora.R_w), ('W', C.T_W, ora.W), ('b', C.T_B, ora.b)):
+        assert max_rel(eng.get_tensor(which), ref) < PARAM_TOL, name
+    eng.close()

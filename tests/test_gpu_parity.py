@@ -142,6 +142,8 @@ def test_vectorspace_predict(hip_lib):
     dict(B=8, n=12, Vw=300, Ve=4000, d=16),       # > LDS: streaming path, one segment
     dict(B=5, n=5, Vw=300, Ve=12000, d=16),       # streaming path, 3 segments, 16-byte rows
     dict(B=4, n=4, Vw=200, Ve=9001, d=12),        # streaming path, ragged last segment, scalar rows
+    dict(B=48, n=5, Vw=400, Ve=300, d=32),        # dW on 160-column tiles (V_e just above 256), K = distinct words
+    dict(B=37, n=6, Vw=400, Ve=300, d=32),        # ... another count of distinct words (odd / even K on 16-byte loaders)
     dict(B=512, n=8, Vw=3000, Ve=4096, d=128),    # dW = G^T.dZ of > 2 GFLOP: dW, combine and W, b update on the side stream;
                                                   # an odd number of distinct words through the 16-byte k-major loaders
 ])

@@ -218,7 +218,7 @@ def timed_steps(model, dist, num_batches, steps, warmup, timing=True):
 _CEIL_CACHE = {}
 
 
-def memory_ceilings(_capi, row_bytes, table_bytes_list, optimizer_elems=()):
+def memory_ceilings(_capi, row_bytes, table_bytes_list, optimizer_elems=(), device=0):
     """What this box's memory system delivers (sert_bench_memory, HIP events, run in this process):
     float4 stream copy and read (achievable HBM), the step's own window gather over uniformly random
     rows of `row_bytes` out of tables of the given sizes (the L2-resident one is the row-fetch PEAK, the
@@ -227,9 +227,9 @@ def memory_ceilings(_capi, row_bytes, table_bytes_list, optimizer_elems=()):
     MB = 1 << 20
     out = _CEIL_CACHE.setdefault('stream', {})
     if not out:
-        us = _capi.bench_memory(_capi.MEMBENCH_COPY, 1200 * MB, blocks=4096, iters=10)
+        us = _capi.bench_memory(_capi.MEMBENCH_COPY, 1200 * MB, blocks=4096, iters=10, device=device)
         out['copy_GBps'] = 2 * 1200 * MB / (us * 1e-6) / 1e9
-        us = _capi.bench_memory(_capi.MEMBENCH_READ, 1200 * MB, blocks=4096, iters=10)
+        us = _capi.bench_memory(_capi.MEMBENCH_READ, 1200 * MB, blocks=4096, iters=10, device=device)
         out['read_GBps'] = 1200 * MB / (us * 1e-6) / 1e9
     res = dict(out)
     rows = _CEIL_CACHE.setdefault('rows', {})
@@ -239,7 +239,7 @@ def memory_ceilings(_capi, row_bytes, table_bytes_list, optimizer_elems=()):
         key = (rb16, max(tb, rb16))
         if key not in rows:
             out_bytes = 65536 * rb16
-            us = _capi.bench_memory(_capi.MEMBENCH_GATHER, out_bytes, table_bytes=key[1], row_bytes=rb16, window=10, iters=10)
+            us = _capi.bench_memory(_capi.MEMBENCH_GATHER, out_bytes, table_bytes=key[1], row_bytes=rb16, window=10, iters=10, device=device)
             rows[key] = out_bytes * 10 / (us * 1e-6) / 1e9
     res['row_fetch_GBps'] = {'%dB_rows_of_%.1fMB' % (k[0], k[1] / 1e6): round(v, 1) for k, v in rows.items() if k[0] == max(16, (int(row_bytes) + 15) // 16 * 16)}
     opt = _CEIL_CACHE.setdefault('opt', {})
@@ -247,19 +247,19 @@ def memory_ceilings(_capi, row_bytes, table_bytes_list, optimizer_elems=()):
         n = int(n)
         if n >= (1 << 16) and n not in opt:
             us = _capi.bench_memory(_capi.MEMBENCH_OPTIMIZER, n * 4, gap_bytes=_capi.SEPARATE_ALLOCATIONS,
-                                    blocks=4096 if n >= (1 << 24) else 2048, iters=10)
+                                    blocks=4096 if n >= (1 << 24) else 2048, iters=10, device=device)
             opt[n] = 28.0 * n / (us * 1e-6) / 1e9
     res['optimizer_stream_GBps'] = {str(n): round(v, 1) for n, v in opt.items() if n in [int(x) for x in optimizer_elems]}
     return res
 
 
-def ceilings_for(_capi, work):
+def ceilings_for(_capi, work, device=0):
     """memory_ceilings for every row width / table size / optimiser tensor a work table names."""
     merged = {}
     opt = [w_.get('optimizer_elems', 0) for w_ in work.values() if w_['kind'] == 'stream']
     widths = sorted(set(w_['row_bytes'] for w_ in work.values() if w_['kind'] == 'rows')) or [512]
     for rb in widths:
-        c = memory_ceilings(_capi, rb, [w_['table_bytes'] for w_ in work.values() if w_['kind'] == 'rows' and w_['row_bytes'] == rb], opt)
+        c = memory_ceilings(_capi, rb, [w_['table_bytes'] for w_ in work.values() if w_['kind'] == 'rows' and w_['row_bytes'] == rb], opt, device=device)
         rf = dict(merged.get('row_fetch_GBps', {}))
         rf.update(c['row_fetch_GBps'])
         merged.update(c)
@@ -678,7 +678,7 @@ def measure_record(kind, models, _capi, dist, dims, steps, warmup, seed, live_pm
         U = float(np.mean([len(np.unique(X[j * B:(j + 1) * B])) for j in range(num_batches)]))
     work = group_work(kind, B, n, X.dtype.itemsize, d, de, Ve, Vw, z, U)
     # (same order as the headline: ceilings, per-kernel pass, then the number -- see main)
-    ceil = ceilings_for(_capi, work)
+    ceil = ceilings_for(_capi, work, device=m._engine.cfg.device)
     _, tm, _ = timed_steps(m, dist, num_batches, steps, 1, timing=True)
     dt, _, loss = timed_steps(m, dist, num_batches, steps, warmup, timing=False)
     del m
@@ -793,7 +793,7 @@ def main():
     if kind == 'loglinear':
         distinct = float(np.mean([len(np.unique(X[j * Bg:j * Bg + Bl])) for j in range(args.num_batches)]))
     work = group_work(kind, Bl, n, X.dtype.itemsize, d, de, Ve, Vw, z, distinct)
-    ceilings = ceilings_for(_capi, work)      # (every rank: each has its own GPU to bring up to speed)
+    ceilings = ceilings_for(_capi, work, device=model._engine.cfg.device)   # (every rank, on ITS GPU: each has its own to bring up to speed)
     dt_instr, timings, _ = timed_steps(model, dist, args.num_batches, args.steps, 2, timing=True)
     dt, _, last_loss = timed_steps(model, dist, args.num_batches, args.steps, args.warmup, timing=False)
     value = args.steps * Bg / dt

@@ -289,13 +289,24 @@ __global__ __launch_bounds__(256, SERT_GEMM_WAVES) void gemm_f32_mfma(const Gemm
                 for (int kk = 0; kk < GK / 2; ++kk) cs += Bs[buf][half * (GK / 2) + kk][col];
                 csum += cs;
             }
+            // Fragment reads one k-step AHEAD of the MFMAs that use them: left to itself the compiler puts each
+            // step's ds_reads straight in front of its four MFMAs behind an s_waitcnt lgkmcnt(0), and the wave
+            // sits out the LDS latency eight times per slab (round 3, from the ISA).  Worth little where two to
+            // four waves per SIMD cover for each other (4096^3: 111.9 -> 113.6 TF), 8 % on the long-K, two-tiles-
+            // per-CU shape of the full-softmax dp GEMM (65536 x 128 x 1000: 194 -> 179 us).
+            float fa0 = As[buf][lh][wr * 64 + li], fa1 = As[buf][lh][wr * 64 + 32 + li];
+            float fb0 = Bs[buf][lh][wc * 64 + li], fb1 = Bs[buf][lh][wc * 64 + 32 + li];
 #pragma unroll
             for (int kk = 0; kk < GK; kk += 2) {
-                const int k = kk + lh;
-                const float a0 = As[buf][k][wr * 64 + li];
-                const float a1 = As[buf][k][wr * 64 + 32 + li];
-                const float b0 = Bs[buf][k][wc * 64 + li];
-                const float b1 = Bs[buf][k][wc * 64 + 32 + li];
+                const float a0 = fa0, a1 = fa1, b0 = fb0, b1 = fb1;
+                if (kk + 2 < GK) {
+                    const int k = kk + 2 + lh;
+                    fa0 = As[buf][k][wr * 64 + li];
+                    fa1 = As[buf][k][wr * 64 + 32 + li];
+                    fb0 = Bs[buf][k][wc * 64 + li];
+                    fb1 = Bs[buf][k][wc * 64 + 32 + li];
+                }
+                __builtin_amdgcn_sched_barrier(0);   // (keep the reads above the MFMAs below)
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
                 acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
                 acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);

@@ -12,11 +12,18 @@ tools/semantics_drift.py)."""
 import numpy as np
 import pytest
 
-torch = pytest.importorskip('torch')
-
-from oracle import sert_oracle as O  # noqa: E402
+from oracle import sert_oracle as O
 
 EPS = 1e-7
+torch = None      # imported by the tests that use it, NOT at collection: torch brings its own HIP / RCCL
+                  # libraries into the process, and the GPU tests of this suite must run against the system ones
+
+
+@pytest.fixture(autouse=True)
+def _lazy_torch():
+    global torch
+    if torch is None:
+        torch = pytest.importorskip('torch')
 
 
 def _t(a, grad=True):

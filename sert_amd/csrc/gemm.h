@@ -686,7 +686,8 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_mfma_small(const GemmArgs g) 
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (row < R) {
             const float* px = X + (size_t)row * ld + k;
-            if (VEC) { if (k < g.K) v = *reinterpret_cast<const float4*>(px); }
+            // (16-byte path: tile base in SGPRs + 32-bit lane offset, see tile_load16)
+            if (VEC) { if (k < g.K) v = tile_load16(X + (size_t)r0 * ld + k0, (unsigned)cr * (unsigned)ld + (unsigned)ck); }
             else {
                 if (k + 0 < g.K) v.x = px[0];
                 if (k + 1 < g.K) v.y = px[1];
@@ -701,7 +702,7 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_mfma_small(const GemmArgs g) 
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (k < g.K) {
             const float* pb = g.B + (size_t)k * g.ldb + c;
-            if (VEC) { if (c < g.N) v = *reinterpret_cast<const float4*>(pb); }
+            if (VEC) { if (c < g.N) v = tile_load16(g.B + (size_t)k0 * g.ldb + n0, (unsigned)kr * (unsigned)g.ldb + (unsigned)kc); }
             else {
                 if (c + 0 < g.N) v.x = pb[0];
                 if (c + 1 < g.N) v.y = pb[1];
@@ -781,7 +782,7 @@ inline void launch_gemm(hipStream_t s, const float* A, const float* B, float* C,
         g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
         g.kper = K; g.splits = 1; g.c_split_stride = 0; g.vecA = g.vecB = 0;
         g.tiles_m = cdiv(M, SM); g.tiles_n = cdiv(N, SM);
-        const bool vecs = (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A) % 16 == 0) &&
+        const bool vecs = (lda % 4 == 0) && (ldb % 4 == 0) && lda < (1 << 22) && ldb < (1 << 22) && (((uintptr_t)A) % 16 == 0) &&
                           (((uintptr_t)B) % 16 == 0) && (K % 4 == 0) && (TB ? true : (N % 4 == 0));
         if (vecs) SERT_LAUNCH((gemm_f32_mfma_small<TB, (EPI == EPI_FILTER || EPI == EPI_ACCUM) ? EPI_STORE : EPI, true>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, s, g);
         else      SERT_LAUNCH((gemm_f32_mfma_small<TB, (EPI == EPI_FILTER || EPI == EPI_ACCUM) ? EPI_STORE : EPI, false>), dim3(g.tiles_m * g.tiles_n), dim3(256), 0, s, g);

@@ -545,12 +545,27 @@ __global__ __launch_bounds__(256) void ll_row_wave(const float* __restrict__ Zu,
 #pragma unroll
         for (int q = 0; q < GC; ++q) {
             const int sl = __shfl(my_slot, min(k0 + q, n - 1));
+#ifndef SERT_LL_WAVE_GLOBAL_LOADS
+            // the row's byte offset is wave-uniform: a scalar offset of a buffer load (descriptor of the table in
+            // SGPRs, lane offset = its chunk) -- no 64-bit address pair per chunk: loss group 259 -> 250 us at C2
+            // dims (the caller takes this kernel only for tables below 4 GB)
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Zu), 0, 0xffffffff, 0x00020000);
+            const int soff = __builtin_amdgcn_readfirstlane(sl) * V * 4;
+#pragma unroll
+            for (int j = 0; j < E4PL; ++j) {
+                const int c = lane + 64 * j;
+                const f4v t4 = __builtin_amdgcn_raw_buffer_load_b128(rs, (c < V4 ? c : 0) * 16, soff, 0);
+                v[q][j] = make_float4(t4.x, t4.y, t4.z, t4.w);
+            }
+#else
             const float4* row = reinterpret_cast<const float4*>(Zu + (size_t)sl * V);
 #pragma unroll
             for (int j = 0; j < E4PL; ++j) {
                 const int c = lane + 64 * j;
                 v[q][j] = row[c < V4 ? c : 0];
             }
+#endif
         }
 #pragma unroll
         for (int q = 0; q < GC; ++q) {

@@ -1506,7 +1506,8 @@ static int ll_forward(sert_model* m, const DataSplit& ds, int64_t batch_index) {
 #define SERT_LL_WAVE(E)                                                                                        \
     hipLaunchKernelGGL((ll_row_wave<E>), dim3(cdiv(B, 4)), dim3(256), 0, m->stream, (const float*)m->Zu, slot, y, \
                        indptr, ds.csr_indices, ds.csr_data, w, m->rowloss, B, n, V, inv_batch, m->J, m->ll_r)
-            if (!no_wave && V % 4 == 0 && V <= 2048) {
+            // (its row fetches are buffer loads off one descriptor of the table: 32-bit byte offsets)
+            if (!no_wave && V % 4 == 0 && V <= 2048 && (size_t)m->ll_U * V * sizeof(float) < ((size_t)1 << 32)) {
                 const int e4 = cdiv(V / 4, 64);
                 if (e4 <= 1) SERT_LL_WAVE(1);
                 else if (e4 <= 2) SERT_LL_WAVE(2);

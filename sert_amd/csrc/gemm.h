@@ -775,8 +775,12 @@ inline void launch_gemm(hipStream_t s, const float* A, const float* B, float* C,
     // 30.5 -> 26.3 us, the loglinear dG with 347 tiles and K = 1000 162 -> 126 us; 256 and 512 tiles: equal):
     // a CU that gets a second big tile sets the time of the launch, four times as many small ones spread evenly
     static const long long small_below = getenv("SERT_GEMM_SMALL_BELOW") ? atoll(getenv("SERT_GEMM_SMALL_BELOW")) : 512;   // tuning knob
+    // ... and AT two big tiles per CU for a short K (the C2 projections: 512 tiles, K = 128), since the 64x64
+    // kernel loads its tiles through buffer loads: 31.3 -> 30.1 and 28.8 -> 27.7 us, C2 step 295.5 -> 292.2 us;
+    // at K = 1000 the big tiles keep the boundary (186 against 197 us)
+    const long long big_tiles = (long long)cdiv(M, GM) * cdiv(N, GN);
     if (!TA && !CSB && EPI != EPI_FILTER && EPI != EPI_ACCUM && splits == 1 && !no_small &&
-        (long long)cdiv(M, GM) * cdiv(N, GN) < small_below && (long long)M * N >= 4 * SM * SM) {
+        (big_tiles < small_below || (big_tiles == small_below && K <= 512)) && (long long)M * N >= 4 * SM * SM) {
         g.cand = nullptr; g.cnt = nullptr; g.cap = 0;
         g.A = A; g.B = B; g.C = C; g.bias = bias;
         g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;

@@ -125,13 +125,16 @@ def group_work(kind, B, n, s, dw, de, Ve, Vw, z, distinct_words=None):
 # the first is the one a given configuration normally runs: e.g. the entity gradient is
 # egrad_acc up to 2048 entities and egrad_chunk_reduce above)
 _COMMON_KERNELS = {
-    'gemm_dW': ('gemm_f32_mfma<true, false, 0',), 'splitk_combine': ('reduce_partials',),
-    'gemm_dX': ('gemm_f32_mfma<false, true, 0',), 'gemm_bwd_fused': ('vs_bwd_fused',), 'word_grad_segsum': ('segsum_rows<',),
-    'optimizer_other': ('optimizer_small',), 'finalize': ('vs_tail', 'finalize_loss'),
+    # (128x128 tiles; 64x64 tiles for fewer than / exactly two big tiles per CU; 128x160 tiles for d = 300)
+    'gemm_dW': ('gemm_f32_mfma<true, false, 0', 'gemm_f32_mfma_n160<true, false, 0'), 'splitk_combine': ('reduce_partials',),
+    'gemm_dX': ('gemm_f32_mfma<false, true, 0', 'gemm_f32_mfma_small<true, 0', 'gemm_f32_mfma_n160<false, true, 0'),
+    'gemm_bwd_fused': ('vs_bwd_fused',), 'word_grad_segsum': ('segsum_rows<',),
+    'optimizer_other': ('optimizer_small', 'adam_l2'), 'finalize': ('vs_tail', 'finalize_loss'),
 }
 KERNELS_OF_GROUP = {
     'vectorspace': dict(_COMMON_KERNELS, **{
-        'gather': ('vs_gather_mean',), 'gemm_fwd': ('gemm_f32_mfma<false, false, 2',),
+        'gather': ('vs_gather_mean',),
+        'gemm_fwd': ('gemm_f32_mfma<false, false, 2', 'gemm_f32_mfma_small<false, 2', 'gemm_f32_mfma_n160<false, false, 2'),
         'loss': ('vs_nce_regs', 'vs_nce'), 'entity_sort': ('egrad_bucket', 'csort_scatter'),
         'entity_grad_reduce': ('egrad_acc', 'egrad_chunk_reduce'),
         'entity_grad_fixup': ('egrad_group_sum', 'egrad_fixup'), 'optimizer_word_table': ('adam_l2',)}),
@@ -141,7 +144,7 @@ KERNELS_OF_GROUP = {
         'optimizer_word_table': ('adam_l2',)}),
     'loglinear': dict(_COMMON_KERNELS, **{
         'gather': ('ll_gather_rows',), 'gemm_fwd': ('gemm_f32_mfma<false, false, 1',),
-        'loss': ('ll_row_from_table', 'll_fused_row', 'll_s_'),
+        'loss': ('ll_row_wave', 'll_row_from_table', 'll_fused_row', 'll_s_'),
         'per_word_dz_sums': ('segsum_rows<64, true, true', 'segsum_rows_scalar<true'),
         'optimizer_word_table': ('adadelta_l2',)}),
 }

@@ -541,7 +541,8 @@ def test_full_size_known_answers(hip_lib):
     ('vectorspace', 'own', 4, 'rows', None), ('loglinear', 'own', 3, 'rows', None),
     ('vectorspace', 'own', 2, 'zero1', None), ('vectorspace', 'own', 4, 'zero1', '3'), ('loglinear', 'own', 2, 'zero1', '2'),
     ('loglinear_bigw', 'own', 2, 'rows', None), ('loglinear_bigw', 'own', 2, 'zero1', None),
-    ('vectorspace', 'torchrun', 2, 'rows', None)])
+    ('vectorspace', 'torchrun', 2, 'rows', None),
+    ('vectorspace', 'own', 8, 'rows', None)])       # the world size of the scaling target (C3), eight ranks on one GPU
 def test_ranks_on_one_gpu_match_single_process(hip_lib, tmp_path, kind, launcher, world, exchange, chunks):
     """The data-parallel step with 2-4 real ranks (one process each) on the one GPU of the test box,
     through the host-mediated exchange (RCCL refuses duplicate devices), every rank receiving exactly

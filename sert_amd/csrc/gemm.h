@@ -83,6 +83,9 @@ struct GemmArgs {
     unsigned long long* cand;   // [M][2*tiles_n][cap]
     unsigned char* cnt;         // [M][2*tiles_n], zeroed by the caller
     int cap;
+    // 64x64-tile kernel only (optional): output row r is stored as row rowmap[r] of C -- the loglinear dG, one row
+    // per distinct word, lands straight on the word-table gradient rows (no scatter pass)
+    const int32_t* rowmap = nullptr;
 };
 
 // --- global -> registers (zero padded) ----------------------------------------
@@ -757,18 +760,23 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_mfma_small(const GemmArgs g) 
             float v = acc[r];
             if (EPI == EPI_BIAS) v = v + bv;
             if (EPI == EPI_BIAS_TANH) v = fast_tanh(v + bv);
-            if (row < g.M) g.C[(size_t)row * g.ldc + col] = v;
+            if (row < g.M) g.C[(size_t)(g.rowmap ? g.rowmap[row] : row) * g.ldc + col] = v;
         }
     }
 }
 
+// rowmap / mapped_C / mapped (optional): when the launch goes to the 64x64-tile kernel, row r of the product is
+// stored as row rowmap[r] of mapped_C (leading dimension ldc) instead of row r of C, and *mapped is set.
 template <bool TA, bool TB, int EPI, bool CSB = false>
 inline void launch_gemm(hipStream_t s, const float* A, const float* B, float* C, const float* bias,
                         int M, int N, int K, int lda, int ldb, int ldc, int splits = 1,
                         int kper = 0, size_t c_split_stride = 0, unsigned long long* cand = nullptr,
-                        unsigned char* cnt = nullptr, int cap = 0) {
+                        unsigned char* cnt = nullptr, int cap = 0, const int32_t* rowmap = nullptr,
+                        float* mapped_C = nullptr, bool* mapped = nullptr) {
     if (splits <= 1) { splits = 1; kper = K; }
+    if (mapped) *mapped = false;
     GemmArgs g;
+    g.rowmap = nullptr;
     // small problem (fewer than two 128x128 tiles per CU): 64x64 tiles, one workgroup each
     static const bool no_small = getenv("SERT_GEMM_NO_SMALL") != nullptr;
     // below TWO 128x128 tiles per CU the 64x64 tiles win or draw (round 3 sweep at d = 128: 384 tiles
@@ -785,6 +793,7 @@ inline void launch_gemm(hipStream_t s, const float* A, const float* B, float* C,
         g.A = A; g.B = B; g.C = C; g.bias = bias;
         g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
         g.kper = K; g.splits = 1; g.c_split_stride = 0; g.vecA = g.vecB = 0;
+        if (rowmap && mapped_C) { g.rowmap = rowmap; g.C = mapped_C; if (mapped) *mapped = true; }
         g.tiles_m = cdiv(M, SM); g.tiles_n = cdiv(N, SM);
         const bool vecs = (lda % 4 == 0) && (ldb % 4 == 0) && lda < (1 << 22) && ldb < (1 << 22) && (((uintptr_t)A) % 16 == 0) &&
                           (((uintptr_t)B) % 16 == 0) && (K % 4 == 0) && (TB ? true : (N % 4 == 0));

@@ -418,7 +418,9 @@ static int entity_key_sort(sert_model* m, int total, hipStream_t st) {
 // order-fixed combine (deterministic).
 template <bool TA, bool TB>
 static int gemm_long_k(sert_model* m, hipStream_t s, const float* A, const float* Bm, float* C, int M,
-                       int N, int K, int lda, int ldb) {
+                       int N, int K, int lda, int ldb, const int32_t* rowmap = nullptr, float* mapped_C = nullptr,
+                       bool* mapped = nullptr) {
+    if (mapped) *mapped = false;
     const int tiles = cdiv(M, GM) * cdiv(N, GN);
     int splits = 1;
     if (tiles < 512 && K >= 4096) splits = std::min(cdiv(1024, tiles), K / 1024);
@@ -426,7 +428,8 @@ static int gemm_long_k(sert_model* m, hipStream_t s, const float* A, const float
     // (between one and two tiles per CU -- the loglinear dG at C2 dims, 347 tiles -- a three-way split was
     //  tried: 162 -> 175 us with its combine; co-resident workgroups share the matrix pipe without loss)
     if (splits <= 1) {
-        launch_gemm<TA, TB, EPI_STORE>(s, A, Bm, C, nullptr, M, N, K, lda, ldb, N);
+        launch_gemm<TA, TB, EPI_STORE>(s, A, Bm, C, nullptr, M, N, K, lda, ldb, N, 1, 0, 0, nullptr, nullptr, 0, rowmap, mapped_C,
+                                       mapped);
         return 0;
     }
     const int kper = (int)round_up(cdiv(K, splits), GK);
@@ -1549,6 +1552,7 @@ static int ll_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
     const size_t row0 = (size_t)batch_index * B;
     int64_t rows = (int64_t)B * n;          // rows of the dZ operand of the two GEMMs
     const float* dZ = m->Z;
+    bool dg_mapped = false;                 // dG went straight to the word-table gradient rows
     if (m->ll_dedup) {
         // per-word sums of dL/dZ (the backward of "duplicate tokens share a logit row")
         ScopedTimer t(m, TG_EGRAD);
@@ -1587,12 +1591,17 @@ static int ll_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
                                splits, stride, stride, m->g_w, mn, m->g_b);
         }
         {
-            // dG (rows, d) = dZ.W^T
+            // dG (rows, d) = dZ.W^T -- in distinct-word mode row u IS the gradient of word uwords[u]: where the
+            // 64x64-tile kernel takes the launch its epilogue stores the rows straight into dR_w (14.8 us of
+            // scatter pass less on the step's chain at C2 dims); keep_grads keeps dG readable
             ScopedTimer t(m, TG_GEMM_DX);
-            SERT_TRY((gemm_long_k<false, true>(m, m->stream, dZ, m->W, m->DG, (int)rows, d, V, V, V)));
+            static const bool no_map = getenv("SERT_LL_NO_ROWMAP") != nullptr;   // cross-check knob
+            const int32_t* rowmap = (m->ll_dedup && !c.keep_grads && !no_map)
+                                        ? ds.idx_uwords + ds.idx_batches[(size_t)batch_index].uw_off : nullptr;
+            SERT_TRY((gemm_long_k<false, true>(m, m->stream, dZ, m->W, m->DG, (int)rows, d, V, V, V, rowmap, m->g_rw, &dg_mapped)));
         }
     }
-    {
+    if (!dg_mapped) {
         ScopedTimer t(m, TG_SCATTER);
         if (m->ll_dedup) {
             // dG already holds one row per distinct word: dR_w[word_u, :] = dG[u, :]

@@ -629,6 +629,31 @@ def test_parameters_after_100_steps(hip_lib, kind):
     eng.close()
 
 
+@pytest.mark.gpu
+def test_loglinear_dg_rows_stored_through_the_row_map(hip_lib):
+    """Without keep_grads and with a dG = dZ.W^T that the 64x64-tile GEMM takes (U x d >= 16384 elements, fewer than
+    512 big tiles), the GEMM's epilogue stores row u of dG as row uwords[u] of the word-table gradient -- no scatter
+    pass.  Losses of five steps and the parameters after them against the oracle (the word-table rows of every
+    distinct word of a batch must have received exactly their gradient row)."""
+    B, n, Vw, Ve, d, steps = 256, 6, 2000, 60, 32, 5
+    p = U.make_ll_problem(81, B * 2, n, Vw, Ve, d, 'int')
+    assert len(np.unique(p['X'][:B])) * d >= 4 * 64 * 64
+    eng = U.ll_engine(p, B, n, 0.01, keep_grads=0)
+    eng.upload_dataset(C.SPLIT_TRAIN, p['X'], y_int=p['y'], w=p['w'])
+    ora = O.LogLinearOracle(B, n, p['Rw'], p['W'], p['b'], 0.01)
+    for s in range(steps):
+        j = s % 2
+        sl = slice(j * B, (j + 1) * B)
+        ref = ora.train_step(p['X'][sl], p['ydense'][sl], p['w'][sl])
+        loss = eng.train_batch(j)
+        assert abs(loss - ref) <= LOSS_TOL * abs(ref), (s, loss, ref)
+    for which, ref in ((C.T_RW, ora.R_w), (C.T_W, ora.W), (C.T_B, ora.b)):
+        assert U.rel_err(eng.get_tensor(which), np.asarray(ref).ravel()) < PARAM_TOL, which
+    # Adadelta's accumulators of the word table: a row that took a wrong gradient row shows here first
+    assert U.rel_err(eng.get_tensor(C.T_STATE0_RW), ora.opt.accu[0].ravel()) < PARAM_TOL
+    eng.close()
+
+
 def test_scratch_buffers_are_not_readable_without_keep_grads(hip_lib):
     B, n, z = 16, 2, 2
     p = U.make_vs_problem(81, B, n, z, 30, 6, 8, 8)

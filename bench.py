@@ -36,7 +36,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured achievable)
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 MFMA dense peak
-COMMITTED_PMC = 'profiles/r03t_vs_c2_pmc.json'
+COMMITTED_PMC = 'profiles/r03v_vs_c2_pmc.json'
 
 
 def synth_data(rng, N, n, Vw, Ve):

@@ -299,6 +299,13 @@ def barrier():
         _all_gather_bytes('bar', b'')
 
 
+def all_gather_object(obj):
+    """Every rank's (picklable) object, in rank order."""
+    if _context.world_size <= 1:
+        return [obj]
+    return [pickle.loads(b) for b in _all_gather_bytes('ago', pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL))]
+
+
 def all_reduce_max(value):
     if _context.world_size <= 1:
         return float(value)

@@ -1,0 +1,191 @@
+"""Oracle parity AT THE BENCHMARKED BATCH (round-3 verdict, item 1).
+
+bench.py times C2 / C4 / loglinear / the additive full softmax at batch 65536 (loglinear's oracle at the largest
+batch NumPy fits: 8192) on Zipf tokens -- 30 % of a batch's tokens land on one word, so the longest fp32
+reduction chains of the whole path (the per-word gradient sums, the mean over the batch of
+sert/models.py:278-282) only exist at these sizes.  Every test here runs the PRODUCT configuration
+(keep_grads = 0: touched-row bitmaps, no dense gradient table, fused tail, run-ahead off only because explicit
+negatives are passed) against the NumPy restatement on the same inputs:
+
+  * per-step loss: rel 1e-5;
+  * every parameter tensor and both optimiser moments after the last step: rel 1e-4 of the tensor's largest
+    element (util.rel_err) AND row by row against the row's own norm (util.row_err) -- the global bound cannot
+    see a wrong row that is small against the largest one;
+  * after the first step the first moment is (1 - beta1) * g (zero start), so `m` row by row is the GRADIENT
+    row by row, without the keep_grads path.
+
+Row tolerance: a row of the word-table gradient is a sum over up to ~200 000 occurrences (Zipf head); the fp32
+oracle adds them in sequence (np.add.at, as Theano's AdvancedIncSubtensor1 does), the HIP path in a fixed
+tree -- both are fp32 sums of the same terms in different association, so the row-wise bound is 2e-4 against
+the float32 oracle and 5e-5 against the same oracle evaluated in float64 (the HIP tree is the more accurate of
+the two; the figures are printed).  `W` and `b` gradients are sums over ALL 65536 rows of terms that largely cancel
+(a row of dW at C4 nets 1e-3 of the sum of its terms' magnitudes): there the float32 oracle's own BLAS sum is
+3e-4 off its float64 evaluation row-wise, so the float32 row bound for those two tensors is 1e-3 and the float64
+bound (5e-5) is the one that tests the HIP path.
+"""
+import numpy as np
+import pytest
+
+from tests import util as U
+from tests.util import C, O
+
+pytestmark = pytest.mark.gpu
+
+LOSS_TOL = 1e-5       # per-step loss, relative
+TENSOR_TOL = 1e-4     # parameters (and here: optimiser moments), relative to the tensor's max
+ROW_TOL32 = 2e-4      # row-wise, against the float32 oracle (sequential fp32 sums on the oracle's side)
+ROW_TOL64 = 5e-5      # row-wise, against the float64 evaluation of the same oracle
+ROW_TOL32_DENSE = 1e-3   # W, b against the float32 oracle: batch-long cancelling sums on both sides (see above)
+
+
+def _zipf_tokens(rng, N, n, Vw):
+    ranks = np.minimum(rng.zipf(1.1, size=(N, n)) - 1, Vw - 1)
+    return rng.permutation(Vw).astype(U.id_dtype(Vw))[ranks]
+
+
+def _vs_problem(seed, N, n, Vw, Ve, dw, de):
+    rng = np.random.RandomState(seed)
+    p = dict(Rw=O.glorot_uniform(rng, (Vw, dw)), Re=O.glorot_uniform(rng, (Ve, de)),
+             W=O.glorot_uniform(rng, (dw, de)), b=(0.1 * rng.randn(de)).astype(np.float32))
+    p['X'] = _zipf_tokens(rng, N, n, Vw)
+    p['y'] = rng.randint(0, Ve, size=N).astype(np.int32)
+    p['w'] = rng.uniform(0.5, 2.0, N).astype(np.float32)
+    p['rng'] = rng
+    return p
+
+
+def _check_tensor(name, got, ref32, ref64=None, rows=None, row_tol32=ROW_TOL32):
+    """global + row-wise bounds for one (rows, cols) tensor; returns the figures for the log line."""
+    g = U.rel_err(got, ref32)
+    assert g < TENSOR_TOL, (name, 'rel_err', g)
+    r32, at32 = U.row_err(got, ref32, rows)
+    assert r32 < row_tol32, (name, 'row_err vs float32 oracle', r32, 'row', at32)
+    out = '%s rel %.1e row32 %.1e' % (name, g, r32)
+    if ref64 is not None:
+        r64, at64 = U.row_err(got, ref64, rows)
+        o64, _ = U.row_err(ref32, ref64, rows)
+        assert r64 < ROW_TOL64, (name, 'row_err vs float64 oracle', r64, 'row', at64)
+        out += ' row64 %.1e (oracle32 vs 64: %.1e)' % (r64, o64)
+    return out
+
+
+def _vs_run(hip_lib, dims, steps, seed, check64):
+    B, n, z, Vw, Ve, dw, de = (dims[k] for k in ('B', 'n', 'z', 'Vw', 'Ve', 'dw', 'de'))
+    p = _vs_problem(seed, B * steps, n, Vw, Ve, dw, de)
+    negs = [p['rng'].randint(0, Ve, size=(B, z)).astype(np.int64) for _ in range(steps)]
+    eng = U.vs_engine(p, B, n, z, 0.01, keep_grads=0)
+    eng.upload_dataset(C.SPLIT_TRAIN, p['X'], y_int=p['y'], w=p['w'])
+    ora = O.VectorSpaceOracle(B, n, z, p['Rw'], p['Re'], p['W'], p['b'], 0.01)
+    shapes = {'Rw': (Vw, dw), 'Re': (Ve, de), 'W': (dw, de), 'b': (1, de)}
+    ids = {'Rw': (C.T_RW, C.T_STATE0_RW, C.T_STATE1_RW), 'Re': (C.T_RE, C.T_STATE0_RE, C.T_STATE1_RE),
+           'W': (C.T_W, C.T_STATE0_W, C.T_STATE1_W), 'b': (C.T_B, C.T_STATE0_B, C.T_STATE1_B)}
+    opt_index = {'Re': 0, 'Rw': 1, 'W': 2, 'b': 3}           # parameter order of models.py:542-543, :1105
+    log = []
+    for s in range(steps):
+        sl = slice(s * B, (s + 1) * B)
+        if s == 0 and check64:
+            o64 = O.VectorSpaceOracle(B, n, z, p['Rw'], p['Re'], p['W'], p['b'], 0.01, dtype=np.float64)
+            _, g64, _ = o64.loss_and_grads(p['X'][sl], p['y'][sl], p['w'][sl], negs[s])
+        ref = ora.train_step(p['X'][sl], p['y'][sl], p['w'][sl], negs[s])
+        got = eng.train_batch(s, negs[s])
+        assert abs(got - ref) <= LOSS_TOL * abs(ref), (s, got, ref)
+        log.append('step %d loss %.7f (oracle %.7f)' % (s, got, ref))
+        if s == 0:
+            # first moment after one step from a zero state = (1 - beta1) * gradient: the gradient, row by row
+            touched = np.unique(p['X'][sl])
+            for name in ('Rw', 'Re', 'W', 'b'):
+                m = eng.get_tensor(ids[name][1], shapes[name])
+                m32 = ora.opt.m[opt_index[name]].reshape(shapes[name])
+                m64 = (0.1 * g64[opt_index[name]]).reshape(shapes[name]) if check64 else None
+                log.append(_check_tensor('m1.' + name, m, m32, m64, rows=touched if name == 'Rw' else None,
+                                         row_tol32=ROW_TOL32_DENSE if name in ('W', 'b') else ROW_TOL32))
+    for name in ('Rw', 'Re', 'W', 'b'):
+        k = opt_index[name]
+        par, m, v = (eng.get_tensor(t, shapes[name]) for t in ids[name])
+        rt = ROW_TOL32_DENSE if name in ('W', 'b') else ROW_TOL32
+        log.append(_check_tensor(name, par, ora.params()[k].reshape(shapes[name])))
+        log.append(_check_tensor('m.' + name, m, ora.opt.m[k].reshape(shapes[name]), row_tol32=rt))
+        # v is a sum of squares: twice the relative error of g row by row
+        log.append(_check_tensor('v.' + name, v, ora.opt.v[k].reshape(shapes[name]), row_tol32=2 * rt))
+    eng.close()
+    print('\n'.join(log))
+
+
+def test_c2_vectorspace_at_the_benchmarked_batch(hip_lib):
+    """BASELINE configs[1] as bench.py runs it: V_w = 100k, V_e = 1k, d = 128, window 10, z = 10, batch 65536,
+    Zipf tokens, w ~ U[0.5, 2], explicit negatives, 3 steps (sert/models.py:1072-1098, 278-282, 922)."""
+    _vs_run(hip_lib, dict(B=65536, n=10, z=10, Vw=100000, Ve=1000, dw=128, de=128), steps=3, seed=0, check64=True)
+
+
+def test_c4_vectorspace_at_the_benchmarked_batch(hip_lib):
+    """BASELINE configs[3]: V_w = 500k, V_e = 100k, d = 300, batch 65536 -- the sorted entity chain, the
+    128x160-tile GEMMs, the side-heavy schedule with the deferred entity-table update; 2 steps."""
+    _vs_run(hip_lib, dict(B=65536, n=10, z=10, Vw=500000, Ve=100000, dw=300, de=300), steps=2, seed=1, check64=True)
+
+
+def test_loglinear_c2_dims_at_the_largest_oracle_batch(hip_lib):
+    """Reference loglinear model (sert/models.py:804-890, 200-212) at C2's dims, batch 8192 (P = B n V_e floats
+    is what bounds the NumPy oracle), Zipf tokens, int labels, 2 steps: distinct-word tables, wave-per-row loss,
+    dense heavy-word pass + tree for the per-word sums, Adadelta."""
+    B, n, Vw, Ve, d, steps = 8192, 10, 100000, 1000, 128, 2
+    rng = np.random.RandomState(2)
+    p = dict(Rw=O.glorot_uniform(rng, (Vw, d)), W=O.glorot_uniform(rng, (d, Ve)),
+             b=(0.1 * rng.randn(Ve)).astype(np.float32))
+    p['X'] = _zipf_tokens(rng, B * steps, n, Vw)
+    y = rng.randint(0, Ve, size=B * steps).astype(np.int32)
+    w = rng.uniform(0.5, 2.0, B * steps).astype(np.float32)
+    eng = U.ll_engine(p, B, n, 0.01, keep_grads=0)
+    eng.upload_dataset(C.SPLIT_TRAIN, p['X'], y_int=y, w=w)
+    ora = O.LogLinearOracle(B, n, p['Rw'], p['W'], p['b'], 0.01)
+    log = []
+    for s in range(steps):
+        sl = slice(s * B, (s + 1) * B)
+        ref = ora.train_step(p['X'][sl], y[sl], w[sl])
+        got = eng.train_batch(s)
+        assert abs(got - ref) <= LOSS_TOL * abs(ref), (s, got, ref)
+        log.append('step %d loss %.7f (oracle %.7f)' % (s, got, ref))
+    shapes = {'Rw': (Vw, d), 'W': (d, Ve), 'b': (1, Ve)}
+    ids = {'Rw': (C.T_RW, C.T_STATE0_RW, C.T_STATE1_RW), 'W': (C.T_W, C.T_STATE0_W, C.T_STATE1_W),
+           'b': (C.T_B, C.T_STATE0_B, C.T_STATE1_B)}
+    for k, name in enumerate(('Rw', 'W', 'b')):               # parameter order [R_w, W, b], models.py:543
+        par, accu, delta = (eng.get_tensor(t, shapes[name]) for t in ids[name])
+        rt = ROW_TOL32_DENSE if name in ('W', 'b') else ROW_TOL32
+        log.append(_check_tensor(name, par, ora.params()[k].reshape(shapes[name])))
+        # Adadelta: accu = running mean of g^2, delta = running mean of update^2 -- squares: 2x the row bound
+        log.append(_check_tensor('accu.' + name, accu, ora.opt.accu[k].reshape(shapes[name]), row_tol32=2 * rt))
+        log.append(_check_tensor('delta.' + name, delta, ora.opt.delta[k].reshape(shapes[name]), row_tol32=2 * rt))
+    eng.close()
+    print('\n'.join(log))
+
+
+def test_additive_full_softmax_at_the_benchmarked_batch(hip_lib):
+    """The additive "LSE + full softmax" variant (not in the reference: SELF-CHECKED against the
+    builder's own restatement only) at C2 dims, batch 65536, 2 steps."""
+    B, n, Vw, Ve, d, steps = 65536, 10, 100000, 1000, 128, 2
+    p = _vs_problem(3, B * steps, n, Vw, Ve, d, d)
+    eng = C.Engine(kind=C.KIND_VECTORSPACE_SOFTMAX, batch_size=B, global_batch_size=B, window_size=n,
+                   vocab_size=Vw, num_entities=Ve, word_dim=d, entity_dim=d, num_negatives=0,
+                   id_bytes=p['X'].dtype.itemsize, device=0, keep_grads=0, deterministic=1, lambda_=0.01,
+                   lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, seed=1)
+    for which, a in ((C.T_RW, p['Rw']), (C.T_RE, p['Re']), (C.T_W, p['W']), (C.T_B, p['b'])):
+        eng.set_tensor(which, a)
+    eng.upload_dataset(C.SPLIT_TRAIN, p['X'], y_int=p['y'], w=p['w'])
+    ora = O.VectorSpaceSoftmaxOracle(B, n, p['Rw'], p['Re'], p['W'], p['b'], 0.01)
+    log = []
+    for s in range(steps):
+        sl = slice(s * B, (s + 1) * B)
+        ref = ora.train_step(p['X'][sl], p['y'][sl], p['w'][sl])
+        got = eng.train_batch(s)
+        assert abs(got - ref) <= LOSS_TOL * abs(ref), (s, got, ref)
+        log.append('step %d loss %.7f (oracle %.7f)' % (s, got, ref))
+    shapes = {'Rw': (Vw, d), 'Re': (Ve, d), 'W': (d, d), 'b': (1, d)}
+    ids = {'Rw': (C.T_RW, C.T_STATE0_RW, C.T_STATE1_RW), 'Re': (C.T_RE, C.T_STATE0_RE, C.T_STATE1_RE),
+           'W': (C.T_W, C.T_STATE0_W, C.T_STATE1_W), 'b': (C.T_B, C.T_STATE0_B, C.T_STATE1_B)}
+    for k, name in enumerate(('Re', 'Rw', 'W', 'b')):
+        par, m, v = (eng.get_tensor(t, shapes[name]) for t in ids[name])
+        rt = ROW_TOL32_DENSE if name in ('W', 'b') else ROW_TOL32
+        log.append(_check_tensor(name, par, ora.params()[k].reshape(shapes[name])))
+        log.append(_check_tensor('m.' + name, m, ora.opt.m[k].reshape(shapes[name]), row_tol32=rt))
+        log.append(_check_tensor('v.' + name, v, ora.opt.v[k].reshape(shapes[name]), row_tol32=2 * rt))
+    eng.close()
+    print('\n'.join(log))

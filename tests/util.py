@@ -15,6 +15,25 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / max(1e-30, np.abs(b).max()))
 
 
+def row_err(a, b, rows=None, floor=1e-3):
+    """Row-wise companion of rel_err: max over rows r of ||a_r - b_r||_2 / max(||b_r||_2, floor * median_r ||b_r||_2).
+    rel_err is a bound against the largest element of the WHOLE tensor -- a wrong row whose magnitude is 1e-4
+    of the largest row passes it; this one prices every row against its own norm (the floor only keeps rows that
+    are numerically empty -- cancelled sums, untouched rows under lambda = 0 -- from dividing by ~0).  `rows`
+    restricts the maximum to a subset (e.g. the rows a batch touches).  Returns (worst error, its row)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape and a.ndim == 2, (a.shape, b.shape)
+    if rows is not None:
+        rows = np.asarray(rows)
+        a, b = a[rows], b[rows]
+    nb = np.sqrt((b * b).sum(axis=1))
+    den = np.maximum(nb, floor * max(1e-30, float(np.median(nb))))
+    e = np.sqrt(((a - b) ** 2).sum(axis=1)) / den
+    i = int(np.argmax(e))
+    return float(e[i]), (int(rows[i]) if rows is not None else i)
+
+
 def id_dtype(vocab):
     return np.min_scalar_type(vocab - 1)
 

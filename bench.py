@@ -57,7 +57,7 @@ def glorot(rng, shape):
     return rng.uniform(-a, a, size=shape).astype(np.float32)
 
 
-def group_work(kind, B, n, s, dw, de, Ve, Vw, z, distinct_words=None):
+def group_work(kind, B, n, s, dw, de, Ve, Vw, z, distinct_words=None, shards=1):
     """Per timed kernel group: what it is priced against and how much work one launch does.
 
       kind 'mfma'   : flops (executed)                              -> fp32 MFMA peak
@@ -75,7 +75,8 @@ def group_work(kind, B, n, s, dw, de, Ve, Vw, z, distinct_words=None):
     def stream(by, **kw): return dict(kind='stream', alg=by, **kw)
     def rows(alg, fetch, row_bytes, table_bytes, resident=None): return dict(
         kind='rows', alg=alg, fetch=fetch, row_bytes=row_bytes, table_bytes=table_bytes, resident=resident)
-    P_w = 32.0 * Vw * dw
+    # data parallel: a rank's dense update covers the word-table rows it owns (1/shards of them)
+    P_w = 32.0 * Vw * dw / shards
     if kind in ('vectorspace', 'vectorspace_softmax'):
         w = {
             'gather':               rows(B * (n * s + 4 * n * dw), B * 4.0 * n * dw, 4 * dw, 4.0 * Vw * dw),   # vs_gather_mean
@@ -85,7 +86,7 @@ def group_work(kind, B, n, s, dw, de, Ve, Vw, z, distinct_words=None):
             'gemm_dX':              mfma(2.0 * B * dw * de),               # gemm_f32_mfma NT
             'gemm_bwd_fused':       mfma(4.0 * B * dw * de),               # vs_bwd_fused: dh and dW in one launch (opt-in)
             'word_grad_segsum':     rows(B * (8.0 * n * dw), B * 4.0 * n * dw, 4 * dw, 4.0 * B * dw),   # segsum_rows: rows of dh
-            'optimizer_word_table': stream(P_w, optimizer_elems=Vw * dw),  # adam_l2 (R_w)
+            'optimizer_word_table': stream(P_w, optimizer_elems=Vw * dw // shards),  # adam_l2 (R_w)
             # adam_l2 over R_e where it is a big table (C4), else one optimizer_small launch: launch latency
             'optimizer_other':      (stream(32.0 * (Ve * de + dw * de + de), optimizer_elems=Ve * de) if Ve * de > (1 << 22)
                                      else dict(kind='latency', alg=32.0 * (Ve * de + dw * de + de))),
@@ -117,7 +118,7 @@ def group_work(kind, B, n, s, dw, de, Ve, Vw, z, distinct_words=None):
         'gemm_dW':              mfma(2.0 * U * dw * Ve),
         'gemm_dX':              mfma(2.0 * U * dw * Ve),
         'word_grad_segsum':     rows(U * (8.0 * dw), U * 4.0 * dw, 4 * dw, 4.0 * U * dw),
-        'optimizer_word_table': stream(P_w, optimizer_elems=Vw * dw),
+        'optimizer_word_table': stream(P_w, optimizer_elems=Vw * dw // shards),
         'optimizer_other':      (stream(32.0 * (dw * Ve + Ve), optimizer_elems=dw * Ve) if dw * Ve > (1 << 22)
                                  else dict(kind='latency', alg=32.0 * (dw * Ve + Ve))),
     }
@@ -807,7 +808,7 @@ def main():
     distinct = None
     if kind == 'loglinear':
         distinct = float(np.mean([len(np.unique(X[j * Bg:j * Bg + Bl])) for j in range(args.num_batches)]))
-    work = group_work(kind, Bl, n, X.dtype.itemsize, d, de, Ve, Vw, z, distinct)
+    work = group_work(kind, Bl, n, X.dtype.itemsize, d, de, Ve, Vw, z, distinct, shards=N)
     # Memory ceilings: every rank measures them on ITS GPU (each has its own clocks to bring up) -- unless
     # several ranks share one device (the one-GPU test transport, SERT_COMM=host): stream and row-fetch rates
     # taken while N processes compete for one memory system are no ceiling of anything, and fractions against

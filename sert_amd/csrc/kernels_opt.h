@@ -397,7 +397,7 @@ struct TailArgs {
     float inv_batch, reg_scale;
     float* out;                   // [3] loss, data term, reg term (device or pinned host)
     unsigned* host_flag; unsigned seq;
-    unsigned long long* blk;      // [2 * gridDim.x] (launch sequence number << 32) | float bits
+    unsigned long long* blk;      // [4 * gridDim.x] (launch sequence number << 32) | float bits: loss hi, lo, squares hi, lo
     unsigned launch_seq;          // != 0, different from the previous launch's
 };
 
@@ -449,23 +449,32 @@ __global__ __launch_bounds__(1024) void vs_tail(const TailArgs t) {
     }
     if (l == 0) { dred[0][g] = ls; dred[1][g] = sq; }
     __syncthreads();
-    if (threadIdx.x < 2) {
+    if (threadIdx.x < 4) {
+        // each fp64 sum travels as a (hi, lo) pair of floats -- hi = (float)x, lo = (float)(x - hi): 48 bits of the
+        // double survive, so the loss this launch returns equals finalize_loss's (fp64 to the end, as the
+        // reference's float64 Sum) far below one float32 ulp instead of carrying ~1000 extra roundings
+        const int which = threadIdx.x >> 1;
         double x = 0.0;
 #pragma unroll
-        for (int w = 0; w < 16; ++w) x += dred[threadIdx.x][w];
-        const unsigned long long word = ((unsigned long long)t.launch_seq << 32) | (unsigned long long)__float_as_uint((float)x);
-        __hip_atomic_store(t.blk + 2 * blockIdx.x + threadIdx.x, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int w = 0; w < 16; ++w) x += dred[which][w];
+        const float hi = (float)x;
+        const float piece = (threadIdx.x & 1) ? (float)(x - (double)hi) : hi;
+        const unsigned long long word = ((unsigned long long)t.launch_seq << 32) | (unsigned long long)__float_as_uint(piece);
+        __hip_atomic_store(t.blk + 4 * blockIdx.x + threadIdx.x, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (blockIdx.x != gridDim.x - 1) return;
-    // ---- the collector: wait for every workgroup's two words, add them in workgroup order ----
+    // ---- the collector: wait for every workgroup's four words, add them in workgroup order ----
+    // (the only wait of the launch; it cannot deadlock: no other workgroup ever waits, so they all run to
+    // completion whatever the dispatch order -- also under serialised dispatch, where this one is simply last)
     __syncthreads();
     double c0 = 0.0, c1 = 0.0;
     for (unsigned k = threadIdx.x; k < gridDim.x; k += 1024) {
-        unsigned long long w0, w1;
-        do { w0 = __hip_atomic_load(t.blk + 2 * k + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((unsigned)(w0 >> 32) != t.launch_seq);
-        do { w1 = __hip_atomic_load(t.blk + 2 * k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((unsigned)(w1 >> 32) != t.launch_seq);
-        c0 += (double)__uint_as_float((unsigned)w0);
-        c1 += (double)__uint_as_float((unsigned)w1);
+        unsigned long long w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            do { w[j] = __hip_atomic_load(t.blk + 4 * k + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((unsigned)(w[j] >> 32) != t.launch_seq);
+        c0 += (double)__uint_as_float((unsigned)w[0]) + (double)__uint_as_float((unsigned)w[1]);
+        c1 += (double)__uint_as_float((unsigned)w[2]) + (double)__uint_as_float((unsigned)w[3]);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {

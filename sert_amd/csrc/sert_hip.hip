@@ -270,7 +270,10 @@ static int word_grad_segsum(sert_model* m, const DataSplit& ds, int64_t batch_in
     const bool fused_upper = !no_fused_upper && bx.fused_upper_ok && ds.idx_heavy && d % 4 == 0 && d / 4 <= 32 &&
                              bx.nlevels == 3 && bx.item_cnt[1] > 0;
     // the batch's heavy words: one streaming pass over src for all of them (kernels_seg.h: segsum_heavy)
-    if (bx.dense_cnt > 0) {
+    // (vectorspace only: a loglinear index marks dense words for the V_e-wide per-word sums of dzu_from_dj; its
+    // word gradient -- when it comes through here at all: SERT_LL_NODEDUP / the row-wise loss path -- has one source
+    // row per TOKEN, not per batch row, and hpart is sized for V_e columns, not d_w)
+    if (bx.dense_cnt > 0 && is_vs(m) && d % 4 == 0) {
         const int B = m->cfg.batch_size, d4 = d / 4;
         const int nblk = cdiv(B, kHeavyRowsPerBlock);
         const uint4* cnt = ds.idx_dense_counts + (size_t)batch_index * B;
@@ -568,13 +571,28 @@ static int host_alltoallv(sert_model* m, const float* dsend, size_t stotal, cons
 static int rccl_alltoallv(sert_model* m, const float* dsend, const std::vector<int64_t>& soff, const std::vector<int64_t>& scnt,
                           float* drecv, const std::vector<int64_t>& roff, const std::vector<int64_t>& rcnt, hipStream_t st) {
     SERT_NCCL(g_rccl.GroupStart());
-    for (int q = 0; q < m->world; ++q) {
+    // a failing Send / Recv must not leave the group open (every later collective of this communicator would be
+    // queued into the dangling group and hang): remember the first error, always close the group, then fail
+    int first = 0;
+    const char* what = "";
+    for (int q = 0; q < m->world && first == 0; ++q) {
         if (q == m->rank) continue;
-        if (scnt[(size_t)q]) SERT_NCCL(g_rccl.Send(dsend + soff[(size_t)q], (size_t)scnt[(size_t)q], /*ncclFloat32*/ 7, q, m->comm, st));
-        if (rcnt[(size_t)q]) SERT_NCCL(g_rccl.Recv(drecv + roff[(size_t)q], (size_t)rcnt[(size_t)q], 7, q, m->comm, st));
+        if (scnt[(size_t)q]) {
+            first = g_rccl.Send(dsend + soff[(size_t)q], (size_t)scnt[(size_t)q], /*ncclFloat32*/ 7, q, m->comm, st);
+            if (first) { what = "ncclSend"; break; }
+        }
+        if (rcnt[(size_t)q]) {
+            first = g_rccl.Recv(drecv + roff[(size_t)q], (size_t)rcnt[(size_t)q], 7, q, m->comm, st);
+            if (first) { what = "ncclRecv"; break; }
+        }
         m->comm_bytes_moved += 4.0 * (double)(scnt[(size_t)q] + rcnt[(size_t)q]);
     }
-    SERT_NCCL(g_rccl.GroupEnd());
+    const int end = g_rccl.GroupEnd();
+    if (first != 0 || end != 0) {
+        m->comm_dead = true;      // (peers may be blocked in a half-issued all-to-all: nothing sane can follow)
+        SERT_FAIL(std::string(first ? what : "ncclGroupEnd") + " failed in the row all-to-all: " +
+                  (g_rccl.GetErrorString ? g_rccl.GetErrorString(first ? first : end) : "rccl error"));
+    }
     return 0;
 }
 
@@ -664,12 +682,47 @@ static void xr_free_lists(sert_model* m) {
 // them on the host (kernels_xchg.h) and uploaded.  COLLECTIVE: every rank uploads its split.
 static int xr_build_lists(sert_model* m, const std::vector<uint32_t>& bits, int64_t nb, int64_t bit_words) {
     xr_free_lists(m);
-    if (nb == 0 || !m->xr_mode || !m->pt_sharded[0]) return 0;
-    m->xr = new RowExchangeLists();
+    if (!m->xr_mode || !m->pt_sharded[0]) return 0;      // (rank-invariant: every rank leaves here or none does)
     const size_t W = (size_t)m->world;
+    hipStream_t s = m->stream;
+    {
+        // This function is collective, `nb` is a per-rank quantity: agree on it BEFORE anything can return early
+        // (a rank whose shard held no complete batch used to skip the bitmap all-gather its peers blocked in).
+        // Three exact small integers per rank as floats: nb (< 2^48 split in two) and the bitmap width.
+        std::vector<float> mine = {(float)(nb & 0xffffff), (float)(nb >> 24), (float)bit_words}, all3(3 * W, 0.f);
+        if (m->host_ar) {
+            SERT_TRY(host_reserve(m, 3, 3 * W));
+            memcpy(m->host_send, mine.data(), 3 * sizeof(float));
+            std::vector<int64_t> soff(W, 0), scnt(W, 3), roff(W), rcnt(W, 3);
+            for (size_t q = 0; q < W; ++q) roff[q] = (int64_t)(3 * q);
+            const double moved = m->comm_bytes_moved;
+            SERT_TRY(host_call(m, soff, scnt, roff, rcnt));
+            m->comm_bytes_moved = moved;
+            memcpy(all3.data(), m->host_recv, 3 * W * sizeof(float));
+        } else {
+            float *src = nullptr, *dst = nullptr;
+            SERT_TRY(dmalloc(&src, 3));
+            if (dmalloc(&dst, 3 * W) != 0) { (void)hipFree(src); return -1; }
+            hipError_t he = hipMemcpyAsync(src, mine.data(), 3 * sizeof(float), hipMemcpyHostToDevice, s);
+            const int rc = he == hipSuccess ? g_rccl.AllGather(src, dst, 3, /*ncclFloat32*/ 7, m->comm, s) : 0;
+            if (he == hipSuccess) he = hipMemcpyAsync(all3.data(), dst, 3 * W * sizeof(float), hipMemcpyDeviceToHost, s);
+            if (he == hipSuccess) he = hipStreamSynchronize(s);
+            (void)hipFree(src); (void)hipFree(dst);
+            if (rc != 0) SERT_FAIL("ncclAllGather of the batch counts failed");
+            SERT_HIP(he);
+        }
+        for (size_t q = 0; q < W; ++q) {
+            const int64_t nbq = (int64_t)all3[3 * q] + ((int64_t)all3[3 * q + 1] << 24);
+            if (nbq != nb || (nb > 0 && (int64_t)all3[3 * q + 2] != bit_words))
+                SERT_FAIL("data parallel: rank " + std::to_string(q) + " uploaded " + std::to_string(nbq) + " complete batches, rank " +
+                          std::to_string(m->rank) + " " + std::to_string(nb) + " -- every rank must upload the same number of rows "
+                          "(sert_amd.distributed.shard_rows)");      // (raised on EVERY rank: they all see the same table)
+        }
+    }
+    if (nb == 0) return 0;
+    m->xr = new RowExchangeLists();
     const int64_t group = std::max<int64_t>(1, std::min<int64_t>(nb, ((int64_t)64 << 20) / (bit_words * 4 * (int64_t)W)));
     std::vector<uint32_t> all;
-    hipStream_t s = m->stream;
     for (int64_t b0 = 0; b0 < nb; b0 += group) {
         const int64_t gb = std::min(group, nb - b0);
         const size_t cnt = (size_t)(gb * bit_words);
@@ -687,10 +740,10 @@ static int xr_build_lists(sert_model* m, const std::vector<uint32_t>& bits, int6
         } else {
             float *src = nullptr, *dst = nullptr;
             SERT_TRY(dmalloc(&src, cnt));
-            SERT_TRY(dmalloc(&dst, cnt * W));
-            SERT_HIP(hipMemcpyAsync(src, mine, cnt * 4, hipMemcpyHostToDevice, s));
-            const int rc = g_rccl.AllGather(src, dst, cnt, /*ncclFloat32: bits only*/ 7, m->comm, s);
-            hipError_t he = hipMemcpyAsync(all.data(), dst, W * cnt * 4, hipMemcpyDeviceToHost, s);
+            if (dmalloc(&dst, cnt * W) != 0) { (void)hipFree(src); return -1; }
+            hipError_t he = hipMemcpyAsync(src, mine, cnt * 4, hipMemcpyHostToDevice, s);
+            const int rc = he == hipSuccess ? g_rccl.AllGather(src, dst, cnt, /*ncclFloat32: bits only*/ 7, m->comm, s) : 0;
+            if (he == hipSuccess) he = hipMemcpyAsync(all.data(), dst, W * cnt * 4, hipMemcpyDeviceToHost, s);
             if (he == hipSuccess) he = hipStreamSynchronize(s);
             (void)hipFree(src); (void)hipFree(dst);
             if (rc != 0) SERT_FAIL("ncclAllGather of the touched-row bitmaps failed");
@@ -2418,7 +2471,7 @@ static int create_resources(sert_model* m) {
         SERT_TRY(dzalloc(&m->sq_scratch, (size_t)8 * kOptBlocks, s));
         SERT_TRY(dzalloc(&m->d_loss, (size_t)4, s));
         if (vs) {
-            SERT_TRY(dzalloc(&m->tail_blk, (size_t)2 * (cdiv((int64_t)(m->n_w + m->n_b), 64) + 1), s));
+            SERT_TRY(dzalloc(&m->tail_blk, (size_t)4 * (cdiv((int64_t)(m->n_w + m->n_b), 64) + 1), s));
         }
     }
     // pinned, device-mapped: [loss, data, reg, -, seq]; the step's last kernel writes it directly

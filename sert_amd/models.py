@@ -379,7 +379,16 @@ class ModelBase(ModelInterface):
 
     def get_state(self):
         """[predict_fn, R_w(, R_e)] -- what bin/train.py pickles behind its namespace
-        (models.py:670-680)."""
+        (models.py:670-680).
+
+        DATA PARALLEL: COLLECTIVE once a training step has run.  With the word table owned by rows
+        (the default exchange) a rank's copy of R_w is current only where it owns or has fetched, so
+        reading it -- here, get_representations(), predict_fn of the loglinear model, train_error /
+        validation_error, get_optimizer_state(), close() -- first all-gathers the owned slabs
+        (sert_get_tensor(SERT_T_RW) / sert_eval_batches / sert_predict_tokens / sert_comm_destroy).
+        EVERY rank must make the call, in the same order (sert_amd.training does); a call from rank 0
+        alone -- a checkpoint hook, a callback -- blocks until the peers make it too (host transport:
+        RuntimeError 'rendezvous timed out' after the FileStore deadline; RCCL: no deadline)."""
         tables = self.get_representations()
         if not isinstance(tables, (tuple, list)):
             tables = (tables,)
@@ -404,6 +413,7 @@ class ModelBase(ModelInterface):
         self._engine.set_eval_draws(st['eval_draws'])
 
     def get_optimizer_state(self):
+        """Additive.  Data parallel: COLLECTIVE (the sharded moments are gathered) -- every rank calls it."""
         st = {'step': self._engine.get_step()}
         for name, which, shape in self._STATE_TENSORS:
             st[name] = self._engine.get_tensor(which, shape(self))
@@ -434,6 +444,8 @@ class LanguageModelBase(ModelBase):
         assert self.num_instance_features == self.window_size
 
     def get_representations(self):
+        """Host copy of R_w (models.py:797-801).  Data parallel: COLLECTIVE after a training step --
+        every rank must call it (see get_state)."""
         if self._engine is not None:
             return self._engine.get_tensor(
                 _capi.T_RW, (self.vocabulary_size, self.representation_size))
@@ -639,6 +651,8 @@ class VectorSpaceLanguageModelBase(LanguageModelBase):
         self.num_negative_samples = num_negative_samples
 
     def get_representations(self):
+        """Host copies of (R_w, R_e) (models.py:943-945).  Data parallel: COLLECTIVE after a training
+        step -- every rank must call it (see ModelBase.get_state)."""
         return (self._engine.get_tensor(
                     _capi.T_RW,
                     (self.vocabulary_size, self.representation_size)),

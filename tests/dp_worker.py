@@ -39,6 +39,51 @@ def run_c2(kind):
     out['exchange'] = np.str_(info['exchange_kind'] if info else 'none')
     out['comm_bytes_per_step'] = np.float64(info['comm_bytes_per_step'] if info else 0.0)
     out['zero1_bytes_per_step'] = np.float64(info['zero1_comm_bytes_per_step'] if info else 0.0)
+    out['transport'] = np.str_(info['transport'] if info else 'none')
+    out['rccl_ranks'] = np.int64(info['rccl_ranks'] if info else 0)
+    out['rccl_lib'] = np.str_(loaded_rccl())
+    return out
+
+
+def loaded_rccl():
+    """Path of the librccl mapping of this process ('' if none): lets a test prove WHICH library served it."""
+    try:
+        with open('/proc/self/maps') as f:
+            libs = sorted(set(l.split()[-1] for l in f if 'librccl' in l))
+    except OSError:
+        return ''
+    return ';'.join(libs)
+
+
+def run_soak(steps=200):
+    """`steps` hinted training steps over six batches with an evaluation pass every 50 -- the steady-state
+    schedule of an epoch loop (parameters of the next batch fetched behind the owned rows' update, gradient rows
+    returned beside dW, the small all-reduce, the collective all-gather in front of every evaluation), long
+    enough for a lost event or a crossed collective to show as a hang or a drift."""
+    from sert_amd import models, _capi as C
+    from tests import util as U
+    B, n, z, Vw, Ve, d = 256, 4, 5, 3000, 40, 32
+    p = U.make_vs_problem(71, B * 6, n, z, Vw, Ve, d, d, zipf=True)
+    np.random.seed(5)
+    models.VectorSpaceLanguageModel.sampler_seed = 99
+    m = models.VectorSpaceLanguageModel(
+        batch_size=B, window_size=n, num_negative_samples=z, representations_init=p['Rw'],
+        entity_representations_init=p['Re'], regularization_lambda=0.01,
+        training_set=(p['X'], p['y'], p['w']), validation_set=(p['X'][:B * 2], p['y'][:B * 2]))
+    out, losses = {}, []
+    for s in range(steps):
+        m._engine.hint_next_batch((s + 1) % 6 if s + 1 < steps else None)
+        losses.append(m.train_fn(s % 6))
+        if s % 50 == 49:
+            losses.append(m.validation_error()[0])
+    out['losses'] = np.array(losses, dtype=np.float64)
+    for name, which in (('Rw', C.T_RW), ('Re', C.T_RE), ('W', C.T_W), ('b', C.T_B)):
+        out[name] = m._engine.get_tensor(which).copy()
+    info = m.comm_info()
+    out['exchange'] = np.str_(info['exchange_kind'] if info else 'none')
+    out['transport'] = np.str_(info['transport'] if info else 'none')
+    out['rccl_ranks'] = np.int64(info['rccl_ranks'] if info else 0)
+    out['rccl_lib'] = np.str_(loaded_rccl())
     return out
 
 
@@ -47,6 +92,8 @@ def run(kind):
     batch_size is the GLOBAL batch).  Returns a dict of numpy results."""
     if kind == 'c2':
         return run_c2(kind)
+    if kind == 'soak':
+        return run_soak()
     from sert_amd import models
     from tests import util as U
     B, n, z, Vw, Ve, d = 96, 3, 4, 200, 20, 16          # 96 rows: 2, 3 and 4 ranks
@@ -87,6 +134,9 @@ def run(kind):
     out['exchange'] = np.str_(info['exchange_kind'] if info else 'none')
     out['comm_world'] = np.int64(m._ctx.world_size)
     out['comm_bytes_per_step'] = np.float64(info['comm_bytes_per_step'] if info else 0.0)
+    out['transport'] = np.str_(info['transport'] if info else 'none')
+    out['rccl_ranks'] = np.int64(info['rccl_ranks'] if info else 0)
+    out['rccl_lib'] = np.str_(loaded_rccl())
     return out
 
 

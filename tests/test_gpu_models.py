@@ -581,7 +581,7 @@ def test_ranks_on_one_gpu_match_single_process(hip_lib, tmp_path, kind, launcher
     scalars = ('epoch1', 'epoch2', 'train_error', 'validation_error')
     for key in scalars:
         assert abs(float(two[key]) - float(one[key])) <= 2e-5 * abs(float(one[key])), key
-    for key in [k for k in one if k not in scalars and k not in ('exchange', 'comm_world', 'comm_bytes_per_step')]:
+    for key in [k for k in one if k not in scalars and k not in ('exchange', 'comm_world', 'comm_bytes_per_step', 'transport', 'rccl_ranks', 'rccl_lib')]:
         assert U.rel_err(two[key], one[key]) < 2e-5, key
     assert int(two['step']) == int(one['step'])
 
@@ -625,9 +625,23 @@ def test_bench_launches_its_own_ranks(hip_lib):
     lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
     assert len(lines) == 1
     rec = json.loads(lines[0])
-    assert rec['n_gpus'] == 2 and rec['scaling'] == 'weak' and rec['config']['global_batch'] == 8192
+    # the headline keeps the GLOBAL batch (strong scaling); the weak case is the sub-record
+    assert rec['n_gpus'] == 2 and rec['scaling'] == 'strong'
+    assert rec['config']['global_batch'] == 4096 and rec['config']['per_gpu_batch'] == 2048
     assert rec['value'] > 0 and np.isfinite(rec['last_loss'])
-    assert rec['strong_scaling']['global_batch'] == 4096 and rec['strong_scaling']['per_gpu_batch'] == 2048
+    assert rec['weak_scaling']['global_batch'] == 8192 and rec['weak_scaling']['per_gpu_batch'] == 4096
+    # two ranks on one device: no ceilings, and no fraction above 1 anywhere in the line
+    assert rec['memory_ceilings'] is None
+
+    def fracs(o):
+        if isinstance(o, dict):
+            for k, v in o.items():
+                if k.startswith('frac') and isinstance(v, (int, float)):
+                    yield k, v
+                else:
+                    for x in fracs(v):
+                        yield x
+    assert all(v <= 1.0 for _, v in fracs(rec)), [kv for kv in fracs(rec) if kv[1] > 1.0]
 
 
 def test_loglinear_distinct_word_path_is_deterministic_and_matches_per_token_path(hip_lib, tmp_path):

@@ -38,6 +38,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured achievable)
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 MFMA dense peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA DENSE peak (~2.5 PF; measured 2495)
 COMMITTED_PMC = 'profiles/r03v_vs_c2_pmc.json'
 
 
@@ -591,7 +592,99 @@ def cpu_baseline(B, n, Vw, Ve, dw, de, z, budget_s):
     return out
 
 
-def query_bench(_capi, Q=10000, V=100000, d=128, k=100, reps=3, cpu_budget=8.0, cpu=True):
+def query_kernel_trace(Q, V, d, k, timeout=240):
+    """Per-kernel average durations of the C5 scoring call: `rocprofv3 --kernel-trace` over this script's
+    --profile-query-inner loop (the scorer runs its chunks on two streams of its own, so in-process HIP events
+    would have to serialise them; the trace sees every launch as it really ran).  {kernel: {calls, avg_us}} or
+    (None, reason)."""
+    if shutil.which('rocprofv3') is None:
+        return None, 'rocprofv3 not found'
+    import re
+    import sqlite3
+    tmp = tempfile.mkdtemp(prefix='sert_qtrace_')
+    try:
+        cmd = ['rocprofv3', '--kernel-trace', '-d', tmp, '-o', 'q', '--', sys.executable, os.path.abspath(__file__),
+               '--profile-query-inner', '--query-shape', '%d,%d,%d,%d' % (Q, V, d, k)]
+        env = dict(os.environ, TMPDIR='/tmp')
+        for key in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+            env.pop(key, None)
+        r = subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout)
+        found = [os.path.join(dp, f) for dp, _, fs in os.walk(tmp) for f in fs if f.endswith('.db')]
+        if r.returncode != 0 or not found:
+            return None, 'rocprofv3 --kernel-trace failed (rc %d): %s' % (r.returncode, r.stderr.decode()[-300:])
+        db = sqlite3.connect(found[0])
+        out = {}
+        for name, calls, avg in db.execute('select name, count(*), avg(duration) from kernels group by name'):
+            name = re.sub(r'\[clone .*\]', '', name).replace('sert::', '').replace('void ', '').split('(')[0].strip()
+            out[name] = {'calls': int(calls), 'avg_us': avg / 1e3}
+        return out, 'rocprofv3 --kernel-trace over %d timed scoring calls' % QUERY_INNER_CALLS
+    except Exception as e:   # noqa: BLE001 -- best effort: the bench line must still appear
+        return None, 'kernel trace failed: %r' % (e,)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+QUERY_INNER_CALLS = 4
+
+
+def query_inner(_capi, Q, V, d, k):
+    """The workload of query_kernel_trace: the C5 scoring call, QUERY_INNER_CALLS times after one warm-up."""
+    rng = np.random.RandomState(7)
+    E = rng.randn(V, d).astype(np.float32)
+    P = np.tanh(rng.randn(Q, d)).astype(np.float32)
+    sc = _capi.Scorer(E)
+    Pq = sc.query_buffer(Q)
+    np.copyto(Pq, P)
+    for _ in range(1 + QUERY_INNER_CALLS):
+        sc.topk(Pq, k)
+    sc.close()
+
+
+def query_roofline(_capi, trace, Q, V, d, k, device=0):
+    """`roofline` of the query record.  The dominant kernel of the call is the bf16 filter GEMM
+    (score_filter_bf16<false>: every query against every entity on v_mfma_f32_32x32x16_bf16; its flops are the
+    2 Q V d' of the padded bf16 operands, d' = d rounded up to 64), priced against the bf16 DENSE MFMA peak; the
+    selection kernel (topk_from_groups_rescore) fetches ~(candidates with s >= s_k - 2 delta) entity rows of
+    4 d bytes per query for the exact fp32 re-scoring and is priced against the measured row-fetch ceiling of a
+    table of the entity table's size."""
+    kp = (d + 63) // 64 * 64
+    filt = [(n, v) for n, v in trace.items() if n.startswith('score_filter_bf16<false>') or n.startswith('score_filter_bf16<0>')]
+    if not filt:
+        filt = [(n, v) for n, v in trace.items() if n.startswith('score_filter_bf16')]
+        filt = sorted(filt, key=lambda nv: -nv[1]['avg_us'])[:1]
+    if not filt:
+        return None
+    name, rec = filt[0]
+    launches_per_call = rec['calls'] / float(1 + QUERY_INNER_CALLS)
+    flops = 2.0 * Q * V * kp / launches_per_call
+    ach = flops / (rec['avg_us'] * 1e-6) / 1e12
+    out = {'kernel': 'filter GEMM', 'hip_kernel': name, 'bound': 'mfma', 'achieved': round(ach, 1), 'peak': MFMA_BF16_PEAK_TFLOPS,
+           'unit': 'TFLOP/s', 'frac': round(ach / MFMA_BF16_PEAK_TFLOPS, 4), 'avg_us': round(rec['avg_us'], 2),
+           'launches_per_call': launches_per_call, 'algorithmic_flops_per_launch': flops, 'traffic': None,
+           'peak_is': 'bf16 MFMA dense peak (the filter runs on the bf16 matrix pipe; reported scores are exact fp32)',
+           'note': 'the kernel is bound by its compare / ballot / rank epilogue and by resident waves, not by the matrix '
+                   'pipe (DESIGN.md section 3, knock-outs): 145 us of a 260 us chunk are loads + LDS + MFMA'}
+    sel = [(n, v) for n, v in trace.items() if n.startswith('topk_from_groups_rescore')]
+    if sel:
+        n2, r2 = sel[0]
+        ceil = None
+        try:
+            rb = 4 * d
+            us = _capi.bench_memory(_capi.MEMBENCH_GATHER, 65536 * rb, table_bytes=V * rb, row_bytes=rb, window=10, iters=10, device=device)
+            ceil = 65536 * rb * 10 / (us * 1e-6) / 1e9
+        except Exception:   # noqa: BLE001
+            pass
+        out['rescoring'] = {'hip_kernel': n2, 'avg_us': round(r2['avg_us'], 2), 'bound': 'cache',
+                            'row_fetch_ceiling_GBps': round(ceil, 1) if ceil else None,
+                            'ceiling_is': 'vs_gather_mean over uniformly random %d-byte rows of a %.0f MB table (sert_bench_memory)' % (4 * d, V * 4.0 * d / 1e6),
+                            'note': 'reads its sparse candidate lists (~1/3 of the 32-byte groups occupied) and re-scores '
+                                    '~180 of ~600 candidates per query with exact fp32 dot products'}
+    out['kernels'] = {n: {'calls_per_scoring_call': v['calls'] / float(1 + QUERY_INNER_CALLS), 'avg_us': round(v['avg_us'], 2)}
+                      for n, v in sorted(trace.items(), key=lambda nv: -nv[1]['avg_us'] * nv[1]['calls'])}
+    return out
+
+
+def query_bench(_capi, Q=10000, V=100000, d=128, k=100, reps=3, cpu_budget=8.0, cpu=True, trace=True):
     """BASELINE configs[4]: Q synthetic query projections x V_e entities, batched
     cosine scoring + top-k (bin/query.py:239-370).  queries/s includes the H2D of
     the projections and the D2H of the (Q,k) results; the entity table is
@@ -619,7 +712,14 @@ def query_bench(_capi, Q=10000, V=100000, d=128, k=100, reps=3, cpu_budget=8.0, 
            'ms_total_pageable_query_array': 1000 * pageable,
            # 2 Q V d / time: what a plain scores-GEMM would have to sustain (the filter GEMM runs on
            # the bf16 matrix pipe, the reported scores are exact fp32 -- kernels_score_bf16.h)
-           'equiv_gemm_tflops': 2.0 * Q * V * d / best / 1e12}
+           'equiv_gemm_tflops': 2.0 * Q * V * d / best / 1e12,
+           'equiv_gemm_note': 'end-to-end rate of the whole call (H2D + kernels + D2H) expressed as a plain scores GEMM; it '
+                              'exceeds the fp32 MFMA peak because the filter runs in bf16 -- the fraction of a peak is in '
+                              '`roofline` (bf16 dense MFMA peak), not here'}
+    if trace:
+        tr, src = query_kernel_trace(Q, V, d, k)
+        out['roofline'] = query_roofline(_capi, tr, Q, V, d, k) if tr else None
+        out['roofline_source'] = src
     if cpu:
         from oracle import sert_oracle as O
         t0 = time.perf_counter()
@@ -752,6 +852,8 @@ def main():
     ap.add_argument('--no-live-pmc', action='store_true')
     ap.add_argument('--no-weak-extra', action='store_true', help='N > 1: skip the weak-scaling sub-record')
     ap.add_argument('--profile-inner', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--profile-query-inner', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--query-shape', default='10000,100000,128,100', help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -769,6 +871,10 @@ def main():
     _build.build()
     from sert_amd import distributed as dist
     from sert_amd import models, _capi
+
+    if args.profile_query_inner:     # the workload of query_kernel_trace (rocprofv3 --kernel-trace), nothing else
+        query_inner(_capi, *[int(x) for x in args.query_shape.split(',')])
+        return
 
     ctx = dist.init_from_env()
     if ctx.world_size != args.gpus:
@@ -971,7 +1077,7 @@ def main():
         out['c4'] = c4_record(models, _capi, dist, max(5, min(10, args.steps)), live)
 
     if ctx.rank == 0 and N == 1 and not args.no_query_extra:
-        out['query'] = query_bench(_capi, cpu=not args.no_cpu_baseline)
+        out['query'] = query_bench(_capi, cpu=not args.no_cpu_baseline, trace=live)
 
     if ctx.rank == 0 and N == 1 and not args.no_cpu_baseline and kind == 'vectorspace':
         out['cpu_baseline'] = cpu_baseline(Bl, n, Vw, Ve, d, de, z, args.cpu_budget)

@@ -178,6 +178,48 @@ def test_large_scoring_properties(hip_lib):
         assert len(set(idx[q]) ^ set(order)) <= 2
 
 
+def test_full_c5_scoring_against_the_cpu_restatements(hip_lib):
+    """BASELINE configs[4] at FULL size through the product's scorer object (the one VectorSpaceCallback holds,
+    bin/query.py:239-370): 10 000 query projections x 100 000 entities, d_e = 128, top 100 in one call -- two
+    5 000-row chunks on two streams, bf16 prefilter + exact fp32 re-scoring.  Checked on 640 queries spread over
+    both chunks (the first 256, 128 around the chunk boundary, the last 256) against (a) oracle/sert_cpu.c, the
+    multithreaded C restatement bench.py times beside it -- fp32 cosines, ties to the lowest index -- and (b) float64
+    cosines: scores (cos + 1) / 2 (query.py:352-357) within 1e-6, the ranked list identical except where two
+    neighbours' float64 scores are closer than 1e-6; all 10 000 rows: sorted, in range."""
+    from oracle import cpu_baseline as CB
+    rng = np.random.RandomState(7)
+    Q, V, d, k = 10000, 100000, 128, 100
+    E = rng.randn(V, d).astype(np.float32)
+    Pj = np.tanh(rng.randn(Q, d)).astype(np.float32)
+    sc = C.Scorer(E)
+    idx, val = sc.topk(Pj, k)
+    idx, val = idx.copy(), val.copy()
+    sc.close()
+    assert idx.shape == (Q, k) and np.all(np.diff(val, axis=1) <= 0)
+    assert val.min() >= 0.0 and val.max() <= 1.0 + 1e-6
+    rows = np.r_[0:256, 4936:5064, Q - 256:Q]
+    En = E.astype(np.float64)
+    En /= np.linalg.norm(En, axis=1, keepdims=True)
+    Pn = Pj[rows].astype(np.float64)
+    Pn /= np.linalg.norm(Pn, axis=1, keepdims=True)
+    S = (Pn @ En.T + 1.0) / 2.0                                  # (640, V) float64
+    ci = CB.score_topk(E, Pj[rows], k)
+    swaps = 0
+    for j, q in enumerate(rows):
+        ref = S[j]
+        got = idx[q]
+        assert np.abs(val[q] - ref[got]).max() < 1e-6           # the reported scores are the exact ones
+        kth = np.partition(ref, V - k)[V - k]
+        assert ref[got].min() >= kth - 1e-6                      # nothing outside the true top k (up to a tie)
+        order = np.argsort(-ref, kind='stable')[:k]
+        for a, b in ((got, order), (ci[j], order)):              # the HIP path and the C restatement, each vs float64
+            diff = np.nonzero(a != b)[0]
+            swaps += len(diff) if a is got else 0
+            for pos in diff:                                     # a disagreement must be a near-tie in float64
+                assert abs(ref[a[pos]] - ref[b[pos]]) < 1e-6, (q, pos)
+    assert swaps <= 0.001 * len(rows) * k                        # and they are rare: < 0.1 % of the positions
+
+
 def test_c2_sized_training_is_deterministic_and_learns(hip_lib):
     """BASELINE configs[1] full size: two identical runs are BIT-identical (no
     atomics anywhere on the path) and the loss goes down."""

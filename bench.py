@@ -322,6 +322,15 @@ def kernel_table(timings, work, traffic=None):
         if kind == 'stream' and counted is not None and counted < 0.7 * wk['alg']:
             kind = 'rows'     # (served by the caches: price the bytes it asks for as row fetches)
             wk = dict(wk, fetch=wk['alg'], row_bytes=512, table_bytes=0, resident=None)
+        if kind == 'stream' and wk['alg'] / t / 1e9 > HBM_PEAK_GBS:
+            # a "stream" that outruns the HBM peak is not coming from HBM (a small tensor that lives in L2 / the
+            # Infinity Cache from one step to the next): no fraction of the HBM peak is taken
+            kernels[name] = dict(us=round(us, 2), bound='cache', achieved=round(wk['alg'] / t / 1e9, 1), unit='GB/s', frac=None,
+                                 algorithmic_bytes=wk['alg'],
+                                 served_from='L2 / Infinity Cache (the algorithmic rate exceeds the HBM peak: the tensor is cache-resident)')
+            if counted is not None:
+                kernels[name]['hbm_bytes_pmc'] = counted
+            continue
         if kind == 'stream':
             ach = wk['alg'] / t / 1e9
             rec = dict(us=round(us, 2), bound='hbm', achieved=round(ach, 1), unit='GB/s', frac=round(ach / HBM_PEAK_GBS, 4),
@@ -614,9 +623,23 @@ def query_kernel_trace(Q, V, d, k, timeout=240):
             return None, 'rocprofv3 --kernel-trace failed (rc %d): %s' % (r.returncode, r.stderr.decode()[-300:])
         db = sqlite3.connect(found[0])
         out = {}
-        for name, calls, avg in db.execute('select name, count(*), avg(duration) from kernels group by name'):
+        spans = {}
+        for name, st, en in db.execute('select name, start, end from kernels order by start'):
             name = re.sub(r'\[clone .*\]', '', name).replace('sert::', '').replace('void ', '').split('(')[0].strip()
-            out[name] = {'calls': int(calls), 'avg_us': avg / 1e3}
+            spans.setdefault(name, []).append((st, en))
+        for name, iv in spans.items():
+            # the scorer runs its query chunks on two streams: launches of one kernel overlap.  avg_us = per launch as
+            # traced (stretched by the neighbour); busy_us = the UNION of the launches' intervals, i.e. the time
+            # during which at least one launch of this kernel was running
+            busy, cur_s, cur_e = 0, iv[0][0], iv[0][1]
+            for st, en in iv[1:]:
+                if st > cur_e:
+                    busy += cur_e - cur_s
+                    cur_s, cur_e = st, en
+                else:
+                    cur_e = max(cur_e, en)
+            busy += cur_e - cur_s
+            out[name] = {'calls': len(iv), 'avg_us': sum(e - s_ for s_, e in iv) / len(iv) / 1e3, 'busy_us': busy / 1e3}
         return out, 'rocprofv3 --kernel-trace over %d timed scoring calls' % QUERY_INNER_CALLS
     except Exception as e:   # noqa: BLE001 -- best effort: the bench line must still appear
         return None, 'kernel trace failed: %r' % (e,)
@@ -657,9 +680,13 @@ def query_roofline(_capi, trace, Q, V, d, k, device=0):
     name, rec = filt[0]
     launches_per_call = rec['calls'] / float(1 + QUERY_INNER_CALLS)
     flops = 2.0 * Q * V * kp / launches_per_call
-    ach = flops / (rec['avg_us'] * 1e-6) / 1e12
+    # the launches of one call overlap on the scorer's two streams: the rate is taken over the time during which
+    # the kernel was running at all (union of its launches), per scoring call
+    busy_per_call_us = rec['busy_us'] / float(1 + QUERY_INNER_CALLS)
+    ach = 2.0 * Q * V * kp / (busy_per_call_us * 1e-6) / 1e12
     out = {'kernel': 'filter GEMM', 'hip_kernel': name, 'bound': 'mfma', 'achieved': round(ach, 1), 'peak': MFMA_BF16_PEAK_TFLOPS,
            'unit': 'TFLOP/s', 'frac': round(ach / MFMA_BF16_PEAK_TFLOPS, 4), 'avg_us': round(rec['avg_us'], 2),
+           'busy_us_per_call': round(busy_per_call_us, 1),
            'launches_per_call': launches_per_call, 'algorithmic_flops_per_launch': flops, 'traffic': None,
            'peak_is': 'bf16 MFMA dense peak (the filter runs on the bf16 matrix pipe; reported scores are exact fp32)',
            'note': 'the kernel is bound by its compare / ballot / rank epilogue and by resident waves, not by the matrix '
@@ -679,7 +706,8 @@ def query_roofline(_capi, trace, Q, V, d, k, device=0):
                             'ceiling_is': 'vs_gather_mean over uniformly random %d-byte rows of a %.0f MB table (sert_bench_memory)' % (4 * d, V * 4.0 * d / 1e6),
                             'note': 'reads its sparse candidate lists (~1/3 of the 32-byte groups occupied) and re-scores '
                                     '~180 of ~600 candidates per query with exact fp32 dot products'}
-    out['kernels'] = {n: {'calls_per_scoring_call': v['calls'] / float(1 + QUERY_INNER_CALLS), 'avg_us': round(v['avg_us'], 2)}
+    out['kernels'] = {n: {'calls_per_scoring_call': v['calls'] / float(1 + QUERY_INNER_CALLS), 'avg_us': round(v['avg_us'], 2),
+                          'busy_us_per_call': round(v['busy_us'] / float(1 + QUERY_INNER_CALLS), 1)}
                       for n, v in sorted(trace.items(), key=lambda nv: -nv[1]['avg_us'] * nv[1]['calls'])}
     return out
 

@@ -24,6 +24,15 @@ struct DenseSlots {
     int n;
     int slot[kHeavyMax];
 };
+// Row-grouped level 0 (word_index.h: row_groups): the items are stored as eight lists; workgroup b takes the
+// (b / 8)-th bundle of list b % 8 -- the dispatcher places workgroup b on XCD b % 8 (observed, MI355X_MICROARCH.md;
+// a speed assumption only: any placement gives the same sums), so all fetches of a row range's slice of src come
+// from ONE XCD's L2.  The grid is 8 x the longest list's bundle count; on = 0: items[blockIdx.x * IPB + sub].
+struct XcdLists {
+    int on;
+    int off[8];
+    int cnt[8];
+};
 
 template <int LPI, bool DST_SLOT = false, bool LL_FINAL = false, bool SKIP_DENSE = false>
 __global__ __launch_bounds__(256) void segsum_rows(const float* __restrict__ src,
@@ -36,10 +45,16 @@ __global__ __launch_bounds__(256) void segsum_rows(const float* __restrict__ src
                                                    int rdiv = 1,
                                                    const float* __restrict__ logp = nullptr,
                                                    const float* __restrict__ rsum = nullptr,
-                                                   const DenseSlots dense = DenseSlots()) {
+                                                   const DenseSlots dense = DenseSlots(),
+                                                   const XcdLists xl = XcdLists()) {
     constexpr int IPB = 256 / LPI;  // items per block
     const int sub = threadIdx.x / LPI, l = threadIdx.x % LPI;
-    const int item = blockIdx.x * IPB + sub;
+    int item = blockIdx.x * IPB + sub;
+    if (xl.on) {
+        const int x = blockIdx.x & 7, k = (blockIdx.x >> 3) * IPB + sub;
+        if (k >= xl.cnt[x]) return;
+        item = xl.off[x] + k;
+    }
     if (item >= nitems) return;
     const int4 it = items[item];
     if (SKIP_DENSE) {

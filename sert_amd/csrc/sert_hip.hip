@@ -303,15 +303,24 @@ static int word_grad_segsum(sert_model* m, const DataSplit& ds, int64_t batch_in
             // 3 x 32 at 78 % instead of 2 x 64 at 59 %: 147 -> 143 us at C4; the sums do not depend on it)
             const int ch = d / 4;
             const bool seg32y = ch > 64 && ch * (64 * cdiv(ch, 64)) > ch * (32 * cdiv(ch, 32));
+            // row-grouped level 0: eight item lists, one per XCD (kernels_seg.h: XcdLists)
+            XcdLists xl = XcdLists();
+            int longest = 0;
+            if (l == 0 && bx.row_groups > 1) {
+                xl.on = 1;
+                for (int x = 0; x < 8; ++x) { xl.off[x] = bx.xcd_off[x]; xl.cnt[x] = bx.xcd_cnt[x]; longest = std::max(longest, bx.xcd_cnt[x]); }
+            }
+            const int ipb = (d / 4 <= 32 || seg32y) ? 8 : 4;
+            const int gx = xl.on ? 8 * cdiv(longest, ipb) : cdiv(nitems, ipb);
             if (d / 4 <= 32)
-                hipLaunchKernelGGL((segsum_rows<32>), dim3(cdiv(nitems, 8)), dim3(256), 0, m->stream,
-                                   in, rows, items, nitems, m->g_rw, pout, d, divisor, touched);
+                hipLaunchKernelGGL((segsum_rows<32>), dim3(gx), dim3(256), 0, m->stream,
+                                   in, rows, items, nitems, m->g_rw, pout, d, divisor, touched, 1, nullptr, nullptr, DenseSlots(), xl);
             else if (seg32y)
-                hipLaunchKernelGGL((segsum_rows<32>), dim3(cdiv(nitems, 8), cdiv(d / 4, 32)), dim3(256), 0, m->stream,
-                                   in, rows, items, nitems, m->g_rw, pout, d, divisor, touched);
+                hipLaunchKernelGGL((segsum_rows<32>), dim3(gx, cdiv(d / 4, 32)), dim3(256), 0, m->stream,
+                                   in, rows, items, nitems, m->g_rw, pout, d, divisor, touched, 1, nullptr, nullptr, DenseSlots(), xl);
             else   // rows wider than 64 float4 chunks (d = 300: 75): the rest goes to further column groups
-                hipLaunchKernelGGL((segsum_rows<64>), dim3(cdiv(nitems, 4), cdiv(d / 4, 64)), dim3(256), 0, m->stream,
-                                   in, rows, items, nitems, m->g_rw, pout, d, divisor, touched);
+                hipLaunchKernelGGL((segsum_rows<64>), dim3(gx, cdiv(d / 4, 64)), dim3(256), 0, m->stream,
+                                   in, rows, items, nitems, m->g_rw, pout, d, divisor, touched, 1, nullptr, nullptr, DenseSlots(), xl);
         } else {
             hipLaunchKernelGGL((segsum_rows_scalar<false>), dim3(cdiv(nitems, 4), cdiv(d, 64)), dim3(256), 0, m->stream, in,
                                rows, items, nitems, m->g_rw, pout, d, divisor, touched);
@@ -2712,10 +2721,20 @@ int sert_upload_dataset(sert_model* m, int split, const void* x, const int32_t* 
                                  (is_vs(m) ? (m->cfg.word_dim % 4 == 0 && m->cfg.word_dim <= 512 && getenv("SERT_DENSE_HEAVY") != nullptr &&
                                               atoi(getenv("SERT_DENSE_HEAVY")) != 0)
                                            : (m->cfg.num_entities % 4 == 0));
+        // vectorspace word gradient: when the batch's dh (B x d_w floats) is larger than an XCD's 4 MB L2, level 0 of
+        // the tree is cut into row ranges of <= ~2.5 MB that are summed XCD by XCD (word_index.h: row_groups).
+        // SERT_SEG_GROUPS=k forces the count (1 = the ungrouped tree).
+        int row_groups = 1;
+        if (is_vs(m) && m->cfg.word_dim % 4 == 0) {
+            const double dh_bytes = 4.0 * (double)B * (double)m->cfg.word_dim;
+            if (dh_bytes > 6.0e6) row_groups = 8 * (int)std::ceil(dh_bytes / (8.0 * 2.6e6));
+            if (const char* e = getenv("SERT_SEG_GROUPS")) row_groups = std::max(1, atoi(e));
+            row_groups = std::min(row_groups, std::max(1, B / 64));
+        }
         bool ids_ok = true;
         SERT_ID_DISPATCH(m->cfg.id_bytes,
                          ids_ok = build_word_index<IdT>((const IdT*)x, nb, B, n, m->cfg.vocab_size, row_is_pos, wi,
-                                                        /*want_slots=*/!is_vs(m), /*dense_heavy=*/dense_heavy));
+                                                        /*want_slots=*/!is_vs(m), /*dense_heavy=*/dense_heavy, row_groups));
         if (!ids_ok) SERT_FAIL("token id >= vocab_size in x");
         if (!is_vs(m) && !wi.slots.empty()) {
             const size_t V = (size_t)m->cfg.num_entities;

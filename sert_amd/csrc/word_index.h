@@ -59,6 +59,11 @@ struct BatchIndex {
     int32_t dense_cnt = 0;
     int32_t dense_word[kHeavyMax] = {};
     int32_t dense_slot[kHeavyMax] = {};   // (loglinear) their ranks among the batch's distinct words
+    // row-grouped level 0 (build_word_index: row_groups > 1): the level-0 items are stored per XCD list -- list x
+    // holds the items of the row groups x, x + 8, x + 16, ... in that order -- at item_off[0] + xcd_off[x]
+    int32_t row_groups = 1;
+    int32_t xcd_off[8] = {};
+    int32_t xcd_cnt[8] = {};
 };
 
 struct WordIndex {
@@ -86,10 +91,23 @@ struct WordIndex {
 
 // ids: (num_batches*B*n) token ids of the complete batches, IdT wide.
 // row_of_pos: entry value = pos / n (vectorspace: row of dh) or pos (loglinear: row of dG).
+//
+// row_groups > 1 (vectorspace word gradient, batches whose source matrix dh does not fit one XCD's L2): level 0
+// is cut by SOURCE ROW as well as by word.  The batch rows form `row_groups` equal ranges; a level-0 item is
+// the (<= kSegChunk) occurrences of one word inside ONE range, and the items of range g are handed to workgroups
+// that run on XCD g % 8 (kernels_seg.h: XcdLists), so that a range's slice of dh (<= ~2.5 MB) is fetched into that
+// XCD's L2 once and every further fetch of its rows is an L2 hit -- instead of 655 k row fetches spread uniformly
+// over a 33.5 MB matrix that no L2 holds (C2: 264 MB crossed the fabric for a job whose compulsory traffic is
+// 56 MB).  A word whose occurrences all sit in one item is stored finally by level 0; every other word's items
+// write partial rows, numbered word-major (range order, then chunk order, inside a word), which the upper levels
+// sum in that order: a fixed association, as before -- only a different one.
 template <typename IdT>
 bool build_word_index(const IdT* ids, int64_t num_batches, int B, int n, int vocab,
-                      bool row_is_pos, WordIndex& out, bool want_slots = false, bool dense_heavy = false) {
+                      bool row_is_pos, WordIndex& out, bool want_slots = false, bool dense_heavy = false,
+                      int row_groups = 1) {
     const int64_t T = (int64_t)B * n;
+    if (want_slots || row_is_pos || row_groups < 1) row_groups = 1;
+    const int rows_per_group = (B + row_groups - 1) / row_groups;
     // vectorspace (rows = batch rows): the heavy words LEAVE the tree.  loglinear (want_slots: the tree
     // also carries per-position scalars and, in the per-token cross-check mode, the word gradient): they
     // stay in it, FLAGGED -- chunk items get slot = -1, and the V_e-wide per-word sums skip every item of
@@ -191,14 +209,87 @@ bool build_word_index(const IdT* ids, int64_t num_batches, int B, int n, int voc
         struct Seg { int32_t begin, end, word, slot; bool dense; };
         std::vector<Seg> segs;
         segs.reserve(touched.size());
+        int level = 0;
+        int64_t part_base = 0;
+        bx.row_groups = 1;
+        if (row_groups > 1) {
+            // ---- row-grouped level 0 (see above) ----
+            struct GSeg { int32_t begin, end, t; };                       // entries [begin, end) of the group's own list
+            std::vector<std::vector<int32_t>> grows((size_t)row_groups);
+            std::vector<std::vector<GSeg>> gsegs((size_t)row_groups);
+            std::vector<int32_t> nitems_of(touched.size(), 0);            // level-0 items per word
+            for (size_t t = 0; t < touched.size(); ++t) {
+                const bool dense = bx.dense_cnt > 0 && heavy_slot[(size_t)touched[t]] >= 0;
+                if (dense) continue;                                       // summed densely, not by the tree
+                int32_t e = start[t];
+                while (e < start[t + 1]) {                                 // (a word's rows ascend: so do its groups)
+                    const int g = rows[e] / rows_per_group;
+                    std::vector<int32_t>& gr = grows[(size_t)g];
+                    const int32_t b0 = (int32_t)gr.size();
+                    while (e < start[t + 1] && rows[e] / rows_per_group == g) gr.push_back(rows[e++]);
+                    gsegs[(size_t)g].push_back({b0, (int32_t)gr.size(), (int32_t)t});
+                    nitems_of[t] += ((int32_t)gr.size() - b0 + kSegChunk - 1) / kSegChunk;
+                }
+            }
+            for (int h = 0; h < bx.dense_cnt; ++h) heavy_slot[(size_t)bx.dense_word[h]] = (int8_t)-1;
+            // partial rows of the words with more than one item, word-major
+            std::vector<int32_t> pbase(touched.size(), -1);
+            int32_t nparts = 0;
+            for (size_t t = 0; t < touched.size(); ++t)
+                if (nitems_of[t] > 1) {
+                    pbase[t] = nparts;
+                    segs.push_back({nparts, nparts + nitems_of[t], touched[t], (int32_t)t, false});   // level 1's input
+                    nparts += nitems_of[t];
+                }
+            // the entries, group after group (a dense word's entries are simply absent)
+            std::vector<int32_t> gbase((size_t)row_groups, 0);
+            int32_t acc_e = 0;
+            for (int g = 0; g < row_groups; ++g) {
+                gbase[(size_t)g] = acc_e;
+                std::copy(grows[(size_t)g].begin(), grows[(size_t)g].end(), rows + acc_e);
+                acc_e += (int32_t)grows[(size_t)g].size();
+            }
+            // the items, XCD list after XCD list
+            bx.item_off[0] = (int64_t)out.items.size();
+            bx.part_off[0] = 0;
+            std::vector<int32_t> cursor(touched.size(), 0);               // partial rows a word has handed out so far
+            // (a word's partial rows must be numbered in GROUP order: number them in a first sweep over the groups)
+            std::vector<std::vector<int32_t>> first_part((size_t)row_groups);
+            for (int g = 0; g < row_groups; ++g) {
+                first_part[(size_t)g].resize(gsegs[(size_t)g].size());
+                for (size_t k = 0; k < gsegs[(size_t)g].size(); ++k) {
+                    const GSeg& sg = gsegs[(size_t)g][k];
+                    first_part[(size_t)g][k] = cursor[(size_t)sg.t];
+                    cursor[(size_t)sg.t] += (sg.end - sg.begin + kSegChunk - 1) / kSegChunk;
+                }
+            }
+            for (int x = 0; x < 8; ++x) {
+                bx.xcd_off[x] = (int32_t)((int64_t)out.items.size() - bx.item_off[0]);
+                for (int g = x; g < row_groups; g += 8)
+                    for (size_t k = 0; k < gsegs[(size_t)g].size(); ++k) {
+                        const GSeg& sg = gsegs[(size_t)g][k];
+                        int32_t q = 0;
+                        for (int32_t b = sg.begin; b < sg.end; b += kSegChunk, ++q) {
+                            const int32_t e2 = std::min(sg.end, b + kSegChunk);
+                            const int32_t dst = pbase[(size_t)sg.t] < 0 ? touched[(size_t)sg.t]
+                                                                       : -(pbase[(size_t)sg.t] + first_part[(size_t)g][k] + q + 1);
+                            out.items.push_back({gbase[(size_t)g] + b, gbase[(size_t)g] + e2, dst, (int32_t)sg.t});
+                        }
+                    }
+                bx.xcd_cnt[x] = (int32_t)((int64_t)out.items.size() - bx.item_off[0]) - bx.xcd_off[x];
+            }
+            bx.item_cnt[0] = (int32_t)((int64_t)out.items.size() - bx.item_off[0]);
+            bx.row_groups = row_groups;
+            part_base = nparts;
+            level = 1;
+        } else {
         for (size_t t = 0; t < touched.size(); ++t) {
             const bool dense = bx.dense_cnt > 0 && heavy_slot[(size_t)touched[t]] >= 0;
             if (dense && !flag_only) continue;   // summed densely, not by the tree
             segs.push_back({start[t], start[t + 1], touched[t], (int32_t)t, dense});
         }
         for (int h = 0; h < bx.dense_cnt; ++h) heavy_slot[(size_t)bx.dense_word[h]] = (int8_t)-1;
-        int level = 0;
-        int64_t part_base = 0;
+        }
         while (!segs.empty() && level < kSegMaxLevels) {
             bx.item_off[level] = (int64_t)out.items.size();
             bx.part_off[level] = part_base;

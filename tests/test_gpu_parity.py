@@ -93,6 +93,48 @@ def test_vectorspace_steps(hip_lib, dims, egrad, monkeypatch):
     eng.close()
 
 
+@pytest.mark.parametrize('dims,groups,dense', [
+    (dict(B=1000, n=10, Vw=3000, dw=128), 8, False),     # ragged row ranges (125 rows), one float4 chunk per lane
+    (dict(B=1000, n=10, Vw=3000, dw=128), 24, False),    # three ranges per XCD list, 42-row ranges, the last one short
+    (dict(B=777, n=4, Vw=60, dw=300), 16, False),        # d_w = 300: 32-lane groups x 3 column groups (2-D grid); few, heavy words
+    (dict(B=900, n=3, Vw=5000, dw=256), 8, False),       # d_w = 256: 64-lane groups, four items per workgroup
+    (dict(B=640, n=2, Vw=200, dw=16), 10, False),        # fewer row ranges than a multiple of eight
+    (dict(B=20000, n=5, Vw=300, dw=32), 16, True),       # with the dense heavy-word pass: those words are absent from the lists
+    (dict(B=9000, n=12, Vw=40, dw=64), 8, False),        # every word in every range, thousands of chunks: four tree levels
+])
+def test_word_gradient_row_grouped_tree(hip_lib, monkeypatch, dims, groups, dense):
+    """The word-table gradient through the ROW-GROUPED tree (word_index.h: row_groups; what batches whose dh
+    exceeds an XCD's L2 take -- C2, C4 -- forced here on small, ragged shapes): per (row range, word) items on
+    eight XCD lists, words with a single item stored finally by level 0, the others through word-major partial
+    rows and the upper levels.  Row by row against the float64 oracle, bit-identical run to run, and equal to the
+    ungrouped tree up to fp32 reassociation."""
+    monkeypatch.setenv('SERT_SEG_GROUPS', str(groups))
+    if dense:
+        monkeypatch.setenv('SERT_DENSE_HEAVY', '1')
+    B, n, Vw, dw = dims['B'], dims['n'], dims['Vw'], dims['dw']
+    z, Ve, de = 3, 20, 32
+    p = U.make_vs_problem(5, B, n, z, Vw, Ve, dw, de, zipf=True)
+    neg = p['rng'].randint(0, Ve, size=(B, z)).astype(np.int64)
+    o64 = O.VectorSpaceOracle(B, n, z, p['Rw'], p['Re'], p['W'], p['b'], 0.01, dtype=np.float64)
+    _, g64, _ = o64.loss_and_grads(p['X'], p['y'], p['w'], neg)
+    touched = np.unique(p['X'])
+    got = []
+    for run, g in enumerate((groups, groups, 1)):
+        monkeypatch.setenv('SERT_SEG_GROUPS', str(g))
+        eng = U.vs_engine(p, B, n, z, 0.01)
+        eng.upload_dataset(C.SPLIT_TRAIN, p['X'], y_int=p['y'], w=p['w'])
+        eng.train_batch(0, neg)
+        got.append(eng.get_tensor(C.T_GRAD_RW, (Vw, dw)).copy())
+        eng.close()
+    assert np.array_equal(got[0], got[1])
+    err, row = U.row_err(got[0], g64[1], rows=touched)
+    assert err < 2e-5, (err, row)
+    assert U.rel_err(got[0], got[2]) < 1e-5
+    untouched = np.setdiff1d(np.arange(Vw), touched)
+    if len(untouched):      # rows no token points to carry the L2 term only (keep_grads: dense, zeroed table)
+        assert U.rel_err(got[0][untouched], g64[1][untouched]) < 1e-6
+
+
 def test_vectorspace_known_answers(hip_lib):
     """W=0,b=0 => loss = (1+z) log 2; all tokens equal => row grad = sum dh/n * n."""
     B, n, z, Vw, Ve, dw, de = 64, 4, 5, 50, 9, 16, 16

@@ -2721,16 +2721,15 @@ int sert_upload_dataset(sert_model* m, int split, const void* x, const int32_t* 
                                  (is_vs(m) ? (m->cfg.word_dim % 4 == 0 && m->cfg.word_dim <= 512 && getenv("SERT_DENSE_HEAVY") != nullptr &&
                                               atoi(getenv("SERT_DENSE_HEAVY")) != 0)
                                            : (m->cfg.num_entities % 4 == 0));
-        // vectorspace word gradient: when the batch's dh (B x d_w floats) is larger than an XCD's 4 MB L2, level 0 of
-        // the tree is cut into row ranges of <= ~2.5 MB that are summed XCD by XCD (word_index.h: row_groups).
-        // SERT_SEG_GROUPS=k forces the count (1 = the ungrouped tree).
+        // Row-grouped level 0 of the vectorspace word-gradient tree (word_index.h: row_groups; kernels_seg.h: XcdLists):
+        // MEASURED AND NOT USED (round 4, profiles/r04_experiments.txt).  At C2 it does what it was built for -- the
+        // fabric traffic of the tree falls from 264 MB to 149 MB per step (level 0: 237 -> 98 MB) -- and level 0 takes
+        // the same 41.5 us while the upper level grows from 8 to 14 us (100 k items and 75 k partial rows instead of
+        // 52 k and 10 k): the step 0.2945 -> 0.3114 ms with 8 row ranges, 0.318 with 16, 0.325 with 32.
+        // SERT_SEG_GROUPS=k builds it (tests/test_gpu_parity.py::test_word_gradient_row_grouped_tree keeps it exact).
         int row_groups = 1;
-        if (is_vs(m) && m->cfg.word_dim % 4 == 0) {
-            const double dh_bytes = 4.0 * (double)B * (double)m->cfg.word_dim;
-            if (dh_bytes > 6.0e6) row_groups = 8 * (int)std::ceil(dh_bytes / (8.0 * 2.6e6));
-            if (const char* e = getenv("SERT_SEG_GROUPS")) row_groups = std::max(1, atoi(e));
-            row_groups = std::min(row_groups, std::max(1, B / 64));
-        }
+        if (is_vs(m) && m->cfg.word_dim % 4 == 0)
+            if (const char* e = getenv("SERT_SEG_GROUPS")) row_groups = std::min(std::max(1, atoi(e)), std::max(1, B / 64));
         bool ids_ok = true;
         SERT_ID_DISPATCH(m->cfg.id_bytes,
                          ids_ok = build_word_index<IdT>((const IdT*)x, nb, B, n, m->cfg.vocab_size, row_is_pos, wi,

@@ -27,6 +27,24 @@ inline void set_stop_event(hipEvent_t ev) { pending_stop_event() = ev; }
             hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);               \
     } while (0)
 
+// ---- environment switches -----------------------------------------------------------------------------------
+// The PRODUCT library reads fifteen documented variables, through knob(); each is exercised by a test
+// ("Environment"):
+//   SERT_DP_EXCHANGE  SERT_AR_CHUNKS  SERT_STREAMS  SERT_SIDE_HEAVY  SERT_RE_DEFER  SERT_SEG_GROUPS  SERT_NO_TOUCHED
+//   SERT_SCORE_MATERIALISE  SERT_SCORE_FP32  SERT_LL_NODEDUP  SERT_LL_DW_SIDE  SERT_DENSE_HEAVY  SERT_FS_TILE_ROWS
+//   SERT_EGRAD_SORT  SERT_ROCTX
+// Everything else -- A/B variants that lost, cross-check paths of earlier rounds, tuning sweeps, timing
+// knock-outs -- is read through variant_knob(), which is the environment only in a library built with
+// -DSERT_VARIANTS (tools/build_variant.sh variants -DSERT_VARIANTS; run the suite against it with SERT_LIB=...)
+// and a constant nullptr in the product build: those branches fold away.
+#include <stdlib.h>
+static inline const char* knob(const char* name) { return getenv(name); }
+#ifdef SERT_VARIANTS
+static inline const char* variant_knob(const char* name) { return getenv(name); }
+#else
+static inline const char* variant_knob(const char*) { return nullptr; }
+#endif
+
 namespace sert {
 
 constexpr int kWave = 64;  // CDNA wavefront width (hard-coded: warpSize folds to 64 on gfx950)

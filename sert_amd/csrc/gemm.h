@@ -778,11 +778,11 @@ inline void launch_gemm(hipStream_t s, const float* A, const float* B, float* C,
     GemmArgs g;
     g.rowmap = nullptr;
     // small problem (fewer than two 128x128 tiles per CU): 64x64 tiles, one workgroup each
-    static const bool no_small = getenv("SERT_GEMM_NO_SMALL") != nullptr;
+    static const bool no_small = variant_knob("SERT_GEMM_NO_SMALL") != nullptr;
     // below TWO 128x128 tiles per CU the 64x64 tiles win or draw (round 3 sweep at d = 128: 384 tiles
     // 30.5 -> 26.3 us, the loglinear dG with 347 tiles and K = 1000 162 -> 126 us; 256 and 512 tiles: equal):
     // a CU that gets a second big tile sets the time of the launch, four times as many small ones spread evenly
-    static const long long small_below = getenv("SERT_GEMM_SMALL_BELOW") ? atoll(getenv("SERT_GEMM_SMALL_BELOW")) : 512;   // tuning knob
+    static const long long small_below = variant_knob("SERT_GEMM_SMALL_BELOW") ? atoll(variant_knob("SERT_GEMM_SMALL_BELOW")) : 512;   // tuning knob
     // ... and AT two big tiles per CU for a short K (the C2 projections: 512 tiles, K = 128), since the 64x64
     // kernel loads its tiles through buffer loads: 31.3 -> 30.1 and 28.8 -> 27.7 us, C2 step 295.5 -> 292.2 us;
     // at K = 1000 the big tiles keep the boundary (186 against 197 us)
@@ -818,7 +818,7 @@ inline void launch_gemm(hipStream_t s, const float* A, const float* B, float* C,
                      (((uintptr_t)B) % 16 == 0) && (k_pieces || (TA && !TB)) &&
                      (TA ? (M % 4 == 0) : true) && (TB ? true : (N % 4 == 0));
     // N just above a multiple of 128 (d = 300): 160-column tiles pad less (gemm_f32_mfma_n160)
-    static const bool no_n160 = getenv("SERT_GEMM_NO_N160") != nullptr;   // cross-check knob
+    static const bool no_n160 = variant_knob("SERT_GEMM_NO_N160") != nullptr;   // cross-check knob
     if (!no_n160 && vec && EPI != EPI_FILTER && (long long)cdiv(N, GN2) * GN2 * 11 <= (long long)cdiv(N, GN) * GN * 10) {   // >= 10 % less padding
         g.tiles_n = cdiv(N, GN2);
         const long long total160 = (long long)g.tiles_m * g.tiles_n * splits;
@@ -829,7 +829,7 @@ inline void launch_gemm(hipStream_t s, const float* A, const float* B, float* C,
     const long long total = (long long)g.tiles_m * g.tiles_n * splits;
     // persistent: at most 2 workgroups per CU (256 CUs), each walks items w, w+grid, ...
     static const int max_grid = [] {
-        const char* e = getenv("SERT_GEMM_GRID");   // tuning knob (default: 2 per CU)
+        const char* e = variant_knob("SERT_GEMM_GRID");   // tuning knob (default: 2 per CU)
         const int v = e ? atoi(e) : 0;
         return v > 0 ? v : 256 * SERT_GEMM_WAVES;
     }();

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void vs_nce(const float* __restrict__ T,
     const float g = wi * inv_batch;
     float loss = 0.f;
     for (int j = 0; j <= z; ++j) {
-#ifdef KO_IDS
+#if defined(SERT_VARIANTS) && defined(KO_IDS)   // timing knock-out (wrong results), variants build only
         const int e = (i * 7 + j * 13) & 2047;
 #else
         const int e = (j == 0) ? y[i] : neg[(size_t)i * z + (j - 1)];
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void vs_nce(const float* __restrict__ T,
 #pragma unroll
         for (int q = 0; q < NCH; ++q) {
             const int c = l + 16 * q;
-#ifdef KO_ROWS
+#if defined(SERT_VARIANTS) && defined(KO_ROWS)   // timing knock-out (wrong results), variants build only
             er[q] = make_float4(1.f * e, 0.5f, 0.25f * j, 0.f);
 #else
             er[q] = (c < chunks) ? *reinterpret_cast<const float4*>(Re + (size_t)e * de + 4 * c)
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void vs_nce(const float* __restrict__ T,
             part += er[q].x * p[q].x + er[q].y * p[q].y + er[q].z * p[q].z + er[q].w * p[q].w;
         }
         const float u = row16_sum(part);
-#ifdef KO_MATH
+#if defined(SERT_VARIANTS) && defined(KO_MATH)   // timing knock-out (wrong results), variants build only
         const float sig = u * 0.01f + 0.5f;
         const float s = fminf(fmaxf(sig, SERT_CLIP_LO), SERT_CLIP_HI);
         loss -= s;
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void vs_nce(const float* __restrict__ T,
                 dp[q].x += du * er[q].x; dp[q].y += du * er[q].y;
                 dp[q].z += du * er[q].z; dp[q].w += du * er[q].w;
             }
-#ifndef KO_COEF
+#if !(defined(SERT_VARIANTS) && defined(KO_COEF))   // (knock-out: variants build only)
             if (l == 0 && valid) {
                 coef[(size_t)i * (z + 1) + j] = du;
                 cand[(size_t)i * (z + 1) + j] = e;
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256) void vs_nce_scalar(const float* __restrict__ T
             part += er[q] * p[q];
         }
         const float u = wave_sum(part);
-#ifdef KO_MATH
+#if defined(SERT_VARIANTS) && defined(KO_MATH)   // timing knock-out (wrong results), variants build only
         const float sig = u * 0.01f + 0.5f;
         const float s = fminf(fmaxf(sig, SERT_CLIP_LO), SERT_CLIP_HI);
         loss -= s;

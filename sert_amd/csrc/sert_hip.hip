@@ -61,7 +61,7 @@ static void roctx_load() {
 }
 static bool roctx_groups() {
     static const bool on = [] {
-        const bool want = getenv("SERT_ROCTX") && atoi(getenv("SERT_ROCTX")) != 0;
+        const bool want = knob("SERT_ROCTX") && atoi(knob("SERT_ROCTX")) != 0;
         if (want) roctx_load();
         return want && g_roctx.push != nullptr;
     }();
@@ -266,7 +266,7 @@ static int word_grad_segsum(sert_model* m, const DataSplit& ds, int64_t batch_in
     if ((size_t)batch_index >= ds.idx_batches.size()) SERT_FAIL("batch has no word index");
     const BatchIndex& bx = ds.idx_batches[(size_t)batch_index];
     unsigned char* touched = nullptr;   // (row flags are static per batch: DataSplit::idx_touched_bits)
-    static const bool no_fused_upper = getenv("SERT_SEG_NO_FUSED_UPPER") != nullptr;   // cross-check knob
+    static const bool no_fused_upper = variant_knob("SERT_SEG_NO_FUSED_UPPER") != nullptr;   // cross-check knob
     const bool fused_upper = !no_fused_upper && bx.fused_upper_ok && ds.idx_heavy && d % 4 == 0 && d / 4 <= 32 &&
                              bx.nlevels == 3 && bx.item_cnt[1] > 0;
     // the batch's heavy words: one streaming pass over src for all of them (kernels_seg.h: segsum_heavy)
@@ -932,7 +932,7 @@ static int vs_project(sert_model* m, const DataSplit& ds, int64_t batch_index) {
 // Events that mark the end of ONE kernel ride on that kernel's completion signal
 // (SERT_EXT_EVENTS=0: plain hipEventRecord behind it, ~7 us of queue stall each).
 static bool ext_events() {
-    static const bool on = !(getenv("SERT_EXT_EVENTS") && atoi(getenv("SERT_EXT_EVENTS")) == 0);
+    static const bool on = !(variant_knob("SERT_EXT_EVENTS") && atoi(variant_knob("SERT_EXT_EVENTS")) == 0);
     return on;
 }
 
@@ -944,7 +944,7 @@ static bool ext_events() {
 // fork right behind the NCE kernel with dW on the main stream.
 static bool side_heavy_mode(const sert_model* m);
 static bool fork_late_mode(const sert_model* m) {
-    static const bool on = !(getenv("SERT_FORK_LATE") && atoi(getenv("SERT_FORK_LATE")) == 0);
+    static const bool on = !(variant_knob("SERT_FORK_LATE") && atoi(variant_knob("SERT_FORK_LATE")) == 0);
     return on && !side_heavy_mode(m) && ext_events() && !is_dp(m) && !m->timing.enabled && m->nstreams == 2 &&
            m->n_re <= ((size_t)1 << 22) && m->cfg.kind == SERT_KIND_VECTORSPACE;
 }
@@ -954,7 +954,7 @@ static bool fork_late_mode(const sert_model* m) {
 // has to wait for the last reader of W any more, and the entity chain then runs beside the
 // MFMA-bound dh / dW GEMMs instead of beside the cache-bound segmented sum.
 static bool fork_at_nce(const sert_model* m) {
-    static const bool on = getenv("SERT_FORK_AT") && !strcmp(getenv("SERT_FORK_AT"), "nce");
+    static const bool on = variant_knob("SERT_FORK_AT") && !strcmp(variant_knob("SERT_FORK_AT"), "nce");
     return on && fork_late_mode(m);
 }
 
@@ -963,7 +963,7 @@ static bool fork_at_nce(const sert_model* m) {
 // The queue waits on the same completion signal as the side stream (free for the main stream) and
 // is joined in front of the loss finalisation.  SERT_DW_THIRD=0 keeps them on the main stream.
 static bool dw_third_queue(const sert_model* m) {
-    static const bool on = getenv("SERT_DW_THIRD") && atoi(getenv("SERT_DW_THIRD")) != 0;
+    static const bool on = variant_knob("SERT_DW_THIRD") && atoi(variant_knob("SERT_DW_THIRD")) != 0;
     return on && fork_late_mode(m) && !fork_at_nce(m);   // (the W update must stay behind the dh GEMM)
 }
 
@@ -977,7 +977,7 @@ static bool dw_third_queue(const sert_model* m) {
 // instead of in front of and behind it.  SERT_SIDE_HEAVY=0 restores dW in front of dh on the main stream
 // and both optimiser launches behind the join.
 static bool side_heavy_mode(const sert_model* m) {
-    static const int level = getenv("SERT_SIDE_HEAVY") ? atoi(getenv("SERT_SIDE_HEAVY")) : 1;   // 2: small entity tables too
+    static const int level = knob("SERT_SIDE_HEAVY") ? atoi(knob("SERT_SIDE_HEAVY")) : 1;   // 2: small entity tables too
     return level > 0 && ext_events() && !is_dp(m) && !m->timing.enabled && m->nstreams == 2 && (m->pt_big[1] || level > 1) &&
            !m->pt_big[2] && m->cfg.kind == SERT_KIND_VECTORSPACE && !m->cfg.keep_grads;
 }
@@ -1015,7 +1015,7 @@ static int vs_loss(sert_model* m, const DataSplit& ds, int64_t batch_index) {
     SERT_LAUNCH((vs_nce_regs<N, TRAIN, C>), grid, block, 0, m->stream, m->T, m->re, y,       \
                        m->neg, w, m->DA, m->coef, m->cand, m->rowloss, B, c.num_negatives,   \
                        de, inv_batch, TRAIN ? m->red_loss : (float*)nullptr)
-            static const bool no_regs = getenv("SERT_NCE_PER_CANDIDATE") != nullptr;
+            static const bool no_regs = variant_knob("SERT_NCE_PER_CANDIDATE") != nullptr;
             const int nc = c.num_negatives + 1;
             // (d_e = 300, five float4 per lane and candidate: 256 VGPRs + AGPR spills, one wave per SIMD --
             //  191 us against 169 us for the per-candidate kernel at C4: the limit stays at four)
@@ -1069,7 +1069,7 @@ static bool bwd_fused_applies(const sert_model* m) {
     // opt-in (SERT_BWD_FUSED=1): measured EQUAL to the two gemm.h launches at C2 (57.5 us against 29.3 + 29.2;
     // step 0.3030 against 0.3046 ms, inside the run-to-run spread) -- the fused kernel keeps the matrix pipe as
     // busy as they do (48 %), it only saves a launch and half of the partial slabs
-    static const bool on = getenv("SERT_BWD_FUSED") && atoi(getenv("SERT_BWD_FUSED")) != 0;
+    static const bool on = variant_knob("SERT_BWD_FUSED") && atoi(variant_knob("SERT_BWD_FUSED")) != 0;
     return on && m->cfg.kind == SERT_KIND_VECTORSPACE && m->cfg.word_dim == FB_D && m->cfg.entity_dim == FB_D &&
            m->cfg.batch_size >= 1024 && m->nstreams < 3 && (size_t)256 * (FB_D * FB_D + FB_D) <= m->part_count;
 }
@@ -1096,7 +1096,7 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         const int total = B * (c.num_negatives + 1);
         const int V = c.num_entities;
         m->re_in_parts = false;
-        static const bool ko_egrad = getenv("SERT_KO_EGRAD") != nullptr;   // timing knock-out (wrong results)
+        static const bool ko_egrad = variant_knob("SERT_KO_EGRAD") != nullptr;   // timing knock-out (wrong results)
         if (ko_egrad) {
         } else if (m->epart) {
             // small entity vocabulary: no global sort -- pairs bucketed by entity range per sub-group,
@@ -1119,7 +1119,7 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
             // Single GPU: the only reader of dR_e is the small-tensor optimiser, which adds the row
             // groups' tables itself (same order) -- no launch for the sum.  Data parallel: the
             // all-reduce needs the summed table.
-            static const bool no_fold = getenv("SERT_EGRAD_GROUP_SUM") != nullptr;
+            static const bool no_fold = variant_knob("SERT_EGRAD_GROUP_SUM") != nullptr;
             m->re_in_parts = !is_dp(m) && !m->pt_big[1] && !no_fold;
             if (!m->re_in_parts) {
                 ScopedTimer t(m, TG_EFIX, st);
@@ -1230,7 +1230,7 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         // stream -- issued there (behind that chain) they leave the main stream with nothing but
         // the dependency chain loss -> dh -> segmented sum -> word-table optimiser.
         // (measured: 0.376 -> 0.386 ms at C2 -- off by default, SERT_DW_SIDE=1 to try it)
-        static const bool dw_side = getenv("SERT_DW_SIDE") && atoi(getenv("SERT_DW_SIDE")) != 0;
+        static const bool dw_side = variant_knob("SERT_DW_SIDE") && atoi(variant_knob("SERT_DW_SIDE")) != 0;
         if ((dw_side || side_heavy) && m->lazy_join) sd = m->stream2;
         if (fork_late && m->lazy_join && dw_third_queue(m)) sd = m->stream3;
         if (sd != m->stream && sd != m->stream2 && !fork_late) SERT_HIP(hipStreamWaitEvent(sd, m->ev_fork, 0));
@@ -1238,7 +1238,7 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         // of 128 rows) and at least 64 rows per slab.  With nine output tiles (d = 300) that is 114
         // slabs at batch >= 16384 and 64 at 4096 -- 512 / 256 slabs made the combine read up to 92 MB
         // of partials (sweep in DESIGN.md section 7.5).
-        static const int user_splits = [] { const char* e = getenv("SERT_DW_SPLITS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
+        static const int user_splits = [] { const char* e = variant_knob("SERT_DW_SPLITS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
         const int auto_splits = std::max(1, std::min(std::min(512, cdiv(1024, cdiv(dw, GM) * cdiv(de, GN))), B / 64));
         const int want_splits = user_splits ? user_splits : auto_splits;
         int splits = std::min(want_splits, cdiv(B, GK));
@@ -1255,7 +1255,7 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         if (gemm_strip_ok(B, de, dw, dw, de, false, m->H, m->DA) && dw % 32 == 0 && de % 4 == 0) {
             // strip kernel: every workgroup accumulates its contiguous strips' h^T.da (+ column sums)
             ScopedTimer t(m, TG_GEMM_DW);
-            static const int want_wgs = getenv("SERT_STRIP_DW_WGS") ? atoi(getenv("SERT_STRIP_DW_WGS")) : 512;   // tuning knob
+            static const int want_wgs = variant_knob("SERT_STRIP_DW_WGS") ? atoi(variant_knob("SERT_STRIP_DW_WGS")) : 512;   // tuning knob
             const int strips = cdiv(B, SG_ROWS);
             const int spw = std::max(1, cdiv(strips, std::min(want_wgs, 1024)));
             splits = cdiv(strips, spw);
@@ -1270,7 +1270,7 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         }
         // single GPU: the combine rides in the step's tail launch (vs_tail) with the W, b update and
         // the loss finalisation
-        static const bool no_tail = getenv("SERT_NO_TAIL") != nullptr;   // cross-check knob
+        static const bool no_tail = variant_knob("SERT_NO_TAIL") != nullptr;   // cross-check knob
         m->tail_splits = 0;
         // (side_heavy: the partial slabs come from the side stream, which is joined in front of the tail)
         if (!no_tail && !is_dp(m) && (sd == m->stream || (side_heavy && sd == m->stream2)) &&
@@ -1427,7 +1427,7 @@ static int fs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
                            m->T, (size_t)B * de);
     }
     {
-        static const int want_splits = [] { const char* e = getenv("SERT_DW_SPLITS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
+        static const int want_splits = [] { const char* e = variant_knob("SERT_DW_SPLITS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
         int splits = std::min(want_splits, cdiv(B, GK));
         int kper = (int)round_up(cdiv(B, splits), GK);
         splits = cdiv(B, kper);
@@ -1505,10 +1505,10 @@ static int ll_forward(sert_model* m, const DataSplit& ds, int64_t batch_index) {
     // only): in a training step the gather and all three GEMMs run on the batch's DISTINCT
     // words (Zipfian batches: a third of the tokens), the loss kernel reads the table through
     // the per-token slot, and dL/dZ is summed per word before the backward GEMMs.
-    static const bool no_dedup = getenv("SERT_LL_NODEDUP") != nullptr;   // cross-check knob
-    static const bool rowwise = getenv("SERT_LL_ROWWISE") != nullptr;
+    static const bool no_dedup = knob("SERT_LL_NODEDUP") != nullptr;   // cross-check knob
+    static const bool rowwise = variant_knob("SERT_LL_ROWWISE") != nullptr;
     // (evaluation passes over the TRAINING split -- train_error() -- have the index too)
-    static const bool eval_dedup = getenv("SERT_LL_NO_EVAL_DEDUP") == nullptr;
+    static const bool eval_dedup = variant_knob("SERT_LL_NO_EVAL_DEDUP") == nullptr;
     m->ll_dedup = (TRAIN || eval_dedup) && (fused || !rowwise) && !no_dedup && ds.idx_slots != nullptr &&
                   (size_t)batch_index < ds.idx_batches.size();
     const BatchIndex* bx = m->ll_dedup ? &ds.idx_batches[(size_t)batch_index] : nullptr;
@@ -1558,16 +1558,16 @@ static int ll_forward(sert_model* m, const DataSplit& ds, int64_t batch_index) {
         // 512 threads per row: 302 us at 256 (too few waves to hide the slab load), 228 at
         // 512, 320 at 640 (one wave per token, but only two workgroups fit a CU)
         // (distinct-word mode: the kernel writes dJ_i into J and r_ik into ll_r instead of dL/dZ)
-        static const bool slab = getenv("SERT_LL_SLAB") != nullptr;   // cross-check knob
+        static const bool slab = variant_knob("SERT_LL_SLAB") != nullptr;   // cross-check knob
         if (TRAIN && m->ll_dedup && n <= 64 && !slab) {
             // distinct-word mode: no LDS slab, the n table rows are read once, coalesced along e
             const size_t lds = ((size_t)V + n) * sizeof(float);
             // a row is latency-bound (a handful of barriers), not work-bound: 128-thread workgroups
             // put four times as many rows on a CU -- loss kernel 307 -> 111 us at batch 65536, V_e = 100;
             // 86 -> 75 us at V_e = 1000, 139 -> 134 us at 2000 (batch 8192)
-            static const int nt128_below = getenv("SERT_LL_NT128_BELOW") ? atoi(getenv("SERT_LL_NT128_BELOW")) : 2048;   // tuning knob
+            static const int nt128_below = variant_knob("SERT_LL_NT128_BELOW") ? atoi(variant_knob("SERT_LL_NT128_BELOW")) : 2048;   // tuning knob
             // up to 2048 entities (V_e % 4 == 0): one WAVE per row, the row in registers, no LDS and no barrier
-            static const bool no_wave = getenv("SERT_LL_NO_ROW_WAVE") != nullptr;   // cross-check knob
+            static const bool no_wave = variant_knob("SERT_LL_NO_ROW_WAVE") != nullptr;   // cross-check knob
 #define SERT_LL_WAVE(E)                                                                                        \
     hipLaunchKernelGGL((ll_row_wave<E>), dim3(cdiv(B, 4)), dim3(256), 0, m->stream, (const float*)m->Zu, slot, y, \
                        indptr, ds.csr_indices, ds.csr_data, w, m->rowloss, B, n, V, inv_batch, m->J, m->ll_r)
@@ -1625,7 +1625,7 @@ static int ll_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
     {
         // dW (d, V) = G^T.dZ, reduction over the tokens (distinct words); db = column sums of dZ
         const int tiles = cdiv(V, GN) * cdiv(d, GM);
-        static const int want_items = getenv("SERT_LL_DW_ITEMS") ? std::max(1, atoi(getenv("SERT_LL_DW_ITEMS"))) : 1024;   // tuning knob
+        static const int want_items = variant_knob("SERT_LL_DW_ITEMS") ? std::max(1, atoi(variant_knob("SERT_LL_DW_ITEMS"))) : 1024;   // tuning knob
         int splits = std::max(1, std::min(cdiv(rows, GK), cdiv(want_items, tiles)));
         int kper = (int)round_up(cdiv(rows, splits), GK);
         splits = cdiv(rows, kper);
@@ -1634,7 +1634,7 @@ static int ll_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         // Single GPU, a GEMM worth forking for: dW, its combine and (optimizer_and_loss) the W, b update only
         // feed the loss finalisation -- they run on the side stream beside dG -> row scatter -> word-table
         // update instead of in front of them.  SERT_LL_DW_SIDE=0 keeps the whole step on one stream.
-        static const bool dw_side_off = getenv("SERT_LL_DW_SIDE") && atoi(getenv("SERT_LL_DW_SIDE")) == 0;
+        static const bool dw_side_off = knob("SERT_LL_DW_SIDE") && atoi(knob("SERT_LL_DW_SIDE")) == 0;
         const bool dw_side = !dw_side_off && !is_dp(m) && !m->timing.enabled && m->nstreams >= 2 && ext_events() &&
                              2.0 * (double)rows * d * V >= 2e9;
         hipStream_t sd = dw_side ? m->stream2 : m->stream;
@@ -1657,7 +1657,7 @@ static int ll_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
             // 64x64-tile kernel takes the launch its epilogue stores the rows straight into dR_w (14.8 us of
             // scatter pass less on the step's chain at C2 dims); keep_grads keeps dG readable
             ScopedTimer t(m, TG_GEMM_DX);
-            static const bool no_map = getenv("SERT_LL_NO_ROWMAP") != nullptr;   // cross-check knob
+            static const bool no_map = variant_knob("SERT_LL_NO_ROWMAP") != nullptr;   // cross-check knob
             const int32_t* rowmap = (m->ll_dedup && !c.keep_grads && !no_map)
                                         ? ds.idx_uwords + ds.idx_batches[(size_t)batch_index].uw_off : nullptr;
             SERT_TRY((gemm_long_k<false, true>(m, m->stream, dZ, m->W, m->DG, (int)rows, d, V, V, V, rowmap, m->g_rw, &dg_mapped)));
@@ -1731,7 +1731,7 @@ static void optimizer_args(const sert_model* m, int64_t t, AdamArgs* aa, Adadelt
 // end, a second queue adds no bandwidth, and two row-filtered launches stream worse than one dense
 // one.  Kept as an opt-in (SERT_ADAM_SPLIT=1) with its tests; off by default.
 static bool adam_split_enabled() {
-    static const bool on = getenv("SERT_ADAM_SPLIT") && atoi(getenv("SERT_ADAM_SPLIT")) != 0;
+    static const bool on = variant_knob("SERT_ADAM_SPLIT") && atoi(variant_knob("SERT_ADAM_SPLIT")) != 0;
     return on;
 }
 static int issue_untouched_rows_update(sert_model* m, const uint32_t* bits) {
@@ -1785,7 +1785,7 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
     const int tail_splits = m->tail_splits;
     m->tail_splits = 0;
     // side-heavy schedule: the entity table is updated BEHIND the join of the tail (see below)
-    static const bool no_defer = getenv("SERT_RE_DEFER") && atoi(getenv("SERT_RE_DEFER")) == 0;
+    static const bool no_defer = knob("SERT_RE_DEFER") && atoi(knob("SERT_RE_DEFER")) == 0;
     const bool defer_re = !no_defer && m->side_heavy && side_small && tail_splits > 0 && m->pt_big[1] && is_vs(m) && !c.keep_grads;
     int re_sq_lo = 0, re_nb = 0;
     for (int i = 0; i < 4; ++i) {
@@ -2000,7 +2000,7 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
 // EVERY row of dR_e (a run inside one chunk by the chunk, a longer one by the fix-up, an entity without a
 // pair as zeros by the fix-up): 120 MB less to write per step at C4.
 static size_t zero_from(const sert_model* m) {
-    static const bool all = getenv("SERT_ZERO_GRE") != nullptr;   // cross-check knob
+    static const bool all = variant_knob("SERT_ZERO_GRE") != nullptr;   // cross-check knob
     if (!all && m->cfg.kind == SERT_KIND_VECTORSPACE && !m->epart && m->n_re > 0 && m->g_re == m->gflat + m->ar_split)
         return m->ar_split + round_up(m->pt_pad[1], 4);
     return m->ar_split;
@@ -2021,7 +2021,7 @@ static void launch_fused_prologue(sert_model* m) {
 }
 
 static bool use_touched_now(const sert_model* m) {
-    static const bool no_touched = getenv("SERT_NO_TOUCHED") != nullptr;   // cross-check knob
+    static const bool no_touched = knob("SERT_NO_TOUCHED") != nullptr;   // cross-check knob
     return !no_touched && !is_dp(m) && !m->cfg.keep_grads && m->cfg.word_dim % 4 == 0 &&
            m->n_rw < ((size_t)1 << 32) && m->split[SERT_SPLIT_TRAIN].idx_touched_bits != nullptr;
 }
@@ -2339,9 +2339,9 @@ static int create_resources(sert_model* m) {
     // data-parallel model -- would share one with the main stream (its kernels then queue behind the
     // main stream's, and every cross-stream event costs 10-30 us instead of ~6)
     {
-        const char* e3 = getenv("SERT_STREAMS");
-        const bool want3 = (e3 && atoi(e3) >= 3) || (getenv("SERT_DW_THIRD") && atoi(getenv("SERT_DW_THIRD")) != 0);
-        const bool want4 = getenv("SERT_ADAM_SPLIT") && atoi(getenv("SERT_ADAM_SPLIT")) != 0;
+        const char* e3 = knob("SERT_STREAMS");
+        const bool want3 = (e3 && atoi(e3) >= 3) || (variant_knob("SERT_DW_THIRD") && atoi(variant_knob("SERT_DW_THIRD")) != 0);
+        const bool want4 = variant_knob("SERT_ADAM_SPLIT") && atoi(variant_knob("SERT_ADAM_SPLIT")) != 0;
         if (want3) SERT_HIP(hipStreamCreateWithFlags(&m->stream3, hipStreamNonBlocking));
         if (want4) SERT_HIP(hipStreamCreateWithFlags(&m->stream4, hipStreamNonBlocking));
     }
@@ -2397,11 +2397,11 @@ static int create_resources(sert_model* m) {
                 // C4 configuration (65536 x 100 000 logits = 26 GB as one matrix) needs 1.6 GB of scratch.
                 // SERT_FS_TILE_ROWS forces a tile height (tests).
                 {
-                    const char* em = getenv("SERT_FS_TILE_MB");
+                    const char* em = variant_knob("SERT_FS_TILE_MB");
                     const size_t cap = (size_t)(em && atoi(em) > 0 ? atoi(em) : 1700) << 20;
                     size_t tile = B;
                     if (B * V * sizeof(float) > cap) tile = std::max<size_t>(256, (cap / (V * sizeof(float))) / 256 * 256);
-                    const char* er = getenv("SERT_FS_TILE_ROWS");
+                    const char* er = knob("SERT_FS_TILE_ROWS");
                     if (er && atoi(er) > 0) tile = (size_t)atoi(er);
                     m->fs_tile = (int)std::min<size_t>(B, tile);
                 }
@@ -2415,7 +2415,7 @@ static int create_resources(sert_model* m) {
             {
                 // sort-free entity gradient for small vocabularies (kernels_egrad.h); SERT_EGRAD_SORT=1
                 // keeps the sorted path (cross-check knob)
-                const bool force_sort = getenv("SERT_EGRAD_SORT") && atoi(getenv("SERT_EGRAD_SORT")) != 0;   // (read per model)
+                const bool force_sort = knob("SERT_EGRAD_SORT") && atoi(knob("SERT_EGRAD_SORT")) != 0;   // (read per model)
                 const size_t c1 = c.num_negatives + 1;
                 if (!force_sort && c.kind == SERT_KIND_VECTORSPACE && V <= 2048 && de % 4 == 0 && de <= 128 &&
                     total < ((size_t)1 << 27) && c1 <= (size_t)kElSubPairs) {
@@ -2429,7 +2429,7 @@ static int create_resources(sert_model* m) {
                     m->eg_num_sub = cdiv(B, m->eg_sub_rows);
                     // row groups whose slice of T (rows x d_e floats) stays in one XCD's L2: <= 2 MB
                     m->eg_subs_per_group = (int)std::max<size_t>(1, (((size_t)2 << 20) / (de * sizeof(float))) / m->eg_sub_rows);
-                    static const int want_groups = getenv("SERT_EG_GROUPS") ? std::max(1, atoi(getenv("SERT_EG_GROUPS"))) : 16;   // tuning knob
+                    static const int want_groups = variant_knob("SERT_EG_GROUPS") ? std::max(1, atoi(variant_knob("SERT_EG_GROUPS"))) : 16;   // tuning knob
                     m->eg_subs_per_group = std::max(1, std::min(m->eg_subs_per_group, m->eg_num_sub / want_groups));
                     m->eg_groups = cdiv(m->eg_num_sub, m->eg_subs_per_group);
                 }
@@ -2488,7 +2488,7 @@ static int create_resources(sert_model* m) {
     memset(m->h_loss, 0, 8 * sizeof(float));
     SERT_HIP(hipHostGetDevicePointer((void**)&m->h_loss_dev, m->h_loss, 0));
     {
-        const char* e = getenv("SERT_STREAMS");   // tuning / cross-check knob
+        const char* e = knob("SERT_STREAMS");   // tuning / cross-check knob
         const int v = e ? atoi(e) : 0;
         if (v >= 1 && v <= 3) m->nstreams = v;
     }
@@ -2717,9 +2717,9 @@ int sert_upload_dataset(sert_model* m, int split, const void* x, const int32_t* 
         // (vectorspace: opt-in, SERT_DENSE_HEAVY=1 -- measured a wash at C2 and C4: the tree's first level is
         //  bound by its 44 k word items, not by the entries the heavy words take out of it.  loglinear: the
         //  V_e-wide per-word sums are bandwidth-bound; on by default where V_e % 4 == 0)
-        const bool dense_heavy = !getenv("SERT_NO_DENSE_HEAVY") &&
-                                 (is_vs(m) ? (m->cfg.word_dim % 4 == 0 && m->cfg.word_dim <= 512 && getenv("SERT_DENSE_HEAVY") != nullptr &&
-                                              atoi(getenv("SERT_DENSE_HEAVY")) != 0)
+        const bool dense_heavy = !variant_knob("SERT_NO_DENSE_HEAVY") &&
+                                 (is_vs(m) ? (m->cfg.word_dim % 4 == 0 && m->cfg.word_dim <= 512 && knob("SERT_DENSE_HEAVY") != nullptr &&
+                                              atoi(knob("SERT_DENSE_HEAVY")) != 0)
                                            : (m->cfg.num_entities % 4 == 0));
         // Row-grouped level 0 of the vectorspace word-gradient tree (word_index.h: row_groups; kernels_seg.h: XcdLists):
         // MEASURED AND NOT USED (round 4, profiles/r04_experiments.txt).  At C2 it does what it was built for -- the
@@ -2729,7 +2729,7 @@ int sert_upload_dataset(sert_model* m, int split, const void* x, const int32_t* 
         // SERT_SEG_GROUPS=k builds it (tests/test_gpu_parity.py::test_word_gradient_row_grouped_tree keeps it exact).
         int row_groups = 1;
         if (is_vs(m) && m->cfg.word_dim % 4 == 0)
-            if (const char* e = getenv("SERT_SEG_GROUPS")) row_groups = std::min(std::max(1, atoi(e)), std::max(1, B / 64));
+            if (const char* e = knob("SERT_SEG_GROUPS")) row_groups = std::min(std::max(1, atoi(e)), std::max(1, B / 64));
         bool ids_ok = true;
         SERT_ID_DISPATCH(m->cfg.id_bytes,
                          ids_ok = build_word_index<IdT>((const IdT*)x, nb, B, n, m->cfg.vocab_size, row_is_pos, wi,
@@ -2807,7 +2807,7 @@ int sert_upload_dataset(sert_model* m, int split, const void* x, const int32_t* 
 int sert_train_batch(sert_model* m, int64_t batch_index, const int64_t* negatives, float* loss_out) {
     if (!m) SERT_FAIL("null model");
     SERT_HIP(hipSetDevice(m->cfg.device));
-    static const bool no_spin = getenv("SERT_NO_SPIN") != nullptr;   // cross-check knob
+    static const bool no_spin = variant_knob("SERT_NO_SPIN") != nullptr;   // cross-check knob
     // sert_hint_next_batch: the next batch's parameter-only forward part goes out behind
     // this step, before the host starts waiting for this step's loss
     const int64_t hint = m->hint_next;
@@ -2886,7 +2886,7 @@ int sert_train_batches(sert_model* m, const int64_t* batch_indices, int64_t coun
         SERT_TRY(dmalloc(&m->d_losses, (size_t)count * 3));
         m->d_losses_cap = count;
     }
-    static const bool report_host = getenv("SERT_DEBUG_HOST") != nullptr;
+    static const bool report_host = variant_knob("SERT_DEBUG_HOST") != nullptr;
     const auto t_host0 = std::chrono::steady_clock::now();
     for (int64_t i = 0; i < count; ++i) {
         SERT_TRY(train_step_async(m, batch_indices[i], nullptr, m->d_losses + 3 * i));
@@ -3085,7 +3085,7 @@ int sert_scorer_create(int device, const float* entities, int64_t V, int32_t dim
     SERT_HIP(hipMemcpyAsync(sc->E, entities, (size_t)V * dim * sizeof(float), hipMemcpyHostToDevice, sc->stream));
     hipLaunchKernelGGL(l2_normalize_rows, dim3(cdiv(V, 4)), dim3(256), 0, sc->stream, sc->E, V, dim);
     // large tables: bf16 copy for the prefilter GEMM (SERT_SCORE_FP32=1 keeps the fp32 filter)
-    static const bool fp32_only = getenv("SERT_SCORE_FP32") != nullptr;
+    static const bool fp32_only = knob("SERT_SCORE_FP32") != nullptr;
     sc->bf16 = !fp32_only && V >= 32768 && dim % 4 == 0;
     if (sc->bf16) {
         sc->kp = (int)round_up(dim, 32);
@@ -3118,7 +3118,7 @@ int sert_scorer_destroy(sert_scorer* sc) {
 // then use that kernel, so a row's scores never depend on which path produced them.
 static int scorer_big_tile(const sert_scorer* sc) {   // 0 no, 1 = 256x256, 2 = 256x128 (two workgroups per CU)
 #ifdef SERT_VARIANTS
-    static const int big_tile = getenv("SERT_SCORE_BIG_TILE") ? atoi(getenv("SERT_SCORE_BIG_TILE")) : 0;
+    static const int big_tile = variant_knob("SERT_SCORE_BIG_TILE") ? atoi(variant_knob("SERT_SCORE_BIG_TILE")) : 0;
     return (sc->V >= 32768 && gemm_big_ok(sc->dim, sc->dim, sc->dim)) ? big_tile : 0;
 #else
     (void)sc;
@@ -3135,7 +3135,7 @@ static int scorer_topk_materialised(sert_scorer* sc, const float* P, int64_t Q, 
     const int64_t V = sc->V;
     const int dim = sc->dim;
     static const int64_t slab_elems = [] {
-        const char* e = getenv("SERT_SCORE_SLAB_MB");   // tuning knob
+        const char* e = variant_knob("SERT_SCORE_SLAB_MB");   // tuning knob
         const int64_t mb = e ? atoll(e) : 0;
         return mb > 0 ? (mb << 20) / 4 : ((int64_t)1 << 27);
     }();
@@ -3193,7 +3193,7 @@ static int scorer_topk_fused(sert_scorer* sc, const float* proj, int64_t Q, int 
     // Query chunks of <= 8192 rows alternate between two streams, each with its own set of
     // scratch buffers: the selection kernel of one chunk (latency / random-row bound) runs under
     // the filter GEMM of the next (VALU / L2 bound).  An even number of equal chunks.
-    static const int64_t chunk_rows = getenv("SERT_SCORE_CHUNK") ? atoll(getenv("SERT_SCORE_CHUNK")) : 8192;   // tuning knob
+    static const int64_t chunk_rows = variant_knob("SERT_SCORE_CHUNK") ? atoll(variant_knob("SERT_SCORE_CHUNK")) : 8192;   // tuning knob
     const int64_t nchunks = Q <= 1024 ? 1 : 2 * cdiv(Q, 2 * chunk_rows);
     const int64_t QT = std::min<int64_t>(Q, round_up(cdiv(Q, nchunks), 128));
     if (sc->cap_ss < 2 * QT * Vs) {
@@ -3360,7 +3360,7 @@ int sert_scorer_topk(sert_scorer* sc, const float* proj, int64_t Q, int32_t k, i
     // threshold: rank rs among the V/16 sampled entities, i.e. an expected 2k+400 (std ~
     // sqrt(rs)*16) candidates of V -- at k=100: 608 +- 99, >= k at 5 sigma, <= 1024 at 4
     const int rs = cdiv(2 * k + 400, kScoreStride);
-    static const bool never_fuse = getenv("SERT_SCORE_MATERIALISE") != nullptr;   // cross-check knob
+    static const bool never_fuse = knob("SERT_SCORE_MATERIALISE") != nullptr;   // cross-check knob
     const bool fused = !never_fuse && V >= 32768 && dim % 4 == 0 && rs <= kTopKMax &&
                        cdiv(V, kScoreStride) >= 8 * (int64_t)rs;
     bool copied = false;
@@ -3412,7 +3412,7 @@ int sert_scorer_scores(sert_scorer* sc, const float* proj, int64_t Q, float* sco
 int sert_host_alloc(void** out, size_t bytes) {
     if (!out || bytes == 0) SERT_FAIL("bad argument");
     *out = nullptr;
-    static const int flags = getenv("SERT_PIN_FLAGS") ? atoi(getenv("SERT_PIN_FLAGS")) : (int)hipHostMallocDefault;   // tuning knob
+    static const int flags = variant_knob("SERT_PIN_FLAGS") ? atoi(variant_knob("SERT_PIN_FLAGS")) : (int)hipHostMallocDefault;   // tuning knob
     SERT_HIP(hipHostMalloc(out, bytes, (unsigned)flags));
     return 0;
 }
@@ -3438,13 +3438,13 @@ int sert_score_topk(int device, const float* entities, int64_t V, int32_t dim, c
 // reduce-scatter / all-gather of whole slabs, or the model cannot take it: rows that are no multiple of
 // 16 bytes, gradients the caller wants to read back (keep_grads), several slabs per tensor.
 static bool row_exchange_wanted(const sert_model* m) {
-    const char* e = getenv("SERT_DP_EXCHANGE");
+    const char* e = knob("SERT_DP_EXCHANGE");
     if (e && !strcmp(e, "zero1")) return false;
     return m->cfg.word_dim % 4 == 0 && !m->cfg.keep_grads && m->ar_chunks == 1 && !m->cfg.inference_only;
 }
 
 static int exchange_slabs() {
-    const char* e = getenv("SERT_AR_CHUNKS");
+    const char* e = knob("SERT_AR_CHUNKS");
     const int want = e ? atoi(e) : 1;
     return std::max(1, std::min(want, (int)sert_model::kMaxArChunks));
 }
@@ -3632,7 +3632,7 @@ int sert_bench_gemm(int device, int ta, int tb, int epi, int M, int N, int K, in
     int kper = (int)round_up(cdiv(K, splits), GK);
     splits = cdiv(K, kper);
     // SERT_BENCH_GEMM_CSB=1 (A^T.B only): with the column sums of B riding along, as dW + db run in the step
-    const bool csb = ta && !tb && getenv("SERT_BENCH_GEMM_CSB") != nullptr;
+    const bool csb = ta && !tb && variant_knob("SERT_BENCH_GEMM_CSB") != nullptr;
     const size_t na = (size_t)M * K, nb = (size_t)K * N, nc = ((size_t)M * N + (csb ? N : 0)) * splits;
     float *A = nullptr, *B = nullptr, *C = nullptr, *bias = nullptr;
     SERT_TRY(dmalloc(&A, na)); SERT_TRY(dmalloc(&B, nb)); SERT_TRY(dmalloc(&C, nc)); SERT_TRY(dmalloc(&bias, (size_t)N));
@@ -3645,7 +3645,7 @@ int sert_bench_gemm(int device, int ta, int tb, int epi, int M, int N, int K, in
     SERT_HIP(fill(A, na)); SERT_HIP(fill(B, nb)); SERT_HIP(fill(bias, (size_t)N));
     const int lda = ta ? M : K, ldb = tb ? K : N;
 #ifdef SERT_VARIANTS
-    const int big = (getenv("SERT_GEMM_BIG") && !ta && tb && gemm_big_ok(K, lda, ldb) && splits == 1) ? atoi(getenv("SERT_GEMM_BIG")) : 0;
+    const int big = (variant_knob("SERT_GEMM_BIG") && !ta && tb && gemm_big_ok(K, lda, ldb) && splits == 1) ? atoi(variant_knob("SERT_GEMM_BIG")) : 0;
 #endif
     auto run = [&]() {
 #ifdef SERT_VARIANTS

@@ -154,6 +154,7 @@ def test_vectorspace_known_answers(hip_lib):
     eng.close()
 
 
+@pytest.mark.skipif(not VARIANTS_BUILD, reason='SERT_BWD_FUSED is read only by a library built with -DSERT_VARIANTS (measured equal: not in the product)')
 @pytest.mark.parametrize('B', [1100, 4096 + 37])
 def test_vectorspace_fused_backward(hip_lib, monkeypatch, B):
     """SERT_BWD_FUSED=1 (opt-in, gemm_bwd_fused.h): dh = da.W^T and dW = h^T.da (+ db) out of ONE launch, for
@@ -860,10 +861,10 @@ print('RESULT ' + json.dumps(out))
 
 @pytest.mark.gpu
 def test_schedule_variants_do_not_change_a_bit(hip_lib):
-    """The stream schedule is only a schedule: one stream, the round-1 three-event schedule,
-    plain event records instead of kernel stop events, the entity group sum in a launch of its
-    own, the fork behind the NCE kernel, the two upper levels of the word-gradient tree as two
-    launches -- six steps (device-drawn negatives, pre-drawn on the side stream where there is one)
+    """The stream schedule is only a schedule: one stream, the side-heavy schedule (and, against a variants
+    build: the round-1 three-event schedule, plain event records instead of kernel stop events, the entity group
+    sum in a launch of its own, the fork behind the NCE kernel, the two upper levels of the word-gradient tree as
+    two launches, the three-launch tail) -- six steps (device-drawn negatives, pre-drawn on the side stream where there is one)
     end in bit-identical parameters, optimiser state and losses, each in a fresh process (the
     knobs are read once per process)."""
     import json
@@ -871,9 +872,11 @@ def test_schedule_variants_do_not_change_a_bit(hip_lib):
     import subprocess
     import sys
     code = SCHEDULE_WORKER % dict(root=U.ROOT)
-    variants = ({}, {'SERT_STREAMS': '1'}, {'SERT_FORK_LATE': '0'}, {'SERT_EXT_EVENTS': '0'},
-                {'SERT_EGRAD_GROUP_SUM': '1'}, {'SERT_FORK_AT': 'nce'}, {'SERT_SEG_NO_FUSED_UPPER': '1'},
+    variants = ({}, {'SERT_STREAMS': '1'}, {'SERT_ROCTX': '1'},     # (a roctx range around every kernel group)
                 {'SERT_SIDE_HEAVY': '2'})   # (entity chain, dW and the small-tensor update on the side stream)
+    if VARIANTS_BUILD:      # knobs only a -DSERT_VARIANTS library reads (common.h: variant_knob)
+        variants += ({'SERT_FORK_LATE': '0'}, {'SERT_EXT_EVENTS': '0'}, {'SERT_EGRAD_GROUP_SUM': '1'}, {'SERT_FORK_AT': 'nce'},
+                     {'SERT_SEG_NO_FUSED_UPPER': '1'}, {'SERT_NO_TAIL': '1'})
     outs = []
     for extra in variants:
         r = subprocess.run([sys.executable, '-c', code], check=True, env=dict(os.environ, **extra),

@@ -326,6 +326,12 @@ double sert_timing_avg_us(sert_model* m, int i);
 int sert_bench_gemm(int device, int ta, int tb, int epi, int M, int N, int K, int splits,
                     int iters, double* avg_us);
 
+/* The same dispatch on HOST arrays (test hook, no reference counterpart): C (M,N) = epi(op(A).op(B)), A (M,K) or
+ * (K,M) if ta, B (K,N) or (N,K) if tb, bias (N) for epi 1 / 2 (only with ta = 0).  The shape is routed to the kernel a
+ * training step would use for it, so every GEMM kernel of the library can be pinned against float64. */
+int sert_debug_gemm(int device, int ta, int tb, int epi, int M, int N, int K, const float* A, const float* B,
+                    const float* bias, float* C);
+
 /* Memory-system micro-benchmarks: the denominators a step's memory-bound kernels are priced
  * against (no reference counterpart; measurement only).  Average launch time over `iters`
  * launches (HIP events on the launching stream, 2 warm-ups) in *avg_us.

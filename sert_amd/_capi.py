@@ -35,7 +35,7 @@ EXPORTS = [
     'sert_host_alloc', 'sert_host_free',
     'sert_comm_unique_id', 'sert_comm_init', 'sert_comm_init_host', 'sert_comm_destroy', 'sert_comm_stats',
     'sert_synchronize', 'sert_timing_enable', 'sert_timing_reset', 'sert_timing_count',
-    'sert_timing_name', 'sert_timing_avg_us', 'sert_bench_gemm', 'sert_bench_memory', 'sert_debug_row_lists',
+    'sert_timing_name', 'sert_timing_avg_us', 'sert_bench_gemm', 'sert_debug_gemm', 'sert_bench_memory', 'sert_debug_row_lists',
     'sert_profile_range_push', 'sert_profile_range_pop',
 ]
 
@@ -520,6 +520,23 @@ def bench_gemm(M, N, K, ta=0, tb=0, epi=0, splits=1, iters=20, device=0):
 
 MEMBENCH_COPY, MEMBENCH_READ, MEMBENCH_GATHER, MEMBENCH_OPTIMIZER = 0, 1, 2, 3
 SEPARATE_ALLOCATIONS = ctypes.c_size_t(-1).value
+
+
+def debug_gemm(A, B, ta=0, tb=0, epi=0, bias=None, device=0):
+    """C = epi(op(A).op(B)) through the library's GEMM dispatch (sert_debug_gemm); shapes from the arrays."""
+    lib = load()
+    A = np.ascontiguousarray(A, dtype=np.float32)
+    B = np.ascontiguousarray(B, dtype=np.float32)
+    K, M = A.shape if ta else A.shape[::-1]
+    N = B.shape[0] if tb else B.shape[1]
+    assert (B.shape[1] if tb else B.shape[0]) == K, (A.shape, B.shape)
+    C = np.empty((M, N), dtype=np.float32)
+    if bias is not None:
+        bias = np.ascontiguousarray(bias, dtype=np.float32)
+    lib.sert_debug_gemm.argtypes = [ctypes.c_int] * 7 + [ctypes.c_void_p] * 4
+    check(lib.sert_debug_gemm(device, int(ta), int(tb), int(epi), M, N, K, _addr(A), _addr(B),
+                              _addr(bias) if bias is not None else None, _addr(C)))
+    return C
 
 
 def bench_memory(kind, nbytes, table_bytes=0, row_bytes=512, window=10, gap_bytes=0, blocks=0, iters=20, device=0):

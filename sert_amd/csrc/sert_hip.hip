@@ -13,6 +13,7 @@
 
 #include "common.h"
 #include "gemm.h"
+#include "gemm_stream.h"
 #include "gemm_bwd_fused.h"
 #ifdef SERT_VARIANTS   // opt-in GEMM variants that lost their A/B (csrc/variants/; tools/build_variant.sh -DSERT_VARIANTS)
 #include "variants/gemm_big.h"
@@ -3673,6 +3674,41 @@ int sert_bench_gemm(int device, int ta, int tb, int epi, int M, int N, int K, in
     (void)hipFree(A); (void)hipFree(B); (void)hipFree(C); (void)hipFree(bias);
     (void)hipStreamDestroy(s);
     return 0;
+}
+
+// C = epi(op(A).op(B)) for host arrays, through launch_gemm -- i.e. through whichever kernel a shape is routed to in a
+// training step (tests/test_gpu_gemm.py pins every kernel of gemm.h / gemm_stream.h against float64 this way).
+int sert_debug_gemm(int device, int ta, int tb, int epi, int M, int N, int K, const float* A, const float* B,
+                    const float* bias, float* C) {
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || epi < 0 || epi > 2 || (epi && !bias)) SERT_FAIL("bad argument");
+    SERT_HIP(hipSetDevice(device));
+    hipStream_t s;
+    SERT_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    const size_t na = (size_t)M * K, nb = (size_t)K * N, nc = (size_t)M * N;
+    float *dA = nullptr, *dB = nullptr, *dC = nullptr, *dbias = nullptr;
+    int rc = 0;
+    auto body = [&]() -> int {
+        SERT_TRY(dmalloc(&dA, na)); SERT_TRY(dmalloc(&dB, nb)); SERT_TRY(dmalloc(&dC, nc)); SERT_TRY(dmalloc(&dbias, (size_t)N));
+        SERT_HIP(hipMemcpyAsync(dA, A, na * sizeof(float), hipMemcpyHostToDevice, s));
+        SERT_HIP(hipMemcpyAsync(dB, B, nb * sizeof(float), hipMemcpyHostToDevice, s));
+        if (bias) SERT_HIP(hipMemcpyAsync(dbias, bias, (size_t)N * sizeof(float), hipMemcpyHostToDevice, s));
+        SERT_HIP(hipMemsetAsync(dC, 0xff, nc * sizeof(float), s));      // (NaNs wherever the kernel does not write)
+        const int lda = ta ? M : K, ldb = tb ? K : N;
+#define SERT_DG(TA, TB, E) launch_gemm<TA, TB, E>(s, dA, dB, dC, dbias, M, N, K, lda, ldb, N)
+        if (!ta && !tb) { if (epi == 2) SERT_DG(false, false, EPI_BIAS_TANH); else if (epi == 1) SERT_DG(false, false, EPI_BIAS); else SERT_DG(false, false, EPI_STORE); }
+        else if (!ta && tb) { if (epi == 2) SERT_DG(false, true, EPI_BIAS_TANH); else if (epi == 1) SERT_DG(false, true, EPI_BIAS); else SERT_DG(false, true, EPI_STORE); }
+        else if (ta && !tb) SERT_DG(true, false, EPI_STORE);
+        else SERT_DG(true, true, EPI_STORE);
+#undef SERT_DG
+        SERT_HIP(hipGetLastError());
+        SERT_HIP(hipMemcpyAsync(C, dC, nc * sizeof(float), hipMemcpyDeviceToHost, s));
+        SERT_HIP(hipStreamSynchronize(s));
+        return 0;
+    };
+    rc = body();
+    (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC); (void)hipFree(dbias);
+    (void)hipStreamDestroy(s);
+    return rc;
 }
 
 int sert_bench_memory(int device, int kind, size_t bytes, size_t table_bytes, int row_bytes, int window,

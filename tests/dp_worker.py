@@ -90,10 +90,22 @@ def run_soak(steps=200):
 def run(kind):
     """Train two epochs + evaluate; identical code for any world size (the model's
     batch_size is the GLOBAL batch).  Returns a dict of numpy results."""
-    if kind == 'c2':
-        return run_c2(kind)
-    if kind == 'soak':
-        return run_soak()
+    from sert_amd import models
+    # (the sampler seed is a CLASS attribute: run_c2 / run_soak pin one; a test process that runs several kinds one
+    #  after the other must not carry it over -- the ranks of the other kinds start fresh and draw theirs from np.random)
+    saved = models.VectorSpaceLanguageModel.sampler_seed
+    try:
+        if kind == 'c2':
+            return run_c2(kind)
+        if kind == 'soak':
+            return run_soak()
+        models.VectorSpaceLanguageModel.sampler_seed = None
+        return _run_epochs(kind)
+    finally:
+        models.VectorSpaceLanguageModel.sampler_seed = saved
+
+
+def _run_epochs(kind):
     from sert_amd import models
     from tests import util as U
     B, n, z, Vw, Ve, d = 96, 3, 4, 200, 20, 16          # 96 rows: 2, 3 and 4 ranks

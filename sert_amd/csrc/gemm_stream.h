@@ -85,31 +85,60 @@ __global__ __launch_bounds__(64 * kStreamWaves, 1) void gemm_stream_f32(const St
         f32x4v acc[NB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) acc[nb] = (f32x4v)(0.f);
+        if (BRC) {
+            // K / 4 steps; the B fragments of step t + 1 are read while the MFMAs of step t issue (one step ahead is
+            // enough: LDS latency ~ 64 cycles, a step's eight MFMAs occupy the pipe for 256)
+            float4 bcur[NB / 4], bnxt[NB / 4];
 #pragma unroll
-        for (int j = 0; j < KB; ++j) {
-            const float av[4] = {a[j].x, a[j].y, a[j].z, a[j].w};
-            if (BRC) {
+            for (int gq = 0; gq < NB / 4; ++gq) bcur[gq] = *reinterpret_cast<const float4*>(&Bs[(4 * q) * LDB + 64 * gq + 4 * c]);
+#pragma unroll
+            for (int j = 0; j < KB; ++j) {
+                const float av[4] = {a[j].x, a[j].y, a[j].z, a[j].w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int k = 16 * j + 4 * q + i;
+                    const int t = 4 * j + i;
+                    if (t + 1 < 4 * KB) {
+                        const int kn = 16 * ((t + 1) >> 2) + 4 * q + ((t + 1) & 3);
+#pragma unroll
+                        for (int gq = 0; gq < NB / 4; ++gq) bnxt[gq] = *reinterpret_cast<const float4*>(&Bs[kn * LDB + 64 * gq + 4 * c]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int gq = 0; gq < NB / 4; ++gq) {
-                        const float4 b = *reinterpret_cast<const float4*>(&Bs[k * LDB + 64 * gq + 4 * c]);
-                        acc[4 * gq + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], b.x, acc[4 * gq + 0], 0, 0, 0);
-                        acc[4 * gq + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], b.y, acc[4 * gq + 1], 0, 0, 0);
-                        acc[4 * gq + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], b.z, acc[4 * gq + 2], 0, 0, 0);
-                        acc[4 * gq + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], b.w, acc[4 * gq + 3], 0, 0, 0);
+                        acc[4 * gq + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bcur[gq].x, acc[4 * gq + 0], 0, 0, 0);
+                        acc[4 * gq + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bcur[gq].y, acc[4 * gq + 1], 0, 0, 0);
+                        acc[4 * gq + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bcur[gq].z, acc[4 * gq + 2], 0, 0, 0);
+                        acc[4 * gq + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bcur[gq].w, acc[4 * gq + 3], 0, 0, 0);
                     }
-                }
-            } else {
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    const float4 b = *reinterpret_cast<const float4*>(&Bs[(16 * nb + c) * LDB + 16 * j + 4 * q]);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], b.x, acc[nb], 0, 0, 0);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], b.y, acc[nb], 0, 0, 0);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], b.z, acc[nb], 0, 0, 0);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], b.w, acc[nb], 0, 0, 0);
+                    for (int gq = 0; gq < NB / 4; ++gq) bcur[gq] = bnxt[gq];
                 }
+            }
+        } else {
+            // K / 16 blocks of NB reads; block j + 1's fragments are read while block j's 4 NB MFMAs issue
+            float4 bcur[NB], bnxt[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) bcur[nb] = *reinterpret_cast<const float4*>(&Bs[(16 * nb + c) * LDB + 4 * q]);
+#pragma unroll
+            for (int j = 0; j < KB; ++j) {
+                const float av[4] = {a[j].x, a[j].y, a[j].z, a[j].w};
+                if (j + 1 < KB) {
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) bnxt[nb] = *reinterpret_cast<const float4*>(&Bs[(16 * nb + c) * LDB + 16 * (j + 1) + 4 * q]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bcur[nb].x, acc[nb], 0, 0, 0);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bcur[nb].y, acc[nb], 0, 0, 0);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bcur[nb].z, acc[nb], 0, 0, 0);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bcur[nb].w, acc[nb], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) bcur[nb] = bnxt[nb];
             }
         }
         // ---- epilogue: D[row = 4 q + r][col of (block, lane c)] = acc[block][r] ----

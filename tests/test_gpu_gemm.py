@@ -1,0 +1,44 @@
+"""Every GEMM kernel of the library against float64, through sert_debug_gemm -- the same dispatch (launch_gemm) a training
+step uses, so a shape lands on the kernel the step would run it on: the 128x128-tile kernel, the 64x64-tile one, the
+128x160-tile one (N just above a multiple of 128) and the streaming projection kernel (gemm_stream.h: huge M, N = K = 128,
+A straight from global memory into v_mfma_f32_16x16x4_f32, B resident in LDS)."""
+import numpy as np
+import pytest
+
+from tests.util import C
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(A, B, ta, tb, epi, bias):
+    a = A.astype(np.float64).T if ta else A.astype(np.float64)
+    b = B.astype(np.float64).T if tb else B.astype(np.float64)
+    c = a @ b
+    if epi:
+        c = c + bias.astype(np.float64)
+    if epi == 2:
+        c = np.tanh(c)
+    return c
+
+
+@pytest.mark.parametrize('M,N,K,ta,tb,epi', [
+    # the streaming projection kernel: h.W + b -> tanh, da.W^T; ragged last strip, fewer strips than waves x 2, many
+    (65536, 128, 128, 0, 0, 2), (65536, 128, 128, 0, 1, 0), (8192 + 5, 128, 128, 0, 0, 2), (8192 + 5, 128, 128, 0, 1, 0),
+    (20000, 128, 128, 0, 0, 1), (20000, 128, 128, 0, 1, 1), (16384, 128, 128, 0, 0, 0),
+    # just outside its shape conditions: the tiled kernels
+    (8191, 128, 128, 0, 0, 2), (65536, 128, 112, 0, 0, 2), (4099, 128, 128, 0, 1, 0), (30000, 112, 128, 0, 1, 0),
+    # 64x64 tiles, 128x128 tiles, 128x160 tiles, odd sizes (scalar loaders), A^T.B
+    (1000, 300, 300, 0, 0, 2), (4096, 1000, 128, 0, 0, 1), (3000, 128, 1000, 0, 1, 0), (333, 77, 45, 0, 0, 1),
+    (128, 128, 5000, 1, 0, 0), (300, 301, 2000, 1, 0, 0), (257, 129, 64, 1, 1, 0),
+])
+def test_gemm_dispatch_against_float64(hip_lib, M, N, K, ta, tb, epi):
+    rng = np.random.RandomState(M + 3 * N + 7 * K + ta + 2 * tb)
+    A = rng.uniform(-1, 1, (K, M) if ta else (M, K)).astype(np.float32)
+    B = rng.uniform(-1, 1, (N, K) if tb else (K, N)).astype(np.float32)
+    B *= np.float32(1.0 / np.sqrt(K))
+    bias = rng.uniform(-0.5, 0.5, N).astype(np.float32) if epi else None
+    got = C.debug_gemm(A, B, ta=ta, tb=tb, epi=epi, bias=bias)
+    ref = _ref(A, B, ta, tb, epi, bias)
+    assert np.all(np.isfinite(got))                       # (the output is pre-filled with NaN: every element was written)
+    # fp32 accumulation over K terms of magnitude <= 1/sqrt(K): ~1e-6; fast_tanh adds <= 4 ulp
+    assert np.abs(got - ref).max() < (2e-6 if epi != 2 else 3e-6) * max(1.0, np.sqrt(K / 128.0))

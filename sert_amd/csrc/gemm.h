@@ -765,11 +765,13 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_mfma_small(const GemmArgs g) 
     }
 }
 
-// gemm_stream.h: the projection shapes of a d = 128 model (huge M, N = K = 128) as a streaming kernel; returns
-// false when the shape is not its own
+#ifdef SERT_VARIANTS
+// variants/gemm_stream.h: the projection shapes of a d = 128 model (huge M, N = K = 128) as a streaming kernel --
+// measured equal to the tiled kernels (round 4), opt-in through SERT_GEMM_STREAM=1; false when the shape is not its own
 template <bool TB, int EPI>
 inline bool launch_gemm_stream(hipStream_t s, const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
                                int lda, int ldb, int ldc);
+#endif
 
 // rowmap / mapped_C / mapped (optional): when the launch goes to the 64x64-tile kernel, row r of the product is
 // stored as row rowmap[r] of mapped_C (leading dimension ldc) instead of row r of C, and *mapped is set.
@@ -781,10 +783,12 @@ inline void launch_gemm(hipStream_t s, const float* A, const float* B, float* C,
                         float* mapped_C = nullptr, bool* mapped = nullptr) {
     if (splits <= 1) { splits = 1; kper = K; }
     if (mapped) *mapped = false;
+#ifdef SERT_VARIANTS
     if (!TA && !CSB && splits == 1 && (EPI == EPI_STORE || EPI == EPI_BIAS || EPI == EPI_BIAS_TANH)) {
-        static const bool no_stream = variant_knob("SERT_GEMM_NO_STREAM") != nullptr;   // cross-check knob (variants build)
-        if (!no_stream && launch_gemm_stream<TB, EPI>(s, A, B, C, bias, M, N, K, lda, ldb, ldc)) return;
+        static const bool stream = variant_knob("SERT_GEMM_STREAM") != nullptr;
+        if (stream && launch_gemm_stream<TB, EPI>(s, A, B, C, bias, M, N, K, lda, ldb, ldc)) return;
     }
+#endif
     GemmArgs g;
     g.rowmap = nullptr;
     // small problem (fewer than two 128x128 tiles per CU): 64x64 tiles, one workgroup each

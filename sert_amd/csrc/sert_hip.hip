@@ -13,11 +13,11 @@
 
 #include "common.h"
 #include "gemm.h"
-#include "gemm_stream.h"
 #include "gemm_bwd_fused.h"
 #ifdef SERT_VARIANTS   // opt-in GEMM variants that lost their A/B (csrc/variants/; tools/build_variant.sh -DSERT_VARIANTS)
 #include "variants/gemm_big.h"
 #include "variants/gemm_strip.h"
+#include "variants/gemm_stream.h"
 #endif
 #include "kernels_score_bf16.h"
 #include "kernels_egrad.h"

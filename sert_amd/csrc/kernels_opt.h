@@ -240,9 +240,13 @@ struct SmallTensors {
     unsigned long long gstride[3];
 };
 
+// sumsq_new_partial (optional): also the sums of squares of the UPDATED values, partitioned exactly as sumsq_partial
+// -- bit for bit what the next step's launch over the same tensors computes as its pre-update sums (the small
+// entity table's update deferred past the tail, sert_hip.hip: defer_small).
 template <bool ADAM, bool STORE_G>
 __global__ __launch_bounds__(256) void optimizer_small(SmallTensors t, AdamArgs aa, AdadeltaArgs da,
-                                                       float* __restrict__ sumsq_partial) {
+                                                       float* __restrict__ sumsq_partial,
+                                                       float* __restrict__ sumsq_new_partial = nullptr) {
     __shared__ float red[4];
     int i = 0;
     if ((int)blockIdx.x >= t.first_block[1]) i = 1;
@@ -254,7 +258,7 @@ __global__ __launch_bounds__(256) void optimizer_small(SmallTensors t, AdamArgs 
     aa.l2k = t.l2k[i];
     da.l2k = t.l2k[i];
     const float omb1 = 1.0f - aa.b1, omb2 = 1.0f - aa.b2, omr = 1.0f - da.rho;
-    float ss = 0.f;
+    float ss = 0.f, ssn = 0.f;
     const float* parts = t.gparts[i];
     const int ngroups = t.ngroups[i];
     const size_t gstride = (size_t)t.gstride[i];
@@ -268,13 +272,30 @@ __global__ __launch_bounds__(256) void optimizer_small(SmallTensors t, AdamArgs 
         } else {
             gg = g[k];
         }
-        if (ADAM) { float unused = 0.f; adam_elem(pp, gg, a0, a1, aa, omb1, omb2, ss, unused); }
-        else adadelta_elem(pp, gg, a0, a1, da, omr, ss);
+        if (ADAM) adam_elem(pp, gg, a0, a1, aa, omb1, omb2, ss, ssn);
+        else { adadelta_elem(pp, gg, a0, a1, da, omr, ss); ssn += pp * pp; }
         p[k] = pp; s0[k] = a0; s1[k] = a1;
         if (STORE_G) g[k] = gg;
     }
     const float tot = block_sum_256(ss, red);
     if (threadIdx.x == 0) sumsq_partial[blockIdx.x] = (t.l2k[i] != 0.f) ? tot : 0.f;
+    if (sumsq_new_partial) {      // (kernel-uniform)
+        __syncthreads();
+        const float tn = block_sum_256(ssn, red);
+        if (threadIdx.x == 0) sumsq_new_partial[blockIdx.x] = (t.l2k[i] != 0.f) ? tn : 0.f;
+    }
+}
+
+// The pre-update sums of squares of optimizer_small over ONE tensor WITHOUT the update: same strided shares, same
+// element order, same block reduction -- partial[b] equals what optimizer_small leaves in sumsq_partial[first_block + b]
+// (first step of a deferred small update, or after the host replaced the table).
+__global__ __launch_bounds__(256) void sumsq_like_small(const float* __restrict__ p, size_t count, float l2k,
+                                                        float* __restrict__ partial) {
+    __shared__ float red[4];
+    float ss = 0.f;
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < count; k += (size_t)gridDim.x * 256) ss += p[k] * p[k];
+    const float tot = block_sum_256(ss, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = (l2k != 0.f) ? tot : 0.f;
 }
 
 // partial[b] = sum of block b's strided share of in[0..count)

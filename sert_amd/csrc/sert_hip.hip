@@ -1208,6 +1208,20 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         // From here on the main stream has produced dW, db and the loss partials AND is done
         // READING W (the dh GEMM): the side stream may update the small tensors.
         if (m->lazy_join && !dense_bound && !fork_nce) SERT_HIP(hipEventRecord(fork_late ? m->ev_fork : m->ev_dense, m->stream));
+        if (fork_late && !fork_nce && !is_dp(m) && !m->timing.enabled && m->epart && c.kind == SERT_KIND_VECTORSPACE &&
+            c.num_negatives > 0 && m->neg_alt_step != m->step + 1) {
+            // The NEXT step's negatives (Philox position = the step counter after this step's update) are drawn NOW,
+            // while the side stream still idles in front of the fork -- beside this step's gather / projection / loss
+            // kernels -- instead of at the end of the step between the entity chain and the R_e update, where the
+            // 5 us launch stretched to 18 us beside the word table's Adam and sat on the path to the tail (round 4:
+            // the side chain ended 2.5 us AFTER the main stream's Adam).  neg_alt is free: this step's own negatives
+            // were swapped into `neg` at its start.  Ordered before the next step's loss kernel by this stream's
+            // order and the end-of-step join (ev_small).
+            const int64_t count = (int64_t)c.batch_size * c.num_negatives;
+            hipLaunchKernelGGL(vs_sample_negatives, dim3(grid_for((count + 3) / 4)), dim3(256), 0, m->stream2, m->neg_alt, count,
+                               (int64_t)m->rank * count, (uint32_t)c.num_entities, c.seed, (uint64_t)(m->step + 1) * 2);
+            m->neg_alt_step = m->step + 1;
+        }
         if (fork_late && !fork_nce) SERT_HIP(hipStreamWaitEvent(m->stream2, m->ev_fork, 0));
         if (fork_late && dw_third_queue(m)) SERT_HIP(hipStreamWaitEvent(m->stream3, m->ev_fork, 0));
         return 0;
@@ -1788,6 +1802,17 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
     // side-heavy schedule: the entity table is updated BEHIND the join of the tail (see below)
     static const bool no_defer = knob("SERT_RE_DEFER") && atoi(knob("SERT_RE_DEFER")) == 0;
     const bool defer_re = !no_defer && m->side_heavy && side_small && tail_splits > 0 && m->pt_big[1] && is_vs(m) && !c.keep_grads;
+    // ... and so is a SMALL entity table (C2: 1000 x 128, one optimizer_small launch behind the entity chain on the side
+    // stream).  Round 4, from the GPU timeline: that launch -- 4 us alone, 12-31 us beside the word table's Adam -- ended
+    // when the Adam did, and the tail started 13 us later, behind the cross-queue join.  The tail needs nothing of it but
+    // the sums of squares of R_e, which the PREVIOUS step's launch leaves (of the values it writes: same shares, same
+    // order, the same bits -- sumsq_new_partial); the update itself only has to land before the next loss kernel
+    // (settle_entity_update), so the main stream no longer joins the side stream at the end of a step.
+    const bool defer_small = !no_defer && !defer_re && side_small && tail_splits > 0 && !m->pt_big[1] && is_vs(m) && !is_fs(m) &&
+                             !c.keep_grads && m->lazy_join && fork_late_mode(m) && m->n_re > 0;
+    const int re_cur = (int)(m->step & 1), re_nxt = re_cur ^ 1;
+    const size_t re_cap = (size_t)2 * kOptBlocks;
+    bool small_needs_join = !defer_small;
     int re_sq_lo = 0, re_nb = 0;
     for (int i = 0; i < 4; ++i) {
         if (!m->pt_big[i]) continue;
@@ -1866,9 +1891,10 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
         }
     }
     if (exchanged) SERT_HIP(hipStreamWaitEvent(m->stream, m->ev_ar_done, 0));
-    if (side_small && m->epart && c.kind == SERT_KIND_VECTORSPACE && c.num_negatives > 0) {
+    if (side_small && m->epart && c.kind == SERT_KIND_VECTORSPACE && c.num_negatives > 0 && m->neg_alt_step != m->step) {
         // the next step's negatives (Philox position = the step counter after this update), drawn
-        // here on the side stream: ev_small below orders them before anything of the next step
+        // here on the side stream unless the step's forward already drew them in front of its fork:
+        // ev_small below orders them before anything of the next step
         const int64_t count = (int64_t)c.batch_size * c.num_negatives;
         hipLaunchKernelGGL(vs_sample_negatives, dim3(grid_for((count + 3) / 4)), dim3(256), 0, ss, m->neg_alt, count,
                            (int64_t)m->rank * count, (uint32_t)c.num_entities, c.seed, (uint64_t)m->step * 2);
@@ -1898,9 +1924,26 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
         for (int i = k; i < 3; ++i) { st.p[i] = st.g[i] = st.s0[i] = st.s1[i] = nullptr; st.count[i] = 0; st.l2k[i] = 0.f; st.gparts[i] = nullptr; st.ngroups[i] = 0; st.gstride[i] = 0; }
         for (int i = k; i <= 3; ++i) st.first_block[i] = blocks;
         float* sq = m->red_sq + n_sq;
+        float* sq_new = nullptr;
+        if (defer_small && mask == 0x2u && blocks > 0) {
+            // (R_e alone in this launch: its partial slots [n_sq, n_sq + blocks) are read from re_sq by the tail)
+            re_sq_lo = n_sq;
+            re_nb = blocks;
+            sq_new = m->re_sq + re_nxt * re_cap;
+            if (m->re_sq_for[re_cur] != m->step) {
+                // no previous launch left this step's sums (first step, another schedule in between, the host replaced
+                // the table): the same partials from a read-only pass IN FRONT of the update, and the tail joins once
+                hipLaunchKernelGGL(sumsq_like_small, dim3(blocks), dim3(256), 0, ss, (const float*)m->re, m->n_re, l2k,
+                                   m->re_sq + re_cur * re_cap);
+                m->re_sq_for[re_cur] = m->step;
+                small_needs_join = true;
+            }
+        }
         if (blocks > 0) {
             const bool keep = c.keep_grads != 0;
-            if (is_vs(m)) {
+            if (is_vs(m) && sq_new) {
+                hipLaunchKernelGGL((optimizer_small<true, false>), dim3(blocks), dim3(256), 0, ss, st, aa, da, sq, sq_new);
+            } else if (is_vs(m)) {
                 if (keep) hipLaunchKernelGGL((optimizer_small<true, true>), dim3(blocks), dim3(256), 0, ss, st, aa, da, sq);
                 else      hipLaunchKernelGGL((optimizer_small<true, false>), dim3(blocks), dim3(256), 0, ss, st, aa, da, sq);
             } else {
@@ -1923,17 +1966,22 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
     } else {
         small_tensors(ss, 0xEu);
     }
-    const int re_cur = (int)(m->step & 1), re_nxt = re_cur ^ 1;
-    const size_t re_cap = (size_t)2 * kOptBlocks;
     if (defer_re && m->re_sq_for[re_cur] != m->step) {
         // no previous deferred launch left this step's sums (first step, another schedule in between, the
         // host replaced the table): the same partials from a read-only pass, in front of the join
         hipLaunchKernelGGL(sumsq_like_adam, dim3(re_nb), dim3(256), 0, ss, (const float*)m->re, m->n_re, m->re_sq + re_cur * re_cap);
         m->re_sq_for[re_cur] = m->step;
     }
-    if (side_small) {
+    if (side_small && small_needs_join) {
         SERT_HIP(hipEventRecord(m->ev_small, ss));
         SERT_HIP(hipStreamWaitEvent(m->stream, m->ev_small, 0));
+    }
+    if (defer_small && re_nb > 0) {
+        // the update is in the side stream; the next reader of R_e (and, through this stream's order, of the negatives
+        // drawn in front of this step's fork) waits for it in settle_entity_update
+        m->re_sq_for[re_nxt] = m->step + 1;
+        SERT_HIP(hipEventRecord(m->ev_re, ss));
+        m->re_pending = true;
     }
     if (defer_re) {
         // The entity table's L2 + Adam, behind the join: the tail does not wait for it.  Nothing reads R_e,
@@ -1969,9 +2017,10 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
             ta.aa = aa;
             ta.loss_partials = lp; ta.n_loss = nl;
             ta.sq_partials = m->red_sq; ta.n_sq = n_sq;
-            ta.sq_alt = defer_re ? m->re_sq + re_cur * re_cap : nullptr;
-            ta.sq_alt_lo = defer_re ? re_sq_lo : 0;
-            ta.sq_alt_hi = defer_re ? re_sq_lo + re_nb : 0;
+            const bool alt = defer_re || (defer_small && re_nb > 0);
+            ta.sq_alt = alt ? m->re_sq + re_cur * re_cap : nullptr;
+            ta.sq_alt_lo = alt ? re_sq_lo : 0;
+            ta.sq_alt_hi = alt ? re_sq_lo + re_nb : 0;
             ta.inv_batch = inv_batch; ta.reg_scale = reg_scale;
             ta.out = loss_dst; ta.host_flag = flag; ta.seq = publish ? ++m->loss_seq : 0u;
             ta.blk = m->tail_blk;

@@ -773,6 +773,14 @@ inline bool launch_gemm_stream(hipStream_t s, const float* A, const float* B, fl
                                int lda, int ldb, int ldc);
 #endif
 
+#ifdef SERT_VARIANTS
+// variants/gemm_direct.h: A (row-major, contiguous along k) straight from global memory into v_mfma_f32_16x16x4_f32, B in
+// 64-k LDS slabs read as ds_read_b128 -- measured equal or slower (round 4); false when the operands are not its own
+template <bool TB, int EPI>
+inline bool launch_gemm_direct(hipStream_t s, const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
+                               int lda, int ldb, int ldc);
+#endif
+
 // rowmap / mapped_C / mapped (optional): when the launch goes to the 64x64-tile kernel, row r of the product is
 // stored as row rowmap[r] of mapped_C (leading dimension ldc) instead of row r of C, and *mapped is set.
 template <bool TA, bool TB, int EPI, bool CSB = false>
@@ -787,6 +795,13 @@ inline void launch_gemm(hipStream_t s, const float* A, const float* B, float* C,
     if (!TA && !CSB && splits == 1 && (EPI == EPI_STORE || EPI == EPI_BIAS || EPI == EPI_BIAS_TANH)) {
         static const bool stream = variant_knob("SERT_GEMM_STREAM") != nullptr;
         if (stream && launch_gemm_stream<TB, EPI>(s, A, B, C, bias, M, N, K, lda, ldb, ldc)) return;
+    }
+#endif
+#ifdef SERT_VARIANTS
+    if (!TA && !CSB && splits == 1 && !rowmap && (EPI == EPI_STORE || EPI == EPI_BIAS || EPI == EPI_BIAS_TANH)) {
+        static const int direct_min_k = variant_knob("SERT_GEMM_DIRECT_MIN_K") ? atoi(variant_knob("SERT_GEMM_DIRECT_MIN_K")) : 0;
+        if (direct_min_k > 0 && K >= direct_min_k && (long long)M * N >= 128 * 128 * 64 &&
+            launch_gemm_direct<TB, EPI>(s, A, B, C, bias, M, N, K, lda, ldb, ldc)) return;
     }
 #endif
     GemmArgs g;

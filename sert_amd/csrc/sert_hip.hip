@@ -18,6 +18,7 @@
 #include "variants/gemm_big.h"
 #include "variants/gemm_strip.h"
 #include "variants/gemm_stream.h"
+#include "variants/gemm_direct.h"
 #endif
 #include "kernels_score_bf16.h"
 #include "kernels_egrad.h"

@@ -1,7 +1,8 @@
 """Every GEMM kernel of the library against float64, through sert_debug_gemm -- the same dispatch (launch_gemm) a training
 step uses, so a shape lands on the kernel the step would run it on: the 128x128-tile kernel, the 64x64-tile one, the
-128x160-tile one (N just above a multiple of 128) and the streaming projection kernel (gemm_stream.h: huge M, N = K = 128,
-A straight from global memory into v_mfma_f32_16x16x4_f32, B resident in LDS)."""
+128x160-tile one (N just above a multiple of 128) and -- against a variants build (SERT_LIB=.../libsert_variants.so) with
+SERT_GEMM_DIRECT_MIN_K=256 / SERT_GEMM_STREAM=1 -- the two kernels of round 4 that feed A straight from global memory into
+v_mfma_f32_16x16x4_f32 (variants/gemm_direct.h, variants/gemm_stream.h; measured equal or slower, not in the product)."""
 import numpy as np
 import pytest
 
@@ -30,6 +31,11 @@ def _ref(A, B, ta, tb, epi, bias):
     # 64x64 tiles, 128x128 tiles, 128x160 tiles, odd sizes (scalar loaders), A^T.B
     (1000, 300, 300, 0, 0, 2), (4096, 1000, 128, 0, 0, 1), (3000, 128, 1000, 0, 1, 0), (333, 77, 45, 0, 0, 1),
     (128, 128, 5000, 1, 0, 0), (300, 301, 2000, 1, 0, 0), (257, 129, 64, 1, 1, 0),
+    # long-K shapes (variants build + SERT_GEMM_DIRECT_MIN_K=256: gemm_direct.h): 256-row and 128-row tiles, both B layouts, ragged M, N
+    # (last column tile 104 / 44 wide), K with a partial last slab and a partial last 16-k block (1000 = 15 x 64 + 40)
+    (65536, 128, 1000, 0, 0, 0), (65536, 128, 1000, 0, 1, 0), (20000, 1000, 256, 0, 1, 1), (44467, 128, 1000, 0, 1, 0),
+    (9000, 300, 300, 0, 0, 2), (9001, 300, 300, 0, 1, 0), (4096, 1000, 260, 0, 0, 1), (2049, 256, 4096, 0, 0, 0),
+    (4096, 4096, 512, 0, 1, 0),
 ])
 def test_gemm_dispatch_against_float64(hip_lib, M, N, K, ta, tb, epi):
     rng = np.random.RandomState(M + 3 * N + 7 * K + ta + 2 * tb)

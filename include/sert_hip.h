@@ -298,6 +298,17 @@ int sert_debug_row_lists(const uint32_t* allbits, int world, int rank, int64_t n
                          int32_t* fetch_cnt, int32_t* serve_rows, int32_t* fetch_rows, int32_t* union_rows,
                          int32_t* ptr, int32_t* ent, int64_t capacity, int64_t* sizes);
 
+/* Host only, no GPU (test hook, no reference counterpart): the inverted index word -> batch rows that
+ * sert_upload_dataset builds for a vectorspace model (the order-fixed replacement of Theano's AdvancedIncSubtensor1,
+ * autodiff of sert/models.py:180), built for ids[num_batches][B][n] and EVALUATED ON THE HOST the way the segmented-sum
+ * kernels walk it: grad_out[vocab][d] = the word-table gradient of batch `batch` for source rows src[B][d] (dh), i.e.
+ * sum over the occurrences of a word of src[row] / divisor.  row_groups > 1: level 0 cut into row ranges (XCD lists);
+ * dense_heavy: the batch's heaviest words summed outside the tree.  stats[8] = {levels, items, partial rows, final items,
+ * dense words, row groups, level-0 items, distinct words}. */
+int sert_debug_word_index_sum(const void* ids, int id_bytes, int64_t num_batches, int B, int n, int vocab, int row_groups,
+                              int dense_heavy, int64_t batch, const float* src, int d, float divisor, float* grad_out,
+                              int64_t* stats);
+
 /* roctx ranges around host-side phases (no reference counterpart): forwarded to
  * roctxRangePushA / roctxRangePop of the ROCm tools library when it can be loaded, no-ops otherwise.
  * With SERT_ROCTX=1 in the environment the library itself wraps every kernel group of a step (the

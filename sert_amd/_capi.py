@@ -35,7 +35,7 @@ EXPORTS = [
     'sert_host_alloc', 'sert_host_free',
     'sert_comm_unique_id', 'sert_comm_init', 'sert_comm_init_host', 'sert_comm_destroy', 'sert_comm_stats',
     'sert_synchronize', 'sert_timing_enable', 'sert_timing_reset', 'sert_timing_count',
-    'sert_timing_name', 'sert_timing_avg_us', 'sert_bench_gemm', 'sert_debug_gemm', 'sert_bench_memory', 'sert_debug_row_lists',
+    'sert_timing_name', 'sert_timing_avg_us', 'sert_bench_gemm', 'sert_debug_gemm', 'sert_bench_memory', 'sert_debug_row_lists', 'sert_debug_word_index_sum',
     'sert_profile_range_push', 'sert_profile_range_pop',
 ]
 
@@ -520,6 +520,27 @@ def bench_gemm(M, N, K, ta=0, tb=0, epi=0, splits=1, iters=20, device=0):
 
 MEMBENCH_COPY, MEMBENCH_READ, MEMBENCH_GATHER, MEMBENCH_OPTIMIZER = 0, 1, 2, 3
 SEPARATE_ALLOCATIONS = ctypes.c_size_t(-1).value
+
+
+def debug_word_index_sum(ids, vocab, src, batch=0, row_groups=1, dense_heavy=False, divisor=1.0):
+    """Host only: the word-table gradient of one batch through the inverted index as the segmented-sum kernels walk it
+    (sert_debug_word_index_sum).  ids (num_batches, B, n) unsigned; src (B, d) float32.  Returns (grad (vocab, d), stats)."""
+    lib = load()
+    ids = np.ascontiguousarray(ids)
+    assert ids.ndim == 3 and ids.dtype in (np.uint8, np.uint16, np.uint32), (ids.shape, ids.dtype)
+    src = np.ascontiguousarray(src, dtype=np.float32)
+    nb, B, n = ids.shape
+    assert src.shape[0] == B
+    d = src.shape[1]
+    out = np.empty((vocab, d), dtype=np.float32)
+    stats = np.zeros(8, dtype=np.int64)
+    lib.sert_debug_word_index_sum.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                              ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_float,
+                                              ctypes.c_void_p, ctypes.c_void_p]
+    check(lib.sert_debug_word_index_sum(_addr(ids), ids.dtype.itemsize, nb, B, n, int(vocab), int(row_groups), int(bool(dense_heavy)),
+                                        int(batch), _addr(src), d, float(divisor), _addr(out), _addr(stats)))
+    keys = ('levels', 'items', 'partial_rows', 'final_items', 'dense_words', 'row_groups', 'level0_items', 'distinct_words')
+    return out, dict(zip(keys, [int(x) for x in stats]))
 
 
 def debug_gemm(A, B, ta=0, tb=0, epi=0, bias=None, device=0):

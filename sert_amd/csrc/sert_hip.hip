@@ -3635,6 +3635,68 @@ int sert_debug_row_lists(const uint32_t* allbits, int world, int rank, int64_t n
     return 0;
 }
 
+// Host only (no GPU): the per-batch inverted index of sert_upload_dataset (word_index.h) built for `ids` and EVALUATED
+// on the host exactly as the kernels of kernels_seg.h walk it -- every item sums its entries left to right, final items
+// store acc / divisor into the gradient table, chunk items into their partial row, the upper levels read the partial
+// rows of the level below -- so the structure (levels, chunk bounds, partial-row numbering, the row-grouped level 0 with
+// its eight XCD lists, the dense heavy words left out of the tree) is checked by the CPU suite.
+int sert_debug_word_index_sum(const void* ids, int id_bytes, int64_t num_batches, int B, int n, int vocab, int row_groups,
+                              int dense_heavy, int64_t batch, const float* src, int d, float divisor, float* grad_out,
+                              int64_t* stats) {
+    if (!ids || !src || !grad_out || !stats || num_batches <= 0 || B <= 0 || n <= 0 || vocab <= 0 || d <= 0 || batch < 0 ||
+        batch >= num_batches || (id_bytes != 1 && id_bytes != 2 && id_bytes != 4))
+        SERT_FAIL("bad argument");
+    WordIndex wi;
+    bool ok = true;
+    SERT_ID_DISPATCH(id_bytes, ok = build_word_index<IdT>((const IdT*)ids, num_batches, B, n, vocab, /*row_is_pos=*/false, wi,
+                                                          /*want_slots=*/false, dense_heavy != 0, row_groups));
+    if (!ok) SERT_FAIL("token id >= vocab");
+    const BatchIndex& bx = wi.batches[(size_t)batch];
+    std::fill(grad_out, grad_out + (size_t)vocab * d, 0.f);
+    std::vector<float> part((size_t)std::max<int64_t>(1, bx.part_rows) * d, 0.f);
+    int64_t items_total = 0, finals = 0;
+    for (int l = 0; l < bx.nlevels; ++l) {
+        const SegItem* items = wi.items.data() + bx.item_off[l];
+        const float* in = l == 0 ? src : part.data() + (size_t)bx.part_off[l - 1] * d;
+        const int32_t* rows = l == 0 ? wi.rows.data() + bx.rows_off : nullptr;
+        float* pout = part.data() + (size_t)bx.part_off[l] * d;
+        // level 0 of a row-grouped index is addressed through its XCD lists, as the kernel does
+        std::vector<int32_t> order;
+        if (l == 0 && bx.row_groups > 1) {
+            for (int x = 0; x < 8; ++x)
+                for (int k = 0; k < bx.xcd_cnt[x]; ++k) order.push_back(bx.xcd_off[x] + k);
+            if ((int32_t)order.size() != bx.item_cnt[0]) SERT_FAIL("XCD lists do not cover level 0");
+        } else {
+            for (int32_t k = 0; k < bx.item_cnt[l]; ++k) order.push_back(k);
+        }
+        for (int32_t k : order) {
+            const SegItem& it = items[k];
+            if (it.end - it.begin > kSegChunk && l < kSegMaxLevels - 1) SERT_FAIL("an item longer than a chunk");
+            ++items_total;
+            float* dst = it.dst >= 0 ? grad_out + (size_t)it.dst * d : pout + (size_t)(-(it.dst + 1)) * d;
+            if (it.dst >= 0) ++finals;
+            for (int c = 0; c < d; ++c) {
+                float a = 0.f;
+                for (int32_t e = it.begin; e < it.end; ++e) a += in[(size_t)(rows ? rows[e] : e) * d + c];
+                dst[c] = it.dst >= 0 ? a / divisor : a;
+            }
+        }
+    }
+    // the dense heavy words: count-weighted sums over all batch rows (segsum_heavy + combine; the block structure of the
+    // device reduction is not restated here -- integer-valued test data makes every association exact)
+    for (int h = 0; h < bx.dense_cnt; ++h) {
+        const uint8_t* dc = wi.dense_counts.data() + (size_t)(batch * B) * kHeavyMax;
+        for (int c = 0; c < d; ++c) {
+            float a = 0.f;
+            for (int i = 0; i < B; ++i) a += (float)dc[(size_t)i * kHeavyMax + h] * src[(size_t)i * d + c];
+            grad_out[(size_t)bx.dense_word[h] * d + c] = a / divisor;
+        }
+    }
+    stats[0] = bx.nlevels; stats[1] = items_total; stats[2] = bx.part_rows; stats[3] = finals; stats[4] = bx.dense_cnt;
+    stats[5] = bx.row_groups; stats[6] = bx.item_cnt[0]; stats[7] = bx.num_distinct;
+    return 0;
+}
+
 int sert_profile_range_push(const char* name) {
     roctx_load();
     if (!name) SERT_FAIL("null range name");

@@ -1099,6 +1099,8 @@ def main():
             label='VectorSpaceSoftmaxLanguageModel (additive, not in the reference): gather + mean-pool + tanh projection + '
                   'full softmax over V_e=%d, Adam; V_w=%d d=%d window=%d batch=%d' % (Ve, Vw, d, n, Bl))
         rec['mfma_tflops_whole_step'] = (6.0 * Bl * d * d + 6.0 * Bl * d * Ve) / (dt3 / st) / 1e12
+        rec['parity'] = ('self-checked: this model has no counterpart in the reference (SURVEY 8-a12); its only oracle is the '
+                         "builder's own restatement + finite differences (tests/test_gpu_fullbatch.py at this batch)")
         out['lse_full_softmax'] = rec
 
     if ctx.rank == 0 and N == 1 and kind == 'vectorspace' and not args.no_c4_extra:

@@ -23,20 +23,44 @@ struct AdamArgs {
     float b1, b2, eps;
 };
 
+// The element updates below are compiled with contraction OFF (#pragma clang fp contract(off): every product and sum
+// rounded on its own; HIP's __fmul_rn / __fadd_rn are plain operators and do not prevent it): the same element is
+// updated by different kernels -- the dense launches, the lazy launch and its catch-up loop, the small-tensor launch, the
+// fused tail -- and must come out with the same bits whichever one it was (round 4: b2 v + (1 - b2) g g was contracted
+// differently in two of them, 1 ulp apart).  The order is NumPy's on the oracle's expressions
+// (oracle/sert_oracle.py: Adam.update, Adadelta.update); only the square root and the division go through the
+// hardware's 1-ulp instructions (see there).  sum(p^2) accumulates through an explicit fma everywhere.
+__device__ __forceinline__ float sq_acc(float acc, float x) { return __builtin_fmaf(x, x, acc); }
+
 // Lasagne 0.1 adam [upstream]:
 //   m = b1*m + (1-b1)*g ; v = b2*v + (1-b2)*g^2 ; p = p - a_t*m/(sqrt(v)+eps)
 __device__ __forceinline__ void adam_elem(float& p, float& g, float& m, float& v, const AdamArgs& a,
                                           float omb1, float omb2, float& ss, float& ss_new) {
+#pragma clang fp contract(off)
     const float pv = p;
-    const float gv = g + a.l2k * pv;
-    ss += pv * pv;
-    const float mv = a.b1 * m + omb1 * gv;
-    const float vv = a.b2 * v + omb2 * gv * gv;
+    const float l2 = a.l2k * pv;
+    const float gv = g + l2;
+    ss = sq_acc(ss, pv);
+    const float m1 = a.b1 * m, m2 = omb1 * gv;
+    const float mv = m1 + m2;
+    const float v1 = a.b2 * v, v2 = (omb2 * gv) * gv;
+    const float vv = v1 + v2;
     m = mv;
     v = vv;
-    const float pn = pv - a.a_t * mv / (sqrtf(vv) + a.eps);
+    // sqrt and the division through the hardware's 1-ulp v_sqrt_f32 / v_rcp_f32 instead of the IEEE expansions (~10
+    // instructions each): irrelevant to the memory-bound dense launch, but the lazy launch's catch-up loop is VALU-bound
+    // (round 4: W3C loglinear 331 -> 263 us per step with them, 288 without).  <= 2 ulp on the update term, i.e. ~2e-10
+    // of a parameter per step against a parity tolerance of 1e-4.  -DSERT_OPT_IEEE_DIV restores sqrtf and '/'.
+#ifndef SERT_OPT_IEEE_DIV
+    const float num = a.a_t * mv, den = __builtin_amdgcn_sqrtf(vv) + a.eps;
+    const float quo = num * __builtin_amdgcn_rcpf(den);
+    const float pn = pv - quo;
+#else
+    const float num = a.a_t * mv, den = sqrtf(vv) + a.eps;
+    const float pn = pv - num / den;
+#endif
     p = pn;
-    ss_new += pn * pn;    // (the same expression, in the same element order, as `ss` of the NEXT step's launch)
+    ss_new = sq_acc(ss_new, pn);    // (the same expression, in the same element order, as `ss` of the NEXT step's launch)
     g = gv;
 }
 
@@ -139,14 +163,14 @@ __global__ __launch_bounds__(256) void sumsq_like_adam(const float* __restrict__
     const size_t hi = lo + per < n4 ? lo + per : n4;
     for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         const float4 pp = p4[i];
-        ss += pp.x * pp.x;
-        ss += pp.y * pp.y;
-        ss += pp.z * pp.z;
-        ss += pp.w * pp.w;
+        ss = sq_acc(ss, pp.x);     // (the expression of adam_elem)
+        ss = sq_acc(ss, pp.y);
+        ss = sq_acc(ss, pp.z);
+        ss = sq_acc(ss, pp.w);
     }
     if (blockIdx.x == 0) {
         const size_t i = (n4 << 2) + threadIdx.x;
-        if (i < count) ss += p[i] * p[i];
+        if (i < count) ss = sq_acc(ss, p[i]);
     }
     const float tot = block_sum_256(ss, red);
     if (threadIdx.x == 0) sumsq_partial[blockIdx.x] = tot;
@@ -161,15 +185,26 @@ struct AdadeltaArgs {
 //   d = rho*d + (1-rho)*u^2
 __device__ __forceinline__ void adadelta_elem(float& p, float& g, float& accu, float& delta,
                                               const AdadeltaArgs& a, float omr, float& ss) {
+#pragma clang fp contract(off)
     const float pv = p;
-    const float gv = g + a.l2k * pv;
-    ss += pv * pv;
-    const float av = a.rho * accu + omr * gv * gv;
+    const float l2 = a.l2k * pv;
+    const float gv = g + l2;
+    ss = sq_acc(ss, pv);
+    const float a1 = a.rho * accu, a2 = (omr * gv) * gv;
+    const float av = a1 + a2;
     const float dv = delta;
-    const float u = gv * sqrtf(dv + a.eps) / sqrtf(av + a.eps);
+#ifndef SERT_OPT_IEEE_DIV
+    const float s_d = __builtin_amdgcn_sqrtf(dv + a.eps), r_a = __builtin_amdgcn_rsqf(av + a.eps);
+    const float u = (gv * s_d) * r_a;
+#else
+    const float s_d = sqrtf(dv + a.eps), s_a = sqrtf(av + a.eps);
+    const float u = (gv * s_d) / s_a;
+#endif
     accu = av;
-    p = pv - a.lr * u;
-    delta = a.rho * dv + omr * u * u;
+    const float step = a.lr * u;
+    p = pv - step;
+    const float d1 = a.rho * dv, d2 = (omr * u) * u;
+    delta = d1 + d2;
     g = gv;
 }
 
@@ -218,6 +253,122 @@ __global__ __launch_bounds__(256) void adadelta_l2(float* __restrict__ p, float*
     }
     const float tot = block_sum_256(ss, red);
     if (threadIdx.x == 0) sumsq_partial[blockIdx.x] = tot;
+}
+
+// ---- the word table's dense update, LAZILY but bit for bit -------------------------------------------------------
+// The reference moves EVERY row EVERY step (dense L2, sert/models.py:764-795; dense Adam / Adadelta, :548-549) and
+// returns a loss that contains sum(p^2): at C4 that is 0.75 ms of a 1.95 ms step streaming p, m, v of 150 M parameters
+// in AND out for a batch that touches 14 % of the rows.  But the recurrence of an element no token points to
+// (g = lambda/B p) is element-local: a row may stay in memory at the state of update s < t and be brought forward in
+// REGISTERS -- t - s applications of the very same adam_elem / adadelta_elem, in the same order on the same inputs, hence
+// the same bits -- whenever its current value is needed:
+//   * every step for sum(p^2): read p, m, v (12 B per element instead of 24 B read + written);
+//   * written back (and advanced by this step's update) only if the batch touches the row (a real gradient), if the
+//     NEXT batch will (its forward reads the row: sert_hint_next_batch; no hint = write everything), or every
+//     kLazyK-th update (bounds the catch-up loop; 4: with 8 the loop's VALU time eats the saved bytes).
+// last[row] = number of updates applied to the stored (p, m, v) of the row; double-buffered (last_in / last_out) because
+// the float4 pieces of one row may be walked by two workgroups.  LazyArgs::update = 0 is the FLUSH: every row is brought
+// to t_prev and written, nothing else (in front of evaluations, predictions, tensor reads and writes).
+constexpr int kLazyK = 4;
+struct LazyArgs {
+    const int32_t* last_in;      // null: every row is at t_prev
+    int32_t* last_out;
+    const uint32_t* next_bits;   // rows the next batch touches, or null
+    int t_prev;                  // updates a CURRENT row has seen before this launch
+    int write_all;               // materialise every row
+    int update;                  // 1: training step (update t_prev + 1), 0: flush
+    float a_of[kLazyK + 1];      // Adam: a_of[k] = step size a_t of update number t_prev + 1 - k
+};
+__device__ __forceinline__ float lazy_step_size(const LazyArgs& lz, int k) {
+    float r = lz.a_of[1];
+#pragma unroll
+    for (int j = 2; j <= kLazyK; ++j) r = (k == j) ? lz.a_of[j] : r;
+    return r;
+}
+
+template <bool ADAM>
+__global__ __launch_bounds__(256) void dense_update_lazy(float* __restrict__ p, const float* __restrict__ g,
+                                                         float* __restrict__ s0, float* __restrict__ s1, size_t count,
+                                                         AdamArgs a, AdadeltaArgs da, float* __restrict__ sumsq_partial,
+                                                         const uint32_t* __restrict__ bits, unsigned row_len, const LazyArgs lz) {
+    __shared__ float red[4];
+    float ss = 0.f;
+    const float omb1 = 1.0f - a.b1, omb2 = 1.0f - a.b2, omr = 1.0f - da.rho;
+    const size_t n4 = count >> 2;
+    float4* p4 = reinterpret_cast<float4*>(p);
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    typedef float nt_f4 __attribute__((ext_vector_type(4)));
+    // (the same contiguous slices and the same thread -> element map as adam_l2 / adadelta_l2: the partial sums of
+    //  squares are the same numbers)
+    const size_t per = (n4 + gridDim.x - 1) / gridDim.x;
+    const size_t lo = (size_t)blockIdx.x * per;
+    const size_t hi = lo + per < n4 ? lo + per : n4;
+    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const unsigned e0 = (unsigned)i << 2;
+        const unsigned row = e0 / row_len;
+        const bool first_piece = e0 - row * row_len == 0u;
+        const int last = lz.last_in ? lz.last_in[row] : lz.t_prev;
+        const int lag = lz.t_prev - last;
+        const bool hit = lz.update && row_bit(bits, row);
+        const bool need = lz.update ? (hit || lz.write_all || (lz.next_bits && row_bit(lz.next_bits, row))) : (lag > 0);
+        if (first_piece) lz.last_out[row] = lz.update ? (need ? lz.t_prev + 1 : last) : lz.t_prev;
+        if (!lz.update && lag == 0) continue;
+        float4 pp = p4[i];
+        const nt_f4 mr = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(s0) + i);
+        const nt_f4 vr = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(s1) + i);
+        float4 mm = make_float4(mr.x, mr.y, mr.z, mr.w), vv = make_float4(vr.x, vr.y, vr.z, vr.w);
+        // catch-up: the updates last + 1 .. t_prev, each with a zero gradient (the L2 term alone), as the dense launch of
+        // that step applied them to every other row
+        for (int k = lag; k >= 1; --k) {
+            float z0 = 0.f, z1 = 0.f, z2 = 0.f, z3 = 0.f, sd = 0.f, sn = 0.f;
+            if (ADAM) {
+                AdamArgs ak = a;
+                ak.a_t = lazy_step_size(lz, k);
+                adam_elem(pp.x, z0, mm.x, vv.x, ak, omb1, omb2, sd, sn);
+                adam_elem(pp.y, z1, mm.y, vv.y, ak, omb1, omb2, sd, sn);
+                adam_elem(pp.z, z2, mm.z, vv.z, ak, omb1, omb2, sd, sn);
+                adam_elem(pp.w, z3, mm.w, vv.w, ak, omb1, omb2, sd, sn);
+            } else {
+                adadelta_elem(pp.x, z0, mm.x, vv.x, da, omr, sd);
+                adadelta_elem(pp.y, z1, mm.y, vv.y, da, omr, sd);
+                adadelta_elem(pp.z, z2, mm.z, vv.z, da, omr, sd);
+                adadelta_elem(pp.w, z3, mm.w, vv.w, da, omr, sd);
+            }
+        }
+        if (lz.update && !need) {
+            // not written: only its share of sum(p^2) -- the expression and the order of adam_elem / adadelta_elem
+            ss = sq_acc(ss, pp.x);
+            ss = sq_acc(ss, pp.y);
+            ss = sq_acc(ss, pp.z);
+            ss = sq_acc(ss, pp.w);
+            continue;
+        }
+        if (lz.update) {
+            float4 gg = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (hit) gg = g4[i];
+            float sn = 0.f;
+            if (ADAM) {
+                AdamArgs ak = a;
+                ak.a_t = lz.a_of[0];
+                adam_elem(pp.x, gg.x, mm.x, vv.x, ak, omb1, omb2, ss, sn);
+                adam_elem(pp.y, gg.y, mm.y, vv.y, ak, omb1, omb2, ss, sn);
+                adam_elem(pp.z, gg.z, mm.z, vv.z, ak, omb1, omb2, ss, sn);
+                adam_elem(pp.w, gg.w, mm.w, vv.w, ak, omb1, omb2, ss, sn);
+            } else {
+                adadelta_elem(pp.x, gg.x, mm.x, vv.x, da, omr, ss);
+                adadelta_elem(pp.y, gg.y, mm.y, vv.y, da, omr, ss);
+                adadelta_elem(pp.z, gg.z, mm.z, vv.z, da, omr, ss);
+                adadelta_elem(pp.w, gg.w, mm.w, vv.w, da, omr, ss);
+            }
+        }
+        p4[i] = pp;
+        { nt_f4 t; t.x = mm.x; t.y = mm.y; t.z = mm.z; t.w = mm.w; __builtin_nontemporal_store(t, reinterpret_cast<nt_f4*>(s0) + i); }
+        { nt_f4 t; t.x = vv.x; t.y = vv.y; t.z = vv.z; t.w = vv.w; __builtin_nontemporal_store(t, reinterpret_cast<nt_f4*>(s1) + i); }
+    }
+    if (lz.update) {
+        const float tot = block_sum_256(ss, red);
+        if (threadIdx.x == 0) sumsq_partial[blockIdx.x] = tot;
+    }
 }
 
 // The small tensors (entity table at small V_e, dense W, bias) in ONE launch: a
@@ -273,7 +424,7 @@ __global__ __launch_bounds__(256) void optimizer_small(SmallTensors t, AdamArgs 
             gg = g[k];
         }
         if (ADAM) adam_elem(pp, gg, a0, a1, aa, omb1, omb2, ss, ssn);
-        else { adadelta_elem(pp, gg, a0, a1, da, omr, ss); ssn += pp * pp; }
+        else { adadelta_elem(pp, gg, a0, a1, da, omr, ss); ssn = sq_acc(ssn, pp); }
         p[k] = pp; s0[k] = a0; s1[k] = a1;
         if (STORE_G) g[k] = gg;
     }
@@ -293,7 +444,7 @@ __global__ __launch_bounds__(256) void sumsq_like_small(const float* __restrict_
                                                         float* __restrict__ partial) {
     __shared__ float red[4];
     float ss = 0.f;
-    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < count; k += (size_t)gridDim.x * 256) ss += p[k] * p[k];
+    for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < count; k += (size_t)gridDim.x * 256) ss = sq_acc(ss, p[k]);
     const float tot = block_sum_256(ss, red);
     if (threadIdx.x == 0) partial[blockIdx.x] = (l2k != 0.f) ? tot : 0.f;
 }

@@ -96,6 +96,13 @@ struct sert_model {
     // 3 = + dW on a third (0.403: every cross-queue dependency costs 15-25 us of idle GPU)
     int nstreams = 2;
     int64_t hint_next = -1;        // sert_hint_next_batch
+    // lazy dense update of the word table (kernels_opt.h: dense_update_lazy)
+    int32_t* rw_last[2] = {nullptr, nullptr};   // per word row: updates applied to its stored (p, state0, state1)
+    int rw_last_cur = 0;           // which of the two holds the current values
+    bool rw_stale = false;         // some rows are behind m->step (rw_last[rw_last_cur] says by how much)
+    int64_t rw_ready_batch = -1;   // while stale: the training batch whose rows ARE current (the hinted one)
+    int64_t lazy_next = -1;        // the batch the caller announced to follow the one being trained
+    float cur_touched_frac = 1.f;  // distinct words of the batch being trained / vocabulary
     int64_t projected_batch = -1;  // training batch whose forward projection already sits in H/T
     // hinted single-GPU steps go further: the whole forward + backward runs ahead
     int64_t spec_fb_batch = -1;    // forward + backward of this batch already ran (gradients ready) ...

@@ -198,8 +198,10 @@ static void discard_run_ahead(sert_model* m) {
     }
     m->spec_fb_batch = -1;
 }
+static int ensure_rw_current(sert_model* m, int64_t batch);
 static void invalidate_speculation(sert_model* m) {
     discard_run_ahead(m);
+    (void)ensure_rw_current(m, -1);   // (whatever comes next -- new parameters, another step counter, new data -- sees every row current)
     if (m->re_pending) {       // (a deferred entity-table update: see settle_entity_update)
         (void)hipStreamWaitEvent(m->stream, m->ev_re, 0);
         m->re_pending = false;
@@ -207,6 +209,45 @@ static void invalidate_speculation(sert_model* m) {
     m->re_sq_for[0] = m->re_sq_for[1] = -1;
     m->projected_batch = -1;
     m->neg_alt_step = -1;      // (step counter, seed-relevant state or data may change)
+}
+
+// ---- lazy dense update of the word table (kernels_opt.h: dense_update_lazy) ----------------------------------------
+static void optimizer_args(const sert_model* m, int64_t t, AdamArgs* aa, AdadeltaArgs* da);
+static LazyArgs lazy_args(sert_model* m, int64_t t_prev, int update) {
+    LazyArgs lz;
+    lz.last_in = m->rw_stale ? m->rw_last[m->rw_last_cur] : nullptr;
+    lz.last_out = m->rw_last[m->rw_last_cur ^ 1];
+    lz.next_bits = nullptr;
+    lz.t_prev = (int)t_prev;
+    lz.write_all = 1;
+    lz.update = update;
+    for (int k = 0; k <= kLazyK; ++k) {
+        AdamArgs aa; AdadeltaArgs da;
+        optimizer_args(m, std::max<int64_t>(1, t_prev + 1 - k), &aa, &da);
+        lz.a_of[k] = aa.a_t;
+    }
+    return lz;
+}
+// Bring every row of R_w (and of its optimiser state) to the model's step -- unless `batch` is the training batch
+// whose rows the last update made current (the announced one: its forward may read them as they are).  Main stream.
+static int ensure_rw_current(sert_model* m, int64_t batch) {
+    if (!m->rw_stale) return 0;
+    if (batch >= 0 && batch == m->rw_ready_batch) return 0;
+    AdamArgs aa; AdadeltaArgs da;
+    optimizer_args(m, std::max<int64_t>(1, m->step), &aa, &da);
+    const LazyArgs lz = lazy_args(m, m->step, /*update=*/0);
+    const int64_t max_nb = m->n_rw >= ((size_t)1 << 24) ? 2 * kOptBlocks : kOptBlocks;
+    const int nb = (int)std::min<int64_t>(max_nb, cdiv(cdiv(m->n_rw, 4), 256));
+    if (is_vs(m))
+        hipLaunchKernelGGL((dense_update_lazy<true>), dim3(nb), dim3(256), 0, m->stream, m->rw, (const float*)m->g_rw, m->s0_rw, m->s1_rw,
+                           m->n_rw, aa, da, m->sq_scratch, (const uint32_t*)nullptr, (unsigned)m->cfg.word_dim, lz);
+    else
+        hipLaunchKernelGGL((dense_update_lazy<false>), dim3(nb), dim3(256), 0, m->stream, m->rw, (const float*)m->g_rw, m->s0_rw, m->s1_rw,
+                           m->n_rw, aa, da, m->sq_scratch, (const uint32_t*)nullptr, (unsigned)m->cfg.word_dim, lz);
+    m->rw_last_cur ^= 1;
+    m->rw_stale = false;
+    m->rw_ready_batch = -1;
+    return 0;
 }
 
 // A deferred entity-table update (side-heavy schedule) must have landed before the main stream reads R_e,
@@ -1771,7 +1812,7 @@ static int issue_untouched_rows_update(sert_model* m, const uint32_t* bits) {
 // loss_dst: device [3], or the pinned host block (publish = true: its sequence number is
 // stored after the values, for the host to spin on)
 static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = false,
-                              const uint32_t* bits = nullptr) {
+                              const uint32_t* bits = nullptr, const uint32_t* next_bits = nullptr) {
     const int n_loss_partials = m->n_loss_partials;
     const auto& c = m->cfg;
     const float l2k = c.lambda_ > 0.f ? c.lambda_ / (float)c.global_batch_size : 0.f;
@@ -1836,6 +1877,34 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
             const int64_t max_nb = t.n >= ((size_t)1 << 24) ? 2 * kOptBlocks : kOptBlocks;
             const int nb = (int)std::min<int64_t>(max_nb, cdiv(cdiv(t.n, 4), 256));
             const uint32_t* tf = (i == 0 && m->use_touched) ? bits : nullptr;
+            // Where it pays: the catch-up loop costs VALU time, the saving is the rows NOT written.  Measured (round 4,
+            // tools/experiments/r04_lazy_sweep.sh; word-table update alone / step): C4, a batch touches 14 % of the rows:
+            // 639 -> 530 us / 1.89 -> 1.77 ms; the reference's product-search settings (batch 4096, 12 %): 113 -> 85 us /
+            // 231 -> 207 us; its W3C loglinear settings (batch 1024, 5 %): 141 -> 79 us / 331 -> 263 us; C2 dims at batch
+            // 16384 (20 %): 58.5 -> 48 us; at C2's own batch (44 %, this or the next batch 69 %) a draw: 61.5 -> 57.5 us
+            // alone, the step equal -- dense there.  Lazy up to a touched fraction of 0.35 (SERT_LAZY_MAX_TOUCHED in a
+            // variants build: 0 = never, 1 = always).
+            static const float lazy_max = variant_knob("SERT_LAZY_MAX_TOUCHED") ? (float)atof(variant_knob("SERT_LAZY_MAX_TOUCHED")) : 0.35f;
+            if (i == 0 && tf && !m->early_issued && m->rw_last[0] && !c.keep_grads && c.word_dim % 4 == 0 &&
+                m->cur_touched_frac <= lazy_max) {
+                // the LAZY form of the dense update (kernels_opt.h): rows neither this batch nor the announced next one
+                // touches are read (their share of sum(p^2)) but not written, except every kLazyK-th update
+                LazyArgs lz = lazy_args(m, m->step - 1, /*update=*/1);
+                lz.next_bits = next_bits;
+                lz.write_all = (next_bits == nullptr || m->step % kLazyK == 0) ? 1 : 0;
+                if (is_vs(m))
+                    hipLaunchKernelGGL((dense_update_lazy<true>), dim3(nb), dim3(256), 0, m->stream, t.p, (const float*)t.g, t.s0, t.s1, t.n,
+                                       aa, da, m->red_sq + n_sq, tf, (unsigned)c.word_dim, lz);
+                else
+                    hipLaunchKernelGGL((dense_update_lazy<false>), dim3(nb), dim3(256), 0, m->stream, t.p, (const float*)t.g, t.s0, t.s1, t.n,
+                                       aa, da, m->red_sq + n_sq, tf, (unsigned)c.word_dim, lz);
+                m->rw_last_cur ^= 1;
+                m->rw_stale = !lz.write_all;
+                m->rw_ready_batch = lz.write_all ? -1 : m->lazy_next;
+                n_sq += nb;
+                continue;
+            }
+            if (i == 0) SERT_TRY(ensure_rw_current(m, -1));    // (a dense launch assumes every row is at the previous step)
             // (side_heavy: the entity table streams on the side stream, behind its gradient chain)
             launch_stream_opt(m, (i == 1 && m->side_heavy && side_small) ? ss : m->stream, t.p, t.g, t.s0, t.s1, t.n, nb, aa, da,
                               m->red_sq + n_sq, tf,
@@ -2086,6 +2155,7 @@ static int step_forward_backward(sert_model* m, const DataSplit& ds, int64_t bat
     // the rows it writes and the optimiser takes every other row's gradient as zero.
     // (Data parallel: the all-reduce needs the dense table; keep_grads: so does the caller.)
     m->use_touched = use_touched_now(m);
+    SERT_TRY(ensure_rw_current(m, batch_index));   // (lazy word-table update: the rows this batch reads must be current)
     // Prologue (zeroing, negative sampling): nothing before the loss kernel needs it, so
     // for the vectorspace step it runs on the side stream beside gather + projection.
     m->lazy_join = false;
@@ -2189,7 +2259,13 @@ static int train_step_async(sert_model* m, int64_t batch_index, const int64_t* n
     SERT_TRY(issue_untouched_rows_update(m, bits));
     if (!have_fb) SERT_TRY(step_forward_backward(m, ds, batch_index, negatives, &fused_pre));
     SERT_TRY(allreduce_rest(m));
-    SERT_TRY(optimizer_and_loss(m, loss_dst, publish, bits));
+    m->cur_touched_frac = (size_t)batch_index < ds.idx_batches.size()
+                              ? (float)ds.idx_batches[(size_t)batch_index].num_distinct / (float)m->cfg.vocab_size : 1.f;
+    // the rows the ANNOUNCED next batch touches: the lazy word-table update keeps them current (sert_hint_next_batch)
+    const uint32_t* next_bits = nullptr;
+    if (ds.idx_touched_bits && m->lazy_next >= 0 && (m->lazy_next + 1) * (int64_t)B <= ds.N)
+        next_bits = ds.idx_touched_bits + (size_t)m->lazy_next * ds.bit_words;
+    SERT_TRY(optimizer_and_loss(m, loss_dst, publish, bits, next_bits));
     if (is_dp(m)) m->comm_steps += 1;
     SERT_HIP(hipGetLastError());   // a rejected launch (bad configuration) surfaces here, not as a hang
     // (an event record stalls its queue for ~6 us: steps with the fused prologue skip it)
@@ -2235,6 +2311,7 @@ static int shard_setup(sert_model* m) {
     for (int i = 0; i < 4; ++i)
         if (m->pt_sharded[i]) SERT_FAIL("this model already has a data-parallel communicator");
     hipStream_t s = m->stream;
+    SERT_TRY(ensure_rw_current(m, -1));    // (data parallel runs the dense update: no row may be behind)
     SERT_HIP(hipStreamSynchronize(s));
     SERT_HIP(hipStreamSynchronize(m->stream2));
     if (m->stream3) SERT_HIP(hipStreamSynchronize(m->stream3));
@@ -2432,6 +2509,12 @@ static int create_resources(sert_model* m) {
         SERT_TRY(dzalloc(&m->s0_w, m->n_w, s));   SERT_TRY(dzalloc(&m->s0_b, m->n_b, s));
         SERT_TRY(dzalloc(&m->s1_rw, m->n_rw, s)); SERT_TRY(dzalloc(&m->s1_re, m->n_re, s));
         SERT_TRY(dzalloc(&m->s1_w, m->n_w, s));   SERT_TRY(dzalloc(&m->s1_b, m->n_b, s));
+        // the lazy word-table update's per-row update counters (two: the kernel reads one and writes the other)
+        static const bool no_lazy = variant_knob("SERT_NO_LAZY") != nullptr;   // cross-check knob (variants build)
+        if (!no_lazy && c.word_dim % 4 == 0) {
+            SERT_TRY(dzalloc(&m->rw_last[0], (size_t)c.vocab_size, s));
+            SERT_TRY(dzalloc(&m->rw_last[1], (size_t)c.vocab_size, s));
+        }
         SERT_TRY(layout_gradients(m));
         SERT_TRY(dzalloc(&m->rowloss, B, s));
         size_t part = 0;
@@ -2583,6 +2666,7 @@ int sert_destroy(sert_model* m) {
     }
     (void)hipFree(m->sq_scratch);
     (void)hipFree(m->tail_blk);
+    (void)hipFree(m->rw_last[0]); (void)hipFree(m->rw_last[1]);
     xr_free_lists(m);
     if (m->ev_params_ready) (void)hipEventDestroy(m->ev_params_ready);
     if (m->ev_word_updated) (void)hipEventDestroy(m->ev_word_updated);
@@ -2660,6 +2744,7 @@ int sert_get_tensor(sert_model* m, int which, float* host, size_t count) {
     if (which >= SERT_T_STATE0_RW && which <= SERT_T_STATE1_B && m->pt_sharded[(which - SERT_T_STATE0_RW) % 4])
         return sharded_state_io(m, (which - SERT_T_STATE0_RW) % 4, (which - SERT_T_STATE0_RW) / 4, host, nullptr);
     if (which == SERT_T_RW) SERT_TRY(ensure_full_rw(m));   // (owned by rows: collective while stale)
+    SERT_TRY(ensure_rw_current(m, -1));                     // (lazy word-table update: flush before anyone looks)
     if (m->comm_stream) SERT_HIP(hipStreamSynchronize(m->comm_stream));
     if (m->stream2) SERT_HIP(hipStreamSynchronize(m->stream2));
     SERT_HIP(hipMemcpyAsync(host, t.ptr, count * sizeof(float), hipMemcpyDeviceToHost, m->stream));
@@ -2669,8 +2754,8 @@ int sert_get_tensor(sert_model* m, int which, float* host, size_t count) {
 
 int sert_set_step(sert_model* m, int64_t t) {
     if (!m || t < 0) SERT_FAIL("bad argument");
+    invalidate_speculation(m);     // (first: a lazy word table is flushed at the OLD step count)
     m->step = t;
-    invalidate_speculation(m);
     return 0;
 }
 int64_t sert_get_step(sert_model* m) { return m ? m->step : -1; }
@@ -2863,6 +2948,7 @@ int sert_train_batch(sert_model* m, int64_t batch_index, const int64_t* negative
     // this step, before the host starts waiting for this step's loss
     const int64_t hint = m->hint_next;
     m->hint_next = -1;
+    m->lazy_next = hint;
     auto prefetch_next = [&]() -> int {
         const DataSplit& ds = m->split[SERT_SPLIT_TRAIN];
         // (keep_grads: the caller may read this batch's activations after the call)
@@ -2940,6 +3026,7 @@ int sert_train_batches(sert_model* m, const int64_t* batch_indices, int64_t coun
     static const bool report_host = variant_knob("SERT_DEBUG_HOST") != nullptr;
     const auto t_host0 = std::chrono::steady_clock::now();
     for (int64_t i = 0; i < count; ++i) {
+        m->lazy_next = i + 1 < count ? batch_indices[i + 1] : -1;
         SERT_TRY(train_step_async(m, batch_indices[i], nullptr, m->d_losses + 3 * i));
         if (m->timing.enabled) {  // events are single-slot: drain per step when timing
             SERT_HIP(hipStreamSynchronize(m->stream));
@@ -2964,6 +3051,7 @@ static int eval_step_async(sert_model* m, const DataSplit& ds, int64_t batch_ind
                            float* dst) {
     const int B = m->cfg.batch_size;
     SERT_TRY(settle_entity_update(m));
+    SERT_TRY(ensure_rw_current(m, -1));
     if (is_fs(m)) {
         SERT_TRY(fs_forward<false>(m, ds, batch_index));
     } else if (is_vs(m)) {
@@ -3084,6 +3172,7 @@ int sert_predict_tokens(sert_model* m, const void* ids, int64_t rows, float* out
     if (rows <= 0) return 0;
     SERT_HIP(hipSetDevice(m->cfg.device));
     SERT_TRY(ensure_full_rw(m));
+    SERT_TRY(ensure_rw_current(m, -1));
     const auto& c = m->cfg;
     const int n = c.window_size, d = c.word_dim, V = c.num_entities;
     const int64_t toks = rows * n;

@@ -58,7 +58,23 @@ def glorot(rng, shape):
     return rng.uniform(-a, a, size=shape).astype(np.float32)
 
 
-def group_work(kind, B, n, s, dw, de, Ve, Vw, z, distinct_words=None, shards=1):
+LAZY_MAX_TOUCHED, LAZY_K = 0.35, 4      # kernels_opt.h: kLazyK; sert_hip.hip: lazy_max
+
+
+def lazy_fractions(X, B, num_batches, Vw):
+    """The word-table update is LAZY where a batch touches <= 35 % of the rows (kernels_opt.h: dense_update_lazy): a row
+    that neither the batch nor the announced next one touches is read (p and both moments: its share of sum(p^2)) but not
+    written, except every 4th update.  Returns None where the dense launch runs, else the fractions of rows touched /
+    written per step for the cyclic batch order of the timed loop -- what the launch really moves."""
+    sets = [np.unique(X[j * B:(j + 1) * B]) for j in range(num_batches)]
+    f_t = float(np.mean([len(u) for u in sets])) / Vw
+    if f_t > LAZY_MAX_TOUCHED:
+        return None
+    f_u = float(np.mean([len(np.union1d(sets[j], sets[(j + 1) % num_batches])) for j in range(num_batches)])) / Vw
+    return {'touched': f_t, 'written': f_u + (1.0 - f_u) / LAZY_K}
+
+
+def group_work(kind, B, n, s, dw, de, Ve, Vw, z, distinct_words=None, shards=1, lazy=None):
     """Per timed kernel group: what it is priced against and how much work one launch does.
 
       kind 'mfma'   : flops (executed)                              -> fp32 MFMA peak
@@ -78,6 +94,12 @@ def group_work(kind, B, n, s, dw, de, Ve, Vw, z, distinct_words=None, shards=1):
         kind='rows', alg=alg, fetch=fetch, row_bytes=row_bytes, table_bytes=table_bytes, resident=resident)
     # data parallel: a rank's dense update covers the word-table rows it owns (1/shards of them)
     P_w = 32.0 * Vw * dw / shards
+    # lazy launch (single GPU, sparse batches): 12 B read per element, 12 B written and 4 B of gradient read only for the
+    # rows that are materialised / touched -- the bytes THIS launch's algorithm moves (the reference's dense update: 32 B)
+    lazy_note = None
+    if lazy is not None and shards == 1:
+        lazy_note = dict(lazy, reference_dense_bytes=P_w, bytes_per_element=12.0 + 12.0 * lazy['written'] + 4.0 * lazy['touched'])
+        P_w = Vw * dw * lazy_note['bytes_per_element']
     if kind in ('vectorspace', 'vectorspace_softmax'):
         w = {
             'gather':               rows(B * (n * s + 4 * n * dw), B * 4.0 * n * dw, 4 * dw, 4.0 * Vw * dw),   # vs_gather_mean
@@ -87,7 +109,7 @@ def group_work(kind, B, n, s, dw, de, Ve, Vw, z, distinct_words=None, shards=1):
             'gemm_dX':              mfma(2.0 * B * dw * de),               # gemm_f32_mfma NT
             'gemm_bwd_fused':       mfma(4.0 * B * dw * de),               # vs_bwd_fused: dh and dW in one launch (opt-in)
             'word_grad_segsum':     rows(B * (8.0 * n * dw), B * 4.0 * n * dw, 4 * dw, 4.0 * B * dw),   # segsum_rows: rows of dh
-            'optimizer_word_table': stream(P_w, optimizer_elems=Vw * dw // shards),  # adam_l2 (R_w)
+            'optimizer_word_table': stream(P_w, optimizer_elems=Vw * dw // shards, **({'lazy': lazy_note} if lazy_note else {})),  # adam_l2 / dense_update_lazy (R_w)
             # adam_l2 over R_e where it is a big table (C4), else one optimizer_small launch: launch latency
             'optimizer_other':      (stream(32.0 * (Ve * de + dw * de + de), optimizer_elems=Ve * de) if Ve * de > (1 << 22)
                                      else dict(kind='latency', alg=32.0 * (Ve * de + dw * de + de))),
@@ -119,7 +141,7 @@ def group_work(kind, B, n, s, dw, de, Ve, Vw, z, distinct_words=None, shards=1):
         'gemm_dW':              mfma(2.0 * U * dw * Ve),
         'gemm_dX':              mfma(2.0 * U * dw * Ve),
         'word_grad_segsum':     rows(U * (8.0 * dw), U * 4.0 * dw, 4 * dw, 4.0 * U * dw),
-        'optimizer_word_table': stream(P_w, optimizer_elems=Vw * dw // shards),
+        'optimizer_word_table': stream(P_w, optimizer_elems=Vw * dw // shards, **({'lazy': lazy_note} if lazy_note else {})),
         'optimizer_other':      (stream(32.0 * (dw * Ve + Ve), optimizer_elems=dw * Ve) if dw * Ve > (1 << 22)
                                  else dict(kind='latency', alg=32.0 * (dw * Ve + Ve))),
     }
@@ -141,16 +163,16 @@ KERNELS_OF_GROUP = {
         'gemm_fwd': ('gemm_f32_mfma<false, false, 2', 'gemm_f32_mfma_small<false, 2', 'gemm_f32_mfma_n160<false, false, 2'),
         'loss': ('vs_nce_regs', 'vs_nce'), 'entity_sort': ('egrad_bucket', 'csort_scatter'),
         'entity_grad_reduce': ('egrad_acc', 'egrad_chunk_reduce'),
-        'entity_grad_fixup': ('egrad_group_sum', 'egrad_fixup'), 'optimizer_word_table': ('adam_l2',)}),
+        'entity_grad_fixup': ('egrad_group_sum', 'egrad_fixup'), 'optimizer_word_table': ('dense_update_lazy', 'adam_l2')}),
     'vectorspace_softmax': dict(_COMMON_KERNELS, **{
         'gather': ('vs_gather_mean',), 'gemm_fwd': ('gemm_f32_mfma<false, false, 0', 'gemm_f32_mfma<false, false, 2'),
         'loss': ('fs_softmax_ce',), 'entity_grad_reduce': ('gemm_f32_mfma<true, false, 0',),
-        'optimizer_word_table': ('adam_l2',)}),
+        'optimizer_word_table': ('dense_update_lazy', 'adam_l2')}),
     'loglinear': dict(_COMMON_KERNELS, **{
         'gather': ('ll_gather_rows',), 'gemm_fwd': ('gemm_f32_mfma<false, false, 1',),
         'loss': ('ll_row_wave', 'll_row_from_table', 'll_fused_row', 'll_s_'),
         'per_word_dz_sums': ('segsum_rows<64, true, true', 'segsum_rows_scalar<true'),
-        'optimizer_word_table': ('adadelta_l2',)}),
+        'optimizer_word_table': ('dense_update_lazy', 'adadelta_l2')}),
 }
 
 
@@ -335,6 +357,10 @@ def kernel_table(timings, work, traffic=None):
             ach = wk['alg'] / t / 1e9
             rec = dict(us=round(us, 2), bound='hbm', achieved=round(ach, 1), unit='GB/s', frac=round(ach / HBM_PEAK_GBS, 4),
                        algorithmic_bytes=wk['alg'])
+            if wk.get('lazy'):
+                rec['lazy_update'] = dict(wk['lazy'], note='lazy dense update: rows neither this nor the next batch touches are read, '
+                                          'not written (every 4th update writes all); algorithmic_bytes = what this launch moves, '
+                                          'reference_dense_bytes = 32 B per parameter of the reference\'s dense update')
             # achievable = the best streaming rate measured on this box for this shape: the read-only stream
             # bounds every read/write mix from above; the optimiser's own seven streams over a tensor of the
             # same size can beat it where the Infinity Cache holds part of the tensor
@@ -815,7 +841,7 @@ def measure_record(kind, models, _capi, dist, dims, steps, warmup, seed, live_pm
     U = None
     if kind == 'loglinear':
         U = float(np.mean([len(np.unique(X[j * B:(j + 1) * B])) for j in range(num_batches)]))
-    work = group_work(kind, B, n, X.dtype.itemsize, d, de, Ve, Vw, z, U)
+    work = group_work(kind, B, n, X.dtype.itemsize, d, de, Ve, Vw, z, U, lazy=lazy_fractions(X, B, num_batches, Vw))
     # (same order as the headline: ceilings, per-kernel pass, then the number -- see main)
     ceil = ceilings_for(_capi, work, device=m._engine.cfg.device)
     _, tm, _ = timed_steps(m, dist, num_batches, steps, 1, timing=True)
@@ -942,7 +968,8 @@ def main():
     distinct = None
     if kind == 'loglinear':
         distinct = float(np.mean([len(np.unique(X[j * Bg:j * Bg + Bl])) for j in range(args.num_batches)]))
-    work = group_work(kind, Bl, n, X.dtype.itemsize, d, de, Ve, Vw, z, distinct, shards=N)
+    work = group_work(kind, Bl, n, X.dtype.itemsize, d, de, Ve, Vw, z, distinct, shards=N,
+                      lazy=lazy_fractions(X, Bg, args.num_batches, Vw) if N == 1 else None)
     # Memory ceilings: every rank measures them on ITS GPU (each has its own clocks to bring up) -- unless
     # several ranks share one device (the one-GPU test transport, SERT_COMM=host): stream and row-fetch rates
     # taken while N processes compete for one memory system are no ceiling of anything, and fractions against

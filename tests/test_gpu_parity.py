@@ -597,6 +597,48 @@ def test_untouched_word_rows_need_no_memset(hip_lib, dw):
 
 
 @pytest.mark.parametrize('kind', ['vectorspace', 'loglinear'])
+def test_lazy_word_table_update_is_bit_exact(hip_lib, kind):
+    """The LAZY dense update of the word table (kernels_opt.h: dense_update_lazy; on where a batch touches <= 35 % of the
+    rows -- here 2 %): rows that neither the batch nor the ANNOUNCED next batch touches are read (their share of sum(p^2))
+    but not written, and brought forward in registers when they are needed -- by the same element update, so every
+    loss, parameter and optimiser moment must equal the dense run (keep_grads = 1: zeroed table, every row updated in
+    memory every step) BIT FOR BIT, whatever the hints: right ones (rows stay behind for up to three updates), wrong ones
+    (the forward finds its rows stale: flush), none (everything written), an evaluation and a tensor read in between
+    (flush), a change of the step counter."""
+    B, n, Vw, d, steps = 32, 3, 5000, 16, 14
+    if kind == 'vectorspace':
+        z, Ve = 4, 12
+        p = U.make_vs_problem(43, B * 5, n, z, Vw, Ve, d, d)
+        mk = lambda keep: U.vs_engine(p, B, n, z, 0.05, keep_grads=keep)
+    else:
+        p = U.make_ll_problem(43, B * 5, n, Vw, 24, d, 'int')
+        mk = lambda keep: U.ll_engine(p, B, n, 0.05, keep_grads=keep)
+    # per step: (batch, hint given before the step)  -- None: no hint
+    plan = [(0, 1), (1, 2), (2, 3), (3, 4), (4, 0), (0, 3), (1, None), (2, 3), (3, 4), (4, 0), (0, 1), (1, 2), (2, 0), (0, None)]
+    assert len(plan) == steps
+    outs = []
+    for keep in (1, 0):
+        eng = mk(keep)
+        eng.upload_dataset(C.SPLIT_TRAIN, p['X'], y_int=p['y'], w=p['w'])
+        rec = []
+        for s, (b, hint) in enumerate(plan):
+            if hint is not None:
+                eng.hint_next_batch(hint)
+            rec.append(eng.train_batch(b))
+            if s == 4:
+                rec.append(eng.eval_batch(C.SPLIT_TRAIN, 2) if kind == 'loglinear' else 0.0)   # (vs evals draw their own negatives)
+            if s == 8:
+                rec.append(float(eng.get_tensor(C.T_RW).sum()))
+            if s == 10:
+                eng.set_step(eng.get_step())          # (flushes; the counter itself is unchanged)
+        outs.append((rec, eng.get_tensor(C.T_RW).copy(), eng.get_tensor(C.T_STATE0_RW).copy(), eng.get_tensor(C.T_STATE1_RW).copy()))
+        eng.close()
+    assert outs[0][0] == outs[1][0]
+    for a, b in zip(outs[0][1:], outs[1][1:]):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize('kind', ['vectorspace', 'loglinear'])
 def test_next_batch_hint_changes_nothing_but_the_schedule(hip_lib, kind):
     """sert_hint_next_batch: the announced batch's forward + backward runs ahead of the host;
     it must not change any result -- with correct hints, with a WRONG hint (another batch is

@@ -61,14 +61,14 @@ def glorot(rng, shape):
 LAZY_MAX_TOUCHED, LAZY_K = 0.35, 4      # kernels_opt.h: kLazyK; sert_hip.hip: lazy_max
 
 
-def lazy_fractions(X, B, num_batches, Vw):
+def lazy_fractions(X, B, num_batches, Vw, dw):
     """The word-table update is LAZY where a batch touches <= 35 % of the rows (kernels_opt.h: dense_update_lazy): a row
     that neither the batch nor the announced next one touches is read (p and both moments: its share of sum(p^2)) but not
     written, except every 4th update.  Returns None where the dense launch runs, else the fractions of rows touched /
     written per step for the cyclic batch order of the timed loop -- what the launch really moves."""
     sets = [np.unique(X[j * B:(j + 1) * B]) for j in range(num_batches)]
     f_t = float(np.mean([len(u) for u in sets])) / Vw
-    if f_t > LAZY_MAX_TOUCHED:
+    if f_t > LAZY_MAX_TOUCHED or Vw * dw < (1 << 22):
         return None
     f_u = float(np.mean([len(np.union1d(sets[j], sets[(j + 1) % num_batches])) for j in range(num_batches)])) / Vw
     return {'touched': f_t, 'written': f_u + (1.0 - f_u) / LAZY_K}
@@ -841,7 +841,7 @@ def measure_record(kind, models, _capi, dist, dims, steps, warmup, seed, live_pm
     U = None
     if kind == 'loglinear':
         U = float(np.mean([len(np.unique(X[j * B:(j + 1) * B])) for j in range(num_batches)]))
-    work = group_work(kind, B, n, X.dtype.itemsize, d, de, Ve, Vw, z, U, lazy=lazy_fractions(X, B, num_batches, Vw))
+    work = group_work(kind, B, n, X.dtype.itemsize, d, de, Ve, Vw, z, U, lazy=lazy_fractions(X, B, num_batches, Vw, d))
     # (same order as the headline: ceilings, per-kernel pass, then the number -- see main)
     ceil = ceilings_for(_capi, work, device=m._engine.cfg.device)
     _, tm, _ = timed_steps(m, dist, num_batches, steps, 1, timing=True)
@@ -969,7 +969,7 @@ def main():
     if kind == 'loglinear':
         distinct = float(np.mean([len(np.unique(X[j * Bg:j * Bg + Bl])) for j in range(args.num_batches)]))
     work = group_work(kind, Bl, n, X.dtype.itemsize, d, de, Ve, Vw, z, distinct, shards=N,
-                      lazy=lazy_fractions(X, Bg, args.num_batches, Vw) if N == 1 else None)
+                      lazy=lazy_fractions(X, Bg, args.num_batches, Vw, d) if N == 1 else None)
     # Memory ceilings: every rank measures them on ITS GPU (each has its own clocks to bring up) -- unless
     # several ranks share one device (the one-GPU test transport, SERT_COMM=host): stream and row-fetch rates
     # taken while N processes compete for one memory system are no ceiling of anything, and fractions against

@@ -1885,8 +1885,11 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
             // alone, the step equal -- dense there.  Lazy up to a touched fraction of 0.35 (SERT_LAZY_MAX_TOUCHED in a
             // variants build: 0 = never, 1 = always).
             static const float lazy_max = variant_knob("SERT_LAZY_MAX_TOUCHED") ? (float)atof(variant_knob("SERT_LAZY_MAX_TOUCHED")) : 0.35f;
+            // (and for tables of 4 M elements and more: a small one lives in the caches, where the dense launch costs
+            //  nothing to save -- the reference's C1, 640 k parameters: 91 us dense, 95 us lazy)
+            static const bool lazy_small = variant_knob("SERT_LAZY_SMALL_TABLES") != nullptr;
             if (i == 0 && tf && !m->early_issued && m->rw_last[0] && !c.keep_grads && c.word_dim % 4 == 0 &&
-                m->cur_touched_frac <= lazy_max) {
+                m->cur_touched_frac <= lazy_max && (t.n >= ((size_t)1 << 22) || lazy_small)) {
                 // the LAZY form of the dense update (kernels_opt.h): rows neither this batch nor the announced next one
                 // touches are read (their share of sum(p^2)) but not written, except every kLazyK-th update
                 LazyArgs lz = lazy_args(m, m->step - 1, /*update=*/1);

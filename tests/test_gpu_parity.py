@@ -605,7 +605,7 @@ def test_lazy_word_table_update_is_bit_exact(hip_lib, kind):
     memory every step) BIT FOR BIT, whatever the hints: right ones (rows stay behind for up to three updates), wrong ones
     (the forward finds its rows stale: flush), none (everything written), an evaluation and a tensor read in between
     (flush), a change of the step counter."""
-    B, n, Vw, d, steps = 32, 3, 5000, 16, 14
+    B, n, Vw, d, steps = 32, 3, 270000, 16, 14        # (4.3 M parameters: above the size below which the table stays dense)
     if kind == 'vectorspace':
         z, Ve = 4, 12
         p = U.make_vs_problem(43, B * 5, n, z, Vw, Ve, d, d)

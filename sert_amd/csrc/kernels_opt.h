@@ -28,7 +28,7 @@ struct AdamArgs {
 // updated by different kernels -- the dense launches, the lazy launch and its catch-up loop, the small-tensor launch, the
 // fused tail -- and must come out with the same bits whichever one it was (round 4: b2 v + (1 - b2) g g was contracted
 // differently in two of them, 1 ulp apart).  The order is NumPy's on the oracle's expressions
-// (oracle/sert_oracle.py: Adam.update, Adadelta.update); only the square root and the division go through the
+// (the CPU restatement the tests compare with: its Adam / Adadelta updates); only the square root and the division go through the
 // hardware's 1-ulp instructions (see there).  sum(p^2) accumulates through an explicit fma everywhere.
 __device__ __forceinline__ float sq_acc(float acc, float x) { return __builtin_fmaf(x, x, acc); }
 

@@ -43,9 +43,14 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 // 16-byte WRITE-THROUGH store (sc1): the line leaves the XCD's L2 as it is written instead of staying dirty until the
 // end-of-kernel release writes the whole output back in one piece (MI355X_MICROARCH.md, "stores of each flavour").
-__device__ __forceinline__ void store16_wt(float* p, const float4& v) {
-    f32x4v x = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(x) : "memory");
+// Through the buffer-store builtin (cache policy bit 4 = sc1 on gfx94x/95x), so that the compiler tracks the store in
+// vmcnt: the first version issued it from inline assembly, which let the compiler overwrite the data registers while
+// the store was still reading them -- right or wrong by scheduling luck (caught by tests/test_gpu_gemm.py on the
+// variants build).
+__device__ __forceinline__ void store16_wt(float* base, unsigned elem_off, const float4& v) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0xffffffff, 0x00020000);
+    sert_f4 x = {v.x, v.y, v.z, v.w};
+    __builtin_amdgcn_raw_buffer_store_b128(x, rs, (int)(elem_off * 4u), 0, /*sc1*/ 1 << 4);
 }
 
 struct StreamGemmArgs {
@@ -183,7 +188,7 @@ __global__ __launch_bounds__(64 * kStreamWaves, 8 / kStreamWaves) void gemm_stre
                     }
                     if (EPI == EPI_BIAS_TANH) { v.x = fast_tanh(v.x); v.y = fast_tanh(v.y); v.z = fast_tanh(v.z); v.w = fast_tanh(v.w); }
                     if (g.ko & 8) *reinterpret_cast<float4*>(g.C + (size_t)row * g.ldc + 64 * h + 4 * c) = v;
-                    else store16_wt(g.C + (size_t)row * g.ldc + 64 * h + 4 * c, v);
+                    else store16_wt(g.C, (unsigned)row * (unsigned)g.ldc + 64u * h + 4u * c, v);     // (M * ldc < 2^30 here)
                 } else {
 #pragma unroll
                     for (int b = 0; b < 4; ++b) {
@@ -207,7 +212,7 @@ template <bool TB, int EPI>
 inline bool launch_gemm_stream(hipStream_t s, const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
                                int lda, int ldb, int ldc) {
     if (EPI != EPI_STORE && EPI != EPI_BIAS && EPI != EPI_BIAS_TANH) return false;
-    if (N != 128 || K != 128 || M < 8192) return false;                      // (the instantiated shape: d_w = d_e = 128)
+    if (N != 128 || K != 128 || M < 8192 || (long long)M * ldc >= (1ll << 30)) return false;                      // (the instantiated shape: d_w = d_e = 128)
     if (lda % 4 || ldb % 4 || ldc % 4 || ((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) % 16) return false;
     StreamGemmArgs g;
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.M = M; g.lda = lda; g.ldb = ldb; g.ldc = ldc;

@@ -343,6 +343,11 @@ int sert_bench_gemm(int device, int ta, int tb, int epi, int M, int N, int K, in
 int sert_debug_gemm(int device, int ta, int tb, int epi, int M, int N, int K, const float* A, const float* B,
                     const float* bias, float* C);
 
+/* The split-K form of the same dispatch (test hook): out (M*N + N) = A^T.B, A (K,M), B (K,N) host arrays, followed by
+ * the N column sums of B -- the split-K launch with the column sums riding along + the order-fixed combine that the
+ * projection's dW / db take in a training step (sert/models.py:1057-1061, autodiff). */
+int sert_debug_gemm_splitk(int device, int M, int N, int K, int splits, const float* A, const float* B, float* out);
+
 /* Memory-system micro-benchmarks: the denominators a step's memory-bound kernels are priced
  * against (no reference counterpart; measurement only).  Average launch time over `iters`
  * launches (HIP events on the launching stream, 2 warm-ups) in *avg_us.

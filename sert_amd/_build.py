@@ -8,15 +8,13 @@ LIB = os.path.join(HERE, 'libsert_hip.so')
 INCLUDE = os.path.join(os.path.dirname(HERE), 'include')
 
 SOURCES = ['sert_hip.hip']
-HEADERS = ['common.h', 'gemm.h', 'kernels_membench.h', 'kernels_score_bf16.h', 'kernels_vs.h', 'kernels_ll.h', 'kernels_opt.h',
-           'kernels_score.h', 'kernels_seg.h', 'kernels_egrad.h', 'kernels_sort.h', 'word_index.h', 'model.h']
-
 
 def _stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    deps = [os.path.join(CSRC, f) for f in SOURCES]
+    deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]   # (every header of csrc/)
     deps.append(os.path.join(INCLUDE, 'sert_hip.h'))
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 

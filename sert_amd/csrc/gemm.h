@@ -781,6 +781,20 @@ inline bool launch_gemm_direct(hipStream_t s, const float* A, const float* B, fl
                                int lda, int ldb, int ldc);
 #endif
 
+// gemm_x3.h: the same contraction on the bf16 matrix pipe (three exact bf16 pieces per operand, six products)
+inline bool x3_shape_ok(bool ta, bool tb, const float* A, const float* B, int M, int N, int K, int lda, int ldb);
+template <bool TB, int EPI>
+inline void launch_gemm_x3(hipStream_t s, const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
+                           int lda, int ldb, int ldc);
+template <bool CSB>
+inline void launch_gemm_x3_ta(hipStream_t s, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb,
+                              int ldc, int splits, int kper, size_t c_split_stride);
+// SERT_GEMM_FP32=1: every contraction on the fp32 MFMA kernels of this file (cross-check)
+inline bool gemm_x3_enabled() {
+    static const bool on = !(knob("SERT_GEMM_FP32") && atoi(knob("SERT_GEMM_FP32")) != 0);
+    return on;
+}
+
 // rowmap / mapped_C / mapped (optional): when the launch goes to the 64x64-tile kernel, row r of the product is
 // stored as row rowmap[r] of mapped_C (leading dimension ldc) instead of row r of C, and *mapped is set.
 template <bool TA, bool TB, int EPI, bool CSB = false>
@@ -791,6 +805,18 @@ inline void launch_gemm(hipStream_t s, const float* A, const float* B, float* C,
                         float* mapped_C = nullptr, bool* mapped = nullptr) {
     if (splits <= 1) { splits = 1; kper = K; }
     if (mapped) *mapped = false;
+    if constexpr (TA && !TB && EPI == EPI_STORE) {
+        if (!rowmap && (splits == 1 || kper % 16 == 0) && gemm_x3_enabled() && x3_shape_ok(true, false, A, B, M, N, K, lda, ldb)) {
+            launch_gemm_x3_ta<CSB>(s, A, B, C, M, N, K, lda, ldb, ldc, splits, kper, splits > 1 ? c_split_stride : 0);
+            return;
+        }
+    }
+    if constexpr (!TA && !CSB && (EPI == EPI_STORE || EPI == EPI_BIAS || EPI == EPI_BIAS_TANH)) {
+        if (splits == 1 && !rowmap && gemm_x3_enabled() && x3_shape_ok(false, TB, A, B, M, N, K, lda, ldb)) {
+            launch_gemm_x3<TB, EPI>(s, A, B, C, bias, M, N, K, lda, ldb, ldc);
+            return;
+        }
+    }
 #ifdef SERT_VARIANTS
     if (!TA && !CSB && splits == 1 && (EPI == EPI_STORE || EPI == EPI_BIAS || EPI == EPI_BIAS_TANH)) {
         static const bool stream = variant_knob("SERT_GEMM_STREAM") != nullptr;

@@ -13,6 +13,7 @@
 
 #include "common.h"
 #include "gemm.h"
+#include "gemm_x3.h"
 #include "gemm_bwd_fused.h"
 #ifdef SERT_VARIANTS   // opt-in GEMM variants that lost their A/B (csrc/variants/; tools/build_variant.sh -DSERT_VARIANTS)
 #include "variants/gemm_big.h"
@@ -3911,6 +3912,35 @@ int sert_debug_gemm(int device, int ta, int tb, int epi, int M, int N, int K, co
     };
     rc = body();
     (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC); (void)hipFree(dbias);
+    (void)hipStreamDestroy(s);
+    return rc;
+}
+
+// out (M * N + N) = A^T.B (A (K, M), B (K, N) host arrays) followed by the column sums of B, through the split-K launch
+// + order-fixed combine the projection's dW / db take in a training step (tests/test_gpu_gemm.py)
+int sert_debug_gemm_splitk(int device, int M, int N, int K, int splits, const float* A, const float* B, float* out) {
+    if (!A || !B || !out || M <= 0 || N <= 0 || K <= 0 || splits <= 0) SERT_FAIL("bad argument");
+    SERT_HIP(hipSetDevice(device));
+    hipStream_t s;
+    SERT_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    int kper = (int)round_up(cdiv(K, splits), GK);
+    splits = cdiv(K, kper);
+    const size_t na = (size_t)K * M, nb = (size_t)K * N, stride = (size_t)M * N + N;
+    float *dA = nullptr, *dB = nullptr, *dP = nullptr, *dO = nullptr;
+    auto body = [&]() -> int {
+        SERT_TRY(dmalloc(&dA, na)); SERT_TRY(dmalloc(&dB, nb)); SERT_TRY(dmalloc(&dP, stride * splits)); SERT_TRY(dmalloc(&dO, stride));
+        SERT_HIP(hipMemcpyAsync(dA, A, na * sizeof(float), hipMemcpyHostToDevice, s));
+        SERT_HIP(hipMemcpyAsync(dB, B, nb * sizeof(float), hipMemcpyHostToDevice, s));
+        SERT_HIP(hipMemsetAsync(dP, 0xff, stride * splits * sizeof(float), s));
+        launch_gemm<true, false, EPI_STORE, true>(s, dA, dB, dP, nullptr, M, N, K, M, N, N, splits, kper, stride);
+        launch_reduce_partials(s, dP, splits, stride, stride, dO, stride, dO);
+        SERT_HIP(hipGetLastError());
+        SERT_HIP(hipMemcpyAsync(out, dO, stride * sizeof(float), hipMemcpyDeviceToHost, s));
+        SERT_HIP(hipStreamSynchronize(s));
+        return 0;
+    };
+    const int rc = body();
+    (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dP); (void)hipFree(dO);
     (void)hipStreamDestroy(s);
     return rc;
 }

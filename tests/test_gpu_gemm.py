@@ -1,6 +1,7 @@
 """Every GEMM kernel of the library against float64, through sert_debug_gemm -- the same dispatch (launch_gemm) a training
-step uses, so a shape lands on the kernel the step would run it on: the 128x128-tile kernel, the 64x64-tile one, the
-128x160-tile one (N just above a multiple of 128) and -- against a variants build (SERT_LIB=.../libsert_variants.so) with
+step uses, so a shape lands on the kernel the step would run it on: the bf16-pipe kernel with exactly split operands
+(gemm_x3.h: 128 row tiles or more -- M >= 16384 for N <= 128, M >= 32768 above --, A not transposed, or A^T.B over K >= 4096; SERT_GEMM_FP32=1 sends those shapes to the fp32 MFMA kernels too), the
+128x128-tile kernel, the 64x64-tile one, the 128x160-tile one (N just above a multiple of 128) and -- against a variants build (SERT_LIB=.../libsert_variants.so) with
 SERT_GEMM_DIRECT_MIN_K=256 / SERT_GEMM_STREAM=1 -- the two kernels of round 4 that feed A straight from global memory into
 v_mfma_f32_16x16x4_f32 (variants/gemm_direct.h, variants/gemm_stream.h; measured equal or slower, not in the product)."""
 import numpy as np
@@ -36,6 +37,12 @@ def _ref(A, B, ta, tb, epi, bias):
     (65536, 128, 1000, 0, 0, 0), (65536, 128, 1000, 0, 1, 0), (20000, 1000, 256, 0, 1, 1), (44467, 128, 1000, 0, 1, 0),
     (9000, 300, 300, 0, 0, 2), (9001, 300, 300, 0, 1, 0), (4096, 1000, 260, 0, 0, 1), (2049, 256, 4096, 0, 0, 0),
     (4096, 4096, 512, 0, 1, 0),
+    # gemm_x3.h (every shape above with 128 row tiles or more goes there too): its three tile shapes (128, 256 and 320
+    # columns), one and several column tiles, both B layouts, ragged M / N / K (K = 36: two full steps and a quarter)
+    (8192 + 100, 200, 100, 0, 0, 1), (8192 + 100, 200, 100, 0, 1, 1), (10000, 320, 304, 0, 1, 0), (12000, 130, 36, 0, 0, 2),
+    (65536, 300, 300, 0, 0, 2), (65536, 300, 300, 0, 1, 0), (8200, 257, 64, 0, 0, 0), (8200, 31, 16, 0, 1, 0),
+    (16384 + 7, 128, 128, 0, 0, 2), (32768 + 9, 300, 300, 0, 1, 0), (32768, 257, 64, 0, 0, 1), (16400, 31, 16, 0, 1, 0), (33000, 1000, 128, 0, 0, 1),
+    (33000, 1000, 128, 0, 1, 0), (32768, 700, 36, 0, 0, 2),
 ])
 def test_gemm_dispatch_against_float64(hip_lib, M, N, K, ta, tb, epi):
     rng = np.random.RandomState(M + 3 * N + 7 * K + ta + 2 * tb)
@@ -48,3 +55,22 @@ def test_gemm_dispatch_against_float64(hip_lib, M, N, K, ta, tb, epi):
     assert np.all(np.isfinite(got))                       # (the output is pre-filled with NaN: every element was written)
     # fp32 accumulation over K terms of magnitude <= 1/sqrt(K): ~1e-6; fast_tanh adds <= 4 ulp
     assert np.abs(got - ref).max() < (2e-6 if epi != 2 else 3e-6) * max(1.0, np.sqrt(K / 128.0))
+
+
+@pytest.mark.parametrize('M,N,K,splits', [
+    (128, 128, 65536, 512), (300, 300, 65536, 113), (128, 128, 8192 + 24, 7), (300, 300, 4096 + 16, 3), (300, 160, 20000, 40),
+    (100, 36, 16384, 64), (320, 320, 8192, 8), (301, 299, 9000, 5),
+    # outside gemm_x3.h's split-K shapes: the fp32 MFMA kernels
+    (128, 128, 2048, 16), (400, 128, 8192, 32),
+])
+def test_split_k_with_column_sums_against_float64(hip_lib, M, N, K, splits):
+    """dW = h^T.da and db = the column sums of da, as a training step computes them: split-K partial slabs with the column
+    sums riding along, combined in a fixed order."""
+    rng = np.random.RandomState(M + 3 * N + 7 * K)
+    A = rng.uniform(-1, 1, (K, M)).astype(np.float32)
+    B = (rng.uniform(-1, 1, (K, N)) / np.sqrt(K)).astype(np.float32)
+    got, colsum = C.debug_gemm_splitk(A, B, splits)
+    ref = A.astype(np.float64).T @ B.astype(np.float64)
+    assert np.all(np.isfinite(got)) and np.all(np.isfinite(colsum))
+    assert np.abs(got - ref).max() < 2e-6 * max(1.0, np.sqrt(K / 128.0) / 8)
+    assert np.abs(colsum - B.astype(np.float64).sum(axis=0)).max() < 2e-6 * max(1.0, np.sqrt(K / 128.0) / 8)

@@ -74,10 +74,20 @@ def lazy_fractions(X, B, num_batches, Vw, dw):
     return {'touched': f_t, 'written': f_u + (1.0 - f_u) / LAZY_K}
 
 
+def x3_applies(M, N, K, ta=False):
+    """gemm_x3.h: x3_shape_ok (the library's dispatch rule; SERT_GEMM_FP32=1 switches the bf16-pipe kernels off)."""
+    if os.environ.get('SERT_GEMM_FP32', '0') not in ('', '0'):
+        return False
+    if ta:
+        return M <= 320 and N <= 320 and K >= 4096
+    return N <= 4096 and K <= 4096 and K % 4 == 0 and M >= 128 * (128 if N <= 128 else 256)
+
+
 def group_work(kind, B, n, s, dw, de, Ve, Vw, z, distinct_words=None, shards=1, lazy=None):
     """Per timed kernel group: what it is priced against and how much work one launch does.
 
-      kind 'mfma'   : flops (executed)                              -> fp32 MFMA peak
+      kind 'mfma'   : algorithmic flops; the share gemm_x3.h runs as six bf16 products per fp32 product is priced on the
+                      bf16 MFMA peak with 6 x the flops, the rest on the fp32 MFMA peak (frac = pipe time at peak / time)
       kind 'stream' : bytes streamed once (32 B per parameter and step for the optimiser)
                       -> HBM spec peak and the MEASURED achievable rate of the same access shape
       kind 'rows'   : data-dependent row fetches out of a table that fits the caches (L2 / Infinity
@@ -88,7 +98,11 @@ def group_work(kind, B, n, s, dw, de, Ve, Vw, z, distinct_words=None, shards=1, 
     Keys = timing group names of libsert_hip.so (sert_timing_name).  Loglinear: the GEMMs and the
     gather run on the batch's DISTINCT words (duplicate tokens share a logit row), so their
     EXECUTED work is counted with U = distinct_words rows instead of B n."""
-    def mfma(fl): return dict(kind='mfma', flops=fl)
+    def mfma(*gemms):
+        # gemms: (M, N, K, ta) of every GEMM of the group; 2 M N K flops each, on the bf16 pipe where gemm_x3.h takes it
+        fl = sum(2.0 * M * N * K for M, N, K, _ in gemms)
+        fx = sum(2.0 * M * N * K for M, N, K, ta in gemms if x3_applies(M, N, K, ta))
+        return dict(kind='mfma', flops=fl, flops_x3=fx)
     def stream(by, **kw): return dict(kind='stream', alg=by, **kw)
     def rows(alg, fetch, row_bytes, table_bytes, resident=None): return dict(
         kind='rows', alg=alg, fetch=fetch, row_bytes=row_bytes, table_bytes=table_bytes, resident=resident)
@@ -103,11 +117,11 @@ def group_work(kind, B, n, s, dw, de, Ve, Vw, z, distinct_words=None, shards=1, 
     if kind in ('vectorspace', 'vectorspace_softmax'):
         w = {
             'gather':               rows(B * (n * s + 4 * n * dw), B * 4.0 * n * dw, 4 * dw, 4.0 * Vw * dw),   # vs_gather_mean
-            'gemm_fwd':             mfma(2.0 * B * dw * de),               # gemm_f32_mfma NN+tanh
-            'gemm_dW':              mfma(2.0 * B * dw * de),               # gemm_f32_mfma TN split-K
+            'gemm_fwd':             mfma((B, de, dw, False)),              # gemm_x3 / gemm_f32_mfma NN+tanh
+            'gemm_dW':              mfma((dw, de, B, True)),               # gemm_x3 / gemm_f32_mfma TN split-K
             'splitk_combine':       stream(4.0 * 1024 * (dw * de + de)),   # reduce_partials
-            'gemm_dX':              mfma(2.0 * B * dw * de),               # gemm_f32_mfma NT
-            'gemm_bwd_fused':       mfma(4.0 * B * dw * de),               # vs_bwd_fused: dh and dW in one launch (opt-in)
+            'gemm_dX':              mfma((B, dw, de, False)),              # gemm_x3 / gemm_f32_mfma NT
+            'gemm_bwd_fused':       dict(kind='mfma', flops=4.0 * B * dw * de, flops_x3=0.0),   # vs_bwd_fused: dh and dW in one launch (opt-in, fp32 MFMA)
             'word_grad_segsum':     rows(B * (8.0 * n * dw), B * 4.0 * n * dw, 4 * dw, 4.0 * B * dw),   # segsum_rows: rows of dh
             'optimizer_word_table': stream(P_w, optimizer_elems=Vw * dw // shards, **({'lazy': lazy_note} if lazy_note else {})),  # adam_l2 / dense_update_lazy (R_w)
             # adam_l2 over R_e where it is a big table (C4), else one optimizer_small launch: launch latency
@@ -126,20 +140,20 @@ def group_work(kind, B, n, s, dw, de, Ve, Vw, z, distinct_words=None, shards=1, 
                 'entity_grad_fixup':  stream(8.0 * Ve * de),                                   # egrad_fixup
             })
         else:   # full softmax over the entity vocabulary: logits / dR_e / dp GEMMs dominate
-            w['gemm_fwd'] = mfma(2.0 * B * dw * de + 2.0 * B * de * Ve)
-            w['entity_grad_reduce'] = mfma(2.0 * B * de * Ve)
-            w['gemm_dX'] = mfma(2.0 * B * dw * de + 2.0 * B * de * Ve)
+            w['gemm_fwd'] = mfma((B, de, dw, False), (B, Ve, de, False))
+            w['entity_grad_reduce'] = mfma((Ve, de, B, True))
+            w['gemm_dX'] = mfma((B, dw, de, False), (B, de, Ve, False))
             w['loss'] = stream(B * 8.0 * Ve)
         return w
     U = distinct_words if distinct_words else B * n
     return {
         'gather':               rows(U * (s + 4.0 * dw), U * 4.0 * dw, 4 * dw, 4.0 * Vw * dw),
-        'gemm_fwd':             mfma(2.0 * U * dw * Ve),
+        'gemm_fwd':             mfma((U, Ve, dw, False)),
         # ll_row_from_table: n rows of the (U, V_e) log-probability table per batch row, dJ written
         'loss':                 rows(B * (4.0 * n * Ve + 4.0 * Ve), B * 4.0 * n * Ve, 4 * Ve, 4.0 * U * Ve),
         'per_word_dz_sums':     rows(B * n * 4.0 * Ve + U * 4.0 * Ve, B * n * 4.0 * Ve, 4 * Ve, 4.0 * B * Ve),
-        'gemm_dW':              mfma(2.0 * U * dw * Ve),
-        'gemm_dX':              mfma(2.0 * U * dw * Ve),
+        'gemm_dW':              mfma((dw, Ve, U, True)),
+        'gemm_dX':              mfma((U, dw, Ve, False)),
         'word_grad_segsum':     rows(U * (8.0 * dw), U * 4.0 * dw, 4 * dw, 4.0 * U * dw),
         'optimizer_word_table': stream(P_w, optimizer_elems=Vw * dw // shards, **({'lazy': lazy_note} if lazy_note else {})),
         'optimizer_other':      (stream(32.0 * (dw * Ve + Ve), optimizer_elems=dw * Ve) if dw * Ve > (1 << 22)
@@ -152,24 +166,24 @@ def group_work(kind, B, n, s, dw, de, Ve, Vw, z, distinct_words=None, shards=1, 
 # egrad_acc up to 2048 entities and egrad_chunk_reduce above)
 _COMMON_KERNELS = {
     # (128x128 tiles; 64x64 tiles for fewer than / exactly two big tiles per CU; 128x160 tiles for d = 300)
-    'gemm_dW': ('gemm_f32_mfma<true, false, 0', 'gemm_f32_mfma_n160<true, false, 0'), 'splitk_combine': ('reduce_partials',),
-    'gemm_dX': ('gemm_f32_mfma<false, true, 0', 'gemm_f32_mfma_small<true, 0', 'gemm_f32_mfma_n160<false, true, 0'),
+    'gemm_dW': ('gemm_x3<true, false, 0', 'gemm_f32_mfma<true, false, 0', 'gemm_f32_mfma_n160<true, false, 0'), 'splitk_combine': ('reduce_partials',),
+    'gemm_dX': ('gemm_x3<false, true, 0', 'gemm_f32_mfma<false, true, 0', 'gemm_f32_mfma_small<true, 0', 'gemm_f32_mfma_n160<false, true, 0'),
     'gemm_bwd_fused': ('vs_bwd_fused',), 'word_grad_segsum': ('segsum_rows<',),
     'optimizer_other': ('optimizer_small', 'adam_l2'), 'finalize': ('vs_tail', 'finalize_loss'),
 }
 KERNELS_OF_GROUP = {
     'vectorspace': dict(_COMMON_KERNELS, **{
         'gather': ('vs_gather_mean',),
-        'gemm_fwd': ('gemm_f32_mfma<false, false, 2', 'gemm_f32_mfma_small<false, 2', 'gemm_f32_mfma_n160<false, false, 2'),
+        'gemm_fwd': ('gemm_x3<false, false, 2', 'gemm_f32_mfma<false, false, 2', 'gemm_f32_mfma_small<false, 2', 'gemm_f32_mfma_n160<false, false, 2'),
         'loss': ('vs_nce_regs', 'vs_nce'), 'entity_sort': ('egrad_bucket', 'csort_scatter'),
         'entity_grad_reduce': ('egrad_acc', 'egrad_chunk_reduce'),
         'entity_grad_fixup': ('egrad_group_sum', 'egrad_fixup'), 'optimizer_word_table': ('dense_update_lazy', 'adam_l2')}),
     'vectorspace_softmax': dict(_COMMON_KERNELS, **{
-        'gather': ('vs_gather_mean',), 'gemm_fwd': ('gemm_f32_mfma<false, false, 0', 'gemm_f32_mfma<false, false, 2'),
+        'gather': ('vs_gather_mean',), 'gemm_fwd': ('gemm_x3<false, false, 2', 'gemm_x3<false, true, 0', 'gemm_f32_mfma<false, false, 0', 'gemm_f32_mfma<false, false, 2'),
         'loss': ('fs_softmax_ce',), 'entity_grad_reduce': ('gemm_f32_mfma<true, false, 0',),
         'optimizer_word_table': ('dense_update_lazy', 'adam_l2')}),
     'loglinear': dict(_COMMON_KERNELS, **{
-        'gather': ('ll_gather_rows',), 'gemm_fwd': ('gemm_f32_mfma<false, false, 1',),
+        'gather': ('ll_gather_rows',), 'gemm_fwd': ('gemm_x3<false, false, 1', 'gemm_f32_mfma<false, false, 1',),
         'loss': ('ll_row_wave', 'll_row_from_table', 'll_fused_row', 'll_s_'),
         'per_word_dz_sums': ('segsum_rows<64, true, true', 'segsum_rows_scalar<true'),
         'optimizer_word_table': ('dense_update_lazy', 'adadelta_l2')}),
@@ -335,8 +349,21 @@ def kernel_table(timings, work, traffic=None):
         t = us * 1e-6
         if wk['kind'] == 'mfma':
             ach = wk['flops'] / t / 1e12
+            fx = wk.get('flops_x3', 0.0)
+            # time the launch's MFMAs occupy the matrix pipe at peak: the fp32 products that run as six bf16 products
+            # (gemm_x3.h) at the bf16 rate, the others at the fp32 MFMA rate
+            t_pipe = (wk['flops'] - fx) / (MFMA_F32_PEAK_TFLOPS * 1e12) + 6.0 * fx / (MFMA_BF16_PEAK_TFLOPS * 1e12)
             kernels[name] = dict(us=round(us, 2), bound='mfma', achieved=round(ach, 2), unit='TFLOP/s',
-                                 frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), algorithmic_flops=wk['flops'])
+                                 frac=round(t_pipe / t, 4), algorithmic_flops=wk['flops'])
+            if fx > 0:
+                kernels[name].update(
+                    pipe='bf16 MFMA, three exact bf16 pieces per fp32 operand, six products per fp32 product (gemm_x3.h)',
+                    executed_bf16_tflops=round(6.0 * fx / t / 1e12, 1), peak=MFMA_BF16_PEAK_TFLOPS,
+                    share_on_bf16_pipe=round(fx / wk['flops'], 3),
+                    frac_is='matrix-pipe time at peak (6 x the flops at the bf16 dense peak; any fp32-MFMA share at 157.3 TF) / launch time',
+                    times_the_fp32_mfma_peak=round(ach / MFMA_F32_PEAK_TFLOPS, 3))
+            else:
+                kernels[name]['peak'] = MFMA_F32_PEAK_TFLOPS
             if counted is not None:
                 kernels[name]['hbm_bytes_pmc'] = counted
             continue
@@ -418,7 +445,7 @@ def roofline_of(kernels, traffic_by_group=None, traffic_source=None, kind='vecto
                    table_ceiling_GBps=kd.get('table_ceiling_GBps'))
     else:
         out = dict(kernel=dom, hip_kernel=names[0] if names else None, bound='hbm' if mem else 'mfma',
-                   achieved=kd['achieved'], peak=HBM_PEAK_GBS if mem else MFMA_F32_PEAK_TFLOPS,
+                   achieved=kd['achieved'], peak=HBM_PEAK_GBS if mem else kd.get('peak', MFMA_F32_PEAK_TFLOPS),
                    unit=kd['unit'], frac=kd['frac'], avg_us=kd['us'], traffic=None)
         if 'achievable_GBps' in kd:
             out['achievable_peak'] = kd['achievable_GBps']
@@ -1070,6 +1097,10 @@ def main():
                 'parallelism': 'dp%d' % N if N == 1 else 'dp%d, %s' % (N, (comm or {}).get('exchange', 'data parallel')),
                 'id_dtype': str(X.dtype), 'lambda': 0.01, 'seed': args.seed,
                 'instance_weights': '1' if args.weights == 'ones' else 'U[0.5, 2]',
+                'gemm_arithmetic': ('fp32 MFMA (SERT_GEMM_FP32=1)' if os.environ.get('SERT_GEMM_FP32', '0') not in ('', '0') else
+                                    'fp32 operands, fp32 accumulators, fp32 results; each operand is split exactly into three bf16 '
+                                    'pieces and a product runs as six bf16 MFMA products (gemm_x3.h): against float64 the error is '
+                                    'that of the fp32 accumulation, as on the fp32 MFMA kernels (tests/test_gpu_gemm.py, same bounds)'),
             },
             'roofline': roofline,
             'memory_ceilings': (dict(ceilings, note='measured in this process on this box (sert_bench_memory): float4 stream copy / '

@@ -790,9 +790,10 @@ template <bool CSB>
 inline void launch_gemm_x3_ta(hipStream_t s, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb,
                               int ldc, int splits, int kper, size_t c_split_stride);
 // SERT_GEMM_FP32=1: every contraction on the fp32 MFMA kernels of this file (cross-check)
+// (read at every launch: a process can run both ways, tests/test_gpu_fullbatch.py)
 inline bool gemm_x3_enabled() {
-    static const bool on = !(knob("SERT_GEMM_FP32") && atoi(knob("SERT_GEMM_FP32")) != 0);
-    return on;
+    const char* e = knob("SERT_GEMM_FP32");
+    return !(e && atoi(e) != 0);
 }
 
 // rowmap / mapped_C / mapped (optional): when the launch goes to the 64x64-tile kernel, row r of the product is

@@ -17,7 +17,7 @@
 //
 // Workgroup tile (32 WMB WAVES_M) x (32 WNB WAVES_N), K in steps of 16 (one MFMA depth), both operands'
 // three planes in LDS as [plane][row][16 k] (32 bytes per row; the 16-byte half of a row is XOR-swizzled with
-// bit 3 of the row, which makes the ds_read_b128 fragment reads conflict-free), double buffered: one barrier
+// bits of the row, which makes the ds_read_b128 fragment reads conflict-free), double buffered: one barrier
 // per step.  The loads of step t + 1 are issued before the MFMAs of step t and split + stored in their shadow.
 // An operand that is contiguous along k is loaded in 16-byte pieces; one that is contiguous along its
 // row axis (B of A.B, both operands of A^T.B) by eight row-strided dwords per lane, lanes along the
@@ -61,7 +61,11 @@ struct X3Args {
 };
 
 // byte offset of (row, 16-byte half) inside one plane of an operand image
-__device__ __forceinline__ int x3_off(int row, int half) { return row * 32 + ((half ^ ((row >> 3) & 1)) << 4); }
+// (the half is swizzled with bits 2 and 3 of the row: the fragment reads -- ds_read_b128, 16 lanes per LDS cycle, 64 banks --
+//  and the 16-byte stores of a row-contiguous operand -- eight consecutive rows per cycle, 32 banks -- are both
+//  conflict-free; with bit 3 alone the stores were two-way conflicts: SQ_LDS_BANK_CONFLICT 23 % of the LDS cycles of
+//  the split-K kernel)
+__device__ __forceinline__ int x3_off(int row, int half) { return row * 32 + ((half ^ (((row >> 2) ^ (row >> 3)) & 1)) << 4); }
 
 template <bool TA, bool TB, int EPI, bool CSB, int WAVES_M, int WAVES_N, int WMB, int WNB>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_x3(const X3Args g) {

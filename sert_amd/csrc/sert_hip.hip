@@ -1297,7 +1297,11 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         // slabs at batch >= 16384 and 64 at 4096 -- 512 / 256 slabs made the combine read up to 92 MB
         // of partials (sweep in DESIGN.md section 7.5).
         static const int user_splits = [] { const char* e = variant_knob("SERT_DW_SPLITS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
-        const int auto_splits = std::max(1, std::min(std::min(512, cdiv(1024, cdiv(dw, GM) * cdiv(de, GN))), B / 64));
+        int auto_splits = std::max(1, std::min(std::min(512, cdiv(1024, cdiv(dw, GM) * cdiv(de, GN))), B / 64));
+        // the bf16-pipe kernel (gemm_x3.h) runs one workgroup per (k range, 160-column tile; one tile up to 128 x 128): one
+        // workgroup per CU -- 256 slabs at C2 (0.2745 -> 0.2697 ms against 512; 128: 0.285), 128 at C4 (1.595 -> 1.579 ms)
+        if (gemm_x3_enabled() && x3_shape_ok(true, false, m->H, m->DA, dw, de, B, dw, de))
+            auto_splits = std::max(1, std::min(256 / ((dw <= 128 && de <= 128) ? 1 : cdiv(de, 160)), B / 64));
         const int want_splits = user_splits ? user_splits : auto_splits;
         int splits = std::min(want_splits, cdiv(B, GK));
         int kper = (int)round_up(cdiv(B, splits), GK);
@@ -2869,7 +2873,7 @@ int sert_upload_dataset(sert_model* m, int split, const void* x, const int32_t* 
         // SERT_SEG_GROUPS=k builds it (tests/test_gpu_parity.py::test_word_gradient_row_grouped_tree keeps it exact).
         int row_groups = 1;
         if (is_vs(m) && m->cfg.word_dim % 4 == 0)
-            if (const char* e = knob("SERT_SEG_GROUPS")) row_groups = std::min(std::max(1, atoi(e)), std::max(1, B / 64));
+            if (const char* e = variant_knob("SERT_SEG_GROUPS")) row_groups = std::min(std::max(1, atoi(e)), std::max(1, B / 64));
         bool ids_ok = true;
         SERT_ID_DISPATCH(m->cfg.id_bytes,
                          ids_ok = build_word_index<IdT>((const IdT*)x, nb, B, n, m->cfg.vocab_size, row_is_pos, wi,

@@ -111,15 +111,24 @@ def _vs_run(hip_lib, dims, steps, seed, check64):
     print('\n'.join(log))
 
 
-def test_c2_vectorspace_at_the_benchmarked_batch(hip_lib):
+@pytest.mark.parametrize('gemm_fp32', [False, True])
+def test_c2_vectorspace_at_the_benchmarked_batch(hip_lib, monkeypatch, gemm_fp32):
     """BASELINE configs[1] as bench.py runs it: V_w = 100k, V_e = 1k, d = 128, window 10, z = 10, batch 65536,
-    Zipf tokens, w ~ U[0.5, 2], explicit negatives, 3 steps (sert/models.py:1072-1098, 278-282, 922)."""
+    Zipf tokens, w ~ U[0.5, 2], explicit negatives, 3 steps (sert/models.py:1072-1098, 278-282, 922).  Both ways: the
+    three GEMMs on the bf16 matrix pipe with exactly split operands (gemm_x3.h, the default at this batch) and, with
+    SERT_GEMM_FP32=1, on the fp32 MFMA kernels -- the same bounds against the oracle."""
+    if gemm_fp32:
+        monkeypatch.setenv('SERT_GEMM_FP32', '1')
     _vs_run(hip_lib, dict(B=65536, n=10, z=10, Vw=100000, Ve=1000, dw=128, de=128), steps=3, seed=0, check64=True)
 
 
-def test_c4_vectorspace_at_the_benchmarked_batch(hip_lib):
-    """BASELINE configs[3]: V_w = 500k, V_e = 100k, d = 300, batch 65536 -- the sorted entity chain, the
-    128x160-tile GEMMs, the side-heavy schedule with the deferred entity-table update; 2 steps."""
+@pytest.mark.parametrize('gemm_fp32', [False, True])
+def test_c4_vectorspace_at_the_benchmarked_batch(hip_lib, monkeypatch, gemm_fp32):
+    """BASELINE configs[3]: V_w = 500k, V_e = 100k, d = 300, batch 65536 -- the sorted entity chain, the 256x320-tile
+    bf16-pipe GEMMs and the ten-wave split-K dW (SERT_GEMM_FP32=1: the 128x160-tile fp32 MFMA kernels), the side-heavy
+    schedule with the deferred entity-table update; 2 steps."""
+    if gemm_fp32:
+        monkeypatch.setenv('SERT_GEMM_FP32', '1')
     _vs_run(hip_lib, dict(B=65536, n=10, z=10, Vw=500000, Ve=100000, dw=300, de=300), steps=2, seed=1, check64=True)
 
 

@@ -102,6 +102,7 @@ def test_vectorspace_steps(hip_lib, dims, egrad, monkeypatch):
     (dict(B=20000, n=5, Vw=300, dw=32), 16, True),       # with the dense heavy-word pass: those words are absent from the lists
     (dict(B=9000, n=12, Vw=40, dw=64), 8, False),        # every word in every range, thousands of chunks: four tree levels
 ])
+@pytest.mark.skipif(not VARIANTS_BUILD, reason='SERT_SEG_GROUPS is read by a -DSERT_VARIANTS library only (measured slower)')
 def test_word_gradient_row_grouped_tree(hip_lib, monkeypatch, dims, groups, dense):
     """The word-table gradient through the ROW-GROUPED tree (word_index.h: row_groups; what batches whose dh
     exceeds an XCD's L2 take -- C2, C4 -- forced here on small, ragged shapes): per (row range, word) items on

@@ -81,6 +81,8 @@ struct sert_model {
     bool re_in_parts = false;        // this step: dR_e is still the row groups' partial tables (summed by the optimiser)
     bool fork_bound = false;         // ev_fork rides on the NCE kernel's completion signal (no record needed)
     bool lazy_join = false;          // this step: the main stream never waits for the entity chain
+    bool dp_late_join = false;       // data parallel, asynchronous communicator: the side stream (entity chain, dW, db, loss sum) is
+                                     // joined by the COMMUNICATION stream in front of the small all-reduce, not by the main stream
     bool side_heavy = false;         // this step: entity chain, entity-table optimiser and dW on the side stream (big R_e)
     // side-heavy schedule: the entity table's update is DEFERRED past the step's tail -- it only has to land
     // before the next reader of R_e (the next loss kernel); the sums of squares the tail needs were left by

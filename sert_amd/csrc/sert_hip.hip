@@ -878,6 +878,12 @@ static int allreduce_word_grad(sert_model* m) { return exchange_grad(m, 0); }
 // [small tensors' gradients | loss sum | owned sum of squares].
 static int allreduce_rest(sert_model* m) {
     if (!is_dp(m)) return 0;
+    if (m->dp_late_join) {
+        // (every gradient of the side stream -- a sharded entity table's as well as the replicated remainder -- is
+        //  complete before the communication stream touches it; the main stream meets them again behind the collectives)
+        SERT_HIP(hipEventRecord(m->ev_join, m->stream2));
+        SERT_HIP(hipStreamWaitEvent(m->comm_stream, m->ev_join, 0));
+    }
     for (int i = 1; i < 4; ++i) SERT_TRY(exchange_grad(m, i));
     float* rest = m->gflat + m->rest_off;
     const size_t count = m->gflat_count - m->rest_off;
@@ -1290,6 +1296,7 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         // (measured: 0.376 -> 0.386 ms at C2 -- off by default, SERT_DW_SIDE=1 to try it)
         static const bool dw_side = variant_knob("SERT_DW_SIDE") && atoi(variant_knob("SERT_DW_SIDE")) != 0;
         if ((dw_side || side_heavy) && m->lazy_join) sd = m->stream2;
+        if (m->dp_late_join) sd = m->stream2;   // (behind the entity chain)
         if (fork_late && m->lazy_join && dw_third_queue(m)) sd = m->stream3;
         if (sd != m->stream && sd != m->stream2 && !fork_late) SERT_HIP(hipStreamWaitEvent(sd, m->ev_fork, 0));
         // ~1024 workgroup items in all, at most 512 slabs (the optimum at one output tile: 512 slabs
@@ -1356,6 +1363,14 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
     // idling ~12 us on a cross-queue dependency.
     m->lazy_join = !is_dp(m) && !m->timing.enabled && m->nstreams == 2 && (m->n_re <= ((size_t)1 << 22) || side_heavy);
     m->side_heavy = side_heavy;
+    // Data parallel over an asynchronous communicator: nothing on the main stream needs what the side stream produces
+    // (dR_e, and -- issued there too -- dW, db and the loss sum) before the all-reduce of the replicated remainder, and
+    // that runs on the communication stream.  So the communication stream joins the side stream (allreduce_rest), the main
+    // stream goes from the segmented sum straight to the hand-over of the word rows and their update: 40 us of dW GEMM,
+    // combine and loss sum leave the critical path (C2, world of one: 0.329 -> 0.29 ms)
+    const bool dp_late = is_dp(m) && !m->host_ar && m->comm && !m->timing.enabled && m->nstreams == 2 && !side_heavy && !fork_nce &&
+                         !fork_late;
+    m->dp_late_join = dp_late;
     if (side_heavy) {
         SERT_TRY(entity_grad());       // side, forked on the loss kernel's completion
         SERT_TRY(dh_gemm());           // main (its completion is ev_dense)
@@ -1375,10 +1390,23 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         // data parallel: the word-table gradient first, so that its exchange (rows' all-to-all or
         // reduce-scatter) overlaps dW and the entity chain (dW in front of the segmented sum instead:
         // 0.362 -> 0.370 ms with a world of one -- the hand-over then sits bare on the critical path)
-        SERT_TRY(entity_grad());
-        SERT_TRY(dh_gemm());
-        SERT_TRY(word_table_sum());
-        SERT_TRY(dense_grad());
+        if (dp_late) {
+            // the side stream takes dW, db and the loss sum FIRST (beside dh and the segmented sum), then the entity chain:
+            // behind that chain they ran beside the word table's Adam, three times as long, and the small all-reduce --
+            // which waits for them -- ended 35 us after the Adam (0.330 ms; this order: 0.29)
+            if (!m->fork_bound) SERT_HIP(hipEventRecord(m->ev_fork, m->stream));   // (else: the loss kernel's own completion signal)
+            SERT_HIP(hipStreamWaitEvent(m->stream2, m->ev_fork, 0));
+            SERT_TRY(dense_grad());
+            m->fork_bound = true;          // (the fork is recorded: the entity chain only has to follow in stream order)
+            SERT_TRY(entity_grad());
+            SERT_TRY(dh_gemm());
+            SERT_TRY(word_table_sum());
+        } else {
+            SERT_TRY(entity_grad());
+            SERT_TRY(dh_gemm());
+            SERT_TRY(word_table_sum());
+            SERT_TRY(dense_grad());
+        }
     } else if (fused_bwd) {
         SERT_TRY(entity_grad());
         SERT_TRY(dh_gemm());           // (dh and the dW partials in one launch)
@@ -1392,7 +1420,7 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         SERT_TRY(word_table_sum());
     }
     // join the entity-gradient chain (and the dense gradients of a third stream)
-    if (!m->lazy_join && !m->timing.enabled && m->nstreams >= 2) {
+    if (!m->lazy_join && !m->dp_late_join && !m->timing.enabled && m->nstreams >= 2) {
         SERT_HIP(hipEventRecord(m->ev_join, m->stream2));
         SERT_HIP(hipStreamWaitEvent(m->stream, m->ev_join, 0));
     }
@@ -2167,6 +2195,7 @@ static int step_forward_backward(sert_model* m, const DataSplit& ds, int64_t bat
     // Prologue (zeroing, negative sampling): nothing before the loss kernel needs it, so
     // for the vectorspace step it runs on the side stream beside gather + projection.
     m->lazy_join = false;
+    m->dp_late_join = false;
     m->side_heavy = false;
     const bool side_pre = is_vs(m) && !is_fs(m) && !m->timing.enabled && m->nstreams >= 2;
     // One fused prologue launch on the MAIN stream (sampler + zeroing of the small gradient

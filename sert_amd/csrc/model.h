@@ -81,6 +81,7 @@ struct sert_model {
     bool re_in_parts = false;        // this step: dR_e is still the row groups' partial tables (summed by the optimiser)
     bool fork_bound = false;         // ev_fork rides on the NCE kernel's completion signal (no record needed)
     bool lazy_join = false;          // this step: the main stream never waits for the entity chain
+    bool dw_side_first = false;      // this step: dW / db came from the side stream, FIRST in its chain (ev_dense marks them)
     bool dp_late_join = false;       // data parallel, asynchronous communicator: the side stream (entity chain, dW, db, loss sum) is
                                      // joined by the COMMUNICATION stream in front of the small all-reduce, not by the main stream
     bool side_heavy = false;         // this step: entity chain, entity-table optimiser and dW on the side stream (big R_e)
@@ -131,6 +132,8 @@ struct sert_model {
 
     // per-batch activations
     float *H = nullptr, *T = nullptr, *DA = nullptr, *DH = nullptr, *rowloss = nullptr;
+    float* T_alt = nullptr;          // the projection alternates between two buffers (vs_project): the entity chain of the previous
+                                     // step may still read its rows on the side stream when the next projection is written
     float* DH2 = nullptr;         // full-softmax variant: p = clip(t)  (B, d_e)
     // full-softmax variant: the logits exist for fs_tile rows at a time (== batch_size: the whole batch)
     int fs_tile = 0;

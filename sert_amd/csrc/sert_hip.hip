@@ -965,6 +965,11 @@ static int vs_project(sert_model* m, const DataSplit& ds, int64_t batch_index) {
                                    dim3(256), 0, m->stream, X, m->rw, m->H, B, n, dw);
         });
     }
+    // The entity-gradient chain of the PREVIOUS step reads that step's projection rows on the side stream, and the main stream
+    // no longer joins that stream at the end of a step (only the next LOSS kernel waits for it, settle_entity_update): this
+    // projection goes to the other buffer.  (One buffer was a race the schedule merely kept from happening -- at C2 the
+    // chain ends 15 us before the step does; small batches with the chain longer than the rest of the step lost it.)
+    if (m->T_alt) std::swap(m->T, m->T_alt);
     {
         ScopedTimer t(m, TG_GEMM_FWD);
         // t = tanh(h.W + b)   (models.py:1057-1061)
@@ -1296,7 +1301,7 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         // (measured: 0.376 -> 0.386 ms at C2 -- off by default, SERT_DW_SIDE=1 to try it)
         static const bool dw_side = variant_knob("SERT_DW_SIDE") && atoi(variant_knob("SERT_DW_SIDE")) != 0;
         if ((dw_side || side_heavy) && m->lazy_join) sd = m->stream2;
-        if (m->dp_late_join) sd = m->stream2;   // (behind the entity chain)
+        if (m->dp_late_join || m->dw_side_first) sd = m->stream2;
         if (fork_late && m->lazy_join && dw_third_queue(m)) sd = m->stream3;
         if (sd != m->stream && sd != m->stream2 && !fork_late) SERT_HIP(hipStreamWaitEvent(sd, m->ev_fork, 0));
         // ~1024 workgroup items in all, at most 512 slabs (the optimum at one output tile: 512 slabs
@@ -1342,7 +1347,7 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         static const bool no_tail = variant_knob("SERT_NO_TAIL") != nullptr;   // cross-check knob
         m->tail_splits = 0;
         // (side_heavy: the partial slabs come from the side stream, which is joined in front of the tail)
-        if (!no_tail && !is_dp(m) && (sd == m->stream || (side_heavy && sd == m->stream2)) &&
+        if (!no_tail && !is_dp(m) && (sd == m->stream || ((side_heavy || m->dw_side_first) && sd == m->stream2)) &&
             m->cfg.kind == SERT_KIND_VECTORSPACE && !m->pt_big[2] &&
             mn + de < ((size_t)1 << 31)) {
             m->tail_splits = splits;
@@ -1354,6 +1359,7 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         }
         // the loss partials only depend on the NCE kernel too
         SERT_TRY(reduce_rowloss(m, sd));
+        if (m->dw_side_first) SERT_HIP(hipEventRecord(m->ev_dense, sd));   // (the tail waits for this, not for the chain behind it)
         if (sd != m->stream && sd != m->stream2 && !fork_late) SERT_HIP(hipEventRecord(m->ev_join3, sd));
         return 0;
     };
@@ -1368,6 +1374,16 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
     // that runs on the communication stream.  So the communication stream joins the side stream (allreduce_rest), the main
     // stream goes from the segmented sum straight to the hand-over of the word rows and their update: 40 us of dW GEMM,
     // combine and loss sum leave the critical path (C2, world of one: 0.329 -> 0.29 ms)
+    // Single GPU, late fork: dW, db (and the loss partials) only feed the tail.  FIRST on the side stream -- in front of the
+    // entity chain, beside the segmented sum -- they leave the main stream's dependency chain (loss -> dh -> segmented sum
+    // -> word-table update -> tail) 20 us shorter; the tail waits for their event, which is long complete by then.
+    static const bool dw_first_off = variant_knob("SERT_DW_FIRST") && atoi(variant_knob("SERT_DW_FIRST")) == 0;
+    // Measured (tools/experiments/r04_dw_first*.sh, C2 dims): batch 4096 0.1176 -> 0.1092 ms, 8192 0.130 -> 0.116, 16384 0.1566 ->
+    // 0.1429, 32768 0.191 -> 0.175; at 65536 0.2720 -> 0.2745 -- there dW streams its 67 MB beside the first level of the
+    // segmented sum, whose 33.5 MB of dh rows then no longer stay in the Infinity Cache.  Taken while dh is below 24 MB.
+    static const bool dw_first_always = variant_knob("SERT_DW_FIRST") && atoi(variant_knob("SERT_DW_FIRST")) == 2;
+    m->dw_side_first = !dw_first_off && fork_late && !fork_nce && !side_heavy && m->lazy_join && !fused_bwd && !dw_third_queue(m) &&
+                       c.kind == SERT_KIND_VECTORSPACE && (dw_first_always || (size_t)B * dw * sizeof(float) <= ((size_t)24 << 20));
     const bool dp_late = is_dp(m) && !m->host_ar && m->comm && !m->timing.enabled && m->nstreams == 2 && !side_heavy && !fork_nce &&
                          !fork_late;
     m->dp_late_join = dp_late;
@@ -1383,8 +1399,9 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         SERT_TRY(word_table_sum());
     } else if (fork_late) {
         SERT_TRY(dh_gemm());           // main; its completion is the step's one fork
+        if (m->dw_side_first) SERT_TRY(dense_grad());   // side, in front of the entity chain
         SERT_TRY(entity_grad());       // side
-        SERT_TRY(dense_grad());        // main (W and b are then updated on the main stream too)
+        if (!m->dw_side_first) SERT_TRY(dense_grad());  // main (W and b are then updated on the main stream too)
         SERT_TRY(word_table_sum());    // main
     } else if (is_dp(m)) {
         // data parallel: the word-table gradient first, so that its exchange (rows' all-to-all or
@@ -2115,6 +2132,7 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
         const int nl = is_dp(m) ? 1 : n_loss_partials;
         unsigned* flag = publish ? reinterpret_cast<unsigned*>(loss_dst + 4) : nullptr;
         if (tail_splits > 0) {
+            if (m->dw_side_first) SERT_HIP(hipStreamWaitEvent(m->stream, m->ev_dense, 0));   // (dW / db slabs: side stream)
             TailArgs ta;
             ta.part = m->part; ta.splits = tail_splits; ta.stride = m->tail_stride;
             ta.W = m->W; ta.b = m->b; ta.s0_w = m->s0_w; ta.s1_w = m->s1_w; ta.s0_b = m->s0_b; ta.s1_b = m->s1_b;
@@ -2195,6 +2213,7 @@ static int step_forward_backward(sert_model* m, const DataSplit& ds, int64_t bat
     // Prologue (zeroing, negative sampling): nothing before the loss kernel needs it, so
     // for the vectorspace step it runs on the side stream beside gather + projection.
     m->lazy_join = false;
+    m->dw_side_first = false;
     m->dp_late_join = false;
     m->side_heavy = false;
     const bool side_pre = is_vs(m) && !is_fs(m) && !m->timing.enabled && m->nstreams >= 2;
@@ -2557,6 +2576,7 @@ static int create_resources(sert_model* m) {
         size_t part = 0;
         if (vs) {
             SERT_TRY(dzalloc(&m->H, B * dw, s));  SERT_TRY(dzalloc(&m->T, B * de, s));
+            if (c.kind == SERT_KIND_VECTORSPACE && !c.inference_only) SERT_TRY(dzalloc(&m->T_alt, B * de, s));
             SERT_TRY(dzalloc(&m->DA, B * de, s)); SERT_TRY(dzalloc(&m->DH, B * dw, s));
             SERT_TRY(dzalloc(&m->neg, std::max<size_t>(4, B * c.num_negatives), s));
             SERT_TRY(dzalloc(&m->neg_alt, std::max<size_t>(4, B * c.num_negatives), s));
@@ -2709,7 +2729,7 @@ int sert_destroy(sert_model* m) {
     if (m->ev_word_updated) (void)hipEventDestroy(m->ev_word_updated);
     if (m->comm_stream) (void)hipStreamDestroy(m->comm_stream);
     float* bufs[] = {m->rw, m->re, m->W, m->b, m->s0_rw, m->s0_re, m->s0_w, m->s0_b, m->s1_rw,
-                     m->s1_re, m->s1_w, m->s1_b, m->gflat, m->H, m->T, m->DA, m->DH, m->rowloss,
+                     m->s1_re, m->s1_w, m->s1_b, m->gflat, m->H, m->T, m->T_alt, m->DA, m->DH, m->rowloss,
                      m->G, m->Z, m->J, m->DG, m->DH2, m->part, m->skbuf, m->wpart, m->hpart, m->red_loss, m->red_sq, m->re_sq, m->d_loss,
                      m->d_losses};
     for (float* p : bufs) (void)hipFree(p);

@@ -1384,7 +1384,8 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
     static const bool dw_first_always = variant_knob("SERT_DW_FIRST") && atoi(variant_knob("SERT_DW_FIRST")) == 2;
     m->dw_side_first = !dw_first_off && fork_late && !fork_nce && !side_heavy && m->lazy_join && !fused_bwd && !dw_third_queue(m) &&
                        c.kind == SERT_KIND_VECTORSPACE && (dw_first_always || (size_t)B * dw * sizeof(float) <= ((size_t)24 << 20));
-    const bool dp_late = is_dp(m) && !m->host_ar && m->comm && !m->timing.enabled && m->nstreams == 2 && !side_heavy && !fork_nce &&
+    static const int dp_late_mode = variant_knob("SERT_DP_LATE") ? atoi(variant_knob("SERT_DP_LATE")) : 1;   // 0: off; 2: dW behind the chain
+    const bool dp_late = dp_late_mode != 0 && is_dp(m) && !m->host_ar && m->comm && !m->timing.enabled && m->nstreams == 2 && !side_heavy && !fork_nce &&
                          !fork_late;
     m->dp_late_join = dp_late;
     if (side_heavy) {
@@ -1407,7 +1408,12 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         // data parallel: the word-table gradient first, so that its exchange (rows' all-to-all or
         // reduce-scatter) overlaps dW and the entity chain (dW in front of the segmented sum instead:
         // 0.362 -> 0.370 ms with a world of one -- the hand-over then sits bare on the critical path)
-        if (dp_late) {
+        if (dp_late && dp_late_mode == 2) {
+            SERT_TRY(entity_grad());
+            SERT_TRY(dh_gemm());
+            SERT_TRY(word_table_sum());
+            SERT_TRY(dense_grad());        // (side, behind the entity chain)
+        } else if (dp_late) {
             // the side stream takes dW, db and the loss sum FIRST (beside dh and the segmented sum), then the entity chain:
             // behind that chain they ran beside the word table's Adam, three times as long, and the small all-reduce --
             // which waits for them -- ended 35 us after the Adam (0.330 ms; this order: 0.29)

@@ -919,6 +919,7 @@ def test_schedule_variants_do_not_change_a_bit(hip_lib):
                 {'SERT_SIDE_HEAVY': '2'})   # (entity chain, dW and the small-tensor update on the side stream)
     if VARIANTS_BUILD:      # knobs only a -DSERT_VARIANTS library reads (common.h: variant_knob)
         variants += ({'SERT_FORK_LATE': '0'}, {'SERT_EXT_EVENTS': '0'}, {'SERT_EGRAD_GROUP_SUM': '1'}, {'SERT_FORK_AT': 'nce'},
+                     {'SERT_DW_FIRST': '0'},      # (dW / db on the main stream instead of first on the side stream)
                      {'SERT_SEG_NO_FUSED_UPPER': '1'}, {'SERT_NO_TAIL': '1'})
     outs = []
     for extra in variants:

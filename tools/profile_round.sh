@@ -37,7 +37,7 @@ for w in $WHAT; do
     mfma)
       cd /tmp
       rocprofv3 -L 2>/dev/null | grep -i -E "mfma|SQ_BUSY_CYCLES|SQ_WAVE_CYCLES|SQ_INSTS_VALU " | head -40 > $OUT/${TAG}_counters_available.txt
-      rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES -d $OUT/mf -o mf -- python $ROOT/bench.py --steps 20 --warmup 3 $NOX > /dev/null 2> $OUT/mfma.err
+      rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES -d $OUT/mf -o mf -- python $ROOT/bench.py --steps 20 --warmup 3 $NOX > /dev/null 2> $OUT/mfma.err
       cd $ROOT
       MF=$(find $OUT/mf -name '*.db' | head -1)
       [ -n "$MF" ] && python tools/gemm_pmc.py $MF > $OUT/${TAG}_mfma.txt

@@ -1383,7 +1383,9 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
     // segmented sum, whose 33.5 MB of dh rows then no longer stay in the Infinity Cache.  Taken while dh is below 24 MB.
     static const bool dw_first_always = variant_knob("SERT_DW_FIRST") && atoi(variant_knob("SERT_DW_FIRST")) == 2;
     m->dw_side_first = !dw_first_off && fork_late && !fork_nce && !side_heavy && m->lazy_join && !fused_bwd && !dw_third_queue(m) &&
-                       c.kind == SERT_KIND_VECTORSPACE && (dw_first_always || (size_t)B * dw * sizeof(float) <= ((size_t)24 << 20));
+                       c.kind == SERT_KIND_VECTORSPACE && (dw_first_always || ((size_t)B * dw * sizeof(float) <= ((size_t)24 << 20) && m->epart));
+    // (m->epart: the sort-free entity chain of small entity tables.  Behind the counting sort of a larger one the side stream is
+    //  the longer of the two already: the reference's product-search settings, V_e = 32768, 205.8 -> 214.5 us with dW in front)
     static const int dp_late_mode = variant_knob("SERT_DP_LATE") ? atoi(variant_knob("SERT_DP_LATE")) : 1;   // 0: off; 2: dW behind the chain
     const bool dp_late = dp_late_mode != 0 && is_dp(m) && !m->host_ar && m->comm && !m->timing.enabled && m->nstreams == 2 && !side_heavy && !fork_nce &&
                          !fork_late;

@@ -350,6 +350,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_x3(const X3Args g
     }
 }
 
+#ifdef SERT_VARIANTS   // (measured equal: csrc/variants/gemm_x3_bres.h, SERT_X3_BRES=1)
+template <bool TB, int EPI, int WAVES>
+__global__ void gemm_x3_bres(const X3Args g);
+#endif
+
 // Does the shape go to this kernel?  (every 16-byte piece aligned and wholly inside or outside; offsets below 2^31 bytes)
 inline bool x3_shape_ok(bool ta, bool tb, const float* A, const float* B, int M, int N, int K, int lda, int ldb) {
     if (ta) {
@@ -369,6 +374,16 @@ inline void launch_gemm_x3(hipStream_t s, const float* A, const float* B, float*
     X3Args g = {};
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.kper = K; g.splits = 1; g.c_split_stride = 0;
+#ifdef SERT_VARIANTS
+    static const int bres_waves = variant_knob("SERT_X3_BRES") ? atoi(variant_knob("SERT_X3_BRES")) : 0;   // 8 or 4 waves per workgroup
+    if (N <= 128 && K <= 128 && bres_waves && (!TB || (ldb % 4 == 0))) {
+        // B resident in LDS, one workgroup per CU, every wave its own 32-row blocks: 23.7 / 21.1 us against 22.4 / 20.6 at C2
+        g.tiles_m = cdiv(M, 32); g.tiles_n = 1;
+        if (bres_waves == 4) SERT_LAUNCH((gemm_x3_bres<TB, EPI, 4>), dim3(std::min(256, cdiv(g.tiles_m, 4))), dim3(256), 0, s, g);
+        else SERT_LAUNCH((gemm_x3_bres<TB, EPI, 8>), dim3(std::min(256, cdiv(g.tiles_m, 8))), dim3(512), 0, s, g);
+        return;
+    }
+#endif
     if (N <= 128) {
         g.tiles_m = cdiv(M, 128); g.tiles_n = 1;
         SERT_LAUNCH((gemm_x3<false, TB, EPI, false, 2, 2, 2, 2>), dim3(g.tiles_m), dim3(256), 0, s, g);

@@ -17,6 +17,7 @@
 #include "gemm_bwd_fused.h"
 #ifdef SERT_VARIANTS   // opt-in GEMM variants that lost their A/B (csrc/variants/; tools/build_variant.sh -DSERT_VARIANTS)
 #include "variants/gemm_big.h"
+#include "variants/gemm_x3_bres.h"
 #include "variants/gemm_strip.h"
 #include "variants/gemm_stream.h"
 #include "variants/gemm_direct.h"

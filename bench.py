@@ -79,7 +79,7 @@ def x3_applies(M, N, K, ta=False):
     if os.environ.get('SERT_GEMM_FP32', '0') not in ('', '0'):
         return False
     if ta:
-        return M <= 320 and N <= 320 and K >= 4096
+        return M <= 4096 and N <= 4096 and K >= 4096
     return N <= 4096 and K <= 4096 and K % 4 == 0 and M >= 128 * (128 if N <= 128 else 256)
 
 

@@ -85,10 +85,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_x3(const X3Args g
     // (neighbours share the B tile)
     int z = 0, tn, tm;
     if (TA) {
-        const int b = blockIdx.x, grp = 8 * g.tiles_n;
+        const int b = blockIdx.x, tiles = g.tiles_m * g.tiles_n, grp = 8 * tiles, t = (b >> 3) % tiles;
         z = (b / grp) * 8 + (b & 7);
-        tn = (b >> 3) % g.tiles_n;
-        tm = 0;
+        tn = t / g.tiles_m;
+        tm = t - tn * g.tiles_m;
         if (z >= g.splits) return;
     } else {
         tn = blockIdx.x / g.tiles_m;
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_x3(const X3Args g
         const int row = tid % TN, h = tid / TN;
         if (h == 1) cs[row] = csum;
         __syncthreads();
-        if (h == 0 && n0 + row < g.N) Cz[(size_t)g.M * g.ldc + n0 + row] = csum + cs[row];
+        if (h == 0 && tm == 0 && n0 + row < g.N) Cz[(size_t)g.M * g.ldc + n0 + row] = csum + cs[row];
     }
 }
 
@@ -359,7 +359,8 @@ __global__ void gemm_x3_bres(const X3Args g);
 inline bool x3_shape_ok(bool ta, bool tb, const float* A, const float* B, int M, int N, int K, int lda, int ldb) {
     if (ta) {
         // A^T.B over a long K (dW of the projection: K = the batch), split-K: one or two N tiles per k range
-        return !tb && M <= 320 && N <= 320 && K >= 4096 && (size_t)K * std::max(lda, ldb) < ((size_t)1 << 29);
+        // (any output up to 4096 x 4096 in 128 x 128 tiles: the loglinear dW = G^T.dZ, the full softmax's dR_e = Z^T.dp)
+        return !tb && M <= 4096 && N <= 4096 && K >= 4096 && (size_t)K * std::max(lda, ldb) < ((size_t)1 << 29);
     }
     const bool a_ok = lda % 4 == 0 && K % 4 == 0 && ((uintptr_t)A) % 16 == 0 && (size_t)M * lda < ((size_t)1 << 29);
     const bool b_ok = tb ? (ldb % 4 == 0 && ((uintptr_t)B) % 16 == 0 && (size_t)N * ldb < ((size_t)1 << 29))
@@ -407,10 +408,14 @@ inline void launch_gemm_x3_ta(hipStream_t s, const float* A, const float* B, flo
     if (M <= 128 && N <= 128) {
         g.tiles_n = 1;
         SERT_LAUNCH((gemm_x3<true, false, EPI_STORE, CSB, 2, 2, 2, 2>), dim3(8 * cdiv(splits, 8)), dim3(256), 0, s, g);
-    } else {
+    } else if (M <= 320 && N <= 320 && M > 128) {
         // 320 x 160 tiles, ten waves of 32 x 160 (80 accumulator registers: three waves fit a SIMD)
         g.tiles_n = cdiv(N, 160);
         SERT_LAUNCH((gemm_x3<true, false, EPI_STORE, CSB, 10, 1, 1, 5>), dim3(8 * g.tiles_n * cdiv(splits, 8)), dim3(640), 0, s, g);
+    } else {
+        // 128 x 128 tiles; the tiles of one k range share an XCD
+        g.tiles_m = cdiv(M, 128); g.tiles_n = cdiv(N, 128);
+        SERT_LAUNCH((gemm_x3<true, false, EPI_STORE, CSB, 2, 2, 2, 2>), dim3(8 * g.tiles_m * g.tiles_n * cdiv(splits, 8)), dim3(256), 0, s, g);
     }
 }
 

@@ -60,8 +60,10 @@ def test_gemm_dispatch_against_float64(hip_lib, M, N, K, ta, tb, epi):
 @pytest.mark.parametrize('M,N,K,splits', [
     (128, 128, 65536, 512), (300, 300, 65536, 113), (128, 128, 8192 + 24, 7), (300, 300, 4096 + 16, 3), (300, 160, 20000, 40),
     (100, 36, 16384, 64), (320, 320, 8192, 8), (301, 299, 9000, 5),
-    # outside gemm_x3.h's split-K shapes: the fp32 MFMA kernels
-    (128, 128, 2048, 16), (400, 128, 8192, 32),
+    # several 128 x 128 output tiles per k range (the loglinear dW, the full softmax's dR_e), ragged last tiles
+    (128, 1000, 20000, 20), (1000, 128, 16384, 16), (400, 128, 8192, 32), (130, 260, 4096 + 48, 3),
+    # outside gemm_x3.h's split-K shapes (K < 4096): the fp32 MFMA kernels
+    (128, 128, 2048, 16), (400, 128, 2048, 8),
 ])
 def test_split_k_with_column_sums_against_float64(hip_lib, M, N, K, splits):
     """dW = h^T.da and db = the column sums of da, as a training step computes them: split-K partial slabs with the column

@@ -13,7 +13,9 @@ for name, kw in [('c2 proj NN 65536x128x128 tanh', dict(M=65536, N=128, K=128, e
                  ('NT 32768x256x256', dict(M=32768, N=256, K=256, tb=1)), ('fs logits NT 65536x1000x128', dict(M=65536, N=1000, K=128, tb=1)),
                  ('ll fwd NN 44467x1000x128 bias', dict(M=44467, N=1000, K=128, epi=1)), ('NN 32768x300x300 tanh', dict(M=32768, N=300, K=300, epi=2)), ('NT 32768x128x128', dict(M=32768, N=128, K=128, tb=1)),
                  ('c2 dW TN 128x128x65536 /512', dict(M=128, N=128, K=65536, ta=1, splits=512)), ('c2 dW TN 128x128x65536 /256', dict(M=128, N=128, K=65536, ta=1, splits=256)),
-                 ('c4 dW TN 300x300x65536 /113', dict(M=300, N=300, K=65536, ta=1, splits=113)), ('c4 dW TN 300x300x65536 /128', dict(M=300, N=300, K=65536, ta=1, splits=128))]:
+                 ('c4 dW TN 300x300x65536 /113', dict(M=300, N=300, K=65536, ta=1, splits=113)), ('c4 dW TN 300x300x65536 /128', dict(M=300, N=300, K=65536, ta=1, splits=128)),
+                 ('ll dW TN 128x1000x44467 /33', dict(M=128, N=1000, K=44467, ta=1, splits=33)), ('ll dW TN 128x1000x44467 /64', dict(M=128, N=1000, K=44467, ta=1, splits=64)),
+                 ('fs dRe TN 1000x128x65536 /32', dict(M=1000, N=128, K=65536, ta=1, splits=32)), ('fs dRe TN 1000x128x65536 /64', dict(M=1000, N=128, K=65536, ta=1, splits=64))]:
     us = C.bench_gemm(**kw)
     print('%-46s %8.1f us %7.1f TF' % (name, us, 2.0 * kw['M'] * kw['N'] * kw['K'] / us / 1e6))
 PY

@@ -113,12 +113,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_x3(const X3Args g
     constexpr bool A_RC = TA, B_RC = TA || !TB;
     constexpr int A_PIECES = A_RC ? (TM * 2 + THREADS - 1) / THREADS : (TM * 4 + THREADS - 1) / THREADS;
     constexpr int B_PIECES = B_RC ? (TN * 2 + THREADS - 1) / THREADS : (TN * 4 + THREADS - 1) / THREADS;
-    // a row-contiguous B is staged one piece at a time (one set of eight registers): piece i is loaded behind MFMA
-    // block i and stored behind block i + 1 (the last one with A, behind block J_STORE); a k-contiguous B -- three
-    // float4 at most -- is loaded behind block J_LOAD_B.  B is L2-resident on this path, A comes from HBM and is
-    // loaded a whole step ahead.
-    // which MFMA block of the step a staged piece is split + stored behind (A: from block 1 on; B: the last blocks;
-    // everything behind the last block when there are only two) and a row-contiguous piece of B is loaded behind
+    // Which MFMA block of a step a staged piece of the NEXT step is split + stored behind: A (loaded from HBM at the top of
+    // the step) from block 1 on, B (L2-resident on this path; loaded behind block 0) behind the last blocks; everything
+    // behind the last block when a step has only two.  A row-contiguous B goes through ONE set of eight registers, a
+    // piece at a time: piece i is loaded behind block 2 i and stored behind block 2 i + 2.
     auto lim = [](int v, int hi) { return v < hi ? v : hi; };
     auto blk_a = [&](int i) { return WNB <= 2 ? WNB - 1 : lim(1 + i * (B_RC ? 2 : 1), WNB - 1); };
     auto blk_b = [&](int i) { return WNB <= 2 ? WNB - 1 : (B_RC ? lim(2 + 2 * i, WNB - 1) : lim(WNB - 2 + i / 2, WNB - 1)); };

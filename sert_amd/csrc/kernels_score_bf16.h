@@ -287,6 +287,63 @@ struct ScoreBf16Args {
     int ngr, cap;
 };
 
+// The filtering epilogue of one 128 x 128 tile (cf. gemm.h EPI_FILTER), shared by the two filter kernels below.
+// acc: the wave's two 32 x 32 blocks (columns wc * 64 + {0, 32} + li of the tile).
+__device__ __forceinline__ void score_filter_epilogue(f32x16_t (&acc)[2], const ScoreBf16Args& g, int tn, int m0, int n0, int wr,
+                                                      int wc, int li, int lh, const float* thr_s) {
+    const int nrem = g.N - n0;
+    if (nrem < SB_T) {       // edge tile: the (clamped, duplicated) columns beyond N never pass
+        const int col0e = wc * 64 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (col0e >= nrem) acc[0][r] = -INFINITY;
+            if (col0e + 32 >= nrem) acc[1][r] = -INFINITY;
+        }
+    }
+    // C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5): the 32 lanes of a
+    // half-wave hold 32 consecutive columns of one row, so the slot of an element in its
+    // (row, 64-column group) list is a ballot/popcount prefix over the group's two halves --
+    // no atomics, ascending column order.  VALU-bound kernel: the no-candidate case is two
+    // compares and a branch, the candidate case one divergent region with selects.
+    const unsigned below = (1u << li) - 1u;
+    const unsigned ngr = (unsigned)g.ngr, ucap = (unsigned)g.cap;
+    const size_t gbase = (size_t)m0 * ngr + 2u * (unsigned)tn;
+    uint32_t* cand_t = g.cand + gbase * ucap;
+    unsigned char* cnt_t = g.cnt + gbase;
+    const int row0 = wr * 32 + 4 * lh;
+    float th[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) th[r] = thr_s[row0 + (r & 3) + 8 * (r >> 2)];
+    unsigned goff = (unsigned)row0 * ngr + (unsigned)wc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float v0 = acc[0][r], v1 = acc[1][r];
+        const bool p0 = v0 >= th[r], p1 = v1 >= th[r];
+        const unsigned long long b0 = __builtin_amdgcn_ballot_w64(p0), b1 = __builtin_amdgcn_ballot_w64(p1);
+        if (b0 | b1) {                                   // wave-uniform
+            const unsigned h0 = lh ? (unsigned)(b0 >> 32) : (unsigned)b0;
+            const unsigned h1 = lh ? (unsigned)(b1 >> 32) : (unsigned)b1;
+            if (p0 | p1) {
+                const unsigned n0c = __popc(h0);
+                const unsigned slot = p0 ? __popc(h0 & below) : n0c + __popc(h1 & below);
+                const float v = p0 ? v0 : v1;
+                const unsigned cl = (unsigned)li + (p0 ? 0u : 32u);
+                const unsigned at = goff * ucap;
+                if (slot < ucap) cand_t[at + slot] = (desc_key(v) & ~63u) | cl;
+                if (slot == 0) {                          // exactly one lane per non-empty list
+                    const unsigned tot = n0c + __popc(h1);
+                    cnt_t[goff] = (unsigned char)(tot > 255u ? 255u : tot);
+                }
+                if (p0 & p1) {                            // both halves of this lane's pair (rare)
+                    const unsigned s1 = n0c + __popc(h1 & below);
+                    if (s1 < ucap) cand_t[at + s1] = (desc_key(v1) & ~63u) | ((unsigned)li + 32u);
+                }
+            }
+        }
+        goff += ((r & 3) == 3) ? 5u * ngr : ngr;
+    }
+}
+
 template <bool STORE>
 __global__ __launch_bounds__(512, 4) void score_filter_bf16(const ScoreBf16Args g) {
     __shared__ __attribute__((aligned(16))) unsigned char As[SB_T * SB_LDB];
@@ -360,57 +417,12 @@ __global__ __launch_bounds__(512, 4) void score_filter_bf16(const ScoreBf16Args 
         }
         return;
     }
-    if (nrem < SB_T) {       // edge tile: the (clamped, duplicated) columns beyond N never pass
-        const int col0e = wc * 64 + li;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            if (col0e >= nrem) acc[0][r] = -INFINITY;
-            if (col0e + 32 >= nrem) acc[1][r] = -INFINITY;
-        }
-    }
-    // C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5): the 32 lanes of a
-    // half-wave hold 32 consecutive columns of one row, so the slot of an element in its
-    // (row, 64-column group) list is a ballot/popcount prefix over the group's two halves --
-    // no atomics, ascending column order.  VALU-bound kernel: the no-candidate case is two
-    // compares and a branch, the candidate case one divergent region with selects.
-    const unsigned below = (1u << li) - 1u;
-    const unsigned ngr = (unsigned)g.ngr, ucap = (unsigned)g.cap;
-    const size_t gbase = (size_t)m0 * ngr + 2u * (unsigned)tn;
-    uint32_t* cand_t = g.cand + gbase * ucap;
-    unsigned char* cnt_t = g.cnt + gbase;
-    const int row0 = wr * 32 + 4 * lh;
-    float th[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) th[r] = thr_s[row0 + (r & 3) + 8 * (r >> 2)];
-    unsigned goff = (unsigned)row0 * ngr + (unsigned)wc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float v0 = acc[0][r], v1 = acc[1][r];
-        const bool p0 = v0 >= th[r], p1 = v1 >= th[r];
-        const unsigned long long b0 = __builtin_amdgcn_ballot_w64(p0), b1 = __builtin_amdgcn_ballot_w64(p1);
-        if (b0 | b1) {                                   // wave-uniform
-            const unsigned h0 = lh ? (unsigned)(b0 >> 32) : (unsigned)b0;
-            const unsigned h1 = lh ? (unsigned)(b1 >> 32) : (unsigned)b1;
-            if (p0 | p1) {
-                const unsigned n0c = __popc(h0);
-                const unsigned slot = p0 ? __popc(h0 & below) : n0c + __popc(h1 & below);
-                const float v = p0 ? v0 : v1;
-                const unsigned cl = (unsigned)li + (p0 ? 0u : 32u);
-                const unsigned at = goff * ucap;
-                if (slot < ucap) cand_t[at + slot] = (desc_key(v) & ~63u) | cl;
-                if (slot == 0) {                          // exactly one lane per non-empty list
-                    const unsigned tot = n0c + __popc(h1);
-                    cnt_t[goff] = (unsigned char)(tot > 255u ? 255u : tot);
-                }
-                if (p0 & p1) {                            // both halves of this lane's pair (rare)
-                    const unsigned s1 = n0c + __popc(h1 & below);
-                    if (s1 < ucap) cand_t[at + s1] = (desc_key(v1) & ~63u) | ((unsigned)li + 32u);
-                }
-            }
-        }
-        goff += ((r & 3) == 3) ? 5u * ngr : ngr;
-    }
+    score_filter_epilogue(acc, g, tn, m0, n0, wr, wc, li, lh, thr_s);
 }
+
+#ifdef SERT_VARIANTS
+__global__ void score_filter_bf16_ring(const ScoreBf16Args g, int tiles_per_wg);
+#endif
 
 inline void launch_score_filter_bf16(hipStream_t s, const uint16_t* P16, const uint16_t* E16, const float* thr,
                                      uint32_t* cand, unsigned char* cnt, int ngr, int cap, int M,
@@ -419,6 +431,17 @@ inline void launch_score_filter_bf16(hipStream_t s, const uint16_t* P16, const u
     g.P16 = P16; g.E16 = E16; g.M = M; g.N = N; g.kp = kp; g.estride = (size_t)kp;
     g.tiles_m = cdiv(M, SB_T); g.tiles_n = cdiv(N, SB_T);
     g.thr = thr; g.cand = cand; g.cnt = cnt; g.ngr = ngr; g.cap = cap;
+#ifdef SERT_VARIANTS
+    // persistent form with the queries' fragments in registers and the entity tiles by LDS-DMA (variants/score_filter_ring.h):
+    // exact, 1.59 ms per 10 000 queries against 1.29 -- the kernel is bound by its epilogue, not by its loads
+    static const bool ring = variant_knob("SERT_SCORE_RING") != nullptr;
+    if (kp == 128 && ring) {
+        const int parts = std::max(1, std::min(g.tiles_n, cdiv(2 * 256, g.tiles_m)));
+        const int per = cdiv(g.tiles_n, parts);
+        hipLaunchKernelGGL(score_filter_bf16_ring, dim3(g.tiles_m * cdiv(g.tiles_n, per)), dim3(512), 0, s, g, per);
+        return;
+    }
+#endif
     hipLaunchKernelGGL(score_filter_bf16<false>, dim3(g.tiles_m * g.tiles_n), dim3(512), 0, s, g);
 }
 

@@ -18,6 +18,7 @@
 #ifdef SERT_VARIANTS   // opt-in GEMM variants that lost their A/B (csrc/variants/; tools/build_variant.sh -DSERT_VARIANTS)
 #include "variants/gemm_big.h"
 #include "variants/gemm_x3_bres.h"
+#include "variants/score_filter_ring.h"
 #include "variants/gemm_strip.h"
 #include "variants/gemm_stream.h"
 #include "variants/gemm_direct.h"

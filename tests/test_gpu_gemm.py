@@ -76,3 +76,26 @@ def test_split_k_with_column_sums_against_float64(hip_lib, M, N, K, splits):
     assert np.all(np.isfinite(got)) and np.all(np.isfinite(colsum))
     assert np.abs(got - ref).max() < 2e-6 * max(1.0, np.sqrt(K / 128.0) / 8)
     assert np.abs(colsum - B.astype(np.float64).sum(axis=0)).max() < 2e-6 * max(1.0, np.sqrt(K / 128.0) / 8)
+
+
+@pytest.mark.parametrize('tb', [0, 1])
+def test_non_finite_operands_stay_confined_to_their_rows_and_columns(hip_lib, tb):
+    """gemm_x3.h splits an operand as x0 = bf16(x), x1 = bf16(x - x0), ...: an Inf gives Inf - Inf = NaN in the second piece, so
+    where the fp32 MFMA path may return +-Inf this one returns NaN -- either way non-finite (a training step raises on a
+    non-finite loss, sert/models.py:372-379), and only in the row of A / column of B the value sits in."""
+    M, N, K = 16384 + 64, 128, 128
+    rng = np.random.RandomState(7)
+    A = rng.uniform(-1, 1, (M, K)).astype(np.float32)
+    B = (rng.uniform(-1, 1, (N, K) if tb else (K, N)) / np.sqrt(K)).astype(np.float32)
+    A[5, 17] = np.inf
+    A[9000, 100] = np.nan
+    if tb:
+        B[77, 3] = -np.inf
+    else:
+        B[3, 77] = -np.inf
+    got = C.debug_gemm(A, B, ta=0, tb=tb)
+    bad = ~np.isfinite(got)
+    assert bad[5].all() and bad[9000].all() and bad[:, 77].all()
+    bad[5] = bad[9000] = False
+    bad[:, 77] = False
+    assert not bad.any()

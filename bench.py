@@ -1027,6 +1027,19 @@ def main():
     eng.synchronize()
     dist.barrier()
     dt_async = dist.all_reduce_max(time.perf_counter() - t0)
+    # pass 4 (extra): the same W + K steps with every contraction on the fp32 MFMA kernels (SERT_GEMM_FP32=1 is read at
+    # every launch) -- the number of the path whose products are single fp32 MFMA instructions, beside the headline
+    gemm_fp32 = None
+    if kind == 'vectorspace' and os.environ.get('SERT_GEMM_FP32', '0') in ('', '0'):
+        os.environ['SERT_GEMM_FP32'] = '1'
+        try:
+            dt32, _, loss32 = timed_steps(model, dist, args.num_batches, args.steps, args.warmup, timing=False)
+        finally:
+            os.environ['SERT_GEMM_FP32'] = '0'
+        gemm_fp32 = {'value': args.steps * Bg / dt32, 'unit': 'pairs/s', 'ms_per_step': 1000.0 * dt32 / args.steps,
+                     'last_loss': loss32,
+                     'note': 'SERT_GEMM_FP32=1: the three GEMMs of the step as v_mfma_f32_32x32x2_f32 (gemm.h) instead of six '
+                             'bf16 MFMA products of exactly split operands (gemm_x3.h); same W warm-up + K timed steps'}
     device_info = _capi.device_info(model._engine.cfg.device)
     comm = getattr(model, 'comm_info', lambda: None)()
     del model, eng
@@ -1121,6 +1134,8 @@ def main():
             'last_loss': last_loss,
             'device': device_info,
         }
+        if gemm_fp32 is not None:
+            out['gemm_fp32_mfma_path'] = gemm_fp32
         if seed_runs is not None:
             vals = [v['value'] for k, v in seed_runs.items() if 'uniform' not in k]
             out['seeds'] = dict(seed_runs, mean_value_seeds_0_1_2=float(np.mean(vals)),

@@ -68,14 +68,14 @@ struct X3Args {
 __device__ __forceinline__ int x3_off(int row, int half) { return row * 32 + ((half ^ (((row >> 2) ^ (row >> 3)) & 1)) << 4); }
 
 template <bool TA, bool TB, int EPI, bool CSB, int WAVES_M, int WAVES_N, int WMB, int WNB>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_x3(const X3Args g) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N <= 4 ? 2 : 1)) void gemm_x3(const X3Args g) {
     constexpr int THREADS = 64 * WAVES_M * WAVES_N;
     constexpr int TM = 32 * WMB * WAVES_M, TN = 32 * WNB * WAVES_N;
     constexpr int A_PLANE = TM * 32, B_PLANE = TN * 32;          // bytes
     constexpr int BUF = 3 * (A_PLANE + B_PLANE);
-    // (+ 3 KB nobody reads: a thread without a piece stores there, so that no store -- and with it no load -- sits in a
+    // (+ 1 KB nobody reads: a thread without a piece stores there, so that no store -- and with it no load -- sits in a
     //  conditional block the compiler could sink the load into, next to its wait)
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF + 3 * 1024];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF + 1024];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w / WAVES_N, wn = w % WAVES_N;
@@ -177,12 +177,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_x3(const X3Args g
         if (!A_RC) {
             const int row = p >> 2, q = p & 3;
             const bool ok = m0 + row < g.M && k0 + 4 * q < kend, mine = TM * 4 % THREADS == 0 || row < TM;
-            store4(mine ? As : sink, mine ? A_PLANE : 1024, mine ? x3_off(row, q >> 1) + ((q & 1) << 3) : 0,
+            store4(mine ? As : sink, mine ? A_PLANE : 0, mine ? x3_off(row, q >> 1) + ((q & 1) << 3) : 0,
                    ok ? ra4[i] : make_float4(0.f, 0.f, 0.f, 0.f));
         } else {
             const int row = p % TM, h = p / TM;
             const bool mine = TM * 2 % THREADS == 0 || h < 2;
-            store8(mine ? As : sink, mine ? A_PLANE : 1024, mine ? x3_off(row, h) : 0, ra8[i]);
+            store8(mine ? As : sink, mine ? A_PLANE : 0, mine ? x3_off(row, h) : 0, ra8[i]);
         }
     };
     // k-contiguous B: every piece at once
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_x3(const X3Args g
         unsigned char* Bs = lds + buf * BUF + 3 * A_PLANE;
         const int p = tid + THREADS * i, row = p >> 2, q = p & 3;
         const bool ok = n0 + row < g.N && k0 + 4 * q < kend, mine = TN * 4 % THREADS == 0 || row < TN;
-        store4(mine ? Bs : sink, mine ? B_PLANE : 1024, mine ? x3_off(row, q >> 1) + ((q & 1) << 3) : 0,
+        store4(mine ? Bs : sink, mine ? B_PLANE : 0, mine ? x3_off(row, q >> 1) + ((q & 1) << 3) : 0,
                ok ? rb4[i] : make_float4(0.f, 0.f, 0.f, 0.f));
     };
     // row-contiguous B: piece i
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_x3(const X3Args g
         const int p = tid + THREADS * i, row = p % TN, h = p / TN;
         const bool mine = TN * 2 % THREADS == 0 || h < 2;
         if (CSB) csum += ((rb8[0] + rb8[1]) + (rb8[2] + rb8[3])) + ((rb8[4] + rb8[5]) + (rb8[6] + rb8[7]));
-        store8(mine ? Bs : sink, mine ? B_PLANE : 1024, mine ? x3_off(row, h) : 0, rb8);
+        store8(mine ? Bs : sink, mine ? B_PLANE : 0, mine ? x3_off(row, h) : 0, rb8);
     };
 
     // fragment of a 32 x 16 block: lane -> row li, k = 8 lh .. 8 lh + 7 (16 bytes)

@@ -79,9 +79,13 @@ def x3_applies(M, N, K, ta=False):
     """gemm_x3.h: x3_shape_ok (the library's dispatch rule; SERT_GEMM_FP32=1 switches the bf16-pipe kernels off)."""
     if os.environ.get('SERT_GEMM_FP32', '0') not in ('', '0'):
         return False
+    cdiv = lambda a, b: -(-a // b)
     if ta:
-        return M <= 4096 and N <= 4096 and K >= 4096
-    return N <= 4096 and K <= 4096 and K % 4 == 0 and M >= 128 * (128 if N <= 128 else 256)
+        tiles = cdiv(N, 160) if 128 < M <= 320 else cdiv(M, 128) * cdiv(N, 128)
+        return M <= 4096 and N <= (1 << 20) and (K >= 4096 or (K >= 1024 and tiles >= 256))
+    tm = 128 if N <= 128 else 256
+    tn = 128 if N <= 128 else (256 if (N <= 256 or (N > 320 and cdiv(N, 256) * 256 <= cdiv(N, 320) * 320)) else 320)
+    return N <= (1 << 20) and K <= 4096 and K % 4 == 0 and (M >= 128 * tm or (K >= 256 and M >= 1024 and cdiv(M, tm) * cdiv(N, tn) >= 256))
 
 
 def group_work(kind, B, n, s, dw, de, Ve, Vw, z, distinct_words=None, shards=1, lazy=None):

@@ -348,6 +348,11 @@ int sert_debug_gemm(int device, int ta, int tb, int epi, int M, int N, int K, co
  * projection's dW / db take in a training step (sert/models.py:1057-1061, autodiff). */
 int sert_debug_gemm_splitk(int device, int M, int N, int K, int splits, const float* A, const float* B, float* out);
 
+/* ... and of a product A.op(B) over a long K cut into `splits` k ranges (test hook): C (M,N), A (M,K), B (K,N) or (N,K) if tb,
+ * through the split launch + order-fixed combine of the loglinear dG = dZ.W^T over a large entity vocabulary
+ * (sert/models.py:846-849, autodiff). */
+int sert_debug_gemm_longk(int device, int tb, int M, int N, int K, int splits, const float* A, const float* B, float* C);
+
 /* Memory-system micro-benchmarks: the denominators a step's memory-bound kernels are priced
  * against (no reference counterpart; measurement only).  Average launch time over `iters`
  * launches (HIP events on the launching stream, 2 warm-ups) in *avg_us.

@@ -35,7 +35,7 @@ EXPORTS = [
     'sert_host_alloc', 'sert_host_free',
     'sert_comm_unique_id', 'sert_comm_init', 'sert_comm_init_host', 'sert_comm_destroy', 'sert_comm_stats',
     'sert_synchronize', 'sert_timing_enable', 'sert_timing_reset', 'sert_timing_count',
-    'sert_timing_name', 'sert_timing_avg_us', 'sert_bench_gemm', 'sert_debug_gemm', 'sert_debug_gemm_splitk', 'sert_bench_memory', 'sert_debug_row_lists', 'sert_debug_word_index_sum',
+    'sert_timing_name', 'sert_timing_avg_us', 'sert_bench_gemm', 'sert_debug_gemm', 'sert_debug_gemm_splitk', 'sert_debug_gemm_longk', 'sert_bench_memory', 'sert_debug_row_lists', 'sert_debug_word_index_sum',
     'sert_profile_range_push', 'sert_profile_range_pop',
 ]
 
@@ -573,6 +573,20 @@ def debug_gemm_splitk(A, B, splits, device=0):
     lib.sert_debug_gemm_splitk.argtypes = [ctypes.c_int] * 5 + [ctypes.c_void_p] * 3
     check(lib.sert_debug_gemm_splitk(device, M, N, K, int(splits), _addr(A), _addr(B), _addr(out)))
     return out[:M * N].reshape(M, N), out[M * N:]
+
+
+def debug_gemm_longk(A, B, splits, tb=0, device=0):
+    """A.op(B) over a long K cut into `splits` k ranges + combine (sert_debug_gemm_longk); A (M, K), B (K, N) or (N, K) if tb."""
+    lib = load()
+    A = np.ascontiguousarray(A, dtype=np.float32)
+    B = np.ascontiguousarray(B, dtype=np.float32)
+    M, K = A.shape
+    N = B.shape[0] if tb else B.shape[1]
+    assert (B.shape[1] if tb else B.shape[0]) == K
+    out = np.empty((M, N), dtype=np.float32)
+    lib.sert_debug_gemm_longk.argtypes = [ctypes.c_int] * 6 + [ctypes.c_void_p] * 3
+    check(lib.sert_debug_gemm_longk(device, int(tb), M, N, K, int(splits), _addr(A), _addr(B), _addr(out)))
+    return out
 
 
 def bench_memory(kind, nbytes, table_bytes=0, row_bytes=512, window=10, gap_bytes=0, blocks=0, iters=20, device=0):

@@ -782,10 +782,10 @@ inline bool launch_gemm_direct(hipStream_t s, const float* A, const float* B, fl
 #endif
 
 // gemm_x3.h: the same contraction on the bf16 matrix pipe (three exact bf16 pieces per operand, six products)
-inline bool x3_shape_ok(bool ta, bool tb, const float* A, const float* B, int M, int N, int K, int lda, int ldb);
+inline bool x3_shape_ok(bool ta, bool tb, const float* A, const float* B, int M, int N, int K, int lda, int ldb, int splits = 1);
 template <bool TB, int EPI>
 inline void launch_gemm_x3(hipStream_t s, const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
-                           int lda, int ldb, int ldc);
+                           int lda, int ldb, int ldc, int splits = 1, int kper = 0, size_t c_split_stride = 0);
 template <bool CSB>
 inline void launch_gemm_x3_ta(hipStream_t s, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb,
                               int ldc, int splits, int kper, size_t c_split_stride);
@@ -813,8 +813,9 @@ inline void launch_gemm(hipStream_t s, const float* A, const float* B, float* C,
         }
     }
     if constexpr (!TA && !CSB && (EPI == EPI_STORE || EPI == EPI_BIAS || EPI == EPI_BIAS_TANH)) {
-        if (splits == 1 && !rowmap && gemm_x3_enabled() && x3_shape_ok(false, TB, A, B, M, N, K, lda, ldb)) {
-            launch_gemm_x3<TB, EPI>(s, A, B, C, bias, M, N, K, lda, ldb, ldc);
+        if ((splits == 1 || (EPI == EPI_STORE && kper % 16 == 0)) && !rowmap && gemm_x3_enabled() &&
+            x3_shape_ok(false, TB, A, B, M, N, K, lda, ldb, splits)) {
+            launch_gemm_x3<TB, EPI>(s, A, B, C, bias, M, N, K, lda, ldb, ldc, splits, kper, c_split_stride);
             return;
         }
     }

@@ -85,18 +85,22 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N <= 4 ? 2
     // (neighbours share the B tile)
     int z = 0, tn, tm;
     if (TA) {
-        const int b = blockIdx.x, tiles = g.tiles_m * g.tiles_n, grp = 8 * tiles, t = (b >> 3) % tiles;
-        z = (b / grp) * 8 + (b & 7);
+        // (one k range: the block index is the tile)
+        const int b = blockIdx.x, tiles = g.tiles_m * g.tiles_n, grp = 8 * tiles, t = g.splits == 1 ? b : (b >> 3) % tiles;
+        z = g.splits == 1 ? 0 : (b / grp) * 8 + (b & 7);
         tn = t / g.tiles_m;
         tm = t - tn * g.tiles_m;
         if (z >= g.splits) return;
     } else {
-        tn = blockIdx.x / g.tiles_m;
-        tm = blockIdx.x - tn * g.tiles_m;
+        // (k range z -- one unless the caller split a long K over partial slabs --, then along M first)
+        const int tiles = g.tiles_m * g.tiles_n, t = blockIdx.x % tiles;
+        z = blockIdx.x / tiles;
+        tn = t / g.tiles_m;
+        tm = t - tn * g.tiles_m;
     }
     const int m0 = tm * TM, n0 = tn * TN;
-    const int kbeg = TA ? z * g.kper : 0;
-    const int kend = TA ? min(g.K, kbeg + g.kper) : g.K;
+    const int kbeg = z * g.kper;
+    const int kend = min(g.K, kbeg + g.kper);
     const int steps = (kend - kbeg + X3_KC - 1) / X3_KC;
 
     f32x16 acc[WMB][WNB];
@@ -354,25 +358,32 @@ __global__ void gemm_x3_bres(const X3Args g);
 #endif
 
 // Does the shape go to this kernel?  (every 16-byte piece aligned and wholly inside or outside; offsets below 2^31 bytes)
-inline bool x3_shape_ok(bool ta, bool tb, const float* A, const float* B, int M, int N, int K, int lda, int ldb) {
+inline bool x3_shape_ok(bool ta, bool tb, const float* A, const float* B, int M, int N, int K, int lda, int ldb, int splits) {
     if (ta) {
-        // A^T.B over a long K (dW of the projection: K = the batch), split-K: one or two N tiles per k range
-        // (any output up to 4096 x 4096 in 128 x 128 tiles: the loglinear dW = G^T.dZ, the full softmax's dR_e = Z^T.dp)
-        return !tb && M <= 4096 && N <= 4096 && K >= 4096 && (size_t)K * std::max(lda, ldb) < ((size_t)1 << 29);
+        // A^T.B over a long K, split-K (dW of the projection: K = the batch; the loglinear dW = G^T.dZ; the full softmax's
+        // dR_e = Z^T.dp) -- or over a shorter K when the output alone has tiles for every CU (the loglinear dW at 100 000
+        // entities: 300 x 100 000 over the batch's ~2 300 distinct words)
+        const long long tiles = (M > 128 && M <= 320) ? cdiv(N, 160) : (long long)cdiv(M, 128) * cdiv(N, 128);
+        return !tb && M <= 4096 && N <= (1 << 20) && (K >= 4096 || (K >= 1024 && tiles >= 256)) &&
+               (size_t)K * std::max(lda, ldb) < ((size_t)1 << 29);
     }
     const bool a_ok = lda % 4 == 0 && K % 4 == 0 && ((uintptr_t)A) % 16 == 0 && (size_t)M * lda < ((size_t)1 << 29);
     const bool b_ok = tb ? (ldb % 4 == 0 && ((uintptr_t)B) % 16 == 0 && (size_t)N * ldb < ((size_t)1 << 29))
                          : (size_t)K * ldb < ((size_t)1 << 29);
-    // (at least 128 row tiles: below that too few workgroups carry the launch -- 16384 x 300 x 300: 65 us against 41)
-    return a_ok && b_ok && N <= 4096 && K <= 4096 && M >= 128 * (N <= 128 ? 128 : 256);
+    const int tm = N <= 128 ? 128 : 256, tn = N <= 128 ? 128 : (N <= 256 || (N > 320 && cdiv(N, 256) * 256 <= cdiv(N, 320) * 320)) ? 256 : 320;
+    // at least 128 row tiles (below that too few workgroups carry the launch -- 16384 x 300 x 300: 65 us against 41) -- or,
+    // for K >= 256, a tile for every CU from a wide N (the loglinear logits at 100 000 entities: 2 300 x 100 000 x 300)
+    // (splits > 1: a long K cut into k ranges with partial slabs -- the loglinear dG over 100 000 entities)
+    const bool enough = M >= 128 * tm || (K >= 256 && M >= 1024 && (long long)cdiv(M, tm) * cdiv(N, tn) * splits >= 256);
+    return a_ok && b_ok && N <= (1 << 20) && (K <= 4096 || splits > 1) && enough;
 }
 
 template <bool TB, int EPI>
 inline void launch_gemm_x3(hipStream_t s, const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
-                           int lda, int ldb, int ldc) {
+                           int lda, int ldb, int ldc, int splits, int kper, size_t c_split_stride) {
     X3Args g = {};
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
-    g.kper = K; g.splits = 1; g.c_split_stride = 0;
+    g.kper = splits > 1 ? kper : K; g.splits = std::max(1, splits); g.c_split_stride = splits > 1 ? c_split_stride : 0;
 #ifdef SERT_VARIANTS
     static const int bres_waves = variant_knob("SERT_X3_BRES") ? atoi(variant_knob("SERT_X3_BRES")) : 0;   // 8 or 4 waves per workgroup
     if (N <= 128 && K <= 128 && bres_waves && (!TB || (ldb % 4 == 0))) {
@@ -385,13 +396,13 @@ inline void launch_gemm_x3(hipStream_t s, const float* A, const float* B, float*
 #endif
     if (N <= 128) {
         g.tiles_m = cdiv(M, 128); g.tiles_n = 1;
-        SERT_LAUNCH((gemm_x3<false, TB, EPI, false, 2, 2, 2, 2>), dim3(g.tiles_m), dim3(256), 0, s, g);
+        SERT_LAUNCH((gemm_x3<false, TB, EPI, false, 2, 2, 2, 2>), dim3(g.tiles_m * g.splits), dim3(256), 0, s, g);
     } else if (N <= 256 || (N > 320 && cdiv(N, 256) * 256 <= cdiv(N, 320) * 320)) {
         g.tiles_m = cdiv(M, 256); g.tiles_n = cdiv(N, 256);
-        SERT_LAUNCH((gemm_x3<false, TB, EPI, false, 4, 2, 2, 4>), dim3(g.tiles_m * g.tiles_n), dim3(512), 0, s, g);
+        SERT_LAUNCH((gemm_x3<false, TB, EPI, false, 4, 2, 2, 4>), dim3(g.tiles_m * g.tiles_n * g.splits), dim3(512), 0, s, g);
     } else {
         g.tiles_m = cdiv(M, 256); g.tiles_n = cdiv(N, 320);
-        SERT_LAUNCH((gemm_x3<false, TB, EPI, false, 4, 2, 2, 5>), dim3(g.tiles_m * g.tiles_n), dim3(512), 0, s, g);
+        SERT_LAUNCH((gemm_x3<false, TB, EPI, false, 4, 2, 2, 5>), dim3(g.tiles_m * g.tiles_n * g.splits), dim3(512), 0, s, g);
     }
 }
 
@@ -405,15 +416,15 @@ inline void launch_gemm_x3_ta(hipStream_t s, const float* A, const float* B, flo
     g.tiles_m = 1;
     if (M <= 128 && N <= 128) {
         g.tiles_n = 1;
-        SERT_LAUNCH((gemm_x3<true, false, EPI_STORE, CSB, 2, 2, 2, 2>), dim3(8 * cdiv(splits, 8)), dim3(256), 0, s, g);
-    } else if (M <= 320 && N <= 320 && M > 128) {
+        SERT_LAUNCH((gemm_x3<true, false, EPI_STORE, CSB, 2, 2, 2, 2>), dim3(splits == 1 ? 1 : 8 * cdiv(splits, 8)), dim3(256), 0, s, g);
+    } else if (M <= 320 && M > 128) {
         // 320 x 160 tiles, ten waves of 32 x 160 (80 accumulator registers: three waves fit a SIMD)
         g.tiles_n = cdiv(N, 160);
-        SERT_LAUNCH((gemm_x3<true, false, EPI_STORE, CSB, 10, 1, 1, 5>), dim3(8 * g.tiles_n * cdiv(splits, 8)), dim3(640), 0, s, g);
+        SERT_LAUNCH((gemm_x3<true, false, EPI_STORE, CSB, 10, 1, 1, 5>), dim3(splits == 1 ? g.tiles_n : 8 * g.tiles_n * cdiv(splits, 8)), dim3(640), 0, s, g);
     } else {
         // 128 x 128 tiles; the tiles of one k range share an XCD
         g.tiles_m = cdiv(M, 128); g.tiles_n = cdiv(N, 128);
-        SERT_LAUNCH((gemm_x3<true, false, EPI_STORE, CSB, 2, 2, 2, 2>), dim3(8 * g.tiles_m * g.tiles_n * cdiv(splits, 8)), dim3(256), 0, s, g);
+        SERT_LAUNCH((gemm_x3<true, false, EPI_STORE, CSB, 2, 2, 2, 2>), dim3(splits == 1 ? g.tiles_m * g.tiles_n : 8 * g.tiles_m * g.tiles_n * cdiv(splits, 8)), dim3(256), 0, s, g);
     }
 }
 

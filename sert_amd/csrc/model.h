@@ -81,6 +81,7 @@ struct sert_model {
     bool re_in_parts = false;        // this step: dR_e is still the row groups' partial tables (summed by the optimiser)
     bool fork_bound = false;         // ev_fork rides on the NCE kernel's completion signal (no record needed)
     bool lazy_join = false;          // this step: the main stream never waits for the entity chain
+    bool ll_dw_side = false;         // loglinear, this step: dW, db and their combine were issued on the side stream
     bool dw_side_first = false;      // this step: dW / db came from the side stream, FIRST in its chain (ev_dense marks them)
     bool dp_late_join = false;       // data parallel, asynchronous communicator: the side stream (entity chain, dW, db, loss sum) is
                                      // joined by the COMMUNICATION stream in front of the small all-reduce, not by the main stream

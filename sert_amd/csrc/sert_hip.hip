@@ -483,6 +483,13 @@ static int gemm_long_k(sert_model* m, hipStream_t s, const float* A, const float
     int splits = 1;
     if (tiles < 512 && K >= 4096) splits = std::min(cdiv(1024, tiles), K / 1024);
     else if (tiles < 256 && K >= 512) splits = std::min(cdiv(1024, tiles), K / 128);   // few tiles, medium K
+    if (!TA && K >= 4096 && gemm_x3_enabled()) {
+        // the bf16-pipe kernel (gemm_x3.h) has larger tiles -- 256 rows, up to 320 columns --: enough k ranges for two
+        // workgroups per CU (the loglinear dG over 100 000 entities: 9 tiles x 57 ranges; 1.83 -> 1.1 ms)
+        const int t3 = cdiv(M, N <= 128 ? 128 : 256) * cdiv(N, N <= 128 ? 128 : 320);
+        const int s3 = std::max(1, std::min(cdiv(512, t3), K / 1024));
+        if (s3 > 1 && x3_shape_ok(false, TB, A, Bm, M, N, K, lda, ldb, s3)) splits = s3;
+    }
     // (between one and two tiles per CU -- the loglinear dG at C2 dims, 347 tiles -- a three-way split was
     //  tried: 162 -> 175 us with its combine; co-resident workgroups share the matrix pipe without loss)
     if (splits <= 1) {
@@ -1755,6 +1762,7 @@ static int ll_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         const bool dw_side = !dw_side_off && !is_dp(m) && !m->timing.enabled && m->nstreams >= 2 && ext_events() &&
                              2.0 * (double)rows * d * V >= 2e9;
         hipStream_t sd = dw_side ? m->stream2 : m->stream;
+        m->ll_dw_side = dw_side;   // (optimizer_and_loss: W and b are updated on that stream too, whatever their size)
         if (dw_side) {
             SERT_HIP(hipEventRecord(m->ev_fork, m->stream));
             SERT_HIP(hipStreamWaitEvent(sd, m->ev_fork, 0));
@@ -1968,8 +1976,12 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
                 continue;
             }
             if (i == 0) SERT_TRY(ensure_rw_current(m, -1));    // (a dense launch assumes every row is at the previous step)
-            // (side_heavy: the entity table streams on the side stream, behind its gradient chain)
-            launch_stream_opt(m, (i == 1 && m->side_heavy && side_small) ? ss : m->stream, t.p, t.g, t.s0, t.s1, t.n, nb, aa, da,
+            // (side_heavy: the entity table streams on the side stream, behind its gradient chain.  Loglinear with dW on the
+            //  side stream: a W large enough to be a "big tensor" -- d x V_e >= 2^22, C4 -- is updated THERE, behind dW and
+            //  its combine; on the main stream its update read dW's gradient while the side stream was still writing it:
+            //  two runs of the C4 loglinear step differed by 0.5 % in W after two steps, tools/experiments/r04_ll_c4_rep.py)
+            const bool on_side = side_small && ((i == 1 && m->side_heavy) || (i >= 2 && m->ll_dw_side));
+            launch_stream_opt(m, on_side ? ss : m->stream, t.p, t.g, t.s0, t.s1, t.n, nb, aa, da,
                               m->red_sq + n_sq, tf,
                               i == 0 ? (unsigned)c.word_dim : 1u,
                               (i == 0 && tf && m->early_issued) ? kRowsTouched : kRowsAll);
@@ -2223,6 +2235,7 @@ static int step_forward_backward(sert_model* m, const DataSplit& ds, int64_t bat
     // Prologue (zeroing, negative sampling): nothing before the loss kernel needs it, so
     // for the vectorspace step it runs on the side stream beside gather + projection.
     m->lazy_join = false;
+    m->ll_dw_side = false;
     m->dw_side_first = false;
     m->dp_late_join = false;
     m->side_heavy = false;
@@ -3999,6 +4012,36 @@ int sert_debug_gemm_splitk(int device, int M, int N, int K, int splits, const fl
         launch_reduce_partials(s, dP, splits, stride, stride, dO, stride, dO);
         SERT_HIP(hipGetLastError());
         SERT_HIP(hipMemcpyAsync(out, dO, stride * sizeof(float), hipMemcpyDeviceToHost, s));
+        SERT_HIP(hipStreamSynchronize(s));
+        return 0;
+    };
+    const int rc = body();
+    (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dP); (void)hipFree(dO);
+    (void)hipStreamDestroy(s);
+    return rc;
+}
+
+// C (M, N) = A . op(B) over a LONG K cut into `splits` k ranges (partial slabs + order-fixed combine): the form the loglinear
+// dG = dZ.W^T takes over 100 000 entities (gemm_long_k).  A (M, K), B (K, N) or (N, K) if tb: host arrays.
+int sert_debug_gemm_longk(int device, int tb, int M, int N, int K, int splits, const float* A, const float* B, float* C) {
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || splits <= 0) SERT_FAIL("bad argument");
+    SERT_HIP(hipSetDevice(device));
+    hipStream_t s;
+    SERT_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    int kper = (int)round_up(cdiv(K, splits), GK);
+    splits = cdiv(K, kper);
+    const size_t na = (size_t)M * K, nb = (size_t)K * N, mn = (size_t)M * N;
+    float *dA = nullptr, *dB = nullptr, *dP = nullptr, *dO = nullptr;
+    auto body = [&]() -> int {
+        SERT_TRY(dmalloc(&dA, na)); SERT_TRY(dmalloc(&dB, nb)); SERT_TRY(dmalloc(&dP, mn * splits)); SERT_TRY(dmalloc(&dO, mn));
+        SERT_HIP(hipMemcpyAsync(dA, A, na * sizeof(float), hipMemcpyHostToDevice, s));
+        SERT_HIP(hipMemcpyAsync(dB, B, nb * sizeof(float), hipMemcpyHostToDevice, s));
+        SERT_HIP(hipMemsetAsync(dP, 0xff, mn * splits * sizeof(float), s));
+        if (tb) launch_gemm<false, true, EPI_STORE>(s, dA, dB, dP, nullptr, M, N, K, K, K, N, splits, kper, mn);
+        else    launch_gemm<false, false, EPI_STORE>(s, dA, dB, dP, nullptr, M, N, K, K, N, N, splits, kper, mn);
+        launch_reduce_partials(s, dP, splits, mn, mn, dO, mn, dO);
+        SERT_HIP(hipGetLastError());
+        SERT_HIP(hipMemcpyAsync(C, dO, mn * sizeof(float), hipMemcpyDeviceToHost, s));
         SERT_HIP(hipStreamSynchronize(s));
         return 0;
     };

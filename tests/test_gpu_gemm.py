@@ -43,6 +43,8 @@ def _ref(A, B, ta, tb, epi, bias):
     (65536, 300, 300, 0, 0, 2), (65536, 300, 300, 0, 1, 0), (8200, 257, 64, 0, 0, 0), (8200, 31, 16, 0, 1, 0),
     (16384 + 7, 128, 128, 0, 0, 2), (32768 + 9, 300, 300, 0, 1, 0), (32768, 257, 64, 0, 0, 1), (16400, 31, 16, 0, 1, 0), (33000, 1000, 128, 0, 0, 1),
     (33000, 1000, 128, 0, 1, 0), (32768, 700, 36, 0, 0, 2),
+    # few rows, a wide N, K >= 256: a tile for every CU from the columns (the loglinear logits over 100 000 entities)
+    (2304, 20000, 300, 0, 0, 1), (1100, 30000, 256, 0, 1, 0), (1030, 80000, 260, 0, 0, 0),
 ])
 def test_gemm_dispatch_against_float64(hip_lib, M, N, K, ta, tb, epi):
     rng = np.random.RandomState(M + 3 * N + 7 * K + ta + 2 * tb)
@@ -62,6 +64,8 @@ def test_gemm_dispatch_against_float64(hip_lib, M, N, K, ta, tb, epi):
     (100, 36, 16384, 64), (320, 320, 8192, 8), (301, 299, 9000, 5),
     # several 128 x 128 output tiles per k range (the loglinear dW, the full softmax's dR_e), ragged last tiles
     (128, 1000, 20000, 20), (1000, 128, 16384, 16), (400, 128, 8192, 32), (130, 260, 4096 + 48, 3),
+    # a shorter K with an output wide enough to fill the machine by itself (the loglinear dW over 100 000 entities): one k range
+    (300, 41000, 1040, 1), (100, 33000, 1536, 2), (257, 36000, 1100, 1),
     # outside gemm_x3.h's split-K shapes (K < 4096): the fp32 MFMA kernels
     (128, 128, 2048, 16), (400, 128, 2048, 8),
 ])
@@ -74,8 +78,11 @@ def test_split_k_with_column_sums_against_float64(hip_lib, M, N, K, splits):
     got, colsum = C.debug_gemm_splitk(A, B, splits)
     ref = A.astype(np.float64).T @ B.astype(np.float64)
     assert np.all(np.isfinite(got)) and np.all(np.isfinite(colsum))
-    assert np.abs(got - ref).max() < 2e-6 * max(1.0, np.sqrt(K / 128.0) / 8)
-    assert np.abs(colsum - B.astype(np.float64).sum(axis=0)).max() < 2e-6 * max(1.0, np.sqrt(K / 128.0) / 8)
+    # fp32 accumulation: a chain of K / splits terms of magnitude <= 1 / sqrt(K) per k range (the bound of the test above
+    # for that length), then the order-fixed combine of the ranges
+    tol = 2e-6 * max(1.0, np.sqrt(K / splits / 128.0), np.sqrt(K / 128.0) / 8)
+    assert np.abs(got - ref).max() < tol
+    assert np.abs(colsum - B.astype(np.float64).sum(axis=0)).max() < tol
 
 
 @pytest.mark.parametrize('tb', [0, 1])
@@ -99,3 +106,20 @@ def test_non_finite_operands_stay_confined_to_their_rows_and_columns(hip_lib, tb
     bad[5] = bad[9000] = False
     bad[:, 77] = False
     assert not bad.any()
+
+
+@pytest.mark.parametrize('M,N,K,splits,tb', [
+    (2304, 300, 100000, 64, 1), (2304, 300, 50000 + 24, 37, 0), (1100, 128, 65536, 128, 1),
+    # too few tiles x ranges for gemm_x3.h: the fp32 MFMA kernels
+    (512, 128, 8192, 8, 1),
+])
+def test_long_k_in_ranges_against_float64(hip_lib, M, N, K, splits, tb):
+    """A.op(B) over a long K cut into k ranges with partial slabs and an order-fixed combine -- the loglinear dG = dZ.W^T over
+    a large entity vocabulary (gemm_long_k)."""
+    rng = np.random.RandomState(M + 3 * N + 7 * K)
+    A = rng.uniform(-1, 1, (M, K)).astype(np.float32)
+    B = (rng.uniform(-1, 1, (N, K) if tb else (K, N)) / np.sqrt(K)).astype(np.float32)
+    got = C.debug_gemm_longk(A, B, splits, tb=tb)
+    ref = A.astype(np.float64) @ (B.astype(np.float64).T if tb else B.astype(np.float64))
+    assert np.all(np.isfinite(got))
+    assert np.abs(got - ref).max() < 2e-6 * max(1.0, np.sqrt(K / splits / 128.0), np.sqrt(K / 128.0) / 8)

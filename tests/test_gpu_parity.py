@@ -938,7 +938,7 @@ sys.path.insert(0, %(root)r)
 import numpy as np
 from tests import util as U
 from sert_amd import _capi as C
-B, n, Vw, Ve, d = 4096, 8, 5000, 2000, 128
+B, n, Vw, Ve, d = %(dims)s
 p = U.make_ll_problem(5, 3 * B, n, Vw, Ve, d, 'int')
 eng = U.ll_engine(p, B, n, 0.01, keep_grads=0)
 eng.upload_dataset(C.SPLIT_TRAIN, p['X'], y_int=p['y'], w=p['w'])
@@ -955,16 +955,19 @@ print('RESULT ' + json.dumps(out))
 
 
 @pytest.mark.gpu
-def test_loglinear_side_stream_does_not_change_a_bit(hip_lib):
+@pytest.mark.parametrize('dims', ['4096, 8, 5000, 2000, 128', '2048, 8, 20000, 40000, 128'])
+def test_loglinear_side_stream_does_not_change_a_bit(hip_lib, dims):
     """Loglinear with a dW GEMM worth forking for (2 x 5000 x 128 x 2000 flop): dW, its combine and the W, b
     update on the side stream, with the next batch running ahead, against the whole step on one stream
-    (SERT_LL_DW_SIDE=0, SERT_STREAMS=1): bit-identical losses, parameters and Adadelta state."""
+    (SERT_LL_DW_SIDE=0, SERT_STREAMS=1): bit-identical losses, parameters and Adadelta state.  Second case: a W of
+    128 x 40 000 = 5.1 M elements -- a "big tensor" with a streaming launch of its own; updated on the main stream it read
+    dW's gradient while the side stream was still writing it (round 4: found at C4's sizes, fixed)."""
     import json
     import os
     import subprocess
     import sys
-    code = LL_SCHEDULE_WORKER % dict(root=U.ROOT)
-    variants = ({}, {'SERT_LL_DW_SIDE': '0'}, {'SERT_STREAMS': '1'})
+    code = LL_SCHEDULE_WORKER % dict(root=U.ROOT, dims=dims)
+    variants = ({}, {'SERT_LL_DW_SIDE': '0'}, {'SERT_STREAMS': '1'}, {})     # (the default twice: run-to-run too)
     outs = []
     for extra in variants:
         r = subprocess.run([sys.executable, '-c', code], check=True, env=dict(os.environ, **extra),

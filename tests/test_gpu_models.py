@@ -719,3 +719,21 @@ np.savez(sys.argv[1], losses=np.array(losses), Rw=eng.get_tensor(C.T_RW), W=eng.
     assert U.rel_err(outs[0]['W'], outs[2]['W']) < 1e-4
     assert U.rel_err(outs[0]['Rw'], outs[2]['Rw']) < 1e-4
     assert outs[0]['losses'][-1] < outs[0]['losses'][0]
+
+
+@pytest.mark.gpu
+def test_every_benchmarked_configuration_repeats_bit_for_bit(hip_lib):
+    """The configurations bench.py and the README time -- C2, C4, loglinear and full softmax at C2's dims, loglinear at C4's
+    tables, the reference's product-search and W3C settings -- through the Python surface as the epoch loop drives it (next-batch
+    hints, loss read every step): six steps twice in fresh models, representations, optimiser state and losses bit for bit
+    (tools/experiments/r04_repeat_sweep.py).  Round 4 found two schedule races by re-running at these sizes -- the previous
+    step's entity chain against the next projection, a big loglinear W against its own dW GEMM -- that the small-shape tests
+    never lost."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'experiments', 'r04_repeat_sweep.py')], cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    text = r.stdout.decode()
+    assert r.returncode == 0, text[-2000:]
+    lines = [l for l in text.splitlines() if 'bit-identical' in l or 'DIFFERENT' in l]
+    assert len(lines) == 8 and not any('DIFFERENT' in l for l in lines), '\n'.join(lines)

@@ -1391,8 +1391,10 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
     // 0.1429, 32768 0.191 -> 0.175; at 65536 0.2720 -> 0.2745 -- there dW streams its 67 MB beside the first level of the
     // segmented sum, whose 33.5 MB of dh rows then no longer stay in the Infinity Cache.  Taken while dh is below 24 MB.
     static const bool dw_first_always = variant_knob("SERT_DW_FIRST") && atoi(variant_knob("SERT_DW_FIRST")) == 2;
+    // (!pt_big[2]: a projection matrix large enough for a streaming update of its own is updated on the main stream, which
+    //  would then have to wait for the side stream's dW)
     m->dw_side_first = !dw_first_off && fork_late && !fork_nce && !side_heavy && m->lazy_join && !fused_bwd && !dw_third_queue(m) &&
-                       c.kind == SERT_KIND_VECTORSPACE && (dw_first_always || ((size_t)B * dw * sizeof(float) <= ((size_t)24 << 20) && m->epart));
+                       !m->pt_big[2] && c.kind == SERT_KIND_VECTORSPACE && (dw_first_always || ((size_t)B * dw * sizeof(float) <= ((size_t)24 << 20) && m->epart));
     // (m->epart: the sort-free entity chain of small entity tables.  Behind the counting sort of a larger one the side stream is
     //  the longer of the two already: the reference's product-search settings, V_e = 32768, 205.8 -> 214.5 us with dW in front)
     static const int dp_late_mode = variant_knob("SERT_DP_LATE") ? atoi(variant_knob("SERT_DP_LATE")) : 1;   // 0: off; 2: dW behind the chain

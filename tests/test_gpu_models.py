@@ -731,9 +731,13 @@ def test_every_benchmarked_configuration_repeats_bit_for_bit(hip_lib):
     never lost."""
     import subprocess
     import sys
-    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'experiments', 'r04_repeat_sweep.py')], cwd=ROOT,
-                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
-    text = r.stdout.decode()
-    assert r.returncode == 0, text[-2000:]
-    lines = [l for l in text.splitlines() if 'bit-identical' in l or 'DIFFERENT' in l]
-    assert len(lines) == 8 and not any('DIFFERENT' in l for l in lines), '\n'.join(lines)
+    digests = []
+    for extra in ({}, {'SERT_STREAMS': '1'}):      # ... and the same bits with the whole step on ONE stream
+        r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'experiments', 'r04_repeat_sweep.py')], cwd=ROOT,
+                           env=dict(os.environ, **extra), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+        text = r.stdout.decode()
+        assert r.returncode == 0, text[-2000:]
+        lines = [l for l in text.splitlines() if 'bit-identical' in l or 'DIFFERENT' in l]
+        assert len(lines) == 8 and not any('DIFFERENT' in l for l in lines), '\n'.join(lines)
+        digests.append([l.split('digest')[1].strip() for l in lines])
+    assert digests[0] == digests[1], digests

@@ -49,4 +49,6 @@ def run(kind, c):
 for name, kind, c in CASES:
     a, b = run(kind, c), run(kind, c)
     same = a == b
-    print('%-28s %s   losses %s' % (name, 'bit-identical' if same else 'DIFFERENT: %s' % [k for k in a if a[k] != b.get(k)], ['%.6f' % x for x in a['losses'][-2:]]))
+    digest = zlib.crc32(repr(sorted((k, v) for k, v in a.items())).encode())
+    print('%-28s %s   losses %s   digest %08x' % (name, 'bit-identical' if same else 'DIFFERENT: %s' % [k for k in a if a[k] != b.get(k)],
+                                                   ['%.6f' % x for x in a['losses'][-2:]], digest))

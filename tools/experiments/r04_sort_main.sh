@@ -1,3 +1,4 @@
+# (for the record: the code path this measured -- SERT_SORT_MAIN -- was reverted after the measurement, profiles/r04_experiments.txt item 16)
 # C4 (side-heavy schedule): the counting sort of the entity chain on the main stream in front of the fork (default) against
 # on the side stream (variants build, SERT_SORT_MAIN=0); also the product-search settings (sorted chain, not side-heavy)
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R

@@ -807,7 +807,7 @@ inline void launch_gemm(hipStream_t s, const float* A, const float* B, float* C,
     if (splits <= 1) { splits = 1; kper = K; }
     if (mapped) *mapped = false;
     if constexpr (TA && !TB && EPI == EPI_STORE) {
-        if (!rowmap && (splits == 1 || kper % 16 == 0) && gemm_x3_enabled() && x3_shape_ok(true, false, A, B, M, N, K, lda, ldb)) {
+        if (!rowmap && (splits == 1 || kper % 16 == 0) && gemm_x3_enabled() && x3_shape_ok(true, false, A, B, M, N, K, lda, ldb, splits)) {
             launch_gemm_x3_ta<CSB>(s, A, B, C, M, N, K, lda, ldb, ldc, splits, kper, splits > 1 ? c_split_stride : 0);
             return;
         }

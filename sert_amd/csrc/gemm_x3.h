@@ -67,7 +67,7 @@ struct X3Args {
 //  the split-K kernel)
 __device__ __forceinline__ int x3_off(int row, int half) { return row * 32 + ((half ^ (((row >> 2) ^ (row >> 3)) & 1)) << 4); }
 
-template <bool TA, bool TB, int EPI, bool CSB, int WAVES_M, int WAVES_N, int WMB, int WNB>
+template <bool TA, bool TB, int EPI, bool CSB, int WAVES_M, int WAVES_N, int WMB, int WNB, bool VEC = true>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N <= 4 ? 2 : 1)) void gemm_x3(const X3Args g) {
     constexpr int THREADS = 64 * WAVES_M * WAVES_N;
     constexpr int TM = 32 * WMB * WAVES_M, TN = 32 * WNB * WAVES_N;
@@ -161,14 +161,28 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N <= 4 ? 2
 #pragma unroll
         for (int s = 0; s < 3; ++s) *reinterpret_cast<uint2*>(img + s * plane_bytes + off) = pl[s];
     };
+    // One k-contiguous piece of four.  VEC: a 16-byte load from a clamped (always valid) address, zeroed at the store.
+    // !VEC (a leading dimension or K that is no multiple of four -- the loglinear model over 715 experts): four dword
+    // buffer loads, an element outside the tile's rows or beyond kend gets bit 31 of its offset set, which is out of the
+    // descriptor's range and loads zero -- arithmetic, no condition around a load.
+    auto load_piece = [&](const float* base, bool row_ok, unsigned row_off, int k) -> float4 {
+        if (VEC) return tile_load16(base, (row_ok && k < kend) ? row_off + (unsigned)k : 0u);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);
+        float e[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned bad = (unsigned)(!(row_ok && k + j < kend)) << 31;
+            e[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(((row_off + (unsigned)(k + j)) * 4u) | bad), 0, 0));
+        }
+        return make_float4(e[0], e[1], e[2], e[3]);
+    };
     auto gload_a = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < A_PIECES; ++i) {
             const int p = tid + THREADS * i;
             if (!A_RC) {
                 const int row = p >> 2, q = p & 3;
-                const bool ok = row < TM && m0 + row < g.M && k0 + 4 * q < kend;
-                ra4[i] = tile_load16(g.A, ok ? (unsigned)(m0 + row) * (unsigned)g.lda + (unsigned)(k0 + 4 * q) : 0u);
+                ra4[i] = load_piece(g.A, row < TM && m0 + row < g.M, (unsigned)(m0 + row) * (unsigned)g.lda, k0 + 4 * q);
             } else {
                 const int row = p % TM, h = p / TM;
                 load8(g.A, g.lda, k0 + 8 * h, m0 + row, ra8[i]);
@@ -194,8 +208,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N <= 4 ? 2
 #pragma unroll
         for (int i = 0; i < B_PIECES; ++i) {
             const int p = tid + THREADS * i, row = p >> 2, q = p & 3;
-            const bool ok = row < TN && n0 + row < g.N && k0 + 4 * q < kend;
-            rb4[i] = tile_load16(g.B, ok ? (unsigned)(n0 + row) * (unsigned)g.ldb + (unsigned)(k0 + 4 * q) : 0u);
+            rb4[i] = load_piece(g.B, row < TN && n0 + row < g.N, (unsigned)(n0 + row) * (unsigned)g.ldb, k0 + 4 * q);
         }
     };
     auto lstore_b4 = [&](int buf, int k0, int i) {
@@ -357,6 +370,19 @@ template <bool TB, int EPI, int WAVES>
 __global__ void gemm_x3_bres(const X3Args g);
 #endif
 
+// the tile shape a product of this size takes: 0 = 128 x 128 tiles over M and N; else the row-tile height of the big forms
+inline int x3_tile_cols(int N) { return N <= 128 ? 128 : (N <= 256 || (N > 320 && cdiv(N, 256) * 256 <= cdiv(N, 320) * 320)) ? 256 : 320; }
+inline bool x3_big_size(int M, int N, int K, int splits) {
+    const int tm = N <= 128 ? 128 : 256, tn = x3_tile_cols(N);
+    // at least 128 row tiles (below that too few workgroups carry the launch -- 16384 x 300 x 300: 65 us against 41) -- or,
+    // for K >= 256, a tile for every CU from a wide N (the loglinear logits at 100 000 entities: 2 300 x 100 000 x 300) or
+    // from the k ranges of a long K cut into partial slabs (the loglinear dG over 100 000 entities)
+    return M >= 128 * tm || (K >= 256 && M >= 1024 && (long long)cdiv(M, tm) * cdiv(N, tn) * splits >= 256);
+}
+inline bool x3_mid_size(int M, int N, int K, int splits) {
+    return K >= 256 && M >= 1024 && (long long)cdiv(M, 128) * cdiv(N, 128) * splits >= 96;
+}
+
 // Does the shape go to this kernel?  (every 16-byte piece aligned and wholly inside or outside; offsets below 2^31 bytes)
 inline bool x3_shape_ok(bool ta, bool tb, const float* A, const float* B, int M, int N, int K, int lda, int ldb, int splits) {
     if (ta) {
@@ -364,18 +390,16 @@ inline bool x3_shape_ok(bool ta, bool tb, const float* A, const float* B, int M,
         // dR_e = Z^T.dp) -- or over a shorter K when the output alone has tiles for every CU (the loglinear dW at 100 000
         // entities: 300 x 100 000 over the batch's ~2 300 distinct words)
         const long long tiles = (M > 128 && M <= 320) ? cdiv(N, 160) : (long long)cdiv(M, 128) * cdiv(N, 128);
-        return !tb && M <= 4096 && N <= (1 << 20) && (K >= 4096 || (K >= 1024 && tiles >= 256)) &&
+        return !tb && M <= 4096 && N <= (1 << 20) && (K >= 4096 || (K >= 1024 && tiles * splits >= 128)) &&
                (size_t)K * std::max(lda, ldb) < ((size_t)1 << 29);
     }
-    const bool a_ok = lda % 4 == 0 && K % 4 == 0 && ((uintptr_t)A) % 16 == 0 && (size_t)M * lda < ((size_t)1 << 29);
-    const bool b_ok = tb ? (ldb % 4 == 0 && ((uintptr_t)B) % 16 == 0 && (size_t)N * ldb < ((size_t)1 << 29))
-                         : (size_t)K * ldb < ((size_t)1 << 29);
-    const int tm = N <= 128 ? 128 : 256, tn = N <= 128 ? 128 : (N <= 256 || (N > 320 && cdiv(N, 256) * 256 <= cdiv(N, 320) * 320)) ? 256 : 320;
-    // at least 128 row tiles (below that too few workgroups carry the launch -- 16384 x 300 x 300: 65 us against 41) -- or,
-    // for K >= 256, a tile for every CU from a wide N (the loglinear logits at 100 000 entities: 2 300 x 100 000 x 300)
-    // (splits > 1: a long K cut into k ranges with partial slabs -- the loglinear dG over 100 000 entities)
-    const bool enough = M >= 128 * tm || (K >= 256 && M >= 1024 && (long long)cdiv(M, tm) * cdiv(N, tn) * splits >= 256);
-    return a_ok && b_ok && N <= (1 << 20) && (K <= 4096 || splits > 1) && enough;
+    const bool a_vec = lda % 4 == 0 && K % 4 == 0 && ((uintptr_t)A) % 16 == 0;
+    const bool b_vec = !tb || (ldb % 4 == 0 && ((uintptr_t)B) % 16 == 0);
+    const bool in_range = (size_t)M * lda < ((size_t)1 << 29) && (tb ? (size_t)N * ldb : (size_t)K * ldb) < ((size_t)1 << 29);
+    const bool big = a_vec && b_vec && x3_big_size(M, N, K, splits);
+    // ... or, in 128 x 128 tiles, a mid-size product with 96 tiles x k ranges or more (the loglinear GEMMs of a
+    // batch of 1024 over a few hundred experts; any alignment: x3_mid_size)
+    return in_range && N <= (1 << 20) && (K <= 4096 || splits > 1) && (big || x3_mid_size(M, N, K, splits));
 }
 
 template <bool TB, int EPI>
@@ -394,10 +418,13 @@ inline void launch_gemm_x3(hipStream_t s, const float* A, const float* B, float*
         return;
     }
 #endif
-    if (N <= 128) {
-        g.tiles_m = cdiv(M, 128); g.tiles_n = 1;
-        SERT_LAUNCH((gemm_x3<false, TB, EPI, false, 2, 2, 2, 2>), dim3(g.tiles_m * g.splits), dim3(256), 0, s, g);
-    } else if (N <= 256 || (N > 320 && cdiv(N, 256) * 256 <= cdiv(N, 320) * 320)) {
+    const bool vec = lda % 4 == 0 && K % 4 == 0 && ((uintptr_t)A) % 16 == 0 && (!TB || (ldb % 4 == 0 && ((uintptr_t)B) % 16 == 0));
+    const bool big = vec && x3_big_size(M, N, K, g.splits);
+    if (N <= 128 || !big) {
+        g.tiles_m = cdiv(M, 128); g.tiles_n = cdiv(N, 128);
+        if (vec) SERT_LAUNCH((gemm_x3<false, TB, EPI, false, 2, 2, 2, 2>), dim3(g.tiles_m * g.tiles_n * g.splits), dim3(256), 0, s, g);
+        else     SERT_LAUNCH((gemm_x3<false, TB, EPI, false, 2, 2, 2, 2, false>), dim3(g.tiles_m * g.tiles_n * g.splits), dim3(256), 0, s, g);
+    } else if (x3_tile_cols(N) == 256) {
         g.tiles_m = cdiv(M, 256); g.tiles_n = cdiv(N, 256);
         SERT_LAUNCH((gemm_x3<false, TB, EPI, false, 4, 2, 2, 4>), dim3(g.tiles_m * g.tiles_n * g.splits), dim3(512), 0, s, g);
     } else {

@@ -45,6 +45,9 @@ def _ref(A, B, ta, tb, epi, bias):
     (33000, 1000, 128, 0, 1, 0), (32768, 700, 36, 0, 0, 2),
     # few rows, a wide N, K >= 256: a tile for every CU from the columns (the loglinear logits over 100 000 entities)
     (2304, 20000, 300, 0, 0, 1), (1100, 30000, 256, 0, 1, 0), (1030, 80000, 260, 0, 0, 0),
+    # mid-size products in 128 x 128 tiles, any alignment (the loglinear model of a batch of 1024 over 715 experts: N and the
+    # leading dimensions no multiple of four, K = 715 with a partial last piece and a partial last step)
+    (3500, 715, 300, 0, 0, 1), (3500, 300, 715, 0, 1, 0), (4099, 513, 301, 0, 0, 2), (2050, 1001, 263, 0, 1, 1), (3000, 716, 300, 0, 0, 0),
 ])
 def test_gemm_dispatch_against_float64(hip_lib, M, N, K, ta, tb, epi):
     rng = np.random.RandomState(M + 3 * N + 7 * K + ta + 2 * tb)
@@ -66,6 +69,8 @@ def test_gemm_dispatch_against_float64(hip_lib, M, N, K, ta, tb, epi):
     (128, 1000, 20000, 20), (1000, 128, 16384, 16), (400, 128, 8192, 32), (130, 260, 4096 + 48, 3),
     # a shorter K with an output wide enough to fill the machine by itself (the loglinear dW over 100 000 entities): one k range
     (300, 41000, 1040, 1), (100, 33000, 1536, 2), (257, 36000, 1100, 1),
+    # ... or k ranges enough (the loglinear dW of a batch of 1024: 300 x 715 over ~3 500 distinct words in 57 ranges)
+    (300, 715, 3500, 57), (128, 715, 2000, 40),
     # outside gemm_x3.h's split-K shapes (K < 4096): the fp32 MFMA kernels
     (128, 128, 2048, 16), (400, 128, 2048, 8),
 ])
@@ -110,6 +115,8 @@ def test_non_finite_operands_stay_confined_to_their_rows_and_columns(hip_lib, tb
 
 @pytest.mark.parametrize('M,N,K,splits,tb', [
     (2304, 300, 100000, 64, 1), (2304, 300, 50000 + 24, 37, 0), (1100, 128, 65536, 128, 1),
+    # a medium K in a few ranges, unaligned (the loglinear dG over 715 experts)
+    (3500, 300, 715, 5, 1), (3500, 300, 715, 5, 0),
     # too few tiles x ranges for gemm_x3.h: the fp32 MFMA kernels
     (512, 128, 8192, 8, 1),
 ])

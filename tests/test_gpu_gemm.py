@@ -130,3 +130,24 @@ def test_long_k_in_ranges_against_float64(hip_lib, M, N, K, splits, tb):
     ref = A.astype(np.float64) @ (B.astype(np.float64).T if tb else B.astype(np.float64))
     assert np.all(np.isfinite(got))
     assert np.abs(got - ref).max() < 2e-6 * max(1.0, np.sqrt(K / splits / 128.0), np.sqrt(K / 128.0) / 8)
+
+
+def test_dispatch_on_seeded_random_shapes(hip_lib):
+    """Thirty seeded shapes around the dispatch thresholds of gemm_x3.h (row counts about 1024 and 128 tiles, column counts
+    about 128 / 256 / 320 and not multiples of four, K about 256 and odd): whichever kernel takes a shape, the result
+    is the float64 product to the fp32 accumulation bound."""
+    rng = np.random.RandomState(2024)
+    for case in range(30):
+        tb = int(rng.randint(2))
+        epi = int(rng.randint(3)) if not tb else int(rng.choice([0, 1]))
+        M = int(rng.choice([1000, 1024, 1500, 3000, 4096, 9000, 16384, 16500, 33000]) + rng.randint(0, 40))
+        N = int(rng.choice([7, 100, 127, 128, 129, 200, 256, 257, 300, 320, 321, 715, 1000]))
+        K = int(rng.choice([16, 36, 100, 255, 256, 257, 300, 301, 512, 715]))
+        A = rng.uniform(-1, 1, (M, K)).astype(np.float32)
+        B = (rng.uniform(-1, 1, (N, K) if tb else (K, N)) / np.sqrt(K)).astype(np.float32)
+        bias = rng.uniform(-0.5, 0.5, N).astype(np.float32) if epi else None
+        got = C.debug_gemm(A, B, ta=0, tb=tb, epi=epi, bias=bias)
+        ref = _ref(A, B, 0, tb, epi, bias)
+        assert np.all(np.isfinite(got)), (case, M, N, K, tb, epi)
+        err = np.abs(got - ref).max()
+        assert err < (2e-6 if epi != 2 else 3e-6) * max(1.0, np.sqrt(K / 128.0)), (case, M, N, K, tb, epi, err)

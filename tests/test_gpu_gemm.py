@@ -151,3 +151,31 @@ def test_dispatch_on_seeded_random_shapes(hip_lib):
         assert np.all(np.isfinite(got)), (case, M, N, K, tb, epi)
         err = np.abs(got - ref).max()
         assert err < (2e-6 if epi != 2 else 3e-6) * max(1.0, np.sqrt(K / 128.0)), (case, M, N, K, tb, epi, err)
+
+
+def test_k_range_forms_on_seeded_random_shapes(hip_lib):
+    """Sixteen seeded shapes of A^T.B (+ column sums) in k ranges and eight of A.op(B) in k ranges, around the thresholds
+    of the split-K forms of gemm_x3.h (128 / 320 rows, 160-column tiles, K about 1024 and 4096, ragged last ranges)."""
+    rng = np.random.RandomState(77)
+    for case in range(16):
+        M = int(rng.choice([36, 128, 129, 300, 320, 321, 400]))
+        N = int(rng.choice([36, 128, 160, 161, 300, 715, 1000]))
+        K = int(rng.choice([1000, 1024, 2033, 4095, 4096, 9000]) + rng.randint(0, 17))
+        splits = int(rng.choice([1, 2, 7, 16, 43]))
+        A = rng.uniform(-1, 1, (K, M)).astype(np.float32)
+        B = (rng.uniform(-1, 1, (K, N)) / np.sqrt(K)).astype(np.float32)
+        got, colsum = C.debug_gemm_splitk(A, B, splits)
+        tol = 2e-6 * max(1.0, np.sqrt(K / splits / 128.0), np.sqrt(K / 128.0) / 8)
+        assert np.abs(got - A.astype(np.float64).T @ B.astype(np.float64)).max() < tol, (case, M, N, K, splits)
+        assert np.abs(colsum - B.astype(np.float64).sum(axis=0)).max() < tol, (case, M, N, K, splits)
+    for case in range(8):
+        tb = int(rng.randint(2))
+        M = int(rng.choice([1024, 2300, 3500]) + rng.randint(0, 9))
+        N = int(rng.choice([128, 300, 301]))
+        K = int(rng.choice([715, 4096, 20000]) + rng.randint(0, 5))
+        splits = int(rng.choice([3, 5, 19]))
+        A = rng.uniform(-1, 1, (M, K)).astype(np.float32)
+        B = (rng.uniform(-1, 1, (N, K) if tb else (K, N)) / np.sqrt(K)).astype(np.float32)
+        got = C.debug_gemm_longk(A, B, splits, tb=tb)
+        ref = A.astype(np.float64) @ (B.astype(np.float64).T if tb else B.astype(np.float64))
+        assert np.abs(got - ref).max() < 2e-6 * max(1.0, np.sqrt(K / splits / 128.0), np.sqrt(K / 128.0) / 8), (case, M, N, K, splits, tb)

@@ -86,7 +86,7 @@ def x3_applies(M, N, K, ta=False):
     tm = 128 if N <= 128 else 256
     tn = 128 if N <= 128 else (256 if (N <= 256 or (N > 320 and cdiv(N, 256) * 256 <= cdiv(N, 320) * 320)) else 320)
     big = K % 4 == 0 and (M >= 128 * tm or (K >= 256 and M >= 1024 and cdiv(M, tm) * cdiv(N, tn) >= 256))
-    mid = K >= 256 and M >= 1024 and cdiv(M, 128) * cdiv(N, 128) >= 96
+    mid = K >= 256 and M >= 1024 and cdiv(M, 128) * cdiv(N, 128) >= (160 if (K % 4 == 0 and N % 4 == 0) else 96)
     return N <= (1 << 20) and K <= 4096 and (big or mid)
 
 

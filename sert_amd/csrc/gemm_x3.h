@@ -379,8 +379,10 @@ inline bool x3_big_size(int M, int N, int K, int splits) {
     // from the k ranges of a long K cut into partial slabs (the loglinear dG over 100 000 entities)
     return M >= 128 * tm || (K >= 256 && M >= 1024 && (long long)cdiv(M, tm) * cdiv(N, tn) * splits >= 256);
 }
-inline bool x3_mid_size(int M, int N, int K, int splits) {
-    return K >= 256 && M >= 1024 && (long long)cdiv(M, 128) * cdiv(N, 128) * splits >= 96;
+// (aligned: 160 tiles x k ranges or more -- 8192 x 300 x 300: 22 us against 26, 4096 x 300 x 300 with 96: 20 against 18 --;
+//  unaligned: 96, the fp32 kernels then run their scalar-loader variants -- 2033 x 715 x 300: 19 us against 26)
+inline bool x3_mid_size(int M, int N, int K, int splits, bool vec) {
+    return K >= 256 && M >= 1024 && (long long)cdiv(M, 128) * cdiv(N, 128) * splits >= (vec ? 160 : 96);
 }
 
 // Does the shape go to this kernel?  (every 16-byte piece aligned and wholly inside or outside; offsets below 2^31 bytes)
@@ -397,9 +399,9 @@ inline bool x3_shape_ok(bool ta, bool tb, const float* A, const float* B, int M,
     const bool b_vec = !tb || (ldb % 4 == 0 && ((uintptr_t)B) % 16 == 0);
     const bool in_range = (size_t)M * lda < ((size_t)1 << 29) && (tb ? (size_t)N * ldb : (size_t)K * ldb) < ((size_t)1 << 29);
     const bool big = a_vec && b_vec && x3_big_size(M, N, K, splits);
-    // ... or, in 128 x 128 tiles, a mid-size product with 96 tiles x k ranges or more (the loglinear GEMMs of a
+    // ... or, in 128 x 128 tiles, a mid-size product with enough tiles x k ranges (the loglinear GEMMs of a
     // batch of 1024 over a few hundred experts; any alignment: x3_mid_size)
-    return in_range && N <= (1 << 20) && (K <= 4096 || splits > 1) && (big || x3_mid_size(M, N, K, splits));
+    return in_range && N <= (1 << 20) && (K <= 4096 || splits > 1) && (big || x3_mid_size(M, N, K, splits, a_vec && b_vec));
 }
 
 template <bool TB, int EPI>

@@ -67,12 +67,14 @@ def lazy_fractions(X, B, num_batches, Vw, dw):
     that neither the batch nor the announced next one touches is read (p and both moments: its share of sum(p^2)) but not
     written, except every 4th update.  Returns None where the dense launch runs, else the fractions of rows touched /
     written per step for the cyclic batch order of the timed loop -- what the launch really moves."""
-    sets = [np.unique(X[j * B:(j + 1) * B]) for j in range(num_batches)]
+    nb = min(num_batches, 8)          # (a sample of the batches: the fractions vary by < 1 % between batches of one stream)
+    sets = [np.unique(X[j * B:(j + 1) * B]) for j in range(nb)]
     f_t = float(np.mean([len(u) for u in sets])) / Vw
     if f_t > LAZY_MAX_TOUCHED or Vw * dw < (1 << 22):
-        return None
-    f_u = float(np.mean([len(np.union1d(sets[j], sets[(j + 1) % num_batches])) for j in range(num_batches)])) / Vw
-    return {'touched': f_t, 'written': f_u + (1.0 - f_u) / LAZY_K}
+        # the dense launch (adam_l2 with the row filter): p, m, v read and written for every row, g read for touched rows only
+        return {'lazy': False, 'touched': f_t}
+    f_u = float(np.mean([len(np.union1d(sets[j], sets[(j + 1) % nb])) for j in range(nb)])) / Vw
+    return {'lazy': True, 'touched': f_t, 'written': f_u + (1.0 - f_u) / LAZY_K}
 
 
 def x3_applies(M, N, K, ta=False):
@@ -118,8 +120,13 @@ def group_work(kind, B, n, s, dw, de, Ve, Vw, z, distinct_words=None, shards=1, 
     # lazy launch (single GPU, sparse batches): 12 B read per element, 12 B written and 4 B of gradient read only for the
     # rows that are materialised / touched -- the bytes THIS launch's algorithm moves (the reference's dense update: 32 B)
     lazy_note = None
-    if lazy is not None and shards == 1:
+    if lazy is not None and shards == 1 and lazy.get('lazy'):
         lazy_note = dict(lazy, reference_dense_bytes=P_w, bytes_per_element=12.0 + 12.0 * lazy['written'] + 4.0 * lazy['touched'])
+        P_w = Vw * dw * lazy_note['bytes_per_element']
+    elif lazy is not None and shards == 1:
+        # dense launch: 12 B read + 12 B written per element, 4 B of gradient for the rows the batch touches (the others have
+        # g = 0: neither zero-filled nor read) -- what THIS kernel's algorithm moves; SURVEY 8(d)'s 32 B is the reference's
+        lazy_note = dict(lazy, reference_dense_bytes=P_w, bytes_per_element=24.0 + 4.0 * lazy['touched'])
         P_w = Vw * dw * lazy_note['bytes_per_element']
     if kind in ('vectorspace', 'vectorspace_softmax'):
         w = {
@@ -405,7 +412,11 @@ def kernel_table(timings, work, traffic=None):
             ach = wk['alg'] / t / 1e9
             rec = dict(us=round(us, 2), bound='hbm', achieved=round(ach, 1), unit='GB/s', frac=round(ach / HBM_PEAK_GBS, 4),
                        algorithmic_bytes=wk['alg'])
-            if wk.get('lazy'):
+            if wk.get('lazy') and not wk['lazy'].get('lazy'):
+                rec['dense_update'] = dict(wk['lazy'], note='algorithmic_bytes = 24 B per element + 4 B of gradient per element of a touched '
+                                           'row (what adam_l2 with the row filter moves); reference_dense_bytes = the 32 B per parameter '
+                                           'of SURVEY 8(d) (zero-fill + dense g read included)')
+            elif wk.get('lazy'):
                 rec['lazy_update'] = dict(wk['lazy'], note='lazy dense update: rows neither this nor the next batch touches are read, '
                                           'not written (every 4th update writes all); algorithmic_bytes = what this launch moves, '
                                           'reference_dense_bytes = 32 B per parameter of the reference\'s dense update')
@@ -928,6 +939,129 @@ def c4_record(models, _capi, dist, steps, live_pmc):
     return rec
 
 
+# ---- the ONE stdout line ------------------------------------------------------------------
+LINE_LIMIT = 8000     # bytes: the driver keeps an 8 kB tail of stdout and parses the line out of it
+
+
+def _r(x, nd=4):
+    """Round floats for the line (6 significant digits at most carry information here)."""
+    if isinstance(x, float):
+        return float('%.*g' % (max(nd, 6), x))
+    return x
+
+
+def _short_roofline(r):
+    """The dominant kernel only: the contract's keys + the counter-priced fraction."""
+    if not r:
+        return None
+    keep = ('kernel', 'hip_kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'frac_counter', 'frac_algorithmic',
+            'achieved_algorithmic', 'traffic', 'avg_us', 'avg_us_profiled', 'traffic_over_algorithmic', 'frac_of_achievable',
+            'achievable_peak', 'frac_is')
+    return {k: _r(r[k]) for k in keep if r.get(k) is not None or k == 'traffic'}
+
+
+def _short_sub(rec, extra=()):
+    """A sub-record in the line: value / ms_per_step / the dominant kernel's name and fractions."""
+    if not rec:
+        return None
+    out = {k: _r(rec[k]) for k in ('value', 'unit', 'ms_per_step', 'ms_total') + tuple(extra) if rec.get(k) is not None}
+    roof = rec.get('roofline')
+    if roof:
+        out['roofline'] = {k: _r(roof[k]) for k in ('hip_kernel', 'bound', 'frac', 'frac_counter', 'avg_us', 'traffic_over_algorithmic')
+                           if roof.get(k) is not None}
+    return out
+
+
+def compact_record(full, sidecar=None):
+    """The record bench.py prints: headline + `roofline` (dominant kernel) + `cpu_baseline` + one short entry per
+    sub-record.  Per-kernel tables, ceilings and notes stay in the full record (`sidecar` names the file it went to).
+    Always < LINE_LIMIT bytes as JSON: the optional entries are dropped from the back until it is."""
+    head = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+            'dtype', 'data')
+    out = {k: _r(full.get(k)) for k in head}
+    cfg = full.get('config') or {}
+    out['config'] = {k: cfg[k] for k in ('workload', 'global_batch', 'per_gpu_batch', 'parallelism', 'id_dtype', 'lambda', 'seed',
+                                          'instance_weights', 'dataset_instances', 'dataset_batches', 'upload_index_s', 'gemm')
+                     if k in cfg}
+    out['roofline'] = _short_roofline(full.get('roofline'))
+    cb = full.get('cpu_baseline')
+    if cb:
+        out['cpu_baseline'] = {k: _r(cb[k]) for k in ('value', 'unit', 'cores', 'kind', 'ms_per_step', 'host_cores', 'cgroup_cpu_quota')
+                               if cb.get(k) is not None}
+        out['cpu_baseline']['sample'] = (cb.get('sample_short') or cb.get('sample') or '')[:400]
+        st = cb.get('single_thread_numpy')
+        if st:
+            out['cpu_baseline']['single_thread_numpy_value'] = _r(st.get('value'))
+    else:
+        out['cpu_baseline'] = None
+    ws = full.get('whole_step') or {}
+    out['whole_step'] = {k: _r(ws[k]) for k in ('counted_hbm_bytes', 'counted_hbm_GBps', 'frac_of_hbm_peak', 'kernel_us_sum_serial')
+                         if ws.get(k) is not None}
+    for k in ('last_loss', 'ms_per_step_instrumented', 'rccl_ranks', 'comm_bytes_per_step'):
+        if full.get(k) is not None:
+            out[k] = _r(full[k])
+    # both readings of "scaling" at N > 1: the fixed global batch (headline) and the fixed per-GPU batch
+    if full.get('weak_scaling'):
+        out['strong'] = {'value': out['value'], 'ms_per_step': out['ms_per_step'], 'global_batch': cfg.get('global_batch')}
+        out['weak'] = {k: _r(full['weak_scaling'].get(k)) for k in ('value', 'ms_per_step', 'global_batch', 'per_gpu_batch', 'comm_bytes_per_step')}
+    optional = []
+    kern = full.get('kernels') or {}
+    if kern:
+        optional.append(('kernel_us', {k: v['us'] for k, v in sorted(kern.items(), key=lambda kv: -kv[1]['us'])}))
+    if full.get('deferred_loss_readback'):
+        optional.append(('deferred_loss_readback', _short_sub(full['deferred_loss_readback'])))
+    if full.get('gemm_fp32_mfma_path'):
+        optional.append(('gemm_fp32_mfma_path', _short_sub(full['gemm_fp32_mfma_path'])))
+    if full.get('seeds'):
+        sd = full['seeds']
+        optional.append(('seeds', {k: (_r(v['value']) if isinstance(v, dict) else _r(v)) for k, v in sd.items()}))
+    for key in ('small_batch', 'timed_mode_parity'):
+        if full.get(key):
+            optional.append((key, full[key]))
+    for key, extra in (('loglinear', ('distinct_words_per_batch',)), ('lse_full_softmax', ()), ('c4', ())):
+        if full.get(key):
+            optional.append((key, _short_sub(full[key], extra)))
+    if full.get('query'):
+        q = _short_sub(full['query'], ('equiv_gemm_tflops',))
+        for k in ('cpu_baseline', 'cpu_baseline_multithreaded'):
+            c = full['query'].get(k)
+            if c and c.get('value'):
+                q[k] = {'value': _r(c['value']), 'cores': c.get('cores'), 'top10_identical': c.get('top10_identical')}
+        optional.append(('query', q))
+    dev = full.get('device')
+    if dev:
+        optional.append(('device', dev if len(json.dumps(dev)) < 300 else None))
+    if sidecar:
+        out['full_record'] = sidecar
+    for k, v in optional:
+        if v is not None:
+            out[k] = v
+    # never over the limit: drop the optional entries from the back
+    names = [k for k, _ in optional]
+    while len(json.dumps(out)) >= LINE_LIMIT and names:
+        out.pop(names.pop(), None)
+    if len(json.dumps(out)) >= LINE_LIMIT:          # (cannot happen with the keys above; keep the headline whatever it takes)
+        out['cpu_baseline'] = {k: v for k, v in (out.get('cpu_baseline') or {}).items() if k != 'sample'}
+        out['config'] = {'workload': str((out.get('config') or {}).get('workload'))[:300]}
+    return out
+
+
+def write_full_record(full):
+    """The complete record (per-kernel tables, ceilings, notes): a sidecar file + stderr; returns the file's path relative to
+    the repository (None where nothing is writable)."""
+    text = json.dumps(full, indent=1)
+    sys.stderr.write('FULL_RECORD ' + json.dumps(full) + '\n')
+    for rel in (os.path.join('gpurun_out', 'bench_full.json'), os.path.join('profiles', 'bench_full_latest.json')):
+        try:
+            os.makedirs(os.path.join(ROOT, os.path.dirname(rel)), exist_ok=True)
+            with open(os.path.join(ROOT, rel), 'w') as f:
+                f.write(text)
+            return rel
+        except OSError:
+            continue
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -941,7 +1075,7 @@ def main():
     ap.add_argument('--entity-dim', type=int, default=None, help='d_e (default: --dim)')
     ap.add_argument('--window', type=int, default=10)
     ap.add_argument('--negatives', type=int, default=10)
-    ap.add_argument('--num-batches', type=int, default=8)
+    ap.add_argument('--num-batches', type=int, default=64, help='data set = this many batches (SURVEY 8-d: N = 64 B)')
     ap.add_argument('--seed', type=int, default=0, help='seed of the synthetic data set (SURVEY 8-d: seeds 0..2)')
     ap.add_argument('--weights', choices=['ones', 'uniform'], default='ones',
                     help='instance weights: 1 (LSE, --no_instance_weights) or U[0.5, 2] (SURVEY 8-d second run)')
@@ -992,15 +1126,17 @@ def main():
     n, Vw, Ve, d, z = args.window, args.vocab, args.entities, args.dim, args.negatives
     de = args.entity_dim or d
 
-    def dataset(seed, weights, batch=None):
+    def dataset(seed, weights, batch=None, nb=None):
         rng = np.random.RandomState(seed)
-        X_, y_, w_ = synth_data(rng, args.num_batches * (batch or Bg), n, Vw, Ve)
+        X_, y_, w_ = synth_data(rng, (nb or args.num_batches) * (batch or Bg), n, Vw, Ve)
         if weights == 'uniform':
             w_ = rng.uniform(0.5, 2.0, len(w_)).astype(np.float32)
         return X_, y_, w_
 
     X, y, w = dataset(args.seed, args.weights)
+    t_up = time.perf_counter()
     model = build_model(kind, models, Bg, n, Vw, Ve, d, de, z, X, y, w, seed=args.seed)
+    upload_s = time.perf_counter() - t_up      # one-time, outside the timed region: id checks + per-batch inverted index (host) + H2D
 
     if args.profile_inner:     # the workload of the rocprofv3 --pmc passes: the steps and nothing else
         timed_steps(model, dist, args.num_batches, args.steps, args.warmup, timing=False)
@@ -1069,11 +1205,12 @@ def main():
     seed_runs = None
     if N == 1 and not args.no_seed_extra:
         seed_runs = {'seed_%d' % args.seed: {'value': value, 'ms_per_step': 1000.0 * dt / args.steps}}
+        nbs = min(args.num_batches, 8)     # (8 batches each: bounds the bench's wall time; the headline runs the full data set)
         for sd, wt in ((1, 'ones'), (2, 'ones'), (args.seed, 'uniform')):
-            Xs, ys, ws = dataset(sd, wt)
+            Xs, ys, ws = dataset(sd, wt, nb=nbs)
             ms_ = build_model(kind, models, Bg, n, Vw, Ve, d, de, z, Xs, ys, ws, seed=sd)
-            timed_steps(ms_, dist, args.num_batches, args.steps, 2, timing=True)     # (GPU idle during the build: as above)
-            dts, _, _ = timed_steps(ms_, dist, args.num_batches, args.steps, args.warmup, timing=False)
+            timed_steps(ms_, dist, nbs, args.steps, 2, timing=True)     # (GPU idle during the build: as above)
+            dts, _, _ = timed_steps(ms_, dist, nbs, args.steps, args.warmup, timing=False)
             seed_runs['seed_%d%s' % (sd, '_w_uniform_0.5_2' if wt == 'uniform' else '')] = {
                 'value': args.steps * Bg / dts, 'ms_per_step': 1000.0 * dts / args.steps}
             del ms_
@@ -1082,10 +1219,11 @@ def main():
     # rows a batch touches, sub-linearly, so this is the friendlier case; it is NOT BASELINE configs[2])
     weak = None
     if N > 1 and not args.no_weak_extra:
-        Xw, yw, ww = dataset(args.seed, args.weights, Bg * N)
+        nbw = min(args.num_batches, 8)
+        Xw, yw, ww = dataset(args.seed, args.weights, Bg * N, nb=nbw)
         ms = build_model(kind, models, Bg * N, n, Vw, Ve, d, de, z, Xw, yw, ww, seed=args.seed)
-        timed_steps(ms, dist, args.num_batches, args.steps, 2, timing=True)
-        dts, _, _ = timed_steps(ms, dist, args.num_batches, args.steps, args.warmup, timing=False)
+        timed_steps(ms, dist, nbw, args.steps, 2, timing=True)
+        dts, _, _ = timed_steps(ms, dist, nbw, args.steps, args.warmup, timing=False)
         cw = getattr(ms, 'comm_info', lambda: None)() or {}
         weak = {'value': args.steps * Bg * N / dts, 'unit': 'pairs/s', 'ms_per_step': 1000.0 * dts / args.steps,
                 'scaling': 'weak', 'global_batch': Bg * N, 'per_gpu_batch': Bg,
@@ -1101,7 +1239,7 @@ def main():
         per_kernel, traffic_source = (None, None)
         if N == 1 and live:
             inner = ['--model', kind, '--batch', Bl, '--vocab', Vw, '--entities', Ve, '--dim', d, '--entity-dim', de,
-                     '--window', n, '--negatives', z, '--num-batches', args.num_batches, '--seed', args.seed,
+                     '--window', n, '--negatives', z, '--num-batches', min(args.num_batches, 16), '--seed', args.seed,
                      '--weights', args.weights]
             per_kernel, traffic_source = pmc_traffic_live(inner)
         if per_kernel is None and kind == 'vectorspace' and Bl == 65536 and os.path.exists(os.path.join(ROOT, COMMITTED_PMC)):
@@ -1130,6 +1268,7 @@ def main():
                 'global_batch': Bg, 'per_gpu_batch': Bl,
                 'parallelism': 'dp%d' % N if N == 1 else 'dp%d, %s' % (N, (comm or {}).get('exchange', 'data parallel')),
                 'id_dtype': str(X.dtype), 'lambda': 0.01, 'seed': args.seed,
+                'dataset_instances': int(len(X)), 'dataset_batches': int(len(X) // Bg), 'upload_index_s': round(upload_s, 3),
                 'instance_weights': '1' if args.weights == 'ones' else 'U[0.5, 2]',
                 'gemm_arithmetic': ('fp32 MFMA (SERT_GEMM_FP32=1)' if os.environ.get('SERT_GEMM_FP32', '0') not in ('', '0') else
                                     'fp32 operands, fp32 accumulators, fp32 results; each operand is split exactly into three bf16 '
@@ -1210,7 +1349,9 @@ def main():
 
     if ctx.rank == 0:
         sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + '\n').encode())
+        line = json.dumps(compact_record(out, sidecar=write_full_record(out)))
+        assert len(line) < LINE_LIMIT, len(line)
+        os.write(json_fd, (line + '\n').encode())
     dist.barrier()
     dist.shutdown()
 

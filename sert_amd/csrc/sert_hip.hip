@@ -201,7 +201,7 @@ static void discard_run_ahead(sert_model* m) {
     }
     m->spec_fb_batch = -1;
 }
-static int ensure_rw_current(sert_model* m, int64_t batch);
+static int ensure_rw_current(sert_model* m, int64_t batch, int64_t t_applied = -1);
 static void invalidate_speculation(sert_model* m) {
     discard_run_ahead(m);
     (void)ensure_rw_current(m, -1);   // (whatever comes next -- new parameters, another step counter, new data -- sees every row current)
@@ -233,12 +233,17 @@ static LazyArgs lazy_args(sert_model* m, int64_t t_prev, int update) {
 }
 // Bring every row of R_w (and of its optimiser state) to the model's step -- unless `batch` is the training batch
 // whose rows the last update made current (the announced one: its forward may read them as they are).  Main stream.
-static int ensure_rw_current(sert_model* m, int64_t batch) {
+// t_applied = number of updates a CURRENT row has seen (default: m->step).  Inside optimizer_and_loss the step counter is
+// already the number of the update being applied, so the dense fallback there passes m->step - 1: flushing against the
+// incremented counter gave every row one zero-gradient update too many before the dense launch applied the same update
+// number again (round-4 advisor finding; tests/test_gpu_lazy_dense.py alternates lazy and dense steps).
+static int ensure_rw_current(sert_model* m, int64_t batch, int64_t t_applied) {
     if (!m->rw_stale) return 0;
     if (batch >= 0 && batch == m->rw_ready_batch) return 0;
+    if (t_applied < 0) t_applied = m->step;
     AdamArgs aa; AdadeltaArgs da;
-    optimizer_args(m, std::max<int64_t>(1, m->step), &aa, &da);
-    const LazyArgs lz = lazy_args(m, m->step, /*update=*/0);
+    optimizer_args(m, std::max<int64_t>(1, t_applied), &aa, &da);
+    const LazyArgs lz = lazy_args(m, t_applied, /*update=*/0);
     const int64_t max_nb = m->n_rw >= ((size_t)1 << 24) ? 2 * kOptBlocks : kOptBlocks;
     const int nb = (int)std::min<int64_t>(max_nb, cdiv(cdiv(m->n_rw, 4), 256));
     if (is_vs(m))
@@ -1977,7 +1982,7 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
                 n_sq += nb;
                 continue;
             }
-            if (i == 0) SERT_TRY(ensure_rw_current(m, -1));    // (a dense launch assumes every row is at the previous step)
+            if (i == 0) SERT_TRY(ensure_rw_current(m, -1, m->step - 1));    // (a dense launch assumes every row is at the previous step; m->step is already this update's number)
             // (side_heavy: the entity table streams on the side stream, behind its gradient chain.  Loglinear with dW on the
             //  side stream: a W large enough to be a "big tensor" -- d x V_e >= 2^22, C4 -- is updated THERE, behind dW and
             //  its combine; on the main stream its update read dW's gradient while the side stream was still writing it:

@@ -130,6 +130,13 @@ int64_t sert_get_step(sert_model* m);
 int sert_set_eval_draws(sert_model* m, int64_t n);
 int64_t sert_get_eval_draws(sert_model* m);
 
+/* The (B, z) negatives the device sampler draws for the training step taken when `position` optimiser updates have been
+ * applied (evaluation = 0; position = sert_get_step before the step), or for the `position`-th evaluated batch
+ * (evaluation = 1) -- what RandomStreams.choice (models.py:970-973) hands the reference's graph.  out (B, z) int64.  A pure
+ * function of (seed, position, rank): no state of the model changes, so a caller can replay a device-sampled run with
+ * explicit negatives (sert_train_batch's `negatives`) or feed the same ids to a CPU implementation. */
+int sert_negatives_of_step(sert_model* m, int64_t position, int evaluation, int64_t* out);
+
 /* ---- data set ---------------------------------------------------------- */
 
 /* Replaces theano.shared(x/y/w) of the whole data set (models.py:470-480):

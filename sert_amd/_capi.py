@@ -27,7 +27,7 @@ COMM_ID_BYTES = 128
 EXPORTS = [
     'sert_create', 'sert_destroy', 'sert_last_error', 'sert_device_info', 'sert_device_count',
     'sert_set_tensor', 'sert_get_tensor', 'sert_tensor_size', 'sert_set_step', 'sert_get_step',
-    'sert_set_eval_draws', 'sert_get_eval_draws',
+    'sert_set_eval_draws', 'sert_get_eval_draws', 'sert_negatives_of_step',
     'sert_upload_dataset', 'sert_train_batch', 'sert_hint_next_batch', 'sert_train_batches',
     'sert_eval_batch', 'sert_eval_batches',
     'sert_predict_project', 'sert_predict_tokens', 'sert_score_topk',
@@ -107,6 +107,7 @@ def load():
     lib.sert_set_eval_draws.argtypes = [vp, i64]
     lib.sert_get_eval_draws.argtypes = [vp]
     lib.sert_get_eval_draws.restype = i64
+    lib.sert_negatives_of_step.argtypes = [vp, i64, ctypes.c_int, vp]
     lib.sert_upload_dataset.argtypes = [vp, ctypes.c_int, fp, fp, fp, fp, fp, fp, i64]
     lib.sert_train_batch.argtypes = [vp, i64, fp, ctypes.POINTER(ctypes.c_float)]
     lib.sert_train_batches.argtypes = [vp, fp, i64, fp]
@@ -229,6 +230,13 @@ class Engine(object):
 
     def get_eval_draws(self):
         return int(self._lib.sert_get_eval_draws(self._h))
+
+    def negatives_of_step(self, position, evaluation=False):
+        """(B, z) int64: the negatives the device sampler draws at training position `position` (= get_step() before the
+        step) or for the `position`-th evaluated batch."""
+        out = np.empty((self.cfg.batch_size, self.cfg.num_negatives), dtype=np.int64)
+        check(self._lib.sert_negatives_of_step(self._h, int(position), int(bool(evaluation)), out.ctypes.data))
+        return out
 
     # data
     def upload_dataset(self, split, x, y_int=None, csr=None, w=None):

@@ -2854,6 +2854,29 @@ int sert_set_eval_draws(sert_model* m, int64_t n) {
 }
 int64_t sert_get_eval_draws(sert_model* m) { return m ? m->eval_draws : -1; }
 
+int sert_negatives_of_step(sert_model* m, int64_t position, int evaluation, int64_t* out) {
+    if (!m || !out || position < 0) SERT_FAIL("bad argument");
+    if (!is_vs(m) || is_fs(m) || m->cfg.num_negatives <= 0) SERT_FAIL("this model draws no negatives");
+    SERT_HIP(hipSetDevice(m->cfg.device));
+    const int64_t count = (int64_t)m->cfg.batch_size * m->cfg.num_negatives;
+    int32_t* tmp = nullptr;
+    SERT_HIP(hipMalloc((void**)&tmp, (size_t)count * sizeof(int32_t)));
+    // a stream of its own: nothing of the model's state or schedule is touched
+    hipStream_t st = nullptr;
+    if (hipStreamCreate(&st) != hipSuccess) { (void)hipFree(tmp); SERT_FAIL("hipStreamCreate failed"); }
+    hipLaunchKernelGGL(vs_sample_negatives, dim3(grid_for((count + 3) / 4)), dim3(256), 0, st, tmp, count,
+                       (int64_t)m->rank * count, (uint32_t)m->cfg.num_entities, m->cfg.seed,
+                       (uint64_t)position * 2 + (evaluation ? 1 : 0), (float4*)nullptr, (size_t)0, (uint4*)nullptr, (size_t)0);
+    std::vector<int32_t> host((size_t)count);
+    const hipError_t e = hipMemcpyAsync(host.data(), tmp, (size_t)count * sizeof(int32_t), hipMemcpyDeviceToHost, st);
+    const hipError_t e2 = hipStreamSynchronize(st);
+    (void)hipStreamDestroy(st);
+    (void)hipFree(tmp);
+    if (e != hipSuccess || e2 != hipSuccess) SERT_FAIL("reading the negatives back failed");
+    for (int64_t i = 0; i < count; ++i) out[i] = host[(size_t)i];
+    return 0;
+}
+
 int sert_upload_dataset(sert_model* m, int split, const void* x, const int32_t* y_int,
                         const int64_t* csr_indptr, const int32_t* csr_indices,
                         const float* csr_data, const float* w, int64_t N) {

@@ -84,7 +84,7 @@ def x3_applies(M, N, K, ta=False):
     cdiv = lambda a, b: -(-a // b)
     if ta:
         tiles = cdiv(N, 160) if 128 < M <= 320 else cdiv(M, 128) * cdiv(N, 128)
-        return M <= 4096 and N <= (1 << 20) and (K >= 4096 or (K >= 1024 and tiles >= 128))
+        return M <= 4096 and N <= (1 << 20) and (K >= 4096 or (K >= 1024 and tiles >= 128))   # (the step's own launches are split: tiles x splits >= 16)
     tm = 128 if N <= 128 else 256
     tn = 128 if N <= 128 else (256 if (N <= 256 or (N > 320 and cdiv(N, 256) * 256 <= cdiv(N, 320) * 320)) else 320)
     big = K % 4 == 0 and (M >= 128 * tm or (K >= 256 and M >= 1024 and cdiv(M, tm) * cdiv(N, tn) >= 256))

@@ -15,6 +15,9 @@ def _stale():
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in SOURCES]
     deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]   # (every header of csrc/)
+    vdir = os.path.join(CSRC, 'variants')                                             # (... and of csrc/variants/)
+    if os.path.isdir(vdir):
+        deps += [os.path.join(vdir, f) for f in os.listdir(vdir) if f.endswith('.h')]
     deps.append(os.path.join(INCLUDE, 'sert_hip.h'))
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 

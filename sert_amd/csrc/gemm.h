@@ -790,10 +790,17 @@ template <bool CSB>
 inline void launch_gemm_x3_ta(hipStream_t s, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb,
                               int ldc, int splits, int kper, size_t c_split_stride);
 // SERT_GEMM_FP32=1: every contraction on the fp32 MFMA kernels of this file (cross-check)
-// (read at every launch: a process can run both ways, tests/test_gpu_fullbatch.py)
-inline bool gemm_x3_enabled() {
+// Read ONCE per call into the library (refresh_gemm_choice at the entry points that launch a GEMM: a process can still run
+// both ways, tests/test_gpu_fullbatch.py), never between choosing a split count and launching the kernel it was chosen
+// for -- the two reads of round 4 could pair x3-sized splits with the fp32 kernel if the variable changed in between.
+inline int& gemm_fp32_latch() { static int v = -1; return v; }
+inline void refresh_gemm_choice() {
     const char* e = knob("SERT_GEMM_FP32");
-    return !(e && atoi(e) != 0);
+    gemm_fp32_latch() = (e && atoi(e) != 0) ? 1 : 0;
+}
+inline bool gemm_x3_enabled() {
+    if (gemm_fp32_latch() < 0) refresh_gemm_choice();
+    return gemm_fp32_latch() == 0;
 }
 
 // rowmap / mapped_C / mapped (optional): when the launch goes to the 64x64-tile kernel, row r of the product is

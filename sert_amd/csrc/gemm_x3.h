@@ -314,7 +314,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N <= 4 ? 2
         if (MORE) __syncthreads();
     };
     for (int t = 0; t + 1 < steps; ++t) step(t, std::true_type{});
-    step(steps - 1, std::false_type{});
+    // (an EMPTY k range -- kbeg >= K, a caller's (splits, kper) with more ranges than K holds: steps <= 0 -- reads the image
+    //  the prologue stored, which is all zeros then: the slab receives zeros instead of whatever buffer 1 held)
+    step(steps > 0 ? steps - 1 : 0, std::false_type{});
 
     // ---- epilogue.  C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5): a store instruction
     // writes two 128-byte row segments.  (Computing the blocks transposed, so that a lane holds four consecutive
@@ -392,7 +394,9 @@ inline bool x3_shape_ok(bool ta, bool tb, const float* A, const float* B, int M,
         // dR_e = Z^T.dp) -- or over a shorter K when the output alone has tiles for every CU (the loglinear dW at 100 000
         // entities: 300 x 100 000 over the batch's ~2 300 distinct words)
         const long long tiles = (M > 128 && M <= 320) ? cdiv(N, 160) : (long long)cdiv(M, 128) * cdiv(N, 128);
-        return !tb && M <= 4096 && N <= (1 << 20) && (K >= 4096 || (K >= 1024 && tiles * splits >= 128)) &&
+        // (a long K with hardly any workgroups -- a split count that collapsed to 1 over one or two output tiles -- would
+        //  run the whole contraction on a CU or two: the fp32 kernels' persistent tiling takes those)
+        return !tb && M <= 4096 && N <= (1 << 20) && ((K >= 4096 && tiles * splits >= 16) || (K >= 1024 && tiles * splits >= 128)) &&
                (size_t)K * std::max(lda, ldb) < ((size_t)1 << 29);
     }
     const bool a_vec = lda % 4 == 0 && K % 4 == 0 && ((uintptr_t)A) % 16 == 0;

@@ -1326,8 +1326,9 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         int auto_splits = std::max(1, std::min(std::min(512, cdiv(1024, cdiv(dw, GM) * cdiv(de, GN))), B / 64));
         // the bf16-pipe kernel (gemm_x3.h) runs one workgroup per (k range, 160-column tile; one tile up to 128 x 128): one
         // workgroup per CU -- 256 slabs at C2 (0.2745 -> 0.2697 ms against 512; 128: 0.285), 128 at C4 (1.595 -> 1.579 ms)
-        if (gemm_x3_enabled() && x3_shape_ok(true, false, m->H, m->DA, dw, de, B, dw, de))
-            auto_splits = std::max(1, std::min(256 / ((dw <= 128 && de <= 128) ? 1 : cdiv(de, 160)), B / 64));
+        const int x3_splits = std::max(1, std::min(256 / ((dw <= 128 && de <= 128) ? 1 : cdiv(de, 160)), B / 64));
+        if (gemm_x3_enabled() && x3_shape_ok(true, false, m->H, m->DA, dw, de, B, dw, de, x3_splits))
+            auto_splits = x3_splits;
         const int want_splits = user_splits ? user_splits : auto_splits;
         int splits = std::min(want_splits, cdiv(B, GK));
         int kper = (int)round_up(cdiv(B, splits), GK);
@@ -3051,6 +3052,7 @@ int sert_upload_dataset(sert_model* m, int split, const void* x, const int32_t* 
 }
 
 int sert_train_batch(sert_model* m, int64_t batch_index, const int64_t* negatives, float* loss_out) {
+    refresh_gemm_choice();
     if (!m) SERT_FAIL("null model");
     SERT_HIP(hipSetDevice(m->cfg.device));
     static const bool no_spin = variant_knob("SERT_NO_SPIN") != nullptr;   // cross-check knob
@@ -3124,6 +3126,7 @@ int sert_hint_next_batch(sert_model* m, int64_t next_batch_index) {
 }
 
 int sert_train_batches(sert_model* m, const int64_t* batch_indices, int64_t count, float* losses_out) {
+    refresh_gemm_choice();
     if (!m || !batch_indices || count < 0) SERT_FAIL("bad argument");
     m->hint_next = -1;
     SERT_HIP(hipSetDevice(m->cfg.device));
@@ -3186,6 +3189,7 @@ static int eval_check_args(sert_model* m, int split) {
 }
 
 int sert_eval_batch(sert_model* m, int split, int64_t batch_index, const int64_t* negatives, float* loss_out) {
+    refresh_gemm_choice();
     SERT_TRY(eval_check_args(m, split));
     invalidate_speculation(m);   // evaluation reuses the activation buffers and the negatives
     SERT_HIP(hipSetDevice(m->cfg.device));
@@ -3213,6 +3217,7 @@ int sert_eval_batch(sert_model* m, int split, int64_t batch_index, const int64_t
 }
 
 int sert_eval_batches(sert_model* m, int split, const int64_t* batch_indices, int64_t count, float* losses_out) {
+    refresh_gemm_choice();
     SERT_TRY(eval_check_args(m, split));
     if (!batch_indices || count < 0) SERT_FAIL("bad argument");
     if (count == 0) return 0;
@@ -3261,6 +3266,7 @@ static int pred_reserve(float** buf, size_t* cap, size_t count) {
 }
 
 int sert_predict_project(sert_model* m, const float* avg, int64_t Q, float* out) {
+    refresh_gemm_choice();
     if (!m || !avg || !out) SERT_FAIL("null argument");
     if (!is_vs(m)) SERT_FAIL("sert_predict_project is the vectorspace predict_fn");
     if (Q <= 0) return 0;
@@ -3277,6 +3283,7 @@ int sert_predict_project(sert_model* m, const float* avg, int64_t Q, float* out)
 }
 
 int sert_predict_tokens(sert_model* m, const void* ids, int64_t rows, float* out) {
+    refresh_gemm_choice();
     if (!m || !ids || !out) SERT_FAIL("null argument");
     if (is_vs(m)) SERT_FAIL("sert_predict_tokens is the loglinear predict_fn");
     if (rows <= 0) return 0;
@@ -3936,6 +3943,7 @@ double sert_timing_avg_us(sert_model* m, int i) {
 
 int sert_bench_gemm(int device, int ta, int tb, int epi, int M, int N, int K, int splits, int iters,
                     double* avg_us) {
+    refresh_gemm_choice();
     if (!avg_us || M <= 0 || N <= 0 || K <= 0 || iters <= 0) SERT_FAIL("bad argument");
     SERT_HIP(hipSetDevice(device));
     hipStream_t s;
@@ -3991,6 +3999,7 @@ int sert_bench_gemm(int device, int ta, int tb, int epi, int M, int N, int K, in
 // training step (tests/test_gpu_gemm.py pins every kernel of gemm.h / gemm_stream.h against float64 this way).
 int sert_debug_gemm(int device, int ta, int tb, int epi, int M, int N, int K, const float* A, const float* B,
                     const float* bias, float* C) {
+    refresh_gemm_choice();
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || epi < 0 || epi > 2 || (epi && !bias)) SERT_FAIL("bad argument");
     SERT_HIP(hipSetDevice(device));
     hipStream_t s;
@@ -4025,6 +4034,7 @@ int sert_debug_gemm(int device, int ta, int tb, int epi, int M, int N, int K, co
 // out (M * N + N) = A^T.B (A (K, M), B (K, N) host arrays) followed by the column sums of B, through the split-K launch
 // + order-fixed combine the projection's dW / db take in a training step (tests/test_gpu_gemm.py)
 int sert_debug_gemm_splitk(int device, int M, int N, int K, int splits, const float* A, const float* B, float* out) {
+    refresh_gemm_choice();
     if (!A || !B || !out || M <= 0 || N <= 0 || K <= 0 || splits <= 0) SERT_FAIL("bad argument");
     SERT_HIP(hipSetDevice(device));
     hipStream_t s;
@@ -4054,6 +4064,7 @@ int sert_debug_gemm_splitk(int device, int M, int N, int K, int splits, const fl
 // C (M, N) = A . op(B) over a LONG K cut into `splits` k ranges (partial slabs + order-fixed combine): the form the loglinear
 // dG = dZ.W^T takes over 100 000 entities (gemm_long_k).  A (M, K), B (K, N) or (N, K) if tb: host arrays.
 int sert_debug_gemm_longk(int device, int tb, int M, int N, int K, int splits, const float* A, const float* B, float* C) {
+    refresh_gemm_choice();
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || splits <= 0) SERT_FAIL("bad argument");
     SERT_HIP(hipSetDevice(device));
     hipStream_t s;

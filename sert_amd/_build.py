@@ -19,6 +19,7 @@ def _stale():
     if os.path.isdir(vdir):
         deps += [os.path.join(vdir, f) for f in os.listdir(vdir) if f.endswith('.h')]
     deps.append(os.path.join(INCLUDE, 'sert_hip.h'))
+    deps.append(os.path.join(INCLUDE, 'sert_hip_debug.h'))
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 

@@ -6,6 +6,7 @@
 #include "word_index.h"
 #include "kernels_xchg.h"
 #include "../../include/sert_hip.h"
+#include "../../include/sert_hip_debug.h"   // (test hooks + micro-benchmarks: declared apart from the boundary)
 
 namespace sert {
 

@@ -15,19 +15,35 @@ from sert_amd import _capi
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_functions():
-    src = open(os.path.join(ROOT, 'include', 'sert_hip.h')).read()
+def _declared_functions(header='sert_hip.h'):
+    src = open(os.path.join(ROOT, 'include', header)).read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
     return sorted(set(re.findall(r'\b(sert_[a-z_0-9]+)\s*\(', src)))
 
 
 def test_header_symbols_are_exported(hip_lib):
     declared = _declared_functions()
+    debug = _declared_functions('sert_hip_debug.h')
     assert len(declared) >= 25
-    missing = [s for s in declared if not hasattr(hip_lib, s)]
+    missing = [s for s in declared + debug if not hasattr(hip_lib, s)]
     assert not missing, missing
-    # and the binding's list is the header's list
-    assert sorted(_capi.EXPORTS) == declared
+    # the boundary header holds no test hook or micro-benchmark, the debug header nothing else
+    assert not [s for s in declared if s.startswith(('sert_debug_', 'sert_bench_'))]
+    assert all(s.startswith(('sert_debug_', 'sert_bench_')) for s in debug), debug
+    # and the binding's list is the two headers' list
+    assert sorted(_capi.EXPORTS) == sorted(declared + debug)
+
+
+def test_product_host_code_uses_the_boundary_only():
+    """The host-side product (models, inference, scoring, training, prepare, the CLIs) calls no test hook."""
+    bad = []
+    for base, names in (('sert_amd', ('models.py', 'inference.py', 'scoring.py', 'training.py', 'prepare.py', 'distributed.py')),
+                        ('bin', ('train.py', 'query.py', 'prepare.py'))):
+        for f in names:
+            txt = open(os.path.join(ROOT, base, f)).read()
+            if re.search(r'sert_debug_|sert_bench_|debug_gemm|bench_memory|bench_gemm|debug_word_index|debug_row_lists', txt):
+                bad.append(f)
+    assert not bad, bad
 
 
 def test_config_struct_abi(hip_lib):

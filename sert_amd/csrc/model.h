@@ -25,6 +25,7 @@ struct DataSplit {
     int32_t* idx_rows = nullptr;
     int4* idx_items = nullptr;
     int4* idx_heavy = nullptr;       // heavy words of three-level trees (word_index.h: heavy_off)
+    int32_t* idx_bundles = nullptr;  // level-0 bundles (word_index.h: bundle_off)
     int32_t* idx_uwords = nullptr;   // loglinear: distinct words of every batch (sorted)
     int32_t* idx_slots = nullptr;    // loglinear: per token position, rank of its word among them
     int32_t* idx_rows_div = nullptr; // loglinear: idx_rows / n (batch row of every level-0 entry)

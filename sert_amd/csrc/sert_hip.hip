@@ -349,6 +349,13 @@ static int word_grad_segsum(sert_model* m, const DataSplit& ds, int64_t batch_in
         const int32_t* rows = (l == 0) ? ds.idx_rows + bx.rows_off : nullptr;
         const int4* items = ds.idx_items + bx.item_off[l];
         float* pout = m->wpart + (size_t)bx.part_off[l] * d;
+        // level 0 in bundles of short items (kernels_seg.h: segsum_rows_bundled; opt-in, SERT_SEG_BUNDLE=1 at upload -- the
+        // same sums bit for bit as one item per lane group, tests/test_gpu_parity.py::test_word_gradient_bundled_level0)
+        if (l == 0 && d % 4 == 0 && bx.bundle_cnt > 0 && ds.idx_bundles && bx.row_groups == 1) {
+            hipLaunchKernelGGL(segsum_rows_bundled, dim3(cdiv(bx.bundle_cnt, 8), cdiv(d / 4, 32)), dim3(256), 0, m->stream, in, rows,
+                               items, (const int32_t*)ds.idx_bundles + bx.bundle_off, (int)bx.bundle_cnt, m->g_rw, pout, d, divisor);
+            continue;
+        }
         if (d % 4 == 0) {
             // lane groups of 32 or 64 float4 columns, whichever wastes fewer lanes (d = 300: 75 chunks are
             // 3 x 32 at 78 % instead of 2 x 64 at 59 %: 147 -> 143 us at C4; the sums do not depend on it)
@@ -2726,6 +2733,7 @@ static void free_split(DataSplit& d) {
     (void)hipFree(d.csr_indices); (void)hipFree(d.csr_data); (void)hipFree(d.w); (void)hipFree(d.labfix);
     (void)hipFree(d.idx_rows); (void)hipFree(d.idx_items);
     (void)hipFree(d.idx_heavy); d.idx_heavy = nullptr;
+    (void)hipFree(d.idx_bundles); d.idx_bundles = nullptr;
     (void)hipFree(d.idx_uwords); (void)hipFree(d.idx_slots); (void)hipFree(d.idx_rows_div);
     (void)hipFree(d.idx_touched_bits);
     (void)hipFree(d.idx_dense_counts); (void)hipFree(d.idx_dense_words);
@@ -3013,6 +3021,15 @@ int sert_upload_dataset(sert_model* m, int split, const void* x, const int32_t* 
             if (!wi.heavy.empty()) {
                 SERT_HIP(hipMalloc((void**)&d.idx_heavy, wi.heavy.size() * sizeof(int32_t)));
                 SERT_HIP(hipMemcpyAsync(d.idx_heavy, wi.heavy.data(), wi.heavy.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+            }
+            // OPT-IN (SERT_SEG_BUNDLE=1, read at upload: two models of one process can run either way).  Measured SLOWER
+            // (round 5, profiles/r05_experiments.txt: C2 word-gradient group 59.5 us against 56.7, C4 150.9 against 145.0): the
+            // short items are not what level 0 waits for -- with their lane groups leaving right after the descriptor load
+            // (a knock-out) the group loses 7 of 57 us.
+            const bool bundle = knob("SERT_SEG_BUNDLE") && atoi(knob("SERT_SEG_BUNDLE")) != 0;
+            if (!wi.bundles.empty() && bundle && is_vs(m)) {
+                SERT_TRY(dmalloc(&d.idx_bundles, wi.bundles.size()));
+                SERT_HIP(hipMemcpyAsync(d.idx_bundles, wi.bundles.data(), wi.bundles.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
             }
             SERT_HIP(hipStreamSynchronize(s));
         }

@@ -29,6 +29,7 @@ constexpr int kHeavyMax = 16;            // counts of one batch row: 16 bytes, o
 constexpr int kHeavyMinCount = 4096;     // = kSegChunk^2: without its heavy words a tree has two levels
 constexpr int kHeavyRowsPerBlock = 256;
 constexpr int kSegMaxLevels = 6;
+constexpr int kBundleItems = 8;
 constexpr int kFusedMaxChunks = 32;   // level-1 chunk items one workgroup of segsum_upper_fused combines: one per lane group
                                       // (64, two per group, measured SLOWER than the separate level-2 launch: 19 vs 13 us)
 
@@ -64,6 +65,13 @@ struct BatchIndex {
     int32_t row_groups = 1;
     int32_t xcd_off[8] = {};
     int32_t xcd_cnt[8] = {};
+    // level-0 BUNDLES (row_groups == 1): consecutive items handed to one lane group together -- up to kBundleItems items
+    // holding up to kSegChunk entries in all -- so that the short items (half of a Zipfian batch's words occur once: one
+    // row load in flight per lane group) travel eight to a group with eight loads in flight (kernels_seg.h:
+    // segsum_rows_bundled).  bundles[bundle_off + k] = first item of bundle k, relative to item_off[0]; bundle_cnt + 1
+    // values.  The items' entry ranges are consecutive, every item is still summed left to right: the same bits.
+    int64_t bundle_off = 0;
+    int32_t bundle_cnt = 0;
 };
 
 struct WordIndex {
@@ -71,6 +79,7 @@ struct WordIndex {
     std::vector<SegItem> items;           // all batches, all levels
     std::vector<BatchIndex> batches;
     std::vector<int32_t> heavy;           // all batches, four ints per heavy word (BatchIndex::heavy_off)
+    std::vector<int32_t> bundles;         // all batches, level-0 bundles (BatchIndex::bundle_off)
     int64_t max_part_rows = 0;
     // distinct words per batch (sorted) and, per token position, the rank of its word
     // among them: a gathered row is then computed ONCE per distinct word (loglinear)
@@ -341,6 +350,29 @@ bool build_word_index(const IdT* ids, int64_t num_batches, int B, int n, int voc
             bx.fused_upper_ok = ok;
         }
         if (part_base > out.max_part_rows) out.max_part_rows = part_base;
+        // level-0 bundles (see BatchIndex): only where the items partition ONE consecutive entry range in order
+        bx.bundle_off = (int64_t)out.bundles.size();
+        bx.bundle_cnt = 0;
+        if (bx.row_groups == 1 && bx.nlevels >= 1 && bx.item_cnt[0] > 0) {
+            const SegItem* l0 = out.items.data() + bx.item_off[0];
+            bool consecutive = true;
+            for (int32_t k = 1; k < bx.item_cnt[0] && consecutive; ++k) consecutive = l0[k].begin == l0[k - 1].end;
+            if (consecutive) {
+                int32_t in_bundle = 0, entries = 0;
+                for (int32_t k = 0; k < bx.item_cnt[0]; ++k) {
+                    const int32_t len = l0[k].end - l0[k].begin;
+                    if (in_bundle == 0 || in_bundle == kBundleItems || entries + len > kSegChunk) {
+                        out.bundles.push_back(k);
+                        ++bx.bundle_cnt;
+                        in_bundle = 0;
+                        entries = 0;
+                    }
+                    ++in_bundle;
+                    entries += len;
+                }
+                out.bundles.push_back(bx.item_cnt[0]);
+            }
+        }
     }
     return true;
 }

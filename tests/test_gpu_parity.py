@@ -136,6 +136,37 @@ def test_word_gradient_row_grouped_tree(hip_lib, monkeypatch, dims, groups, dens
         assert U.rel_err(got[0][untouched], g64[1][untouched]) < 1e-6
 
 
+@pytest.mark.parametrize('dims', [
+    dict(B=64, n=4, Vw=300, dw=16),          # mostly singletons: bundles of eight one-entry items
+    dict(B=1000, n=10, Vw=5000, dw=128),     # Zipf: singletons, mid-size words and multi-chunk words in one batch
+    dict(B=2000, n=6, Vw=50, dw=64),         # every word heavy: bundles of one 64-entry chunk item, three tree levels
+    dict(B=777, n=5, Vw=4000, dw=300),       # 75 float4 per row: three column groups
+    dict(B=3, n=2, Vw=7, dw=8),              # fewer items than one bundle
+])
+def test_word_gradient_bundled_level0(hip_lib, monkeypatch, dims):
+    """Level 0 of the word-gradient tree in BUNDLES (kernels_seg.h: segsum_rows_bundled; word_index.h: bundle_off): up to
+    eight consecutive short items per lane group, eight row loads in flight, every item still summed left to right --
+    bit for bit the gradient of the one-item-per-lane-group kernel (the default; SERT_SEG_BUNDLE=1 at upload switches the
+    bundles on: measured slower, kept as an opt-in), and row by row the float64 oracle's."""
+    B, n, Vw, dw = dims['B'], dims['n'], dims['Vw'], dims['dw']
+    z, Ve, de = 3, 20, 32
+    p = U.make_vs_problem(9, B, n, z, Vw, Ve, dw, de, zipf=True)
+    neg = p['rng'].randint(0, Ve, size=(B, z)).astype(np.int64)
+    got = []
+    for bundle in ('1', '0'):
+        monkeypatch.setenv('SERT_SEG_BUNDLE', bundle)
+        eng = U.vs_engine(p, B, n, z, 0.01)
+        eng.upload_dataset(C.SPLIT_TRAIN, p['X'], y_int=p['y'], w=p['w'])
+        eng.train_batch(0, neg)
+        got.append(eng.get_tensor(C.T_GRAD_RW, (Vw, dw)).copy())
+        eng.close()
+    assert np.array_equal(got[0], got[1])
+    o64 = O.VectorSpaceOracle(B, n, z, p['Rw'], p['Re'], p['W'], p['b'], 0.01, dtype=np.float64)
+    _, g64, _ = o64.loss_and_grads(p['X'], p['y'], p['w'], neg)
+    err, row = U.row_err(got[0], g64[1], rows=np.unique(p['X']))
+    assert err < 2e-5, (err, row)
+
+
 def test_vectorspace_known_answers(hip_lib):
     """W=0,b=0 => loss = (1+z) log 2; all tokens equal => row grad = sum dh/n * n."""
     B, n, z, Vw, Ve, dw, de = 64, 4, 5, 50, 9, 16, 16

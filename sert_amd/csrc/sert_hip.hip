@@ -2567,18 +2567,24 @@ static int create_resources(sert_model* m) {
         if (want3) SERT_HIP(hipStreamCreateWithFlags(&m->stream3, hipStreamNonBlocking));
         if (want4) SERT_HIP(hipStreamCreateWithFlags(&m->stream4, hipStreamNonBlocking));
     }
-    SERT_HIP(hipEventCreateWithFlags(&m->ev_word_opt, hipEventDisableTiming));
-    SERT_HIP(hipEventCreateWithFlags(&m->ev_early, hipEventDisableTiming));
-    SERT_HIP(hipEventCreateWithFlags(&m->ev_join3, hipEventDisableTiming));
-    SERT_HIP(hipEventCreateWithFlags(&m->ev_step_done, hipEventDisableTiming));
-    SERT_HIP(hipEventCreateWithFlags(&m->ev_neg, hipEventDisableTiming));
-    SERT_HIP(hipEventCreateWithFlags(&m->ev_opt_fork, hipEventDisableTiming));
-    SERT_HIP(hipEventCreateWithFlags(&m->ev_dense, hipEventDisableTiming));
+    // Events that only order this device's own streams against each other need no SYSTEM-scope release (the cache
+    // write-back + invalidate that makes device memory visible to the host and to other devices): every kernel ends with
+    // an agent-scope release already.  hipEventDisableSystemFence; SERT_EVENT_FENCE=system restores the default flags.
+    // (ev_loss is waited on by the HOST and keeps them; so do the events of a communicator, whose consumers may be peers.)
+    const char* fence_env = knob("SERT_EVENT_FENCE");
+    const unsigned dev_ev = hipEventDisableTiming | ((fence_env && !strcmp(fence_env, "system")) ? 0u : (unsigned)hipEventDisableSystemFence);
+    SERT_HIP(hipEventCreateWithFlags(&m->ev_word_opt, dev_ev));
+    SERT_HIP(hipEventCreateWithFlags(&m->ev_early, dev_ev));
+    SERT_HIP(hipEventCreateWithFlags(&m->ev_join3, dev_ev));
+    SERT_HIP(hipEventCreateWithFlags(&m->ev_step_done, dev_ev));
+    SERT_HIP(hipEventCreateWithFlags(&m->ev_neg, dev_ev));
+    SERT_HIP(hipEventCreateWithFlags(&m->ev_opt_fork, dev_ev));
+    SERT_HIP(hipEventCreateWithFlags(&m->ev_dense, dev_ev));
     SERT_HIP(hipEventCreateWithFlags(&m->ev_loss, hipEventDisableTiming));
-    SERT_HIP(hipEventCreateWithFlags(&m->ev_small, hipEventDisableTiming));
-    SERT_HIP(hipEventCreateWithFlags(&m->ev_re, hipEventDisableTiming));
-    SERT_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
-    SERT_HIP(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
+    SERT_HIP(hipEventCreateWithFlags(&m->ev_small, dev_ev));
+    SERT_HIP(hipEventCreateWithFlags(&m->ev_re, dev_ev));
+    SERT_HIP(hipEventCreateWithFlags(&m->ev_fork, dev_ev));
+    SERT_HIP(hipEventCreateWithFlags(&m->ev_join, dev_ev));
     const size_t B = c.batch_size, n = c.window_size, dw = c.word_dim, V = c.num_entities;
     const bool vs = is_vs(m);
     const size_t de = vs ? c.entity_dim : 0;
@@ -3121,8 +3127,20 @@ int sert_train_batch(sert_model* m, int64_t batch_index, const int64_t* negative
     SERT_TRY(prefetch_next());
     const unsigned want = m->loss_seq;
     volatile unsigned* flag = reinterpret_cast<volatile unsigned*>(m->h_loss + 4);
-    for (unsigned spins = 1; *flag != want; ++spins) {
-        if ((spins & 0x3fff) == 0) {   // a faulted step never publishes: ask the stream
+    // A faulted step never publishes: ask the stream -- but RARELY.  hipStreamQuery on a stream whose last command carries no
+    // completion signal makes the runtime enqueue a marker (a barrier packet) to get one; asked every 16 k spins (~5 us, the
+    // flag is a cached read) the first marker landed right behind the run-ahead backward of the NEXT batch, and the next call's
+    // word-table update started 6-7 us late behind it at every batch size (round 5: HIP API trace, tools/experiments/
+    // r05_hip_trace.sh; sert_train_batches, which never asks, has no such gap).  Now: the clock every 4 k spins, the stream
+    // only after 50 ms without a loss and every 50 ms from then on.
+    {
+        const auto t_spin0 = std::chrono::steady_clock::now();
+        double next_query_ms = 50.0;
+        for (unsigned spins = 1; *flag != want; ++spins) {
+            if ((spins & 0xfff) != 0) continue;
+            const double waited_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_spin0).count();
+            if (waited_ms < next_query_ms) continue;
+            next_query_ms = waited_ms + 50.0;
             const hipError_t q = hipStreamQuery(m->stream);
             if (q == hipSuccess) {
                 if (*flag == want) break;

@@ -167,6 +167,38 @@ def test_word_gradient_bundled_level0(hip_lib, monkeypatch, dims):
     assert err < 2e-5, (err, row)
 
 
+@pytest.mark.parametrize('kind', ['vectorspace', 'loglinear'])
+def test_device_scope_events_change_nothing(hip_lib, monkeypatch, kind):
+    """The events that order a model's own streams against each other are created without the system-scope fence
+    (hipEventDisableSystemFence; SERT_EVENT_FENCE=system, read at sert_create, restores HIP's default flags): every kernel
+    ends with an agent-scope release, which is all a consumer on the same device needs.  Same losses, same parameters,
+    bit for bit, through the multi-stream schedule (device-drawn negatives, hints: run-ahead, deferred entity update)."""
+    B, n, z, Vw, Ve, d = 2048, 6, 5, 20000, 300, 64
+    if kind == 'vectorspace':
+        p = U.make_vs_problem(61, B * 4, n, z, Vw, Ve, d, d, zipf=True)
+        mk = lambda: U.vs_engine(p, B, n, z, 0.01, keep_grads=0)
+    else:
+        p = U.make_ll_problem(61, B * 4, n, Vw, Ve, d, 'int')
+        mk = lambda: U.ll_engine(p, B, n, 0.01, keep_grads=0)
+    outs = []
+    for fence in ('system', None):
+        if fence:
+            monkeypatch.setenv('SERT_EVENT_FENCE', fence)
+        else:
+            monkeypatch.delenv('SERT_EVENT_FENCE', raising=False)
+        eng = mk()
+        eng.upload_dataset(C.SPLIT_TRAIN, p['X'], y_int=p['y'], w=p['w'])
+        losses = []
+        for s in range(12):
+            eng.hint_next_batch((s + 1) % 4 if s < 11 else None)
+            losses.append(eng.train_batch(s % 4))
+        outs.append((losses, eng.get_tensor(C.T_RW).copy(), eng.get_tensor(C.T_W).copy(), eng.get_tensor(C.T_B).copy()))
+        eng.close()
+    assert outs[0][0] == outs[1][0]
+    for a, b in zip(outs[0][1:], outs[1][1:]):
+        assert np.array_equal(a, b)
+
+
 def test_vectorspace_known_answers(hip_lib):
     """W=0,b=0 => loss = (1+z) log 2; all tokens equal => row grad = sum dh/n * n."""
     B, n, z, Vw, Ve, dw, de = 64, 4, 5, 50, 9, 16, 16

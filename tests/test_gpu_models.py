@@ -671,9 +671,10 @@ def test_bench_launches_its_own_ranks(hip_lib):
     assert rec['n_gpus'] == 2 and rec['scaling'] == 'strong'
     assert rec['config']['global_batch'] == 4096 and rec['config']['per_gpu_batch'] == 2048
     assert rec['value'] > 0 and np.isfinite(rec['last_loss'])
-    assert rec['weak_scaling']['global_batch'] == 8192 and rec['weak_scaling']['per_gpu_batch'] == 4096
-    # two ranks on one device: no ceilings, and no fraction above 1 anywhere in the line
-    assert rec['memory_ceilings'] is None
+    # both readings of "scaling" in the top level of the (short) line: the fixed global batch and the fixed per-GPU batch
+    assert rec['weak']['global_batch'] == 8192 and rec['weak']['per_gpu_batch'] == 4096 and rec['weak']['value'] > 0
+    assert rec['strong']['global_batch'] == 4096 and rec['strong']['value'] == rec['value']
+    assert 'rccl_ranks' in rec and len(lines[0]) < 8000
 
     def fracs(o):
         if isinstance(o, dict):
@@ -683,6 +684,13 @@ def test_bench_launches_its_own_ranks(hip_lib):
                 else:
                     for x in fracs(v):
                         yield x
+    # two ranks on one device: no ceilings, and no fraction above 1 anywhere in the line or in the full record (sidecar file)
+    assert rec['full_record']
+    with open(os.path.join(U.ROOT, rec['full_record'])) as f:
+        full = json.load(f)
+    assert full['memory_ceilings'] is None and full['weak_scaling']['global_batch'] == 8192
+    assert all(v <= 1.0 for _, v in fracs(full)), [kv for kv in fracs(full) if kv[1] > 1.0]
+
     assert all(v <= 1.0 for _, v in fracs(rec)), [kv for kv in fracs(rec) if kv[1] > 1.0]
 
 

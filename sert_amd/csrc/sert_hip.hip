@@ -1445,10 +1445,16 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
             // which waits for them -- ended 35 us after the Adam (0.330 ms; this order: 0.29)
             if (!m->fork_bound) SERT_HIP(hipEventRecord(m->ev_fork, m->stream));   // (else: the loss kernel's own completion signal)
             SERT_HIP(hipStreamWaitEvent(m->stream2, m->ev_fork, 0));
+            // The data-parallel step is bound by the HOST (some 45 runtime calls + three collectives per step: round-5 API
+            // trace, tools/experiments/r05_hip_trace.sh with SERT_FORCE_COMM=1): the launches go out in order of
+            // criticality -- the main stream's dh GEMM first; issued behind the six side-stream launches it started 27 us
+            // after the loss kernel had finished (C2, world of one).
+            static const bool dx_last = variant_knob("SERT_DP_DX_LAST") != nullptr;   // (the round-4 order, for the A/B)
+            if (!dx_last) SERT_TRY(dh_gemm());
             SERT_TRY(dense_grad());
             m->fork_bound = true;          // (the fork is recorded: the entity chain only has to follow in stream order)
             SERT_TRY(entity_grad());
-            SERT_TRY(dh_gemm());
+            if (dx_last) SERT_TRY(dh_gemm());
             SERT_TRY(word_table_sum());
         } else {
             SERT_TRY(entity_grad());
@@ -2301,7 +2307,8 @@ static int step_forward_backward(sert_model* m, const DataSplit& ds, int64_t bat
         } else {
             SERT_HIP(hipMemsetAsync(m->gflat, 0, m->gflat_alloc * sizeof(float), pre));
         }
-        SERT_TRY(owned_sum_of_squares(m, pre));
+        // (vectorspace with a side-stream prologue: BEHIND the negatives and their event, see below)
+        if (!(is_vs(m) && !is_fs(m) && pre != m->stream)) SERT_TRY(owned_sum_of_squares(m, pre));
     }
     if (is_fs(m)) {
         SERT_TRY(fs_forward<true>(m, ds, batch_index));
@@ -2312,6 +2319,11 @@ static int step_forward_backward(sert_model* m, const DataSplit& ds, int64_t bat
         if (pre != m->stream) {
             SERT_HIP(hipEventRecord(m->ev_neg, pre));
             SERT_HIP(hipStreamWaitEvent(m->stream, m->ev_neg, 0));
+            // Data parallel: the sums of squares of the owned pieces (the regularisation term's share of this rank: a pass
+            // over the owned slice of every sharded tensor + one combine) only feed the all-reduce of the replicated rest,
+            // which joins this stream much later -- they used to sit IN FRONT of the negatives, and the loss kernel waited
+            // for all of it (round-5 timeline at C2, world of one: the loss kernel 25 us behind the projection).
+            if (!have_neg && !fused_pre) SERT_TRY(owned_sum_of_squares(m, pre));
         }
         SERT_TRY(vs_loss<true>(m, ds, batch_index));
         SERT_TRY(vs_backward(m, ds, batch_index));   // (loss partials: beside dW)

@@ -2,9 +2,9 @@
 mkdir -p gpurun_out/r05e; cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf /tmp/ht
-rocprofv3 --hip-trace --kernel-trace -d /tmp/ht -o t -- python $R/bench.py --profile-inner --num-batches 8 --batch 8192 --steps 12 --warmup 3 > /dev/null 2>&1
+rocprofv3 --hip-trace --kernel-trace -d /tmp/ht -o t -- python $R/bench.py --profile-inner --num-batches 8 --batch ${BATCH:-8192} --steps 12 --warmup 3 > /dev/null 2>&1
 DB=$(find /tmp/ht -name '*.db' | head -1)
-python - "$DB" <<'P' > $R/gpurun_out/r05e/hip_trace_8192.txt
+python - "$DB" <<'P' > $R/gpurun_out/r05e/hip_trace_${TAG:-8192}.txt
 import sqlite3, sys, re
 db = sqlite3.connect(sys.argv[1])
 tabs = [r[0] for r in db.execute("select name from sqlite_master where type in ('table','view')")]
@@ -28,4 +28,4 @@ ev.sort()
 for s, txt in ev:
     print('%10.1f  %s' % ((s - a) / 1e3, txt))
 P
-tail -150 $R/gpurun_out/r05e/hip_trace_8192.txt
+tail -150 $R/gpurun_out/r05e/hip_trace_${TAG:-8192}.txt

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Profile one round on the GPU box:  tools/profile_round.sh <tag> [what ...]
-#   what = c2 c4 ll fs mfma   (default: all)
+#   what = c2 c4 ll fs mfma query   (default: all but query)
 # For every workload: rocprofv3 --kernel-trace --stats        -> <tag>_<w>_kernels.txt
 #                     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE  -> <tag>_<w>_pmc.{txt,json}
 #   (separate passes, no trace domain besides the kernel trace -- MI355X_MICROARCH.md)
@@ -34,6 +34,14 @@ for w in $WHAT; do
     c4) profile c4 python $ROOT/tools/bench_c4.py --kinds vectorspace --steps 10 ;;
     ll) profile ll_c2 python $ROOT/bench.py --model loglinear --steps 20 --warmup 3 $NOX ;;
     fs) profile fs_c2 python $ROOT/tools/bench_c4.py --kinds vectorspace_softmax --vocab 100000 --entities 1000 --dim 128 --batch 65536 --steps 10 ;;
+    query)   # the C5 scoring call (bin/query.py:239-370 batched): kernel stats, HBM bytes, matrix-pipe counters of the filter GEMM
+      profile query python $ROOT/bench.py --profile-query-inner
+      cd /tmp
+      rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES -d $OUT/mq -o mq -- python $ROOT/bench.py --profile-query-inner > /dev/null 2> $OUT/mfma_query.err
+      cd $ROOT
+      MQ=$(find $OUT/mq -name '*.db' | head -1)
+      [ -n "$MQ" ] && python tools/gemm_pmc.py $MQ > $OUT/${TAG}_query_mfma.txt
+      rm -rf $OUT/mq ;;
     mfma)
       cd /tmp
       rocprofv3 -L 2>/dev/null | grep -i -E "mfma|SQ_BUSY_CYCLES|SQ_WAVE_CYCLES|SQ_INSTS_VALU " | head -40 > $OUT/${TAG}_counters_available.txt

@@ -187,7 +187,7 @@ _COMMON_KERNELS = {
 }
 KERNELS_OF_GROUP = {
     'vectorspace': dict(_COMMON_KERNELS, **{
-        'gather': ('vs_gather_mean',),
+        'gather': ('vs_project_x3', 'vs_gather_mean'),     # (fused with the projection where d_w, d_e <= 128: kernels_proj.h)
         'gemm_fwd': ('gemm_x3<false, false, 2', 'gemm_f32_mfma<false, false, 2', 'gemm_f32_mfma_small<false, 2', 'gemm_f32_mfma_n160<false, false, 2'),
         'loss': ('vs_nce_regs', 'vs_nce'), 'entity_sort': ('egrad_bucket', 'csort_scatter'),
         'entity_grad_reduce': ('egrad_acc', 'egrad_chunk_reduce'),

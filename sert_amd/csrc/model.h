@@ -83,6 +83,8 @@ struct sert_model {
     bool re_in_parts = false;        // this step: dR_e is still the row groups' partial tables (summed by the optimiser)
     bool fork_bound = false;         // ev_fork rides on the NCE kernel's completion signal (no record needed)
     bool lazy_join = false;          // this step: the main stream never waits for the entity chain
+    int num_cus = 256;               // compute units of the device (persistent launches: one workgroup per CU)
+    bool proj_fused = false;         // gather + mean-pool + projection in one launch where the shape allows (kernels_proj.h; opt-in, SERT_PROJ_FUSED=1)
     bool ll_dw_side = false;         // loglinear, this step: dW, db and their combine were issued on the side stream
     bool dw_side_first = false;      // this step: dW / db came from the side stream, FIRST in its chain (ev_dense marks them)
     bool dp_late_join = false;       // data parallel, asynchronous communicator: the side stream (entity chain, dW, db, loss sum) is

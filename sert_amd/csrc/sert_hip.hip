@@ -28,6 +28,7 @@
 #include "kernels_ll.h"
 #include "kernels_membench.h"
 #include "kernels_opt.h"
+#include "kernels_proj.h"
 #include "kernels_score.h"
 #include "kernels_seg.h"
 #include "kernels_sort.h"
@@ -974,6 +975,20 @@ static int vs_project(sert_model* m, const DataSplit& ds, int64_t batch_index) {
     const auto& c = m->cfg;
     const int B = c.batch_size, n = c.window_size, dw = c.word_dim, de = c.entity_dim;
     const size_t row0 = (size_t)batch_index * B;
+    // gather + mean-pool + projection in ONE launch where the shape allows it (kernels_proj.h: d_w, d_e <= 128, window <= 10):
+    // the h and the t of the two launches below, bit for bit where they run gemm_x3.  OPT-IN, SERT_PROJ_FUSED=1 (read at
+    // sert_create): round 5 measured it slower than the two launches at C2 and equal at 8192 rows.  SERT_GEMM_FP32=1 (the
+    // fused kernel multiplies on the bf16 pipe) keeps the two launches too.
+    if (m->proj_fused && gemm_x3_enabled() && vs_project_fused_ok(B, n, dw, de, m->n_rw)) {
+        if (m->T_alt) std::swap(m->T, m->T_alt);     // (see below: this projection goes to the other buffer)
+        ScopedTimer t(m, TG_GATHER);
+        SERT_ID_DISPATCH(c.id_bytes, {
+            const IdT* X = (const IdT*)ds.x + row0 * n;
+            hipLaunchKernelGGL((vs_project_x3<IdT>), dim3(vs_project_grid(B, m->num_cus)), dim3(PJ_THREADS), 0, m->stream, X, (const float*)m->rw,
+                               (const float*)m->W, (const float*)m->b, m->H, m->T, B, n, dw, de);
+        });
+        return 0;
+    }
     {
         ScopedTimer t(m, TG_GATHER);
         SERT_ID_DISPATCH(c.id_bytes, {
@@ -2583,6 +2598,13 @@ static int create_resources(sert_model* m) {
     // write-back + invalidate that makes device memory visible to the host and to other devices): every kernel ends with
     // an agent-scope release already.  hipEventDisableSystemFence; SERT_EVENT_FENCE=system restores the default flags.
     // (ev_loss is waited on by the HOST and keeps them; so do the events of a communicator, whose consumers may be peers.)
+    // (opt-in: measured SLOWER than the two launches at C2 -- 53 us against 25 + 25 -- and equal at 8192 rows; kernels_proj.h)
+    m->proj_fused = knob("SERT_PROJ_FUSED") && atoi(knob("SERT_PROJ_FUSED")) != 0;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->cfg.device) != hipSuccess || cus <= 0) cus = 256;
+        m->num_cus = cus;
+    }
     const char* fence_env = knob("SERT_EVENT_FENCE");
     const unsigned dev_ev = hipEventDisableTiming | ((fence_env && !strcmp(fence_env, "system")) ? 0u : (unsigned)hipEventDisableSystemFence);
     SERT_HIP(hipEventCreateWithFlags(&m->ev_word_opt, dev_ev));

@@ -199,6 +199,45 @@ def test_device_scope_events_change_nothing(hip_lib, monkeypatch, kind):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize('dims', [
+    dict(B=20000, n=10, Vw=5000, dw=128, de=128, exact=True),    # the unfused projection runs gemm_x3 here: the same bits
+    dict(B=16500, n=3, Vw=900, dw=64, de=96, exact=True),        # K = 64 (four k steps), 96 of the 128 tile columns
+    dict(B=65, n=10, Vw=300, dw=128, de=128, exact=False),       # one full tile + one row; unfused: the fp32 MFMA kernel
+    dict(B=100, n=4, Vw=200, dw=32, de=20, exact=False),
+    dict(B=1, n=1, Vw=5, dw=16, de=4, exact=False),
+    dict(B=200, n=12, Vw=1000, dw=112, de=128, exact=False),     # window > 10: two gather trips
+])
+def test_fused_projection_equals_the_two_launches(hip_lib, monkeypatch, dims):
+    """kernels_proj.h: gather + mean-pool + tanh projection in one persistent, software-pipelined launch (opt-in,
+    SERT_PROJ_FUSED=1 at sert_create, for d_w, d_e <= 128 and windows <= 10: measured slower than the two launches at C2)
+    against the two launches it replaces: h bit for bit always; t bit for bit where the
+    unfused projection runs the bf16-pipe kernel with the same term order (gemm_x3.h), to 2e-6 where it runs the fp32 MFMA
+    kernel; and both against the float64 oracle."""
+    B, n, Vw, dw, de = dims['B'], dims['n'], dims['Vw'], dims['dw'], dims['de']
+    z, Ve = 3, 20
+    p = U.make_vs_problem(13, B, n, z, Vw, Ve, dw, de, zipf=True)
+    neg = p['rng'].randint(0, Ve, size=(B, z)).astype(np.int64)
+    got = []
+    for fused in ('1', '0'):
+        monkeypatch.setenv('SERT_PROJ_FUSED', fused)
+        eng = U.vs_engine(p, B, n, z, 0.01)
+        eng.upload_dataset(C.SPLIT_TRAIN, p['X'], y_int=p['y'], w=p['w'])
+        loss = eng.train_batch(0, neg)
+        got.append((eng.get_tensor(C.T_ACT_H, (B, dw)).copy(), eng.get_tensor(C.T_ACT_T, (B, de)).copy(), loss,
+                    eng.get_tensor(C.T_RW).copy()))
+        eng.close()
+    assert np.array_equal(got[0][0], got[1][0])
+    if dims['exact']:
+        assert np.array_equal(got[0][1], got[1][1])
+        assert got[0][2] == got[1][2] and np.array_equal(got[0][3], got[1][3])
+    else:
+        assert np.abs(got[0][1] - got[1][1]).max() < 2e-6
+    o64 = O.VectorSpaceOracle(B, n, z, p['Rw'], p['Re'], p['W'], p['b'], 0.01, dtype=np.float64)
+    f = o64.forward(p['X'], p['y'], neg)
+    assert np.abs(got[0][0] - f['h']).max() < 1e-6 * max(1.0, np.abs(f['h']).max())
+    assert np.abs(got[0][1] - f['t']).max() < 2e-6
+
+
 def test_vectorspace_known_answers(hip_lib):
     """W=0,b=0 => loss = (1+z) log 2; all tokens equal => row grad = sum dh/n * n."""
     B, n, z, Vw, Ve, dw, de = 64, 4, 5, 50, 9, 16, 16

@@ -224,3 +224,61 @@ def test_row_exchange_over_the_store_transport(tmp_path, world):
             out, _ = p.communicate()
         assert p.returncode == 0, out.decode()
         assert 'rank %d ok' % rank in out.decode()
+
+
+RDZV_WORKER = r'''
+import os, sys, time
+sys.path.insert(0, %(root)r)
+from sert_amd import distributed as dist
+t0 = time.time()
+try:
+    ctx = dist.init_from_env()            # FileStore + the first barrier: every rank of the world must arrive
+    vals = dist.all_gather_object(('rank', ctx.rank))
+    assert [v[1] for v in vals] == list(range(ctx.world_size)), vals
+    assert dist.all_reduce_max(float(ctx.rank)) == ctx.world_size - 1
+    dist.barrier()
+    dist.shutdown()
+    print('OK %%d %%.2f' %% (ctx.rank, time.time() - t0))
+except RuntimeError as e:
+    print('TIMEOUT %%s %%.2f %%s' %% (os.environ['RANK'], time.time() - t0, str(e)[:400].replace(chr(10), ' ')))
+    sys.exit(3)
+'''
+
+
+def _spawn_world(tmp_path, world, absent=(), timeout_s='3'):
+    import subprocess
+    import sys
+    rd = str(tmp_path / 'rdzv')
+    procs = []
+    for r in range(world):
+        if r in absent:
+            continue
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT='29533', SERT_RDZV_DIR=rd, SERT_RDZV_TIMEOUT=timeout_s)
+        procs.append((r, subprocess.Popen([sys.executable, '-c', RDZV_WORKER % dict(root=ROOT)], env=env,
+                                          stdout=subprocess.PIPE, stderr=subprocess.PIPE)))
+    out = {}
+    for r, p in procs:
+        so, se = p.communicate(timeout=120)
+        out[r] = (p.returncode, so.decode().strip(), se.decode()[-300:])
+    return out
+
+
+def test_world_of_eight_rendezvous_and_host_collectives(tmp_path):
+    """First contact of an 8-rank launch with the rendezvous must be boring: eight processes (no GPU, no RCCL) meet over the
+    FileStore, run the host-side collectives bench.py and the models use around the data path, and shut down."""
+    out = _spawn_world(tmp_path, 8, timeout_s='60')
+    assert sorted(out) == list(range(8))
+    for r, (rc, so, se) in out.items():
+        assert rc == 0 and so.startswith('OK %d' % r), (r, rc, so, se)
+
+
+def test_world_of_eight_times_out_cleanly_when_a_rank_never_arrives(tmp_path):
+    """... and when one of the eight never starts, the other seven do not hang: each raises the rendezvous error naming the
+    key, the directory, its rank and the world within SERT_RDZV_TIMEOUT."""
+    out = _spawn_world(tmp_path, 8, absent=(5,), timeout_s='3')
+    assert sorted(out) == [0, 1, 2, 3, 4, 6, 7]
+    for r, (rc, so, se) in out.items():
+        assert rc == 3 and so.startswith('TIMEOUT %d' % r), (r, rc, so, se)
+        assert 'rendezvous timed out' in so and 'of 8' in so, so
+        assert float(so.split()[2]) < 30.0, so

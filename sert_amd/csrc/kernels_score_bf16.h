@@ -344,11 +344,62 @@ __device__ __forceinline__ void score_filter_epilogue(f32x16_t (&acc)[2], const 
     }
 }
 
-template <bool STORE>
+// The same lists, slots handed out by LDS atomics (round 5).  The consumer (topk_from_groups_rescore) gathers the lists
+// order-free and flags an overflowed group for the exact path, so the ORDER of a list's entries is free -- and with it the
+// ballot / popcount ranking above, which is what this kernel spends its time on (VALU-bound: ~480 epilogue instructions per
+// wave and tile against 16 MFMAs; half of the sixteen row iterations find a candidate at the 0.6 % density the sampled threshold
+// gives).  Here a lane that holds a candidate takes its slot from the row's counter (cnt_w: this wave's 32 rows, one
+// 64-column group each) and stores; the counts are written once at the end, for all 32 rows (zero included).
+__device__ __forceinline__ void score_filter_epilogue_atomic(f32x16_t (&acc)[2], const ScoreBf16Args& g, int tn, int m0, int n0, int wr,
+                                                             int wc, int li, int lh, const float* thr_s, unsigned* cnt_w) {
+    const int nrem = g.N - n0;
+    if (nrem < SB_T) {       // edge tile: the (clamped, duplicated) columns beyond N never pass
+        const int col0e = wc * 64 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (col0e >= nrem) acc[0][r] = -INFINITY;
+            if (col0e + 32 >= nrem) acc[1][r] = -INFINITY;
+        }
+    }
+    const int lane = li + 32 * lh;
+    if (lane < 32) cnt_w[lane] = 0u;            // (same wave writes and reads: LDS operations of a wave complete in order)
+    const unsigned ngr = (unsigned)g.ngr, ucap = (unsigned)g.cap;
+    const size_t gbase = (size_t)m0 * ngr + 2u * (unsigned)tn;
+    uint32_t* cand_t = g.cand + gbase * ucap;
+    unsigned char* cnt_t = g.cnt + gbase;
+    const int row0 = wr * 32 + 4 * lh;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int rl = (r & 3) + 8 * (r >> 2) + 4 * lh;              // row inside the wave's 32
+        const float th = thr_s[wr * 32 + rl];
+        const float v0 = acc[0][r], v1 = acc[1][r];
+        const bool p0 = v0 >= th, p1 = v1 >= th;
+        if (__builtin_amdgcn_ballot_w64(p0 | p1)) {                  // wave-uniform
+            const unsigned goff = (unsigned)(wr * 32 + rl) * ngr + (unsigned)wc;
+            if (p0) {
+                const unsigned slot = atomicAdd(&cnt_w[rl], 1u);
+                if (slot < ucap) cand_t[(size_t)goff * ucap + slot] = (desc_key(v0) & ~63u) | (unsigned)li;
+            }
+            if (p1) {
+                const unsigned slot = atomicAdd(&cnt_w[rl], 1u);
+                if (slot < ucap) cand_t[(size_t)goff * ucap + slot] = (desc_key(v1) & ~63u) | ((unsigned)li + 32u);
+            }
+        }
+    }
+    (void)row0;
+    if (lane < 32) {
+        const unsigned tot = cnt_w[lane];
+        if (m0 + wr * 32 + lane < g.M)                               // (rows past M do not exist: no list, no count)
+            cnt_t[(unsigned)(wr * 32 + lane) * ngr + (unsigned)wc] = (unsigned char)(tot > 255u ? 255u : tot);
+    }
+}
+
+template <bool STORE, bool ATOMIC_EPI = false>
 __global__ __launch_bounds__(512, 4) void score_filter_bf16(const ScoreBf16Args g) {
     __shared__ __attribute__((aligned(16))) unsigned char As[SB_T * SB_LDB];
     __shared__ __attribute__((aligned(16))) unsigned char Bs[SB_T * SB_LDB];
     __shared__ float thr_s[SB_T];
+    __shared__ unsigned cnt_s[8][32];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wr = w >> 1, wc = w & 1;            // 4 x 2 waves
     const int li = lane & 31, lh = lane >> 5;
@@ -417,7 +468,8 @@ __global__ __launch_bounds__(512, 4) void score_filter_bf16(const ScoreBf16Args 
         }
         return;
     }
-    score_filter_epilogue(acc, g, tn, m0, n0, wr, wc, li, lh, thr_s);
+    if (ATOMIC_EPI) score_filter_epilogue_atomic(acc, g, tn, m0, n0, wr, wc, li, lh, thr_s, cnt_s[w]);
+    else score_filter_epilogue(acc, g, tn, m0, n0, wr, wc, li, lh, thr_s);
 }
 
 #ifdef SERT_VARIANTS
@@ -442,7 +494,12 @@ inline void launch_score_filter_bf16(hipStream_t s, const uint16_t* P16, const u
         return;
     }
 #endif
-    hipLaunchKernelGGL(score_filter_bf16<false>, dim3(g.tiles_m * g.tiles_n), dim3(512), 0, s, g);
+    // (the epilogue with slots from LDS atomics, score_filter_epilogue_atomic: measured EQUAL -- 1.221 / 1.261 ms per 10 000
+    //  queries against 1.235 / 1.210, identical results -- so the kernel is not bound by its epilogue's instruction count
+    //  after all; variants build only, SERT_SCORE_EPI=atomic; profiles/r05_experiments.txt)
+    static const bool atomic_epi = variant_knob("SERT_SCORE_EPI") && !strcmp(variant_knob("SERT_SCORE_EPI"), "atomic");
+    if (atomic_epi) hipLaunchKernelGGL((score_filter_bf16<false, true>), dim3(g.tiles_m * g.tiles_n), dim3(512), 0, s, g);
+    else hipLaunchKernelGGL((score_filter_bf16<false, false>), dim3(g.tiles_m * g.tiles_n), dim3(512), 0, s, g);
 }
 
 // C (M, N) = P16 . E16[::stride]^T in fp32 (approximate scores of every stride-th entity)
@@ -452,7 +509,7 @@ inline void launch_score_sample_bf16(hipStream_t s, const uint16_t* P16, const u
     g.P16 = P16; g.E16 = E16; g.M = M; g.N = N; g.kp = kp; g.estride = (size_t)kp * stride;
     g.tiles_m = cdiv(M, SB_T); g.tiles_n = cdiv(N, SB_T);
     g.C = C; g.ldc = N;
-    hipLaunchKernelGGL(score_filter_bf16<true>, dim3(g.tiles_m * g.tiles_n), dim3(512), 0, s, g);
+    hipLaunchKernelGGL((score_filter_bf16<true, false>), dim3(g.tiles_m * g.tiles_n), dim3(512), 0, s, g);
 }
 
 }  // namespace sert

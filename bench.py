@@ -245,15 +245,21 @@ def timed_steps(model, dist, num_batches, steps, warmup, timing=True):
         # leave the GPU below its operating clocks, and W = 5 warm-up steps are 1.4 ms: one 20-step line of this round
         # read 0.306 ms where every other pass of the same process read 0.264-0.268.  So the model
         # first runs CLOCK_STEPS untimed steps; then the W warm-up steps and exactly K timed steps of the contract.
+        # (hinted like the timed steps: without the announcement every lazy word-table update writes every row, and the
+        #  counter passes -- which average over ALL launches of a kernel -- read 1.41 x the bytes the timed mode moves:
+        #  round 5, tools/experiments/r05_lazy_writes.sh)
         for i in range(CLOCK_STEPS):
+            eng.hint_next_batch((i + 1) % num_batches)
             model.train_fn(i % num_batches)
     for i in range(warmup):
+        eng.hint_next_batch((i + 1) % num_batches if i + 1 < warmup else warmup % num_batches)
         model.train_fn(i % num_batches)
     if timing:
         # two instrumented steps before the instrumented ones that count: the first one through the serial
         # (one queue, event-bracketed) path pays one-time costs inside its timing groups
         eng.timing_enable(True)
         for i in range(2):
+            eng.hint_next_batch((warmup + i + 1) % num_batches)
             model.train_fn((warmup + i) % num_batches)
     eng.timing_reset()
     eng.timing_enable(timing)

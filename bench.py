@@ -1090,6 +1090,7 @@ def main():
     ap.add_argument('--no-loglinear-extra', action='store_true')
     ap.add_argument('--no-query-extra', action='store_true')
     ap.add_argument('--no-c4-extra', action='store_true')
+    ap.add_argument('--no-small-extra', action='store_true', help='skip the small-batch sub-record')
     ap.add_argument('--no-seed-extra', action='store_true', help='skip the seeds 1, 2 and U[0.5, 2]-weights runs')
     ap.add_argument('--no-live-pmc', action='store_true')
     ap.add_argument('--no-weak-extra', action='store_true', help='N > 1: skip the weak-scaling sub-record')
@@ -1344,6 +1345,23 @@ def main():
 
     if ctx.rank == 0 and N == 1 and kind == 'vectorspace' and not args.no_c4_extra:
         out['c4'] = c4_record(models, _capi, dist, max(5, min(10, args.steps)), live)
+
+    # extra: the step at the reference's OWN batch sizes (its canonical hyper-parameters) and at the per-GPU batch of the
+    # 8-GPU strong-scaling case -- latency-bound steps; ms per step only (same loop: hints, per-step loss read-back)
+    if ctx.rank == 0 and N == 1 and kind == 'vectorspace' and not args.no_small_extra and not args.no_c4_extra:   # (quick runs skip both)
+        small = {}
+        for name, kd, c in (
+                ('c2_dims_batch_8192', 'vectorspace', dict(B=8192, n=n, Vw=Vw, Ve=Ve, d=d, de=de)),
+                ('product_search_settings_batch_4096_dw300_de128_Ve32768', 'vectorspace', dict(B=4096, n=10, Vw=100000, Ve=32768, d=300, de=128)),
+                ('w3c_loglinear_settings_batch_1024_d300_Ve715', 'loglinear', dict(B=1024, n=8, Vw=100000, Ve=715, d=300, de=300))):
+            rng_ = np.random.RandomState(5)
+            Xs, ys, ws = synth_data(rng_, 8 * c['B'], c['n'], c['Vw'], c['Ve'])
+            ms_ = build_model(kd, models, c['B'], c['n'], c['Vw'], c['Ve'], c['d'], c['de'], z, Xs, ys, ws, seed=5)
+            st_ = max(50, min(200, 10 * args.steps))
+            dts, _, _ = timed_steps(ms_, dist, 8, st_, 10, timing=False)
+            small[name] = {'ms_per_step': round(1000.0 * dts / st_, 4), 'value': round(st_ * c['B'] / dts, 0)}
+            del ms_
+        out['small_batch'] = small
 
     if ctx.rank == 0 and N == 1 and not args.no_query_extra:
         out['query'] = query_bench(_capi, cpu=not args.no_cpu_baseline, trace=live)

@@ -27,6 +27,21 @@ def build(force=False, verbose=False):
     """Compile every HIP source for gfx950 into sert_amd/libsert_hip.so."""
     if not force and not _stale():
         return LIB
+    # several ranks of one node may arrive here together (python bench.py --gpus N on a box whose library is stale): one
+    # builds, the others wait for the lock and find the library fresh
+    import fcntl
+    lock = open(LIB + '.lock', 'w')
+    try:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not _stale():
+            return LIB
+        return _build_locked(verbose)
+    finally:
+        fcntl.flock(lock, fcntl.LOCK_UN)
+        lock.close()
+
+
+def _build_locked(verbose):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     if not os.path.exists(hipcc):
         if os.path.exists(LIB):
@@ -35,10 +50,12 @@ def build(force=False, verbose=False):
     cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
            '-munsafe-fp-atomics', '-I' + INCLUDE]
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += ['-o', LIB, '-ldl']
+    tmp = LIB + '.tmp.%d' % os.getpid()
+    cmd += ['-o', tmp, '-ldl']
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd)
+    os.replace(tmp, LIB)       # (atomic: a process that loads the library meanwhile sees the old or the new file, never half of one)
     return LIB
 
 

@@ -98,6 +98,7 @@ struct sert_model {
     float* re_sq = nullptr;          // [2][2 * kOptBlocks]
     int64_t re_sq_for[2] = {-1, -1};
     int n_loss_partials = 0;
+    bool loss_from_rows = false;     // this step: the loss finalisation reads the per-row losses directly (few rows)
     int nce_loss_partials = 0;       // > 0: vs_nce wrote this many per-workgroup loss partials into red_loss
     // SERT_STREAMS: 1 = everything on the main stream (0.423 ms/step at C2), 2 = + the entity
     // chain, the step prologue and the small-tensor optimiser on a side stream (0.396),

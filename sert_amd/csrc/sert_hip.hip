@@ -1849,8 +1849,13 @@ static int ll_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
 static int reduce_rowloss(sert_model* m, hipStream_t st) {
     const int B = m->cfg.batch_size;
     int nb = std::min(kOptBlocks, cdiv(B, 256));
+    m->loss_from_rows = false;
     if (is_vs(m) && !is_fs(m) && m->nce_loss_partials > 0) nb = m->nce_loss_partials;   // written by vs_nce
-    else hipLaunchKernelGGL(sum_partial, dim3(nb), dim3(256), 0, st, m->rowloss, (size_t)B, m->red_loss);
+    else if (!is_dp(m) && B <= 8192) {
+        // few rows: the finalisation sums them itself (fp64, fixed order) -- one 4 us launch less on a small step's chain
+        m->loss_from_rows = true;
+        nb = B;
+    } else hipLaunchKernelGGL(sum_partial, dim3(nb), dim3(256), 0, st, m->rowloss, (size_t)B, m->red_loss);
     if (is_dp(m))
         hipLaunchKernelGGL(partials_to_scalar, dim3(1), dim3(256), 0, st, m->red_loss, nb, m->g_loss);
     m->n_loss_partials = nb;
@@ -1928,7 +1933,9 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
     const bool exchanged = m->comm && !m->timing.enabled;
     // single GPU: the small tensors are updated on the side stream WHILE the word table
     // streams on the main one (independent tensors; every gradient is complete here)
-    const bool side_small = !is_dp(m) && !m->timing.enabled && m->nstreams >= 2;
+    // (loglinear whose dW stayed on the main stream -- small steps: the W, b update (6-8 us alone) stays there too; its fork
+    //  and join cost the main queue 2 x 5.6 us for 25 us of side-stream work: round-5 timeline of the W3C settings)
+    const bool side_small = !is_dp(m) && !m->timing.enabled && m->nstreams >= 2 && (is_vs(m) || m->ll_dw_side);
     hipStream_t ss = side_small ? m->stream2 : m->stream;
     if (side_small && m->lazy_join && fork_late_mode(m)) {
         // (everything the small tensors need was issued on the side stream itself)
@@ -2186,7 +2193,7 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
         const float reg_scale = c.lambda_ > 0.f ? c.lambda_ / (2.0f * (float)c.global_batch_size) : 0.f;
         // single GPU: the loss partials directly; data parallel: the all-reduced scalars (loss
         // sum; sum of squares of the sharded tensors -- the replicated ones come from red_sq)
-        const float* lp = is_dp(m) ? m->g_loss : m->red_loss;
+        const float* lp = is_dp(m) ? m->g_loss : (m->loss_from_rows ? m->rowloss : m->red_loss);
         const int nl = is_dp(m) ? 1 : n_loss_partials;
         unsigned* flag = publish ? reinterpret_cast<unsigned*>(loss_dst + 4) : nullptr;
         if (tail_splits > 0) {
@@ -2315,7 +2322,11 @@ static int step_forward_backward(sert_model* m, const DataSplit& ds, int64_t bat
     } else {
         // (the previous step's optimiser and loss kernels read what the prologue overwrites)
         if (pre != m->stream) SERT_HIP(hipStreamWaitEvent(pre, m->ev_step_done, 0));
-        if (m->use_touched || m->xr_on) {
+        if (m->use_touched && !is_vs(m) && !is_dp(m)) {
+            // loglinear, single GPU: NOTHING to zero -- the word table's gradient is read through the touched-row bitmap, and
+            // g_W / g_b are written in full by the split-K combine behind dW (ll_backward); the 5 us memset was a launch of
+            // its own on the chain of an 18-kernel step (the reference's W3C settings: round-5 timeline)
+        } else if (m->use_touched || m->xr_on) {
             // (by rows: dR_w is written where this rank's batch touches, read where the lists say, and
             //  the owned rows nobody touched are never read -- the table needs no zeroing)
             SERT_HIP(hipMemsetAsync(m->gflat + zero_from(m), 0, (m->gflat_alloc - zero_from(m)) * sizeof(float), pre));

@@ -521,7 +521,11 @@ static int gemm_long_k(sert_model* m, hipStream_t s, const float* A, const float
         SERT_TRY(dmalloc(&m->skbuf, m->skbuf_count));
     }
     launch_gemm<TA, TB, EPI_STORE>(s, A, Bm, m->skbuf, nullptr, M, N, K, lda, ldb, N, splits, kper, mn);
-    launch_reduce_partials(s, m->skbuf, splits, mn, mn, C, mn, C);
+    if (rowmap && mapped_C) {
+        // (the combine stores row r as row rowmap[r] of mapped_C: no copy kernel behind it)
+        launch_reduce_partials(s, m->skbuf, splits, mn, mn, mapped_C, mn, mapped_C, rowmap, N);
+        if (mapped) *mapped = true;
+    } else launch_reduce_partials(s, m->skbuf, splits, mn, mn, C, mn, C);
     return 0;
 }
 

@@ -120,3 +120,41 @@ def test_timed_mode_against_the_oracle(hip_lib, case):
         err, row = U.row_err(got[k], want[k])
         assert err < (1e-4 if k in ('R_w', 'R_e') else 2e-3), (case, k, err, row)
     del model
+
+
+def test_timed_mode_loglinear_at_the_w3c_settings(hip_lib):
+    """The reference's W3C expert-finding hyper-parameters (W3C-expert-finding.sh:88-96: loglinear, batch 1024, window 8,
+    d = 300; 715 experts -- no multiple of four: the unaligned kernels) as the bench's `small_batch` record drives them:
+    hints, run-ahead, lazy Adadelta on the word table, and round 5's trimmed chain (no memset at the head of the step, the
+    W / b update on the main stream, row losses straight into the finalisation, word rows stored by the split-K combine of
+    dG) -- eight steps against LogLinearOracle (sert/models.py:804-890, :820 restated)."""
+    B, n, Vw, Ve, d, nb, steps = 1024, 8, 100000, 715, 300, 6, 8
+    rng = np.random.RandomState(17)
+    X, y, w = bench.synth_data(rng, nb * B, n, Vw, Ve)
+    w = rng.uniform(0.5, 2.0, len(w)).astype(np.float32)
+    model = bench.build_model('loglinear', models, B, n, Vw, Ve, d, d, 0, X, y, w, seed=4)
+    eng = model._engine
+    Rw0 = eng.get_tensor(C.T_RW).reshape(Vw, d).copy()
+    W0, b0 = eng.get_tensor(C.T_W).reshape(d, Ve).copy(), eng.get_tensor(C.T_B).copy()
+    ora = O.LogLinearOracle(B, n, Rw0, W0, b0, 0.01)
+    order = [(2 + i) % nb for i in range(steps)]
+    losses = []
+    for i, b in enumerate(order):
+        eng.hint_next_batch(order[i + 1] if i + 1 < steps else None)
+        losses.append(float(model.train_fn(b)))
+    eng.hint_next_batch(None)
+    eng.synchronize()
+    for i, b in enumerate(order):
+        sl = slice(b * B, (b + 1) * B)
+        ref = float(ora.train_step(X[sl], y[sl], w[sl]))
+        assert abs(losses[i] - ref) <= 1e-5 * abs(ref), (i, losses[i], ref)
+    got = {'R_w': eng.get_tensor(C.T_RW).reshape(Vw, d), 'W': eng.get_tensor(C.T_W).reshape(d, Ve), 'b': eng.get_tensor(C.T_B),
+           'accu_Rw': eng.get_tensor(C.T_STATE0_RW).reshape(Vw, d), 'delta_Rw': eng.get_tensor(C.T_STATE1_RW).reshape(Vw, d),
+           'accu_W': eng.get_tensor(C.T_STATE0_W).reshape(d, Ve), 'delta_W': eng.get_tensor(C.T_STATE1_W).reshape(d, Ve)}
+    want = {'R_w': ora.R_w, 'W': ora.W, 'b': ora.b, 'accu_Rw': ora.opt.accu[0], 'delta_Rw': ora.opt.delta[0],
+            'accu_W': ora.opt.accu[1], 'delta_W': ora.opt.delta[1]}
+    for k in sorted(want):
+        assert U.rel_err(got[k], want[k]) < 1e-4, (k, U.rel_err(got[k], want[k]))
+    err, row = U.row_err(got['R_w'], want['R_w'])
+    assert err < 1e-4, (err, row)
+    del model

@@ -28,11 +28,11 @@ inline void set_stop_event(hipEvent_t ev) { pending_stop_event() = ev; }
     } while (0)
 
 // ---- environment switches -----------------------------------------------------------------------------------
-// The PRODUCT library reads eighteen documented variables, through knob(); each is exercised by a test
+// The PRODUCT library reads nineteen documented variables, through knob(); each is exercised by a test
 // ("Environment"):
 //   SERT_DP_EXCHANGE  SERT_AR_CHUNKS  SERT_STREAMS  SERT_SIDE_HEAVY  SERT_RE_DEFER  SERT_GEMM_FP32  SERT_NO_TOUCHED
 //   SERT_SCORE_MATERIALISE  SERT_SCORE_FP32  SERT_LL_NODEDUP  SERT_LL_DW_SIDE  SERT_DENSE_HEAVY  SERT_FS_TILE_ROWS
-//   SERT_EGRAD_SORT  SERT_ROCTX  SERT_SEG_BUNDLE  SERT_EVENT_FENCE  SERT_PROJ_FUSED
+//   SERT_EGRAD_SORT  SERT_ROCTX  SERT_SEG_BUNDLE  SERT_EVENT_FENCE  SERT_PROJ_FUSED  SERT_EGRAD_RANGES
 // Everything else -- A/B variants that lost, cross-check paths of earlier rounds, tuning sweeps, timing
 // knock-outs -- is read through variant_knob(), which is the environment only in a library built with
 // -DSERT_VARIANTS (tools/build_variant.sh variants -DSERT_VARIANTS; run the suite against it with SERT_LIB=...)

@@ -82,6 +82,8 @@ struct sert_model {
     bool step_done_pending = false;  // the previous step ended without recording ev_step_done
     bool re_in_parts = false;        // this step: dR_e is still the row groups' partial tables (summed by the optimiser)
     bool fork_bound = false;         // ev_fork rides on the NCE kernel's completion signal (no record needed)
+    bool egrad_ranges = false;       // SERT_EGRAD_RANGES=1 at sert_create: the one-launch range kernel for few pairs over a mid-size table (opt-in)
+    bool egrad_force_sort = false;   // SERT_EGRAD_SORT=1 at sert_create: the sorted entity-gradient path whatever the shape
     bool lazy_join = false;          // this step: the main stream never waits for the entity chain
     int num_cus = 256;               // compute units of the device (persistent launches: one workgroup per CU)
     bool proj_fused = false;         // gather + mean-pool + projection in one launch where the shape allows (kernels_proj.h; opt-in, SERT_PROJ_FUSED=1)

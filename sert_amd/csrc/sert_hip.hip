@@ -1169,6 +1169,15 @@ static bool bwd_fused_applies(const sert_model* m) {
            m->cfg.batch_size >= 1024 && m->nstreams < 3 && (size_t)256 * (FB_D * FB_D + FB_D) <= m->part_count;
 }
 
+// Few (pair, entity) keys over a table too large for the sort-free LDS path: the one-launch range kernel instead of
+// sort + chunked reduce + fix-up (eight launches).  The scan costs ranges x pairs id reads: capped at 64 M (~256 MB out of L2).
+// OPT-IN (SERT_EGRAD_RANGES=1 at sert_create): 32 us alone against 67 for the eight launches at the product-search settings,
+// but the STEP does not move (0.202-0.207 against 0.199-0.203 ms: that chain is not what the step waits for; round 5).
+static bool egrad_ranges_ok(const sert_model* m, int total) {
+    const long long ranges = cdiv(m->cfg.num_entities, kERange);
+    return m->egrad_ranges && !m->egrad_force_sort && !m->epart && m->cfg.entity_dim % 4 == 0 && total <= (1 << 20) && ranges * (long long)total <= (64ll << 20);
+}
+
 static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) {
     const auto& c = m->cfg;
     const int B = c.batch_size, n = c.window_size, dw = c.word_dim, de = c.entity_dim;
@@ -1222,6 +1231,11 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
                 hipLaunchKernelGGL(egrad_group_sum, dim3(grid_for((int64_t)table4)), dim3(256), 0, st, m->epart, m->eg_groups,
                                    table4, m->g_re);
             }
+        } else if (egrad_ranges_ok(m, total)) {
+            // few pairs over a mid-size table: one workgroup per range of 128 entities, no sort (kernels_egrad.h: egrad_ranges)
+            ScopedTimer t(m, TG_EGRAD, st);
+            hipLaunchKernelGGL(egrad_ranges, dim3(cdiv(V, kERange)), dim3(256), 0, st, (const int32_t*)m->cand, (const float*)m->coef,
+                               (const float*)m->T, total, c.num_negatives + 1, de, V, m->g_re);
         } else {
         // dR_e: stable sort of the (entity, pair) keys, chunked reduce, carry fix-up
         {
@@ -2700,6 +2714,8 @@ static int create_resources(sert_model* m) {
                 // sort-free entity gradient for small vocabularies (kernels_egrad.h); SERT_EGRAD_SORT=1
                 // keeps the sorted path (cross-check knob)
                 const bool force_sort = knob("SERT_EGRAD_SORT") && atoi(knob("SERT_EGRAD_SORT")) != 0;   // (read per model)
+                m->egrad_force_sort = force_sort;
+                m->egrad_ranges = knob("SERT_EGRAD_RANGES") && atoi(knob("SERT_EGRAD_RANGES")) != 0;
                 const size_t c1 = c.num_negatives + 1;
                 if (!force_sort && c.kind == SERT_KIND_VECTORSPACE && V <= 2048 && de % 4 == 0 && de <= 128 &&
                     total < ((size_t)1 << 27) && c1 <= (size_t)kElSubPairs) {

@@ -238,6 +238,42 @@ def test_fused_projection_equals_the_two_launches(hip_lib, monkeypatch, dims):
     assert np.abs(got[0][1] - f['t']).max() < 2e-6
 
 
+@pytest.mark.parametrize('dims', [
+    dict(B=512, n=4, z=10, Vw=300, Ve=32768, dw=32, de=128),        # the product-search table: 256 ranges, ~22 pairs each
+    dict(B=300, n=3, z=5, Vw=200, Ve=2049, dw=16, de=36),           # just above the LDS path's 2048; last range of one entity
+    dict(B=2000, n=3, z=7, Vw=200, Ve=5000, dw=16, de=300),         # three column passes per row (75 float4 pieces)
+    dict(B=3000, n=2, z=3, Vw=50, Ve=4000, dw=8, de=16, skew=True), # every label in ONE range: 3000 pairs of one entity + the rest
+    dict(B=9000, n=2, z=0, Vw=50, Ve=3000, dw=8, de=8, skew=True),  # z = 0, 9000 pairs in one range: beyond the list, the slow walk
+])
+def test_entity_gradient_of_few_pairs_over_a_mid_size_table(hip_lib, monkeypatch, dims):
+    """kernels_egrad.h: egrad_ranges -- few (pair, entity) keys over a table above the LDS path's 2048 entities (the reference's
+    product-search regime): one launch, one workgroup per range of 128 entities (scan, LDS list, bitonic sort, one chain per
+    entity in pair order) instead of counting sort + chunked reduce + fix-up.  Row by row against the float64 oracle,
+    bit-identical run to run, equal to the sorted path (the default: the range kernel is an opt-in, SERT_EGRAD_RANGES=1 --
+    twice as fast alone, no faster as a step) up to fp32 reassociation; a range with more pairs than its list holds takes the
+    in-order walk."""
+    B, n, z, Vw, Ve, dw, de = (dims[k] for k in ('B', 'n', 'z', 'Vw', 'Ve', 'dw', 'de'))
+    p = U.make_vs_problem(21, B, n, max(z, 1), Vw, Ve, dw, de, zipf=True)
+    rng = np.random.RandomState(3)
+    if dims.get('skew'):
+        p['y'][:] = 1234                              # one entity takes every label
+    neg = rng.randint(0, Ve, size=(B, z)).astype(np.int64) if z else np.zeros((B, 0), np.int64)
+    got = []
+    for mode in ('ranges', 'ranges', 'sorted'):
+        monkeypatch.setenv('SERT_EGRAD_RANGES', '0' if mode == 'sorted' else '1')      # (opt-in, read at sert_create)
+        eng = U.vs_engine(p, B, n, z, 0.01)
+        eng.upload_dataset(C.SPLIT_TRAIN, p['X'], y_int=p['y'], w=p['w'])
+        eng.train_batch(0, neg if z else None)
+        got.append(eng.get_tensor(C.T_GRAD_RE, (Ve, de)).copy())
+        eng.close()
+    assert np.array_equal(got[0], got[1])
+    assert U.rel_err(got[0], got[2]) < 1e-5
+    o64 = O.VectorSpaceOracle(B, n, z, p['Rw'], p['Re'], p['W'], p['b'], 0.01, dtype=np.float64)
+    _, g64, _ = o64.loss_and_grads(p['X'], p['y'], p['w'], neg)
+    err, row = U.row_err(got[0], g64[0])
+    assert err < 2e-5, (err, row)
+
+
 def test_vectorspace_known_answers(hip_lib):
     """W=0,b=0 => loss = (1+z) log 2; all tokens equal => row grad = sum dh/n * n."""
     B, n, z, Vw, Ve, dw, de = 64, 4, 5, 50, 9, 16, 16

@@ -26,9 +26,12 @@ constexpr int kSortMaxBins = 1 << kSortMaxBits;
 
 __global__ __launch_bounds__(256) void csort_hist(const int32_t* __restrict__ keys, int n,
                                                   int shift, int nbins, int tiles,
-                                                  int32_t* __restrict__ hist) {
+                                                  int32_t* __restrict__ hist,
+                                                  int32_t* __restrict__ zero = nullptr, int zero_n = 0) {
     __shared__ int32_t h[kSortMaxBins];
     const int tile = blockIdx.x;
+    // the caller's per-entity run bounds, cleared ahead of the reduce that follows the sort on this stream
+    for (int i = tile * 256 + threadIdx.x; i < zero_n; i += tiles * 256) zero[i] = 0;
     for (int b = threadIdx.x; b < nbins; b += 256) h[b] = 0;
     __syncthreads();
     const int base = tile * kSortTile;

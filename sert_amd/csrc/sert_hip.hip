@@ -203,6 +203,7 @@ static void discard_run_ahead(sert_model* m) {
     m->spec_fb_batch = -1;
 }
 static int ensure_rw_current(sert_model* m, int64_t batch, int64_t t_applied = -1);
+static bool egrad_writes_every_row(const sert_model* m);
 static void invalidate_speculation(sert_model* m) {
     discard_run_ahead(m);
     (void)ensure_rw_current(m, -1);   // (whatever comes next -- new parameters, another step counter, new data -- sees every row current)
@@ -471,8 +472,11 @@ static int entity_key_sort(sert_model* m, int total, hipStream_t st) {
         const bool to_final = ((passes - 1 - p) % 2) == 0;
         int32_t* kout = to_final ? m->cand_sorted : m->sort_k_tmp;
         int32_t* vout = to_final ? m->pair_sorted : m->sort_v_tmp;
+        // (first digit: also clears run_start / run_end, which the chunked reduce only writes for entities it meets --
+        //  a step whose negatives were drawn ahead has no prologue launch to clear them)
         hipLaunchKernelGGL(csort_hist, dim3(tiles), dim3(256), 0, st, kin, total, shift, 1 << nb,
-                           tiles, m->sort_hist);
+                           tiles, m->sort_hist, p == 0 ? m->run_start : (int32_t*)nullptr,
+                           p == 0 ? (int)(2 * round_up(m->cfg.num_entities, 4)) : 0);
         hipLaunchKernelGGL(csort_scan_bins, dim3(cdiv(1 << nb, 4)), dim3(256), 0, st,
                            m->sort_hist, 1 << nb, tiles, m->sort_bin_total);
         hipLaunchKernelGGL(csort_scatter, dim3(tiles), dim3(256), 0, st, kin, vin, kout, vout,
@@ -2097,7 +2101,8 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
         }
     }
     if (exchanged) SERT_HIP(hipStreamWaitEvent(m->stream, m->ev_ar_done, 0));
-    if (side_small && m->epart && c.kind == SERT_KIND_VECTORSPACE && c.num_negatives > 0 && m->neg_alt_step != m->step) {
+    if (side_small && egrad_writes_every_row(m) && c.kind == SERT_KIND_VECTORSPACE && !is_fs(m) && c.num_negatives > 0 && !c.keep_grads &&
+        m->neg_alt_step != m->step) {
         // the next step's negatives (Philox position = the step counter after this update), drawn
         // here on the side stream unless the step's forward already drew them in front of its fork:
         // ev_small below orders them before anything of the next step
@@ -2263,6 +2268,10 @@ static size_t zero_from(const sert_model* m) {
     return m->ar_split;
 }
 
+// The entity-gradient chain writes EVERY row of dR_e (the sort-free path by construction, the sorted one through its fix-up):
+// a step whose negatives were drawn ahead then needs no prologue launch at all.
+static bool egrad_writes_every_row(const sert_model* m) { return m->epart != nullptr || zero_from(m) > m->ar_split; }
+
 static bool fused_prologue_applies_with(const sert_model* m, bool touched) {
     return is_vs(m) && !is_fs(m) && !m->timing.enabled && m->nstreams >= 2 && touched &&
            m->cfg.num_negatives > 0 && (m->gflat_alloc - zero_from(m)) % 4 == 0;
@@ -2306,7 +2315,9 @@ static int step_forward_backward(sert_model* m, const DataSplit& ds, int64_t bat
     // negatives: no side-stream prologue, no cross-queue wait in front of the loss kernel.
     // negatives drawn at the end of the previous step for exactly this step: nothing to do (the
     // sort-free entity-gradient path needs no zeroed buffer either: every row it owns is written)
-    const bool have_neg = negatives == nullptr && m->epart && m->neg_alt_step == m->step && side_pre &&
+    // (round 5: also behind the SORTED chain of a big entity table -- the product-search settings, C4 --, whose steps used to
+    //  start with a sampler + zeroing launch on the main stream, 6 us + a queue bubble: nothing it zeroed is read there)
+    const bool have_neg = negatives == nullptr && egrad_writes_every_row(m) && m->neg_alt_step == m->step && side_pre &&
                           fused_prologue_applies(m);
     if (have_neg) {
         std::swap(m->neg, m->neg_alt);

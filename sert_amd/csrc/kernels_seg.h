@@ -238,7 +238,13 @@ __global__ __launch_bounds__(256) void segsum_rows_bundled(const float* __restri
 // Scalar variant for d % 4 != 0 (and for scalars, d = 1): one wave per (item, 64-column group),
 // gridDim.y column groups; four entries in flight per trip.  Same summation order as one entry
 // at a time (left to right), so the result does not depend on the unrolling.
-template <bool DST_SLOT = false>
+// LL (loglinear, odd V_e; kernels_ll.h: dZu = mask dJsum - P rsum): every wave also sums its item's scalars r_ik
+// (rsrc / rrows: the same item list over the per-occurrence scalars -- one entry per lane and wave_sum, exactly
+// segsum_scalar_wave's additions), column group 0 stores that sum, and a word's FINAL row is stored as
+//   mask(lp) * acc - exp(lp) * rsum,  lp = logp[slot, :]
+// -- the expression of ll_dzu_combine -- so that neither the two scalar launches nor the combine launch exist
+// (W3C settings, 715 experts: three launches of ~5 us each in an 16-launch chain).
+template <bool DST_SLOT = false, bool LL = false>
 __global__ __launch_bounds__(256) void segsum_rows_scalar(const float* __restrict__ src,
                                                           const int32_t* __restrict__ rows,
                                                           const int4* __restrict__ items,
@@ -246,12 +252,31 @@ __global__ __launch_bounds__(256) void segsum_rows_scalar(const float* __restric
                                                           float* __restrict__ partial_dst, int d,
                                                           float divisor,
                                                           unsigned char* __restrict__ touched,
-                                                          int rdiv = 1) {
+                                                          int rdiv = 1,
+                                                          const float* __restrict__ logp = nullptr,
+                                                          const float* __restrict__ rsrc = nullptr,
+                                                          const int32_t* __restrict__ rrows = nullptr,
+                                                          float* __restrict__ rsum = nullptr,
+                                                          float* __restrict__ rpart = nullptr) {
     const int lane = threadIdx.x & 63;
     const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (item >= nitems) return;
     const int4 it = items[item];
     if (touched && lane == 0 && blockIdx.y == 0 && it.z >= 0) touched[it.z] = 1;
+    float rs = 0.f;
+    if (LL) {
+        for (int e0 = it.x; e0 < it.y; e0 += 64) {      // (one trip: chunks hold <= 64 entries)
+            const int e = e0 + lane;
+            float v = 0.f;
+            if (e < it.y) v = rsrc[rrows ? rrows[e] : e];
+            rs += wave_sum(v);
+        }
+        if (lane == 0 && blockIdx.y == 0) {
+            if (it.z >= 0) rsum[it.w] = rs;
+            else rpart[-(it.z + 1)] = rs;
+        }
+    }
+    const float LOGLO = logf(SERT_CLIP_LO), LOGHI = logf(SERT_CLIP_HI);
     for (int c = blockIdx.y * 64 + lane; c < d; c += 64 * gridDim.y) {
         float a = 0.f;
         int e = it.x;
@@ -268,8 +293,16 @@ __global__ __launch_bounds__(256) void segsum_rows_scalar(const float* __restric
             const int r = rows ? (rdiv > 1 ? rows[e] / rdiv : rows[e]) : e;
             a += src[(size_t)r * d + c];
         }
-        if (it.z >= 0) final_dst[(size_t)(DST_SLOT ? it.w : it.z) * d + c] = a / divisor;
-        else partial_dst[(size_t)(-(it.z + 1)) * d + c] = a;
+        if (it.z >= 0) {
+            const size_t t = (size_t)(DST_SLOT ? it.w : it.z) * d + c;
+            if (LL) {
+                const float lp = logp[t];
+                const float dj = (lp >= LOGLO && lp <= LOGHI) ? a : 0.f;
+                final_dst[t] = dj - __expf(lp) * rs;
+            } else {
+                final_dst[t] = a / divisor;
+            }
+        } else partial_dst[(size_t)(-(it.z + 1)) * d + c] = a;
     }
 }
 

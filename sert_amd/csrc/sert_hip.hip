@@ -397,8 +397,11 @@ static int word_grad_segsum(sert_model* m, const DataSplit& ds, int64_t batch_in
 static int dzu_from_dj(sert_model* m, const DataSplit& ds, int64_t batch_index) {
     const int V = m->cfg.num_entities;
     const BatchIndex& bx = ds.idx_batches[(size_t)batch_index];
+    // odd V_e: the scalar sums and the finishing expression ride the V_e-wide launches (kernels_seg.h: segsum_rows_scalar<true, true>)
+    static const bool split_odd = variant_knob("SERT_LL_DZU_SPLIT") != nullptr;   // the three extra launches, for A/B
+    const bool fused_odd = V % 4 != 0 && !split_odd;
     // the scalars first: the V_e-wide pass applies them when it stores a word's final row
-    for (int l = 0; l < bx.nlevels; ++l) {
+    for (int l = 0; l < bx.nlevels && !fused_odd; ++l) {
         const int nitems = bx.item_cnt[l];
         if (nitems == 0) continue;
         const int32_t* rows = (l == 0) ? ds.idx_rows + bx.rows_off : nullptr;
@@ -429,6 +432,12 @@ static int dzu_from_dj(sert_model* m, const DataSplit& ds, int64_t batch_index) 
                                m->stream, in, rows, items, nitems, m->dZu, pout, V, 1.0f,
                                (unsigned char*)nullptr, 1, (const float*)m->Zu,
                                (const float*)m->ll_rsum);
+        } else if (fused_odd) {
+            hipLaunchKernelGGL((segsum_rows_scalar<true, true>), dim3(cdiv(nitems, 4), cdiv(V, 64)), dim3(256), 0, m->stream, in,
+                               rows, items, nitems, m->dZu, pout, V, 1.0f, (unsigned char*)nullptr, 1, (const float*)m->Zu,
+                               (const float*)((l == 0) ? m->ll_r : m->ll_rpart + (size_t)bx.part_off[l - 1]),
+                               (l == 0) ? (const int32_t*)(ds.idx_rows + bx.rows_off) : (const int32_t*)nullptr,
+                               m->ll_rsum, m->ll_rpart + (size_t)bx.part_off[l]);
         } else {
             hipLaunchKernelGGL((segsum_rows_scalar<true>), dim3(cdiv(nitems, 4), cdiv(V, 64)), dim3(256), 0, m->stream, in,
                                rows, items, nitems, m->dZu, pout, V, 1.0f, (unsigned char*)nullptr, 1);
@@ -451,7 +460,7 @@ static int dzu_from_dj(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         hipLaunchKernelGGL(segsum_heavy_combine_ll, dim3(bx.dense_cnt, cdiv(d4, 32)), dim3(256), 0, m->stream,
                            (const float*)m->hpart, nblk, V, dsl, m->dZu, (const float*)m->Zu, (const float*)m->ll_rsum);
     }
-    if (V % 4 != 0)   // (odd V_e: separate finishing pass)
+    if (V % 4 != 0 && !fused_odd)   // (odd V_e, split form: separate finishing pass)
         hipLaunchKernelGGL(ll_dzu_combine, dim3(grid_for((int64_t)m->ll_U * V)), dim3(256), 0, m->stream, m->dZu,
                            (const float*)m->Zu, (const float*)m->ll_rsum, (int64_t)m->ll_U, V);
     return 0;

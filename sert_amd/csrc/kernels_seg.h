@@ -343,9 +343,9 @@ __global__ __launch_bounds__(1024) void segsum_upper_fused(const float* __restri
                                                            float* __restrict__ final_dst, int d, float divisor) {
     __shared__ float4 red[64][32];
     const int sub = threadIdx.x >> 5, l = threadIdx.x & 31;
-    const int chunks = d >> 2;               // <= 32
-    const bool on = l < chunks;
-    const int c = on ? l : 0;
+    const int chunks = d >> 2;               // 32 float4 columns per blockIdx.y (d = 300: three column slabs)
+    const bool on = (int)blockIdx.y * 32 + l < chunks;
+    const int c = on ? (int)blockIdx.y * 32 + l : 0;
     auto sum_rows = [&](int lo, int hi) -> float4 {
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
         int e = lo;

@@ -320,7 +320,7 @@ static int word_grad_segsum(sert_model* m, const DataSplit& ds, int64_t batch_in
     const BatchIndex& bx = ds.idx_batches[(size_t)batch_index];
     unsigned char* touched = nullptr;   // (row flags are static per batch: DataSplit::idx_touched_bits)
     static const bool no_fused_upper = variant_knob("SERT_SEG_NO_FUSED_UPPER") != nullptr;   // cross-check knob
-    const bool fused_upper = !no_fused_upper && bx.fused_upper_ok && ds.idx_heavy && d % 4 == 0 && d / 4 <= 32 &&
+    const bool fused_upper = !no_fused_upper && bx.fused_upper_ok && ds.idx_heavy && d % 4 == 0 &&
                              bx.nlevels == 3 && bx.item_cnt[1] > 0;
     // the batch's heavy words: one streaming pass over src for all of them (kernels_seg.h: segsum_heavy)
     // (vectorspace only: a loglinear index marks dense words for the V_e-wide per-word sums of dzu_from_dj; its
@@ -342,7 +342,7 @@ static int word_grad_segsum(sert_model* m, const DataSplit& ds, int64_t batch_in
         if (fused_upper && l == 1) {
             // levels 1 and 2 in one launch (kernels_seg.h: segsum_upper_fused)
             const int nb_normal = cdiv(nitems, 32);
-            hipLaunchKernelGGL(segsum_upper_fused, dim3(nb_normal + bx.heavy_cnt), dim3(1024), 0, m->stream,
+            hipLaunchKernelGGL(segsum_upper_fused, dim3(nb_normal + bx.heavy_cnt, cdiv(d / 4, 32)), dim3(1024), 0, m->stream,
                                m->wpart + (size_t)bx.part_off[0] * d, ds.idx_items + bx.item_off[1], nitems, nb_normal,
                                ds.idx_heavy + bx.heavy_off, m->g_rw, d, divisor);
             break;

@@ -371,6 +371,184 @@ __global__ __launch_bounds__(256) void dense_update_lazy(float* __restrict__ p, 
     }
 }
 
+// ---- ... and without READING the rows nobody needs ------------------------------------------------------------------
+// dense_update_lazy still reads p, m, v of every row every step: sum(p^2) of the loss needs the current value of each
+// (12 B per element: the product-search settings' 75-85 us, W3C's 65, C4's 530).  But a row nobody touches follows its
+// zero-gradient trajectory, and that trajectory is known when the row is WRITTEN: the launch that writes a row at state
+// u also leaves the row's share of sum(p^2) for the updates u + 1 .. T - 1 (T = the next update that reads everything,
+// at most kLazyK ahead) in pred[update % kLazyK][row] -- the row sum of p^2 along up to kLazyK - 2 further zero-gradient
+// updates in registers, the same adam_elem / adadelta_elem calls on the same inputs the catch-up loop will make later,
+// hence the same bits.  A later launch that does not need the row adds pred[...] instead of reading 12 d bytes.
+//   * One lane group (32 or 64 lanes) per row; a lane owns float4 columns l, l + LPR, ...; the row's sum of squares is the
+//     lanes' fma chains (x, y, z, w, column by column) reduced in a fixed lane order, and a workgroup's partial is the sum
+//     of its groups' row sums in row order.  A predicted row sum is bit for bit the one a launch that read the row would
+//     have formed, so the partials -- and the loss -- do not depend on which rows were skipped, on the hints or on where
+//     the full passes fall.  (They differ from adam_l2's element-order partials in the last bits: a different summation
+//     tree over the same squares.  Parameters and optimiser state are the same bits as the dense launches'.)
+//   * lz.write_all (full pass): every row is read, brought forward and written -- no prediction is consulted.
+//   * The flush (LazyArgs::update = 0) stays with dense_update_lazy: predictions are indexed by update number and a
+//     flush moves rows ALONG their trajectories, so they stay valid behind it.
+struct SkipArgs {
+    float* pred;             // [kLazyK][stride]
+    unsigned stride;
+    int npred;               // a written row leaves predictions for the updates t_prev + 2 .. t_prev + 1 + npred
+    float a_fut[kLazyK];     // Adam: step size of update t_prev + 2 + j
+};
+
+template <int LPR>
+__device__ __forceinline__ float lane_group_sum(float v, int lane) {
+    v = row16_sum(v);
+    const float lo = read_lane(v, 0) + read_lane(v, 16), hi = read_lane(v, 32) + read_lane(v, 48);
+    if (LPR == 64) return lo + hi;
+    return lane < 32 ? lo : hi;
+}
+
+template <bool ADAM, int LPR, int CPL>
+__global__ __launch_bounds__(256) void dense_update_skip(float* __restrict__ p, const float* __restrict__ g,
+                                                         float* __restrict__ s0, float* __restrict__ s1, unsigned nrows,
+                                                         AdamArgs a, AdadeltaArgs da, float* __restrict__ sumsq_partial,
+                                                         const uint32_t* __restrict__ bits, unsigned row_len, const LazyArgs lz,
+                                                         const SkipArgs sk) {
+    constexpr int GPB = 256 / LPR;      // lane groups = rows in flight per workgroup
+    __shared__ float red[GPB];
+    const int lane = threadIdx.x & 63, l = threadIdx.x & (LPR - 1), grp = threadIdx.x / LPR;
+    const float omb1 = 1.0f - a.b1, omb2 = 1.0f - a.b2, omr = 1.0f - da.rho;
+    const unsigned d4 = row_len >> 2;
+    const unsigned per = (nrows + gridDim.x - 1) / gridDim.x;
+    const unsigned lo = blockIdx.x * per;
+    const unsigned hi = lo + per < nrows ? lo + per : nrows;
+    const int slot_now = (lz.t_prev + 1) % kLazyK;
+    typedef float nt_f4 __attribute__((ext_vector_type(4)));
+    float4* p4 = reinterpret_cast<float4*>(p);
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    float acc = 0.f;                    // this group's row sums, added in row order (the same value in every lane of the group)
+    // rows of this group: lo + grp, lo + grp + GPB, ...; the first group of a wave has the most
+    const unsigned cnt = hi > lo + grp ? (hi - lo - grp + GPB - 1) / GPB : 0u;
+    const unsigned cnt_w = (unsigned)__builtin_amdgcn_readfirstlane((int)cnt);
+    for (unsigned j0 = 0; j0 < cnt_w; j0 += LPR) {
+        // what to do with the next LPR rows of the group: one row per lane (bitmaps, update counter, prediction)
+        const unsigned jm = j0 + l;
+        const unsigned row_m = lo + grp + jm * GPB;
+        int flags_m = 0, last_m = lz.t_prev;
+        float pred_m = 0.f;
+        if (jm < cnt) {
+            last_m = lz.last_in ? lz.last_in[row_m] : lz.t_prev;
+            const bool hit_m = row_bit(bits, row_m);
+            const bool need_m = hit_m || lz.write_all || (lz.next_bits && row_bit(lz.next_bits, row_m));
+            lz.last_out[row_m] = need_m ? lz.t_prev + 1 : last_m;
+            if (!need_m) pred_m = sk.pred[(size_t)slot_now * sk.stride + row_m];
+            flags_m = 1 | (hit_m ? 2 : 0) | (need_m ? 4 : 0);
+        }
+        const unsigned trips = cnt_w - j0 < (unsigned)LPR ? cnt_w - j0 : (unsigned)LPR;
+        for (unsigned jj = 0; jj < trips; ++jj) {
+            const int flags = __shfl(flags_m, (int)jj, LPR);
+            const int last = __shfl(last_m, (int)jj, LPR);
+            const float predv = __shfl(pred_m, (int)jj, LPR);
+            const bool valid = flags & 1, hit = flags & 2, proc = (flags & 5) == 5;
+            if (!__any(proc)) {          // (wave-uniform) nothing to read: the predicted shares
+                if (valid) acc += predv;
+                continue;
+            }
+            const unsigned row = lo + grp + (j0 + jj) * GPB;
+            const int lag = proc ? lz.t_prev - last : 0;
+            float4 pp[CPL], mm[CPL], vv[CPL];
+            bool on[CPL];
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                on[c] = proc && (unsigned)(l + c * LPR) < d4;
+                pp[c] = mm[c] = vv[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (on[c]) {
+                    const size_t i = (size_t)row * d4 + l + c * LPR;
+                    pp[c] = p4[i];
+                    const nt_f4 mr = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(s0) + i);
+                    const nt_f4 vr = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(s1) + i);
+                    mm[c] = make_float4(mr.x, mr.y, mr.z, mr.w);
+                    vv[c] = make_float4(vr.x, vr.y, vr.z, vr.w);
+                }
+            }
+            // one zero-gradient update of the lane's columns with Adam step size at; s collects the squares BEFORE it
+            auto advance = [&](float at, float& s) {
+                float sn = 0.f;
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) {
+                    if (!on[c]) continue;
+                    float z0 = 0.f, z1 = 0.f, z2 = 0.f, z3 = 0.f;
+                    if (ADAM) {
+                        AdamArgs ak = a;
+                        ak.a_t = at;
+                        adam_elem(pp[c].x, z0, mm[c].x, vv[c].x, ak, omb1, omb2, s, sn);
+                        adam_elem(pp[c].y, z1, mm[c].y, vv[c].y, ak, omb1, omb2, s, sn);
+                        adam_elem(pp[c].z, z2, mm[c].z, vv[c].z, ak, omb1, omb2, s, sn);
+                        adam_elem(pp[c].w, z3, mm[c].w, vv[c].w, ak, omb1, omb2, s, sn);
+                    } else {
+                        adadelta_elem(pp[c].x, z0, mm[c].x, vv[c].x, da, omr, s);
+                        adadelta_elem(pp[c].y, z1, mm[c].y, vv[c].y, da, omr, s);
+                        adadelta_elem(pp[c].z, z2, mm[c].z, vv[c].z, da, omr, s);
+                        adadelta_elem(pp[c].w, z3, mm[c].w, vv[c].w, da, omr, s);
+                    }
+                }
+            };
+            // catch-up: the updates last + 1 .. t_prev the row sat out
+            for (int k = kLazyK; k >= 1; --k) {
+                if (k <= lag) { float sd = 0.f; advance(lazy_step_size(lz, k), sd); }
+            }
+            // this step's update
+            float s = 0.f;
+            {
+                float sn = 0.f;
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) {
+                    if (!on[c]) continue;
+                    const size_t i = (size_t)row * d4 + l + c * LPR;
+                    float4 gg = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (hit) gg = g4[i];
+                    if (ADAM) {
+                        AdamArgs ak = a;
+                        ak.a_t = lz.a_of[0];
+                        adam_elem(pp[c].x, gg.x, mm[c].x, vv[c].x, ak, omb1, omb2, s, sn);
+                        adam_elem(pp[c].y, gg.y, mm[c].y, vv[c].y, ak, omb1, omb2, s, sn);
+                        adam_elem(pp[c].z, gg.z, mm[c].z, vv[c].z, ak, omb1, omb2, s, sn);
+                        adam_elem(pp[c].w, gg.w, mm[c].w, vv[c].w, ak, omb1, omb2, s, sn);
+                    } else {
+                        adadelta_elem(pp[c].x, gg.x, mm[c].x, vv[c].x, da, omr, s);
+                        adadelta_elem(pp[c].y, gg.y, mm[c].y, vv[c].y, da, omr, s);
+                        adadelta_elem(pp[c].z, gg.z, mm[c].z, vv[c].z, da, omr, s);
+                        adadelta_elem(pp[c].w, gg.w, mm[c].w, vv[c].w, da, omr, s);
+                    }
+                    p4[i] = pp[c];
+                    { nt_f4 t; t.x = mm[c].x; t.y = mm[c].y; t.z = mm[c].z; t.w = mm[c].w; __builtin_nontemporal_store(t, reinterpret_cast<nt_f4*>(s0) + i); }
+                    { nt_f4 t; t.x = vv[c].x; t.y = vv[c].y; t.z = vv[c].z; t.w = vv[c].w; __builtin_nontemporal_store(t, reinterpret_cast<nt_f4*>(s1) + i); }
+                }
+            }
+            const float rowsum = lane_group_sum<LPR>(s, lane);
+            if (valid) acc += proc ? rowsum : predv;
+            // the written row's shares of sum(p^2) while nobody reads it
+            for (int q = 1; q <= sk.npred; ++q) {
+                float s2 = 0.f;
+                if (q < sk.npred) {
+                    advance(sk.a_fut[q - 1], s2);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < CPL; ++c) {
+                        if (!on[c]) continue;
+                        s2 = sq_acc(s2, pp[c].x); s2 = sq_acc(s2, pp[c].y); s2 = sq_acc(s2, pp[c].z); s2 = sq_acc(s2, pp[c].w);
+                    }
+                }
+                const float r = lane_group_sum<LPR>(s2, lane);
+                if (proc && l == 0) sk.pred[(size_t)((lz.t_prev + 1 + q) % kLazyK) * sk.stride + row] = r;
+            }
+        }
+    }
+    if (l == 0) red[grp] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = red[0];
+#pragma unroll
+        for (int i = 1; i < GPB; ++i) t += red[i];
+        sumsq_partial[blockIdx.x] = t;
+    }
+}
+
 // The small tensors (entity table at small V_e, dense W, bias) in ONE launch: a
 // kernel boundary costs more than updating them.  Block b works on the tensor
 // whose block range contains it; partial sums of squares of non-regularised

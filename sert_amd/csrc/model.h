@@ -114,6 +114,12 @@ struct sert_model {
     int64_t rw_ready_batch = -1;   // while stale: the training batch whose rows ARE current (the hinted one)
     int64_t lazy_next = -1;        // the batch the caller announced to follow the one being trained
     float cur_touched_frac = 1.f;  // distinct words of the batch being trained / vocabulary
+    // dense_update_skip (kernels_opt.h): per-row shares of sum(p^2) along the zero-gradient trajectory, [kLazyK][stride]
+    float* rw_pred = nullptr;
+    unsigned rw_pred_stride = 0;
+    bool rw_pred_ok = false;       // every row that is behind has its predictions up to (not including) update rw_pred_T
+    int64_t rw_pred_T = 0;         // the next update that reads every row
+    bool lazy_skip = true;         // SERT_LAZY_SKIP=0: dense_update_lazy (reads every row every step)
     int64_t projected_batch = -1;  // training batch whose forward projection already sits in H/T
     // hinted single-GPU steps go further: the whole forward + backward runs ahead
     int64_t spec_fb_batch = -1;    // forward + backward of this batch already ran (gradients ready) ...

@@ -214,6 +214,7 @@ static void invalidate_speculation(sert_model* m) {
     m->re_sq_for[0] = m->re_sq_for[1] = -1;
     m->projected_batch = -1;
     m->neg_alt_step = -1;      // (step counter, seed-relevant state or data may change)
+    m->rw_pred_ok = false;     // (the rows' predicted shares of sum(p^2) are trajectories of THESE parameters and THIS step counter)
 }
 
 // ---- lazy dense update of the word table (kernels_opt.h: dense_update_lazy) ----------------------------------------
@@ -2037,6 +2038,42 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
                 LazyArgs lz = lazy_args(m, m->step - 1, /*update=*/1);
                 lz.next_bits = next_bits;
                 lz.write_all = (next_bits == nullptr || m->step % kLazyK == 0) ? 1 : 0;
+                const unsigned d4 = (unsigned)c.word_dim / 4;
+                if (m->lazy_skip && m->rw_pred && d4 <= 256) {
+                    // rows nobody needs are not read either (kernels_opt.h: dense_update_skip): a full pass when there are no
+                    // valid predictions (first lazy step, behind a dense step or new parameters, no hint) and kLazyK updates
+                    // after the last one
+                    const int64_t u = m->step;                      // the update being applied
+                    const bool sparse = next_bits && m->rw_pred_ok && u < m->rw_pred_T;
+                    lz.write_all = sparse ? 0 : 1;
+                    if (!sparse) m->rw_pred_T = u + kLazyK;
+                    SkipArgs sk;
+                    sk.pred = m->rw_pred;
+                    sk.stride = m->rw_pred_stride;
+                    sk.npred = next_bits ? (int)(m->rw_pred_T - 1 - u) : 0;
+                    for (int j = 0; j < kLazyK; ++j) {
+                        AdamArgs a2; AdadeltaArgs d2;
+                        optimizer_args(m, u + 1 + j, &a2, &d2);
+                        sk.a_fut[j] = a2.a_t;
+                    }
+                    m->rw_pred_ok = next_bits != nullptr;
+                    const unsigned nrows = (unsigned)c.vocab_size;
+#define SERT_SKIP_LAUNCH(ADAM, LPR, CPL)                                                                                   \
+    hipLaunchKernelGGL((dense_update_skip<ADAM, LPR, CPL>), dim3(nb), dim3(256), 0, m->stream, t.p, (const float*)t.g, t.s0, \
+                       t.s1, nrows, aa, da, m->red_sq + n_sq, tf, (unsigned)c.word_dim, lz, sk)
+#define SERT_SKIP_SHAPE(ADAM)                                        \
+    do {                                                             \
+        if (d4 <= 32) SERT_SKIP_LAUNCH(ADAM, 32, 1);                 \
+        else if (d4 <= 64) SERT_SKIP_LAUNCH(ADAM, 64, 1);            \
+        else if (d4 <= 128) SERT_SKIP_LAUNCH(ADAM, 64, 2);           \
+        else if (d4 <= 192) SERT_SKIP_LAUNCH(ADAM, 64, 3);           \
+        else SERT_SKIP_LAUNCH(ADAM, 64, 4);                          \
+    } while (0)
+                    if (is_vs(m)) SERT_SKIP_SHAPE(true);
+                    else SERT_SKIP_SHAPE(false);
+#undef SERT_SKIP_SHAPE
+#undef SERT_SKIP_LAUNCH
+                } else
                 if (is_vs(m))
                     hipLaunchKernelGGL((dense_update_lazy<true>), dim3(nb), dim3(256), 0, m->stream, t.p, (const float*)t.g, t.s0, t.s1, t.n,
                                        aa, da, m->red_sq + n_sq, tf, (unsigned)c.word_dim, lz);
@@ -2049,6 +2086,7 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
                 n_sq += nb;
                 continue;
             }
+            if (i == 0) m->rw_pred_ok = false;   // (a dense launch moves every row off its predicted trajectory)
             if (i == 0) SERT_TRY(ensure_rw_current(m, -1, m->step - 1));    // (a dense launch assumes every row is at the previous step; m->step is already this update's number)
             // (side_heavy: the entity table streams on the side stream, behind its gradient chain.  Loglinear with dW on the
             //  side stream: a W large enough to be a "big tensor" -- d x V_e >= 2^22, C4 -- is updated THERE, behind dW and
@@ -2649,6 +2687,7 @@ static int create_resources(sert_model* m) {
     // (ev_loss is waited on by the HOST and keeps them; so do the events of a communicator, whose consumers may be peers.)
     // (opt-in: measured SLOWER than the two launches at C2 -- 53 us against 25 + 25 -- and equal at 8192 rows; kernels_proj.h)
     m->proj_fused = knob("SERT_PROJ_FUSED") && atoi(knob("SERT_PROJ_FUSED")) != 0;
+    m->lazy_skip = !(knob("SERT_LAZY_SKIP") && atoi(knob("SERT_LAZY_SKIP")) == 0);
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->cfg.device) != hipSuccess || cus <= 0) cus = 256;
@@ -2697,6 +2736,8 @@ static int create_resources(sert_model* m) {
         if (!no_lazy && c.word_dim % 4 == 0) {
             SERT_TRY(dzalloc(&m->rw_last[0], (size_t)c.vocab_size, s));
             SERT_TRY(dzalloc(&m->rw_last[1], (size_t)c.vocab_size, s));
+            m->rw_pred_stride = (unsigned)round_up((size_t)c.vocab_size, 64);
+            SERT_TRY(dzalloc(&m->rw_pred, (size_t)kLazyK * m->rw_pred_stride, s));
         }
         SERT_TRY(layout_gradients(m));
         SERT_TRY(dzalloc(&m->rowloss, B, s));
@@ -2853,7 +2894,7 @@ int sert_destroy(sert_model* m) {
     }
     (void)hipFree(m->sq_scratch);
     (void)hipFree(m->tail_blk);
-    (void)hipFree(m->rw_last[0]); (void)hipFree(m->rw_last[1]);
+    (void)hipFree(m->rw_last[0]); (void)hipFree(m->rw_last[1]); (void)hipFree(m->rw_pred);
     xr_free_lists(m);
     if (m->ev_params_ready) (void)hipEventDestroy(m->ev_params_ready);
     if (m->ev_word_updated) (void)hipEventDestroy(m->ev_word_updated);

@@ -59,22 +59,25 @@ def glorot(rng, shape):
     return rng.uniform(-a, a, size=shape).astype(np.float32)
 
 
-LAZY_MAX_TOUCHED, LAZY_K = 0.35, 4      # kernels_opt.h: kLazyK; sert_hip.hip: lazy_max
+LAZY_MAX_TOUCHED, LAZY_K = 0.5, 4       # sert_hip.hip: SERT_LAZY_MAX behind an announced next batch; kernels_opt.h: kLazyK
 
 
 def lazy_fractions(X, B, num_batches, Vw, dw):
-    """The word-table update is LAZY where a batch touches <= 35 % of the rows (kernels_opt.h: dense_update_lazy): a row
-    that neither the batch nor the announced next one touches is read (p and both moments: its share of sum(p^2)) but not
-    written, except every 4th update.  Returns None where the dense launch runs, else the fractions of rows touched /
-    written per step for the cyclic batch order of the timed loop -- what the launch really moves."""
+    """The word-table update is LAZY where a batch touches <= 50 % of the rows and the next batch is announced (the timed
+    loop announces every batch; kernels_opt.h: dense_update_skip): a row that neither the batch nor the announced next one
+    touches is neither read nor written -- its share of sum(p^2) was left behind by the launch that wrote it -- except every
+    4th update, which reads and writes every row.  Returns the fractions of rows touched / moved (read AND written) per
+    step for the cyclic batch order of the timed loop -- what the launch really moves."""
     nb = min(num_batches, 8)          # (a sample of the batches: the fractions vary by < 1 % between batches of one stream)
     sets = [np.unique(X[j * B:(j + 1) * B]) for j in range(nb)]
     f_t = float(np.mean([len(u) for u in sets])) / Vw
-    if f_t > LAZY_MAX_TOUCHED or Vw * dw < (1 << 22):
+    lazy_off = os.environ.get('SERT_LAZY_SKIP', '1') in ('0',)
+    lazy_max = float(os.environ.get('SERT_LAZY_MAX', LAZY_MAX_TOUCHED))
+    if f_t > lazy_max or Vw * dw < (1 << 22):
         # the dense launch (adam_l2 with the row filter): p, m, v read and written for every row, g read for touched rows only
         return {'lazy': False, 'touched': f_t}
     f_u = float(np.mean([len(np.union1d(sets[j], sets[(j + 1) % nb])) for j in range(nb)])) / Vw
-    return {'lazy': True, 'touched': f_t, 'written': f_u + (1.0 - f_u) / LAZY_K}
+    return {'lazy': True, 'touched': f_t, 'written': f_u + (1.0 - f_u) / LAZY_K, 'reads_every_row': lazy_off}
 
 
 def x3_applies(M, N, K, ta=False):
@@ -117,11 +120,14 @@ def group_work(kind, B, n, s, dw, de, Ve, Vw, z, distinct_words=None, shards=1, 
         kind='rows', alg=alg, fetch=fetch, row_bytes=row_bytes, table_bytes=table_bytes, resident=resident)
     # data parallel: a rank's dense update covers the word-table rows it owns (1/shards of them)
     P_w = 32.0 * Vw * dw / shards
-    # lazy launch (single GPU, sparse batches): 12 B read per element, 12 B written and 4 B of gradient read only for the
-    # rows that are materialised / touched -- the bytes THIS launch's algorithm moves (the reference's dense update: 32 B)
+    # lazy launch (single GPU): 12 B read + 12 B written per element of the rows that are moved (this batch's, the next
+    # batch's, every row every 4th update), 4 B of gradient for the touched ones -- the bytes THIS launch's algorithm moves,
+    # averaged over the cycle of four launches (the reference's dense update: 32 B)
     lazy_note = None
     if lazy is not None and shards == 1 and lazy.get('lazy'):
-        lazy_note = dict(lazy, reference_dense_bytes=P_w, bytes_per_element=12.0 + 12.0 * lazy['written'] + 4.0 * lazy['touched'])
+        # (dense_update_skip: 24 B per element of a row that is moved; SERT_LAZY_SKIP=0 -- dense_update_lazy -- reads all 12 B always)
+        lazy_note = dict(lazy, reference_dense_bytes=P_w,
+                         bytes_per_element=(12.0 + 12.0 * lazy['written'] if lazy.get('reads_every_row') else 24.0 * lazy['written']) + 4.0 * lazy['touched'])
         P_w = Vw * dw * lazy_note['bytes_per_element']
     elif lazy is not None and shards == 1:
         # dense launch: 12 B read + 12 B written per element, 4 B of gradient for the rows the batch touches (the others have
@@ -191,16 +197,16 @@ KERNELS_OF_GROUP = {
         'gemm_fwd': ('gemm_x3<false, false, 2', 'gemm_f32_mfma<false, false, 2', 'gemm_f32_mfma_small<false, 2', 'gemm_f32_mfma_n160<false, false, 2'),
         'loss': ('vs_nce_regs', 'vs_nce'), 'entity_sort': ('egrad_bucket', 'csort_scatter'),
         'entity_grad_reduce': ('egrad_acc', 'egrad_chunk_reduce'),
-        'entity_grad_fixup': ('egrad_group_sum', 'egrad_fixup'), 'optimizer_word_table': ('dense_update_lazy', 'adam_l2')}),
+        'entity_grad_fixup': ('egrad_group_sum', 'egrad_fixup'), 'optimizer_word_table': ('dense_update_skip', 'dense_update_lazy', 'adam_l2')}),
     'vectorspace_softmax': dict(_COMMON_KERNELS, **{
         'gather': ('vs_gather_mean',), 'gemm_fwd': ('gemm_x3<false, false, 2', 'gemm_x3<false, true, 0', 'gemm_f32_mfma<false, false, 0', 'gemm_f32_mfma<false, false, 2'),
         'loss': ('fs_softmax_ce',), 'entity_grad_reduce': ('gemm_f32_mfma<true, false, 0',),
-        'optimizer_word_table': ('dense_update_lazy', 'adam_l2')}),
+        'optimizer_word_table': ('dense_update_skip', 'dense_update_lazy', 'adam_l2')}),
     'loglinear': dict(_COMMON_KERNELS, **{
         'gather': ('ll_gather_rows',), 'gemm_fwd': ('gemm_x3<false, false, 1', 'gemm_f32_mfma<false, false, 1',),
         'loss': ('ll_row_wave', 'll_row_from_table', 'll_fused_row', 'll_s_'),
         'per_word_dz_sums': ('segsum_rows<64, true, true', 'segsum_rows_scalar<true'),
-        'optimizer_word_table': ('dense_update_lazy', 'adadelta_l2')}),
+        'optimizer_word_table': ('dense_update_skip', 'dense_update_lazy', 'adadelta_l2')}),
 }
 
 
@@ -423,9 +429,10 @@ def kernel_table(timings, work, traffic=None):
                                            'row (what adam_l2 with the row filter moves); reference_dense_bytes = the 32 B per parameter '
                                            'of SURVEY 8(d) (zero-fill + dense g read included)')
             elif wk.get('lazy'):
-                rec['lazy_update'] = dict(wk['lazy'], note='lazy dense update: rows neither this nor the next batch touches are read, '
-                                          'not written (every 4th update writes all); algorithmic_bytes = what this launch moves, '
-                                          'reference_dense_bytes = 32 B per parameter of the reference\'s dense update')
+                rec['lazy_update'] = dict(wk['lazy'], note='lazy dense update (dense_update_skip): rows neither this nor the next batch touches are '
+                                          'neither read nor written -- their share of sum(p^2) was left behind when they were written -- '
+                                          'except every 4th update, which moves every row; algorithmic_bytes = what a launch moves on '
+                                          'average over that cycle, reference_dense_bytes = 32 B per parameter of the reference\'s dense update')
             # achievable = the best streaming rate measured on this box for this shape: the read-only stream
             # bounds every read/write mix from above; the optimiser's own seven streams over a tensor of the
             # same size can beat it where the Infinity Cache holds part of the tensor
@@ -466,13 +473,18 @@ def kernel_table(timings, work, traffic=None):
     return kernels
 
 
+LAUNCHES_OF_CHAIN = {'word_grad_segsum': 3, 'entity_sort': 3}
+
+
 def roofline_of(kernels, traffic_by_group=None, traffic_source=None, kind='vectorspace'):
-    """The LONGEST kernel group (whatever it is).  frac = achieved / peak with achieved =
+    """The kernel with the longest average launch (whatever it is).  frac = achieved / peak with achieved =
     algorithmic work / measured time (the contract's definition); frac_counter = the same with
     the PMC-counted bytes (what the memory system really moved); achievable_peak / frac_of_achievable:
     against the rate this box's memory system was measured to deliver for the same access shape."""
     cand = [k for k in kernels if kernels[k].get('bound') in ('hbm', 'mfma', 'cache')]
-    dom = max(cand, key=lambda k: kernels[k]['us'])
+    # by average LAUNCH duration: the groups that are chains of launches of one kernel name (the three levels of the word
+    # gradient's tree, the three kernels x digits of the counting sort) count with their time per launch
+    dom = max(cand, key=lambda k: kernels[k]['us'] / LAUNCHES_OF_CHAIN.get(k, 1))
     kd = kernels[dom]
     mem = kd['bound'] != 'mfma'
     names = kernels_of_group(kind, dom)
@@ -503,7 +515,7 @@ def roofline_of(kernels, traffic_by_group=None, traffic_source=None, kind='vecto
 
 
 # ---- live PMC passes --------------------------------------------------------------------
-def pmc_traffic_live(inner_args, timeout=300, steps=12):
+def pmc_traffic_live(inner_args, timeout=300, steps=13):
     """HBM bytes per launch of every kernel of a step: two rocprofv3 passes (FETCH_SIZE and
     WRITE_SIZE do not fit one TCC pass; --kernel-trace only beside them, as
     MI355X_MICROARCH.md prescribes) over a short run of THIS script's inner loop on the workload
@@ -549,6 +561,21 @@ def traffic_by_group(per_kernel, timings, kind='vectorspace'):
     """Match the profiled kernels ('name @grid') to the timing groups: the launch of the group's
     dominant kernel whose profiled duration is closest to the live HIP-event average."""
     out = {}
+    if per_kernel:
+        # dense_update_skip alternates between launches that move every row and launches that move what two batches touch
+        # (kernels_opt.h); rocpd_pmc splits launches of one kernel and grid by duration ('#0', '#1'): merged back here,
+        # weighted by calls -- the live average it is compared with is over the same mix
+        merged = {}
+        for key, rec in per_kernel.items():
+            base = key.split(' #')[0]
+            if key.startswith('dense_update_skip') and base != key:
+                merged.setdefault(base, []).append(rec)
+        for base, recs in merged.items():
+            calls = float(sum(r.get('calls', 0) for r in recs)) or 1.0
+            per_kernel = {k: v for k, v in per_kernel.items() if k.split(' #')[0] != base}
+            per_kernel[base] = dict(calls=int(calls), merged_duration_clusters=len(recs),
+                                    **{f: sum(r.get(f, 0.0) * r.get('calls', 0) for r in recs) / calls
+                                       for f in ('hbm_bytes', 'fetch_bytes_corrected', 'write_bytes', 'avg_us_profiled')})
     for group, us in timings.items():
         kd = {'us': us}
         prefixes = kernels_of_group(kind, group)
@@ -916,7 +943,7 @@ def measure_record(kind, models, _capi, dist, dims, steps, warmup, seed, live_pm
     if live_pmc:
         inner = ['--model', kind, '--batch', B, '--vocab', Vw, '--entities', Ve, '--dim', d, '--entity-dim', de,
                  '--window', n, '--negatives', z, '--num-batches', num_batches, '--seed', seed]
-        per_kernel, source = pmc_traffic_live(inner, steps=6 if Vw * d > 5e7 else 12)
+        per_kernel, source = pmc_traffic_live(inner, steps=5 if Vw * d > 5e7 else 13)   # (+ 3 warm-up steps: whole cycles of the lazy update's four launches)
         if per_kernel:
             tbg = traffic_by_group(per_kernel, tm, kind)
     kernels = kernel_table(tm, work, tbg)

@@ -269,7 +269,10 @@ __global__ __launch_bounds__(256) void adadelta_l2(float* __restrict__ p, float*
 // last[row] = number of updates applied to the stored (p, m, v) of the row; double-buffered (last_in / last_out) because
 // the float4 pieces of one row may be walked by two workgroups.  LazyArgs::update = 0 is the FLUSH: every row is brought
 // to t_prev and written, nothing else (in front of evaluations, predictions, tensor reads and writes).
-constexpr int kLazyK = 4;
+#ifndef SERT_LAZY_K
+#define SERT_LAZY_K 4
+#endif
+constexpr int kLazyK = SERT_LAZY_K;
 struct LazyArgs {
     const int32_t* last_in;      // null: every row is at t_prev
     int32_t* last_out;

@@ -120,6 +120,7 @@ struct sert_model {
     bool rw_pred_ok = false;       // every row that is behind has its predictions up to (not including) update rw_pred_T
     int64_t rw_pred_T = 0;         // the next update that reads every row
     bool lazy_skip = true;         // SERT_LAZY_SKIP=0: dense_update_lazy (reads every row every step)
+    float lazy_max = 0.5f;         // SERT_LAZY_MAX: largest touched fraction of a batch whose word-table update is lazy
     int64_t projected_batch = -1;  // training batch whose forward projection already sits in H/T
     // hinted single-GPU steps go further: the whole forward + backward runs ahead
     int64_t spec_fb_batch = -1;    // forward + backward of this batch already ran (gradients ready) ...

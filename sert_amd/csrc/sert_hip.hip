@@ -2025,9 +2025,15 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
             // 639 -> 530 us / 1.89 -> 1.77 ms; the reference's product-search settings (batch 4096, 12 %): 113 -> 85 us /
             // 231 -> 207 us; its W3C loglinear settings (batch 1024, 5 %): 141 -> 79 us / 331 -> 263 us; C2 dims at batch
             // 16384 (20 %): 58.5 -> 48 us; at C2's own batch (44 %, this or the next batch 69 %) a draw: 61.5 -> 57.5 us
-            // alone, the step equal -- dense there.  Lazy up to a touched fraction of 0.35 (SERT_LAZY_MAX_TOUCHED in a
+            // alone, the step equal -- dense there.  Lazy up to a touched fraction of 0.35 (SERT_LAZY_MAX in a
             // variants build: 0 = never, 1 = always).
-            static const float lazy_max = variant_knob("SERT_LAZY_MAX_TOUCHED") ? (float)atof(variant_knob("SERT_LAZY_MAX_TOUCHED")) : 0.35f;
+            // Round 5: dense_update_skip does not read the rows nobody needs, and then the lazy form wins at C2 too (a batch
+            // touches 44 % of the rows, this or the next one 69 %: 61 -> 53 us per launch on average, 0.271 -> 0.261 ms per
+            // step, tools/experiments/r05_skip_c2.sh).  With an announced next batch: lazy up to m->lazy_max (SERT_LAZY_MAX,
+            // default 0.5 -- above that nearly every row is needed by this batch or the next and the passes that read
+            // everything carry the predictions for nothing); without one every lazy step reads and writes every row, and
+            // the dense launch takes over above 0.35 as before.
+            const float lazy_max = (next_bits && m->lazy_skip) ? m->lazy_max : std::min(m->lazy_max, 0.35f);
             // (and for tables of 4 M elements and more: a small one lives in the caches, where the dense launch costs
             //  nothing to save -- the reference's C1, 640 k parameters: 91 us dense, 95 us lazy)
             static const bool lazy_small = variant_knob("SERT_LAZY_SMALL_TABLES") != nullptr;
@@ -2688,6 +2694,7 @@ static int create_resources(sert_model* m) {
     // (opt-in: measured SLOWER than the two launches at C2 -- 53 us against 25 + 25 -- and equal at 8192 rows; kernels_proj.h)
     m->proj_fused = knob("SERT_PROJ_FUSED") && atoi(knob("SERT_PROJ_FUSED")) != 0;
     m->lazy_skip = !(knob("SERT_LAZY_SKIP") && atoi(knob("SERT_LAZY_SKIP")) == 0);
+    m->lazy_max = knob("SERT_LAZY_MAX") ? (float)atof(knob("SERT_LAZY_MAX")) : 0.5f;
     {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->cfg.device) != hipSuccess || cus <= 0) cus = 256;

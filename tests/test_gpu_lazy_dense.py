@@ -36,8 +36,19 @@ def _touched(X, j):
     return len(np.unique(X[j * B:(j + 1) * B])) / float(Vw)
 
 
+@pytest.mark.parametrize('lazy_max', ['0.35', None])
 @pytest.mark.parametrize('kind', ['vectorspace', 'loglinear'])
-def test_alternating_lazy_and_dense_steps(hip_lib, kind):
+def test_alternating_lazy_and_dense_steps(hip_lib, kind, lazy_max, monkeypatch):
+    # SERT_LAZY_MAX=0.35: the ~45 % batches take the dense launch whether announced or not (every transition is taken, and the
+    # hinted run equals the unhinted one bit for bit, losses included).  Default (0.5 behind an announcement, 0.35 without):
+    # the hinted run is lazy throughout, the unhinted one alternates -- parameters and optimiser state still agree bit for bit,
+    # the losses to rounding (dense_update_skip sums p^2 row by row, adam_l2 element by element: kernels_opt.h).
+    if lazy_max is not None:
+        monkeypatch.setenv('SERT_LAZY_MAX', lazy_max)
+    else:
+        monkeypatch.delenv('SERT_LAZY_MAX', raising=False)
+    same_loss = (lambda a, b: a == b) if lazy_max is not None else (lambda a, b: all(abs(x - y) <= 2e-6 * abs(y) for x, y in zip(a, b)))
+    close_loss = lambda a, b: all(abs(x - y) <= 2e-6 * abs(y) for x, y in zip(a, b))
     rng = np.random.RandomState(97)
     nb = len(KINDS)
     if kind == 'vectorspace':
@@ -64,11 +75,11 @@ def test_alternating_lazy_and_dense_steps(hip_lib, kind):
         outs.append((losses, eng.get_tensor(C.T_RW).copy(), eng.get_tensor(C.T_STATE0_RW).copy(),
                      eng.get_tensor(C.T_STATE1_RW).copy(), eng.get_tensor(C.T_W).copy()))
         eng.close()
-    assert outs[1][0] == outs[2][0]
+    assert same_loss(outs[1][0], outs[2][0])
     for a, b_ in zip(outs[1][1:], outs[2][1:]):
         assert np.array_equal(a, b_)
     if kind == 'vectorspace':
-        assert outs[0][0] == outs[2][0]
+        assert close_loss(outs[0][0], outs[2][0])
         for a, b_ in zip(outs[0][1:], outs[2][1:]):
             assert np.array_equal(a, b_)
     else:

@@ -737,11 +737,11 @@ def test_untouched_word_rows_need_no_memset(hip_lib, dw):
 
 @pytest.mark.parametrize('kind', ['vectorspace', 'loglinear'])
 def test_lazy_word_table_update_is_bit_exact(hip_lib, kind):
-    """The LAZY dense update of the word table (kernels_opt.h: dense_update_lazy; on where a batch touches <= 35 % of the
-    rows -- here 2 %): rows that neither the batch nor the ANNOUNCED next batch touches are read (their share of sum(p^2))
-    but not written, and brought forward in registers when they are needed -- by the same element update, so every
-    loss, parameter and optimiser moment must equal the dense run (keep_grads = 1: zeroed table, every row updated in
-    memory every step) BIT FOR BIT, whatever the hints: right ones (rows stay behind for up to three updates), wrong ones
+    """The LAZY dense update of the word table (kernels_opt.h: dense_update_skip / dense_update_lazy; here a batch touches
+    2 % of the rows): rows that neither the batch nor the ANNOUNCED next batch touches are neither read nor written (their
+    share of sum(p^2) was left behind by the launch that wrote them), and brought forward in registers when they are needed
+    -- by the same element update, so every parameter and optimiser moment must equal the dense run (keep_grads = 1: zeroed
+    table, every row updated in memory every step) BIT FOR BIT and every loss to rounding, whatever the hints: right ones (rows stay behind for up to three updates), wrong ones
     (the forward finds its rows stale: flush), none (everything written), an evaluation and a tensor read in between
     (flush), a change of the step counter."""
     B, n, Vw, d, steps = 32, 3, 270000, 16, 14        # (4.3 M parameters: above the size below which the table stays dense)
@@ -772,7 +772,9 @@ def test_lazy_word_table_update_is_bit_exact(hip_lib, kind):
                 eng.set_step(eng.get_step())          # (flushes; the counter itself is unchanged)
         outs.append((rec, eng.get_tensor(C.T_RW).copy(), eng.get_tensor(C.T_STATE0_RW).copy(), eng.get_tensor(C.T_STATE1_RW).copy()))
         eng.close()
-    assert outs[0][0] == outs[1][0]
+    # (losses: dense_update_skip adds the squares row by row -- a predicted row sum must be the one a reading launch forms --,
+    #  the dense launches element by element: the same squares through another summation tree)
+    assert all(abs(x - y) <= 2e-6 * abs(y) for x, y in zip(outs[0][0], outs[1][0])), (outs[0][0], outs[1][0])
     for a, b in zip(outs[0][1:], outs[1][1:]):
         assert np.array_equal(a, b)
 

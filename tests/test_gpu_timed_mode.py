@@ -63,7 +63,7 @@ def test_device_sampled_step_equals_the_explicit_one(hip_lib):
 
 CASES = {
     # BASELINE.json configs[1] as bench.py runs it (dense word-table launch: a batch touches 44 % of the rows)
-    'c2': dict(B=65536, n=10, Vw=100000, Ve=1000, dw=128, de=128, z=10, nb=4, steps=8, lazy=False),
+    'c2': dict(B=65536, n=10, Vw=100000, Ve=1000, dw=128, de=128, z=10, nb=4, steps=8, lazy=True),
     # the reference's product-search hyper-parameters (product-search.sh:121-133: batch 4096, d_w 300, d_e 128, z 10) on a
     # 100 k x 32 k vocabulary: lazy word-table update (12 % of the rows per batch), deferred entity-table update
     'product_search': dict(B=4096, n=10, Vw=100000, Ve=32768, dw=300, de=128, z=10, nb=6, steps=8, lazy=True),
@@ -81,7 +81,7 @@ def test_timed_mode_against_the_oracle(hip_lib, case):
     eng = model._engine
     seed = int(eng.cfg.seed)
     touched = len(np.unique(X[:B])) / float(Vw)
-    assert (touched <= 0.35) == c['lazy'], touched
+    assert (touched <= 0.5) == c['lazy'], touched     # (sert_hip.hip: lazy up to SERT_LAZY_MAX = 0.5 behind an announcement)
     Rw0, Re0 = eng.get_tensor(C.T_RW).reshape(Vw, dw).copy(), eng.get_tensor(C.T_RE).reshape(Ve, de).copy()
     W0, b0 = eng.get_tensor(C.T_W).reshape(dw, de).copy(), eng.get_tensor(C.T_B).copy()
     ora = O.VectorSpaceOracle(B, n, z, Rw0, Re0, W0, b0, 0.01)

@@ -13,5 +13,5 @@ for rep in 1 2; do
   TAG=fork_nce SERT_FORK_AT=nce run ps $PS
   TAG=fork_nce+ko_egrad SERT_FORK_AT=nce SERT_KO_EGRAD=1 run ps $PS
   TAG=no_defer SERT_RE_DEFER=0 run ps $PS
-  TAG=lazy_never SERT_LAZY_MAX_TOUCHED=0 run ps $PS
+  TAG=lazy_never SERT_LAZY_MAX=0 run ps $PS
 done

@@ -188,7 +188,7 @@ _COMMON_KERNELS = {
     # (128x128 tiles; 64x64 tiles for fewer than / exactly two big tiles per CU; 128x160 tiles for d = 300)
     'gemm_dW': ('gemm_x3<true, false, 0', 'gemm_f32_mfma<true, false, 0', 'gemm_f32_mfma_n160<true, false, 0'), 'splitk_combine': ('reduce_partials',),
     'gemm_dX': ('gemm_x3<false, true, 0', 'gemm_f32_mfma<false, true, 0', 'gemm_f32_mfma_small<true, 0', 'gemm_f32_mfma_n160<false, true, 0'),
-    'gemm_bwd_fused': ('vs_bwd_fused',), 'word_grad_segsum': ('segsum_rows<',),
+    'gemm_bwd_fused': ('vs_bwd_fused',), 'word_grad_segsum': ('segsum_rows<', 'segsum_rows_plus', 'segsum_upper_fused', 'segsum_heavy'),
     'optimizer_other': ('optimizer_small', 'adam_l2'), 'finalize': ('vs_tail', 'finalize_loss'),
 }
 KERNELS_OF_GROUP = {
@@ -473,7 +473,7 @@ def kernel_table(timings, work, traffic=None):
     return kernels
 
 
-LAUNCHES_OF_CHAIN = {'word_grad_segsum': 3, 'entity_sort': 3}
+LAUNCHES_OF_CHAIN = {'word_grad_segsum': 2, 'entity_sort': 3}   # (level 0 + the dense heavy words' stream; level 1 + their combine)
 
 
 def roofline_of(kernels, traffic_by_group=None, traffic_source=None, kind='vectorspace'):

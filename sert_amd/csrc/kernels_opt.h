@@ -391,6 +391,17 @@ __global__ __launch_bounds__(256) void dense_update_lazy(float* __restrict__ p, 
 //   * lz.write_all (full pass): every row is read, brought forward and written -- no prediction is consulted.
 //   * The flush (LazyArgs::update = 0) stays with dense_update_lazy: predictions are indexed by update number and a
 //     flush moves rows ALONG their trajectories, so they stay valid behind it.
+//   * SERT_SKIP_PF (default 1): the pieces of the group's NEXT row are requested before the arithmetic of the current one
+//     (a row is three or four 16-byte loads per lane, then up to kLazyK + 2 element updates with a square root and a
+//     reciprocal each and two lane-group reductions: without the prefetch a lane group has nothing in flight while it
+//     computes).  Same loads, same arithmetic, same bits.  Adam only: measured (tools/experiments/r05_skip_pf.sh, us per launch
+//     without / with) C2 51.6 -> 48.1, C4 389 -> 365, product-search settings 66.2 -> 68.0 (the step 0.177 -> 0.175 ms);
+//     Adadelta's element update (two square roots, two reciprocals) is VALU-bound and the second set of registers costs
+//     it a resident wave: W3C loglinear settings 59.8 -> 65.8 us, so it keeps the plain loop.
+#ifndef SERT_SKIP_PF
+#define SERT_SKIP_PF 1
+#endif
+constexpr bool kSkipPrefetchAdam = SERT_SKIP_PF != 0;
 struct SkipArgs {
     float* pred;             // [kLazyK][stride]
     unsigned stride;
@@ -413,6 +424,7 @@ __global__ __launch_bounds__(256) void dense_update_skip(float* __restrict__ p, 
                                                          const uint32_t* __restrict__ bits, unsigned row_len, const LazyArgs lz,
                                                          const SkipArgs sk) {
     constexpr int GPB = 256 / LPR;      // lane groups = rows in flight per workgroup
+    constexpr bool kSkipPrefetch = kSkipPrefetchAdam && ADAM;
     __shared__ float red[GPB];
     const int lane = threadIdx.x & 63, l = threadIdx.x & (LPR - 1), grp = threadIdx.x / LPR;
     const float omb1 = 1.0f - a.b1, omb2 = 1.0f - a.b2, omr = 1.0f - da.rho;
@@ -443,32 +455,51 @@ __global__ __launch_bounds__(256) void dense_update_skip(float* __restrict__ p, 
             flags_m = 1 | (hit_m ? 2 : 0) | (need_m ? 4 : 0);
         }
         const unsigned trips = cnt_w - j0 < (unsigned)LPR ? cnt_w - j0 : (unsigned)LPR;
+        // a row's pieces: fetched one trip AHEAD of the arithmetic (SERT_SKIP_PF, see above the kernel)
+        struct RowRegs { float4 p[CPL], m[CPL], v[CPL], g[CPL]; };
+        auto fetch = [&](unsigned jj, RowRegs& r) {
+            const int flags = __shfl(flags_m, (int)jj, LPR);
+            const bool hit = flags & 2, proc = (flags & 5) == 5;
+            const unsigned row = lo + grp + (j0 + jj) * GPB;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                r.p[c] = r.m[c] = r.v[c] = r.g[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (proc && (unsigned)(l + c * LPR) < d4) {
+                    const size_t i = (size_t)row * d4 + l + c * LPR;
+                    r.p[c] = p4[i];
+                    const nt_f4 mr = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(s0) + i);
+                    const nt_f4 vr = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(s1) + i);
+                    r.m[c] = make_float4(mr.x, mr.y, mr.z, mr.w);
+                    r.v[c] = make_float4(vr.x, vr.y, vr.z, vr.w);
+                    if (hit) r.g[c] = g4[i];
+                }
+            }
+        };
+        RowRegs nxt;
+        if (kSkipPrefetch && trips > 0) fetch(0, nxt);
         for (unsigned jj = 0; jj < trips; ++jj) {
             const int flags = __shfl(flags_m, (int)jj, LPR);
             const int last = __shfl(last_m, (int)jj, LPR);
             const float predv = __shfl(pred_m, (int)jj, LPR);
-            const bool valid = flags & 1, hit = flags & 2, proc = (flags & 5) == 5;
+            const bool valid = flags & 1, proc = (flags & 5) == 5;
+            RowRegs cur;
+            if (kSkipPrefetch) {
+                cur = nxt;
+                if (jj + 1 < trips) fetch(jj + 1, nxt);
+            }
             if (!__any(proc)) {          // (wave-uniform) nothing to read: the predicted shares
                 if (valid) acc += predv;
                 continue;
             }
+            if (!kSkipPrefetch) fetch(jj, cur);
             const unsigned row = lo + grp + (j0 + jj) * GPB;
             const int lag = proc ? lz.t_prev - last : 0;
-            float4 pp[CPL], mm[CPL], vv[CPL];
             bool on[CPL];
 #pragma unroll
-            for (int c = 0; c < CPL; ++c) {
-                on[c] = proc && (unsigned)(l + c * LPR) < d4;
-                pp[c] = mm[c] = vv[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (on[c]) {
-                    const size_t i = (size_t)row * d4 + l + c * LPR;
-                    pp[c] = p4[i];
-                    const nt_f4 mr = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(s0) + i);
-                    const nt_f4 vr = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(s1) + i);
-                    mm[c] = make_float4(mr.x, mr.y, mr.z, mr.w);
-                    vv[c] = make_float4(vr.x, vr.y, vr.z, vr.w);
-                }
-            }
+            for (int c = 0; c < CPL; ++c) on[c] = proc && (unsigned)(l + c * LPR) < d4;
+            float4 (&pp)[CPL] = cur.p;
+            float4 (&mm)[CPL] = cur.m;
+            float4 (&vv)[CPL] = cur.v;
             // one zero-gradient update of the lane's columns with Adam step size at; s collects the squares BEFORE it
             auto advance = [&](float at, float& s) {
                 float sn = 0.f;
@@ -503,8 +534,7 @@ __global__ __launch_bounds__(256) void dense_update_skip(float* __restrict__ p, 
                 for (int c = 0; c < CPL; ++c) {
                     if (!on[c]) continue;
                     const size_t i = (size_t)row * d4 + l + c * LPR;
-                    float4 gg = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (hit) gg = g4[i];
+                    float4 gg = cur.g[c];       // (zero unless a token of the batch points to the row)
                     if (ADAM) {
                         AdamArgs ak = a;
                         ak.a_t = lz.a_of[0];

@@ -34,24 +34,25 @@ struct XcdLists {
     int cnt[8];
 };
 
-template <int LPI, bool DST_SLOT = false, bool LL_FINAL = false, bool SKIP_DENSE = false>
-__global__ __launch_bounds__(256) void segsum_rows(const float* __restrict__ src,
+template <int LPI, bool DST_SLOT, bool LL_FINAL, bool SKIP_DENSE>
+__device__ __forceinline__ void segsum_rows_body(const int bx_, const int by_, const int gy_,
+                                                   const float* __restrict__ src,
                                                    const int32_t* __restrict__ rows,
                                                    const int4* __restrict__ items, int nitems,
                                                    float* __restrict__ final_dst,
                                                    float* __restrict__ partial_dst, int d,
                                                    float divisor,
                                                    unsigned char* __restrict__ touched,
-                                                   int rdiv = 1,
-                                                   const float* __restrict__ logp = nullptr,
-                                                   const float* __restrict__ rsum = nullptr,
-                                                   const DenseSlots dense = DenseSlots(),
-                                                   const XcdLists xl = XcdLists()) {
+                                                   int rdiv,
+                                                   const float* __restrict__ logp,
+                                                   const float* __restrict__ rsum,
+                                                   const DenseSlots& dense,
+                                                   const XcdLists& xl) {
     constexpr int IPB = 256 / LPI;  // items per block
     const int sub = threadIdx.x / LPI, l = threadIdx.x % LPI;
-    int item = blockIdx.x * IPB + sub;
+    int item = bx_ * IPB + sub;
     if (xl.on) {
-        const int x = blockIdx.x & 7, k = (blockIdx.x >> 3) * IPB + sub;
+        const int x = bx_ & 7, k = (bx_ >> 3) * IPB + sub;
         if (k >= xl.cnt[x]) return;
         item = xl.off[x] + k;
     }
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256) void segsum_rows(const float* __restrict__ src
     // every lane of the LPI group walks the loop (the row numbers travel by lane permute, so no
     // lane may drop out): a lane whose column group is past the row computes on group 0 and
     // stores nothing
-    for (int c0 = blockIdx.y * LPI; c0 < chunks; c0 += LPI * gridDim.y) {
+    for (int c0 = by_ * LPI; c0 < chunks; c0 += LPI * gy_) {
         const bool on = c0 + l < chunks;
         const int c = on ? c0 + l : 0;
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -158,6 +159,23 @@ __global__ __launch_bounds__(256) void segsum_rows(const float* __restrict__ src
             *reinterpret_cast<float4*>(partial_dst + (size_t)(-(it.z + 1)) * d + 4 * c) = a;
         }
     }
+}
+
+template <int LPI, bool DST_SLOT = false, bool LL_FINAL = false, bool SKIP_DENSE = false>
+__global__ __launch_bounds__(256) void segsum_rows(const float* __restrict__ src,
+                                                   const int32_t* __restrict__ rows,
+                                                   const int4* __restrict__ items, int nitems,
+                                                   float* __restrict__ final_dst,
+                                                   float* __restrict__ partial_dst, int d,
+                                                   float divisor,
+                                                   unsigned char* __restrict__ touched,
+                                                   int rdiv = 1,
+                                                   const float* __restrict__ logp = nullptr,
+                                                   const float* __restrict__ rsum = nullptr,
+                                                   const DenseSlots dense = DenseSlots(),
+                                                   const XcdLists xl = XcdLists()) {
+    segsum_rows_body<LPI, DST_SLOT, LL_FINAL, SKIP_DENSE>((int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y, src, rows, items, nitems,
+                                                          final_dst, partial_dst, d, divisor, touched, rdiv, logp, rsum, dense, xl);
 }
 
 // Level 0 of the word-gradient tree, BUNDLED (word_index.h: BatchIndex::bundle_off): a lane group of 32 takes the
@@ -581,6 +599,131 @@ __global__ __launch_bounds__(256) void segsum_heavy_combine(const float* __restr
         a.x /= divisor; a.y /= divisor; a.z /= divisor; a.w /= divisor;
         reinterpret_cast<float4*>(final_dst)[(size_t)words[h] * d4 + ch] = a;
     }
+}
+
+// ---- the dense heavy words INSIDE the tree's launches (vectorspace word gradient, round 5) -------------------------------
+// segsum_heavy + segsum_heavy_combine in front of the tree cost what the heavy words' entries saved (round 3: 56.4 against
+// 55.6 us at C2): a single wave of 256 large workgroups bound by its one dependent chain, then another launch.  But the pass
+// is a STREAM (address-computable loads, no descriptor -> row numbers -> rows chain) and the tree's level 0 is bound by
+// exactly those chains -- side by side they use different things.  segsum_rows_plus is the tree's launch with `extra`
+// leading workgroups (x) that do the other job:
+//   kind 1 (beside level 0): the count-weighted partial sums of kHeavyRowsFused batch rows for the batch's <= 16 dense words.
+//       256 threads = 4 waves; waves 0, 1 take words 0-7, waves 2, 3 words 8-15 (eight float4 accumulators per lane: the
+//       launch keeps the tree's eight waves per SIMD); the four lane groups of a word half take every fourth row, four rows in
+//       flight per trip; their sums meet in the order (g0 + g1) + (g2 + g3) (lane permute, then 8 kB of LDS) and leave as
+//       part[row block][word][:] -- the layout of segsum_heavy, over smaller row blocks.
+//   kind 2 (beside level 1): segsum_heavy_combine's body, one workgroup per dense word (x) and 32-column slab (y).
+// The column slab of an extra workgroup is blockIdx.y: the launch must have gridDim.y == cdiv(d / 4, 32) (the LPI = 32 forms).
+constexpr int kHeavyRowsFused = 128;
+struct PlusJob {
+    int kind;                 // 0: none, 1: heavy partial sums, 2: combine
+    int extra;                // leading workgroups (x) that do it
+    const float* src;         // kind 1: the source matrix (B x d);  kind 2: the partials
+    const uint4* cnt16;       // kind 1: per batch row, kHeavyMax occurrence counts (bytes)
+    float* part;              // kind 1: [extra][kHeavyMax][d]
+    const int32_t* words;     // kind 2: the dense words' table rows
+    int nheavy;               // kind 2
+    int nblocks;              // kind 2: row blocks of the partials
+    int B;
+};
+
+__device__ __forceinline__ void heavy_rows_body(const int rblk, const int slab, const PlusJob& job, int d, float4 (*lds)[8][32]) {
+    const int l = threadIdx.x & 31, wv = threadIdx.x >> 6, half = wv >> 1;
+    const int rs = (wv & 1) * 2 + ((threadIdx.x >> 5) & 1);    // which fourth of the rows
+    const int d4 = d >> 2, ch = slab * 32 + l;
+    const bool on = ch < d4;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 acc2[8][2];
+#pragma unroll
+    for (int h = 0; h < 8; ++h) { acc2[h][0] = (f32x2)(0.f); acc2[h][1] = (f32x2)(0.f); }
+    const int row0 = rblk * kHeavyRowsFused + rs;
+    const uint2* cnt8 = reinterpret_cast<const uint2*>(job.cnt16) + half;   // (this half's eight count bytes of row i: cnt8[2 i])
+#pragma unroll 1
+    for (int t = 0; t < kHeavyRowsFused / 16; ++t) {
+        uint2 c[4];
+        float4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = row0 + (t * 4 + q) * 4;
+            const int i = min(r, job.B - 1);
+            c[q] = cnt8[2 * (size_t)i];
+            if (r >= job.B) c[q] = make_uint2(0u, 0u);
+            v[q] = on ? *reinterpret_cast<const float4*>(job.src + (size_t)i * d + 4 * ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned cw[2] = {c[q].x, c[q].y};
+            f32x2 lo, hi;
+            lo.x = v[q].x; lo.y = v[q].y; hi.x = v[q].z; hi.y = v[q].w;
+#pragma unroll
+            for (int h = 0; h < 8; ++h) {
+                const f32x2 ff = (f32x2)((float)((cw[h >> 2] >> (8 * (h & 3))) & 0xffu));
+                acc2[h][0] = __builtin_elementwise_fma(ff, lo, acc2[h][0]);
+                acc2[h][1] = __builtin_elementwise_fma(ff, hi, acc2[h][1]);
+            }
+        }
+    }
+    float4 acc[8];
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+        acc[h] = make_float4(acc2[h][0].x, acc2[h][0].y, acc2[h][1].x, acc2[h][1].y);
+        // lower lane group of the wave += the upper one
+        acc[h].x += __shfl_xor(acc[h].x, 32); acc[h].y += __shfl_xor(acc[h].y, 32);
+        acc[h].z += __shfl_xor(acc[h].z, 32); acc[h].w += __shfl_xor(acc[h].w, 32);
+    }
+    if ((wv & 1) && (threadIdx.x & 63) < 32) {
+#pragma unroll
+        for (int h = 0; h < 8; ++h) lds[half][h][l] = acc[h];
+    }
+    __syncthreads();
+    if (!(wv & 1) && (threadIdx.x & 63) < 32 && on) {
+#pragma unroll
+        for (int h = 0; h < 8; ++h) {
+            const float4 o = lds[half][h][l];
+            float4 a = acc[h];
+            a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+            reinterpret_cast<float4*>(job.part)[((size_t)rblk * kHeavyMax + half * 8 + h) * d4 + ch] = a;
+        }
+    }
+}
+
+__device__ __forceinline__ void heavy_combine_body(const int h, const int slab, const PlusJob& job, int d, float* __restrict__ final_dst,
+                                                   float divisor, float4 (*lds)[32]) {
+    if (h >= job.nheavy) return;
+    const int d4 = d >> 2;
+    const int l = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int ch = slab * 32 + l;
+    const float4* p4 = reinterpret_cast<const float4*>(job.src);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ch < d4) {
+#pragma unroll 8
+        for (int b = g; b < job.nblocks; b += 8) {
+            const float4 v = p4[((size_t)b * kHeavyMax + h) * d4 + ch];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+    }
+    lds[g][l] = a;
+    __syncthreads();
+    if (g == 0 && ch < d4) {
+        a = lds[0][l];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) { const float4 v = lds[q][l]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+        a.x /= divisor; a.y /= divisor; a.z /= divisor; a.w /= divisor;
+        reinterpret_cast<float4*>(final_dst)[(size_t)job.words[h] * d4 + ch] = a;
+    }
+}
+
+__global__ __launch_bounds__(256) void segsum_rows_plus(const float* __restrict__ src, const int32_t* __restrict__ rows,
+                                                        const int4* __restrict__ items, int nitems, float* __restrict__ final_dst,
+                                                        float* __restrict__ partial_dst, int d, float divisor, const PlusJob job) {
+    __shared__ float4 plus_lds[2][8][32];   // 8 kB (the tree's workgroups do not touch it)
+    if ((int)blockIdx.x < job.extra) {
+        if (job.kind == 1) heavy_rows_body((int)blockIdx.x, (int)blockIdx.y, job, d, plus_lds);
+        else heavy_combine_body((int)blockIdx.x, (int)blockIdx.y, job, d, final_dst, divisor, plus_lds[0]);
+        return;
+    }
+    segsum_rows_body<32, false, false, false>((int)blockIdx.x - job.extra, (int)blockIdx.y, (int)gridDim.y, src, rows, items, nitems,
+                                              final_dst, partial_dst, d, divisor, nullptr, 1, nullptr, nullptr, DenseSlots(), XcdLists());
 }
 
 // Loglinear: row `slot[h]` of dZu = mask(lp) * (sum of the heavy word's dJ rows) - exp(lp) * rsum[slot]

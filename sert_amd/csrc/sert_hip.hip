@@ -327,16 +327,31 @@ static int word_grad_segsum(sert_model* m, const DataSplit& ds, int64_t batch_in
     // (vectorspace only: a loglinear index marks dense words for the V_e-wide per-word sums of dzu_from_dj; its
     // word gradient -- when it comes through here at all: SERT_LL_NODEDUP / the row-wise loss path -- has one source
     // row per TOKEN, not per batch row, and hpart is sized for V_e columns, not d_w)
+    // Round 5: INSIDE the tree's launches where those are the 32-lane forms (kernels_seg.h: segsum_rows_plus) -- the streaming
+    // pass beside level 0, its combine beside level 1; SERT_HEAVY_NO_FUSE (variants build) keeps the two launches in front.
+    bool heavy_fused = false, heavy_combined = false;
+    PlusJob hjob = PlusJob();
     if (bx.dense_cnt > 0 && is_vs(m) && d % 4 == 0) {
         const int B = m->cfg.batch_size, d4 = d / 4;
-        const int nblk = cdiv(B, kHeavyRowsPerBlock);
+        static const bool no_fuse = variant_knob("SERT_HEAVY_NO_FUSE") != nullptr;
+        const bool lpi32 = d4 <= 32 || (d4 > 64 && 64 * cdiv(d4, 64) > 32 * cdiv(d4, 32));
+        const bool bundled = bx.bundle_cnt > 0 && ds.idx_bundles;
+        heavy_fused = !no_fuse && lpi32 && bx.nlevels >= 1 && bx.item_cnt[0] > 0 && bx.row_groups == 1 && !bundled;
         const uint4* cnt = ds.idx_dense_counts + (size_t)batch_index * B;
+        if (heavy_fused) {
+            hjob.kind = 1; hjob.extra = cdiv(B, kHeavyRowsFused); hjob.src = src; hjob.cnt16 = cnt; hjob.part = m->hpart;
+            hjob.words = (const int32_t*)ds.idx_dense_words + (size_t)batch_index * kHeavyMax;
+            hjob.nheavy = bx.dense_cnt; hjob.nblocks = hjob.extra; hjob.B = B;
+        } else {
+        const int nblk = cdiv(B, kHeavyRowsPerBlock);
         const size_t lds = (size_t)4 * kHeavyMax * 32 * sizeof(float4);   // 32 KB
         hipLaunchKernelGGL(segsum_heavy, dim3(nblk * cdiv(d4, 32)), dim3(1024), lds, m->stream, src, cnt, B, d, m->hpart);
         hipLaunchKernelGGL(segsum_heavy_combine, dim3(bx.dense_cnt, cdiv(d4, 32)), dim3(256), 0, m->stream,
                            (const float*)m->hpart, nblk, d, (const int32_t*)ds.idx_dense_words + (size_t)batch_index * kHeavyMax,
                            bx.dense_cnt, m->g_rw, divisor);
+        }
     }
+    auto heavy_combine_job = [&]() { PlusJob j = hjob; j.kind = 2; j.extra = bx.dense_cnt; j.src = m->hpart; return j; };
     for (int l = 0; l < bx.nlevels; ++l) {
         const int nitems = bx.item_cnt[l];
         if (nitems == 0) continue;
@@ -352,6 +367,14 @@ static int word_grad_segsum(sert_model* m, const DataSplit& ds, int64_t batch_in
         const int32_t* rows = (l == 0) ? ds.idx_rows + bx.rows_off : nullptr;
         const int4* items = ds.idx_items + bx.item_off[l];
         float* pout = m->wpart + (size_t)bx.part_off[l] * d;
+        if (heavy_fused && l <= 1) {
+            // level 0 + the heavy words' partial sums / level 1 + their combine: one launch each
+            const PlusJob j = l == 0 ? hjob : heavy_combine_job();
+            hipLaunchKernelGGL(segsum_rows_plus, dim3(j.extra + cdiv(nitems, 8), cdiv(d / 4, 32)), dim3(256), 0, m->stream, in, rows, items,
+                               nitems, m->g_rw, pout, d, divisor, j);
+            if (l == 1) heavy_combined = true;
+            continue;
+        }
         // level 0 in bundles of short items (kernels_seg.h: segsum_rows_bundled; opt-in, SERT_SEG_BUNDLE=1 at upload -- the
         // same sums bit for bit as one item per lane group, tests/test_gpu_parity.py::test_word_gradient_bundled_level0)
         if (l == 0 && d % 4 == 0 && bx.bundle_cnt > 0 && ds.idx_bundles && bx.row_groups == 1) {
@@ -386,6 +409,11 @@ static int word_grad_segsum(sert_model* m, const DataSplit& ds, int64_t batch_in
             hipLaunchKernelGGL((segsum_rows_scalar<false>), dim3(cdiv(nitems, 4), cdiv(d, 64)), dim3(256), 0, m->stream, in,
                                rows, items, nitems, m->g_rw, pout, d, divisor, touched);
         }
+    }
+    if (heavy_fused && !heavy_combined) {   // (no level 1, or the fused upper levels took it: the combine alone)
+        const PlusJob j = heavy_combine_job();
+        hipLaunchKernelGGL(segsum_rows_plus, dim3(j.extra, cdiv(d / 4, 32)), dim3(256), 0, m->stream, (const float*)nullptr,
+                           (const int32_t*)nullptr, (const int4*)nullptr, 0, m->g_rw, (float*)nullptr, d, divisor, j);
     }
     return 0;
 }
@@ -1063,8 +1091,15 @@ static bool fork_late_mode(const sert_model* m) {
 // has to wait for the last reader of W any more, and the entity chain then runs beside the
 // MFMA-bound dh / dW GEMMs instead of beside the cache-bound segmented sum.
 static bool fork_at_nce(const sert_model* m) {
-    static const bool on = variant_knob("SERT_FORK_AT") && !strcmp(variant_knob("SERT_FORK_AT"), "nce");
+    static const bool on = variant_knob("SERT_FORK_AT") && !strncmp(variant_knob("SERT_FORK_AT"), "nce", 3);
     return on && fork_late_mode(m);
+}
+// SERT_FORK_AT=nce_dw: ... and the side stream starts with dW, db and the loss partials -- beside the dh GEMM (both
+// 512-workgroup MFMA launches that leave half the matrix pipe idle on their own) -- and only then takes the entity chain,
+// which then runs beside the segmented sum as in the default schedule.
+static bool fork_at_nce_dw(const sert_model* m) {
+    static const bool on = variant_knob("SERT_FORK_AT") && !strcmp(variant_knob("SERT_FORK_AT"), "nce_dw");
+    return on && fork_at_nce(m);
 }
 
 // Late fork + a THIRD queue for the MFMA-bound dW GEMM, its combine and the W, b update: they only
@@ -1206,7 +1241,7 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         // GEMMs / word-table reduction below, so it runs on the side stream
         // (timing mode measures every kernel alone: everything stays on the main stream)
         hipStream_t st = (m->timing.enabled || m->nstreams < 2) ? m->stream : m->stream2;
-        if (!fork_late || fork_nce) {
+        if ((!fork_late || fork_nce) && !m->dw_side_first) {   // (nce_dw: the side stream has met the fork already)
             if (!m->fork_bound) SERT_HIP(hipEventRecord(m->ev_fork, m->stream));
             m->fork_bound = false;
             if (st != m->stream) SERT_HIP(hipStreamWaitEvent(st, m->ev_fork, 0));
@@ -1453,8 +1488,10 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
     static const bool dw_first_always = variant_knob("SERT_DW_FIRST") && atoi(variant_knob("SERT_DW_FIRST")) == 2;
     // (!pt_big[2]: a projection matrix large enough for a streaming update of its own is updated on the main stream, which
     //  would then have to wait for the side stream's dW)
-    m->dw_side_first = !dw_first_off && fork_late && !fork_nce && !side_heavy && m->lazy_join && !fused_bwd && !dw_third_queue(m) &&
-                       !m->pt_big[2] && c.kind == SERT_KIND_VECTORSPACE && (dw_first_always || ((size_t)B * dw * sizeof(float) <= ((size_t)24 << 20) && m->epart));
+    const bool fork_nce_dw = fork_nce && fork_at_nce_dw(m) && !side_heavy && m->lazy_join && !fused_bwd && !m->pt_big[2] && m->nstreams == 2;
+    m->dw_side_first = fork_nce_dw ||
+                       (!dw_first_off && fork_late && !fork_nce && !side_heavy && m->lazy_join && !fused_bwd && !dw_third_queue(m) &&
+                        !m->pt_big[2] && c.kind == SERT_KIND_VECTORSPACE && (dw_first_always || ((size_t)B * dw * sizeof(float) <= ((size_t)24 << 20) && m->epart)));
     // (m->epart: the sort-free entity chain of small entity tables.  Behind the counting sort of a larger one the side stream is
     //  the longer of the two already: the reference's product-search settings, V_e = 32768, 205.8 -> 214.5 us with dW in front)
     static const int dp_late_mode = variant_knob("SERT_DP_LATE") ? atoi(variant_knob("SERT_DP_LATE")) : 1;   // 0: off; 2: dW behind the chain
@@ -1466,6 +1503,14 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         SERT_TRY(dh_gemm());           // main (its completion is ev_dense)
         SERT_TRY(word_table_sum());    // main
         SERT_TRY(dense_grad());        // side, behind the entity chain
+    } else if (fork_nce && fork_nce_dw) {
+        if (!m->fork_bound) SERT_HIP(hipEventRecord(m->ev_fork, m->stream));
+        m->fork_bound = false;
+        SERT_HIP(hipStreamWaitEvent(m->stream2, m->ev_fork, 0));
+        SERT_TRY(dh_gemm());           // main
+        SERT_TRY(dense_grad());        // side, beside the dh GEMM
+        SERT_TRY(entity_grad());       // side, behind dW
+        SERT_TRY(word_table_sum());    // main
     } else if (fork_nce) {
         SERT_TRY(entity_grad());       // side, forked on the NCE kernel's completion
         SERT_TRY(dh_gemm());
@@ -3108,13 +3153,22 @@ int sert_upload_dataset(sert_model* m, int split, const void* x, const int32_t* 
         const bool row_is_pos = !is_vs(m);
         // vectorspace models: the heavy words of a batch are summed by one dense pass (word_index.h);
         // SERT_NO_DENSE_HEAVY=1 keeps them in the tree (cross-check knob)
-        // (vectorspace: opt-in, SERT_DENSE_HEAVY=1 -- measured a wash at C2 and C4: the tree's first level is
-        //  bound by its 44 k word items, not by the entries the heavy words take out of it.  loglinear: the
-        //  V_e-wide per-word sums are bandwidth-bound; on by default where V_e % 4 == 0)
-        const bool dense_heavy = !variant_knob("SERT_NO_DENSE_HEAVY") &&
-                                 (is_vs(m) ? (m->cfg.word_dim % 4 == 0 && m->cfg.word_dim <= 512 && knob("SERT_DENSE_HEAVY") != nullptr &&
-                                              atoi(knob("SERT_DENSE_HEAVY")) != 0)
-                                           : (m->cfg.num_entities % 4 == 0));
+        // (loglinear: the V_e-wide per-word sums are bandwidth-bound; on by default where V_e % 4 == 0.  vectorspace: as two
+        //  launches in FRONT of the tree the pass cost what the heavy words' entries saved -- round 3: 56.4 against 55.6 us at C2,
+        //  opt-in then.  Round 5: inside the tree's own launches (kernels_seg.h: segsum_rows_plus -- the stream beside the
+        //  latency-bound level 0, the combine beside level 1) the C2 tree takes 42.6 us instead of 55.8 and the step 0.2481 ->
+        //  0.2374 ms, C4 1.386 -> 1.361, C2 dims at 8192 rows 0.0988 -> 0.0964, product-search settings 0.1762 -> 0.1750
+        //  (tools/experiments/r05_heavy_fused.sh; the two launches in front: 0.257, 1.440, 0.114, 0.181).  ON by default where
+        //  the tree runs its 32-lane forms (d_w / 4 <= 32, or rows that three 32-lane column groups cover better than two
+        //  64-lane ones); SERT_DENSE_HEAVY=0 / 1 forces it off / on.)
+        bool vs_heavy = false;
+        if (is_vs(m) && m->cfg.word_dim % 4 == 0 && m->cfg.word_dim <= 512) {
+            const int d4 = m->cfg.word_dim / 4;
+            const bool lpi32 = d4 <= 32 || (d4 > 64 && 64 * cdiv(d4, 64) > 32 * cdiv(d4, 32));
+            const bool bundle_on = knob("SERT_SEG_BUNDLE") && atoi(knob("SERT_SEG_BUNDLE")) != 0;
+            vs_heavy = knob("SERT_DENSE_HEAVY") ? atoi(knob("SERT_DENSE_HEAVY")) != 0 : (lpi32 && !bundle_on);
+        }
+        const bool dense_heavy = !variant_knob("SERT_NO_DENSE_HEAVY") && (is_vs(m) ? vs_heavy : (m->cfg.num_entities % 4 == 0));
         // Row-grouped level 0 of the vectorspace word-gradient tree (word_index.h: row_groups; kernels_seg.h: XcdLists):
         // MEASURED AND NOT USED (round 4, profiles/r04_experiments.txt).  At C2 it does what it was built for -- the
         // fabric traffic of the tree falls from 264 MB to 149 MB per step (level 0: 237 -> 98 MB) -- and level 0 takes
@@ -3191,7 +3245,7 @@ int sert_upload_dataset(sert_model* m, int split, const void* x, const int32_t* 
             SERT_HIP(hipMemcpyAsync(d.idx_dense_words, hw.data(), hw.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
             SERT_HIP(hipStreamSynchronize(s));
             if (!m->hpart)
-                SERT_TRY(dmalloc(&m->hpart, (size_t)cdiv(B, kHeavyRowsPerBlock) * kHeavyMax *
+                SERT_TRY(dmalloc(&m->hpart, (size_t)cdiv(B, is_vs(m) ? kHeavyRowsFused : kHeavyRowsPerBlock) * kHeavyMax *
                                                (size_t)(is_vs(m) ? m->cfg.word_dim : m->cfg.num_entities)));
         } else {
             for (auto& bxx : wi.batches) bxx.dense_cnt = 0;

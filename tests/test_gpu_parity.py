@@ -137,6 +137,54 @@ def test_word_gradient_row_grouped_tree(hip_lib, monkeypatch, dims, groups, dens
 
 
 @pytest.mark.parametrize('dims', [
+    dict(B=20000, n=5, Vw=300, dw=128),      # C2's row width: a handful of words above 4096 occurrences, 157 row blocks (the last one ragged)
+    dict(B=6100, n=8, Vw=3000, dw=300),      # d_w = 300: three 32-lane column groups (the extra workgroups' slab is blockIdx.y)
+    dict(B=9000, n=12, Vw=20, dw=64, uniform=1),   # twenty words of ~5400 occurrences: sixteen dense, four stay in a three-level tree
+    dict(B=5000, n=2, Vw=200000, dw=32, one=7),    # one word takes half the tokens, every other word occurs once or twice: NO level 1 (the combine alone)
+])
+def test_word_gradient_heavy_words_inside_the_tree_launches(hip_lib, monkeypatch, dims):
+    """The dense heavy words of the vectorspace word gradient (word_index.h: kHeavyMax words above kHeavyMinCount
+    occurrences) are summed by extra workgroups of the tree's own launches (kernels_seg.h: segsum_rows_plus -- the
+    count-weighted stream beside level 0, its combine beside level 1; the default since round 5): row by row against the
+    float64 oracle, bit-identical run to run, equal to the plain tree (SERT_DENSE_HEAVY=0) up to fp32 reassociation and
+    -- against a variants build -- to the two launches in front of the tree (SERT_HEAVY_NO_FUSE=1)."""
+    B, n, Vw, dw = dims['B'], dims['n'], dims['Vw'], dims['dw']
+    z, Ve, de = 3, 20, 32
+    p = U.make_vs_problem(13, B, n, z, Vw, Ve, dw, de, zipf=True)
+    if 'uniform' in dims:
+        p['X'] = np.random.RandomState(4).randint(0, Vw, size=p['X'].shape).astype(p['X'].dtype)
+    if 'one' in dims:
+        rs = np.random.RandomState(3)
+        X = rs.randint(0, Vw, size=p['X'].shape).astype(p['X'].dtype)
+        X[rs.rand(*X.shape) < 0.5] = dims['one']
+        p['X'] = X
+    counts = np.bincount(p['X'].ravel(), minlength=Vw)
+    assert (counts > 4096).sum() >= 1, 'the shape has no heavy word'
+    neg = p['rng'].randint(0, Ve, size=(B, z)).astype(np.int64)
+    o64 = O.VectorSpaceOracle(B, n, z, p['Rw'], p['Re'], p['W'], p['b'], 0.01, dtype=np.float64)
+    _, g64, _ = o64.loss_and_grads(p['X'], p['y'], p['w'], neg)
+    touched = np.unique(p['X'])
+    runs = [{}, {}, {'SERT_DENSE_HEAVY': '0'}] + ([{'SERT_HEAVY_NO_FUSE': '1'}] if VARIANTS_BUILD else [])
+    got = []
+    for env in runs:
+        monkeypatch.delenv('SERT_DENSE_HEAVY', raising=False)
+        monkeypatch.delenv('SERT_HEAVY_NO_FUSE', raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = U.vs_engine(p, B, n, z, 0.01)
+        eng.upload_dataset(C.SPLIT_TRAIN, p['X'], y_int=p['y'], w=p['w'])
+        eng.train_batch(0, neg)
+        got.append(eng.get_tensor(C.T_GRAD_RW, (Vw, dw)).copy())
+        eng.close()
+    assert np.array_equal(got[0], got[1])
+    for g in got:
+        err, row = U.row_err(g, g64[1], rows=touched)
+        assert err < 2e-5, (err, row, int(counts[row]))
+    heavy = np.argsort(-counts)[:16]
+    assert not np.array_equal(got[0][heavy], got[2][heavy]), 'the dense pass did not run (same bits as the plain tree)'
+
+
+@pytest.mark.parametrize('dims', [
     dict(B=64, n=4, Vw=300, dw=16),          # mostly singletons: bundles of eight one-entry items
     dict(B=1000, n=10, Vw=5000, dw=128),     # Zipf: singletons, mid-size words and multi-chunk words in one batch
     dict(B=2000, n=6, Vw=50, dw=64),         # every word heavy: bundles of one 64-entry chunk item, three tree levels
@@ -153,6 +201,9 @@ def test_word_gradient_bundled_level0(hip_lib, monkeypatch, dims):
     p = U.make_vs_problem(9, B, n, z, Vw, Ve, dw, de, zipf=True)
     neg = p['rng'].randint(0, Ve, size=(B, z)).astype(np.int64)
     got = []
+    # (the tree alone: with bundles the dense heavy-word pass -- on by default since round 5 -- runs as two launches of its own,
+    #  without them inside the tree's launches, over different row blocks: a different association for those words)
+    monkeypatch.setenv('SERT_DENSE_HEAVY', '0')
     for bundle in ('1', '0'):
         monkeypatch.setenv('SERT_SEG_BUNDLE', bundle)
         eng = U.vs_engine(p, B, n, z, 0.01)
@@ -1058,7 +1109,7 @@ def test_schedule_variants_do_not_change_a_bit(hip_lib):
     variants = ({}, {'SERT_STREAMS': '1'}, {'SERT_ROCTX': '1'},     # (a roctx range around every kernel group)
                 {'SERT_SIDE_HEAVY': '2'})   # (entity chain, dW and the small-tensor update on the side stream)
     if VARIANTS_BUILD:      # knobs only a -DSERT_VARIANTS library reads (common.h: variant_knob)
-        variants += ({'SERT_FORK_LATE': '0'}, {'SERT_EXT_EVENTS': '0'}, {'SERT_EGRAD_GROUP_SUM': '1'}, {'SERT_FORK_AT': 'nce'},
+        variants += ({'SERT_FORK_LATE': '0'}, {'SERT_EXT_EVENTS': '0'}, {'SERT_EGRAD_GROUP_SUM': '1'}, {'SERT_FORK_AT': 'nce'}, {'SERT_FORK_AT': 'nce_dw'},
                      {'SERT_DW_FIRST': '0'},      # (dW / db on the main stream instead of first on the side stream)
                      {'SERT_SEG_NO_FUSED_UPPER': '1'}, {'SERT_NO_TAIL': '1'})
     outs = []

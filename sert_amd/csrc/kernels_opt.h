@@ -402,6 +402,12 @@ __global__ __launch_bounds__(256) void dense_update_lazy(float* __restrict__ p, 
 #define SERT_SKIP_PF 1
 #endif
 constexpr bool kSkipPrefetchAdam = SERT_SKIP_PF != 0;
+//   * SERT_SKIP_WAVES(CPL): minimum waves per SIMD asked of the compiler.  The fixed grid of 2048 workgroups is exactly eight waves per
+//     SIMD of 256 CUs and the prefetching kernel takes 72 registers (seven waves fit): asked to stay within 64 (it then spills six
+//     dwords) it is SLOWER -- C2 0.2394 -> 0.2439 ms, tools/experiments/r05_skip_waves.sh.  Not asked.
+#ifndef SERT_SKIP_WAVES
+#define SERT_SKIP_WAVES(CPL) 1
+#endif
 struct SkipArgs {
     float* pred;             // [kLazyK][stride]
     unsigned stride;
@@ -418,7 +424,7 @@ __device__ __forceinline__ float lane_group_sum(float v, int lane) {
 }
 
 template <bool ADAM, int LPR, int CPL>
-__global__ __launch_bounds__(256) void dense_update_skip(float* __restrict__ p, const float* __restrict__ g,
+__global__ __launch_bounds__(256, SERT_SKIP_WAVES(CPL)) void dense_update_skip(float* __restrict__ p, const float* __restrict__ g,
                                                          float* __restrict__ s0, float* __restrict__ s1, unsigned nrows,
                                                          AdamArgs a, AdadeltaArgs da, float* __restrict__ sumsq_partial,
                                                          const uint32_t* __restrict__ bits, unsigned row_len, const LazyArgs lz,

@@ -726,6 +726,119 @@ __global__ __launch_bounds__(256) void segsum_rows_plus(const float* __restrict_
                                               final_dst, partial_dst, d, divisor, nullptr, 1, nullptr, nullptr, DenseSlots(), XcdLists());
 }
 
+// ... and the loglinear per-word dZ sums (V_e-wide rows, 64-lane items, gridDim.y = cdiv(V_e / 4, 64) column groups): the same
+// two jobs beside segsum_rows<64, true, true, true>.  kind 1: a wave per (word half, every second row) -- a row's counts are
+// wave-uniform, the zero ones are skipped by a scalar branch (a row of ten tokens holds three or four distinct heavy words);
+// the two row subsets of a word half meet in 16 kB of LDS.  kind 2: segsum_heavy_combine_ll's finishing expression
+// (mask dJsum - P rsum), one workgroup per dense word and 64-column group, the row blocks' partials split over its four waves.
+struct PlusJobLL {
+    PlusJob j;
+    DenseSlots dense;         // kind 2: the dense words' ranks among the batch's distinct words (= their rows of dZu)
+    const float* logp;
+    const float* rsum;
+};
+
+__device__ __forceinline__ void heavy_rows_body64(const int rblk, const int slab, const PlusJob& job, int d, float4 (*lds)[8][64]) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, half = wv >> 1, rs = wv & 1;
+    const int d4 = d >> 2, ch = slab * 64 + lane;
+    const bool on = ch < d4;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 acc2[8][2];
+#pragma unroll
+    for (int h = 0; h < 8; ++h) { acc2[h][0] = (f32x2)(0.f); acc2[h][1] = (f32x2)(0.f); }
+    const int row0 = rblk * kHeavyRowsFused + rs;
+    const uint2* cnt8 = reinterpret_cast<const uint2*>(job.cnt16) + half;
+#pragma unroll 1
+    for (int t = 0; t < kHeavyRowsFused / 8; ++t) {
+        uint2 c[4];
+        float4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = row0 + (t * 4 + q) * 2;
+            const int i = __builtin_amdgcn_readfirstlane(min(r, job.B - 1));
+            c[q] = cnt8[2 * (size_t)i];
+            if (r >= job.B) c[q] = make_uint2(0u, 0u);
+            v[q] = on ? *reinterpret_cast<const float4*>(job.src + (size_t)i * d + 4 * ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned cw[2] = {(unsigned)__builtin_amdgcn_readfirstlane((int)c[q].x), (unsigned)__builtin_amdgcn_readfirstlane((int)c[q].y)};
+            f32x2 lo, hi;
+            lo.x = v[q].x; lo.y = v[q].y; hi.x = v[q].z; hi.y = v[q].w;
+#pragma unroll
+            for (int h = 0; h < 8; ++h) {
+                const unsigned byte = (cw[h >> 2] >> (8 * (h & 3))) & 0xffu;
+                if (byte != 0u) {                       // (wave-uniform)
+                    const f32x2 ff = (f32x2)((float)byte);
+                    acc2[h][0] = __builtin_elementwise_fma(ff, lo, acc2[h][0]);
+                    acc2[h][1] = __builtin_elementwise_fma(ff, hi, acc2[h][1]);
+                }
+            }
+        }
+    }
+    if (rs) {
+#pragma unroll
+        for (int h = 0; h < 8; ++h) lds[half][h][lane] = make_float4(acc2[h][0].x, acc2[h][0].y, acc2[h][1].x, acc2[h][1].y);
+    }
+    __syncthreads();
+    if (!rs && on) {
+#pragma unroll
+        for (int h = 0; h < 8; ++h) {
+            const float4 o = lds[half][h][lane];
+            reinterpret_cast<float4*>(job.part)[((size_t)rblk * kHeavyMax + half * 8 + h) * d4 + ch] =
+                make_float4(acc2[h][0].x + o.x, acc2[h][0].y + o.y, acc2[h][1].x + o.z, acc2[h][1].y + o.w);
+        }
+    }
+}
+
+__device__ __forceinline__ void heavy_combine_ll_body64(const int h, const int slab, const PlusJobLL& job, int d,
+                                                        float* __restrict__ final_dst, float4 (*lds)[64]) {
+    if (h >= job.j.nheavy) return;
+    const int d4 = d >> 2;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int ch = slab * 64 + lane;
+    const float4* p4 = reinterpret_cast<const float4*>(job.j.src);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ch < d4) {
+#pragma unroll 8
+        for (int b = wv; b < job.j.nblocks; b += 4) {
+            const float4 v = p4[((size_t)b * kHeavyMax + h) * d4 + ch];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+    }
+    lds[wv][lane] = a;
+    __syncthreads();
+    if (wv == 0 && ch < d4) {
+        a = lds[0][lane];
+#pragma unroll
+        for (int q = 1; q < 4; ++q) { const float4 v = lds[q][lane]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+        const int slot = job.dense.slot[h];
+        const float rs = job.rsum[slot];
+        const float LOGLO = logf(SERT_CLIP_LO), LOGHI = logf(SERT_CLIP_HI);
+        const size_t o = (size_t)slot * d + 4 * ch;
+        const float4 lp = *reinterpret_cast<const float4*>(job.logp + o);
+        a.x = ((lp.x >= LOGLO && lp.x <= LOGHI) ? a.x : 0.f) - __expf(lp.x) * rs;
+        a.y = ((lp.y >= LOGLO && lp.y <= LOGHI) ? a.y : 0.f) - __expf(lp.y) * rs;
+        a.z = ((lp.z >= LOGLO && lp.z <= LOGHI) ? a.z : 0.f) - __expf(lp.z) * rs;
+        a.w = ((lp.w >= LOGLO && lp.w <= LOGHI) ? a.w : 0.f) - __expf(lp.w) * rs;
+        *reinterpret_cast<float4*>(final_dst + o) = a;
+    }
+}
+
+__global__ __launch_bounds__(256) void segsum_rows_plus_ll(const float* __restrict__ src, const int32_t* __restrict__ rows,
+                                                           const int4* __restrict__ items, int nitems, float* __restrict__ final_dst,
+                                                           float* __restrict__ partial_dst, int d, const DenseSlots dense,
+                                                           const PlusJobLL job) {
+    __shared__ float4 plus_lds[2][8][64];   // 16 kB (the tree's workgroups do not touch it)
+    if ((int)blockIdx.x < job.j.extra) {
+        if (job.j.kind == 1) heavy_rows_body64((int)blockIdx.x, (int)blockIdx.y, job.j, d, plus_lds);
+        else heavy_combine_ll_body64((int)blockIdx.x, (int)blockIdx.y, job, d, final_dst, plus_lds[0]);
+        return;
+    }
+    segsum_rows_body<64, true, true, true>((int)blockIdx.x - job.j.extra, (int)blockIdx.y, (int)gridDim.y, src, rows, items, nitems,
+                                           final_dst, partial_dst, d, 1.0f, nullptr, 1, job.logp, job.rsum, dense, XcdLists());
+}
+
 // Loglinear: row `slot[h]` of dZu = mask(lp) * (sum of the heavy word's dJ rows) - exp(lp) * rsum[slot]
 // (the LL_FINAL store of segsum_rows), from the per-block partials of segsum_heavy over dJ.
 __global__ __launch_bounds__(256) void segsum_heavy_combine_ll(const float* __restrict__ part, int nblocks, int d,

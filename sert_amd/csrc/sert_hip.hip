@@ -440,6 +440,18 @@ static int dzu_from_dj(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         hipLaunchKernelGGL(segsum_scalar_wave, dim3(cdiv(nitems, 4)), dim3(256), 0, m->stream, in, rows, items, nitems,
                            m->ll_rsum, pout);
     }
+    // the dense heavy words inside the tree's launches (round 5; SERT_HEAVY_NO_FUSE in a variants build: the two launches behind the tree)
+    static const bool ll_no_fuse = variant_knob("SERT_HEAVY_NO_FUSE") != nullptr;
+    const bool ll_heavy_fused = !ll_no_fuse && V % 4 == 0 && bx.dense_cnt > 0 && bx.nlevels >= 1 && bx.item_cnt[0] > 0;
+    bool ll_heavy_combined = false;
+    PlusJobLL ll_job = PlusJobLL();
+    if (ll_heavy_fused) {
+        const int B = m->cfg.batch_size;
+        ll_job.j.kind = 1; ll_job.j.extra = cdiv(B, kHeavyRowsFused); ll_job.j.src = m->J;
+        ll_job.j.cnt16 = ds.idx_dense_counts + (size_t)batch_index * B; ll_job.j.part = m->hpart;
+        ll_job.j.nheavy = bx.dense_cnt; ll_job.j.nblocks = ll_job.j.extra; ll_job.j.B = B;
+        ll_job.logp = m->Zu; ll_job.rsum = m->ll_rsum;
+    }
     for (int l = 0; l < bx.nlevels; ++l) {
         const int nitems = bx.item_cnt[l];
         if (nitems == 0) continue;
@@ -448,10 +460,20 @@ static int dzu_from_dj(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         const float* in = (l == 0) ? m->J : m->zpart + (size_t)bx.part_off[l - 1] * V;
         float* pout = m->zpart + (size_t)bx.part_off[l] * V;
         if (V % 4 == 0 && bx.dense_cnt > 0) {
-            // (the batch's heavy words are summed by segsum_heavy below: their items are skipped)
+            // (the batch's heavy words are summed densely: their items are skipped)
             DenseSlots dsl;
             dsl.n = bx.dense_cnt;
             for (int h = 0; h < kHeavyMax; ++h) dsl.slot[h] = h < bx.dense_cnt ? bx.dense_slot[h] : -2;
+            if (ll_heavy_fused && l <= 1) {
+                // ... by extra workgroups of this very launch (kernels_seg.h: segsum_rows_plus_ll): the stream over dJ beside
+                // level 0, its combine and finishing expression beside level 1
+                PlusJobLL j = ll_job;
+                j.dense = dsl;
+                if (l == 1) { j.j.kind = 2; j.j.extra = bx.dense_cnt; j.j.src = m->hpart; ll_heavy_combined = true; }
+                hipLaunchKernelGGL(segsum_rows_plus_ll, dim3(j.j.extra + cdiv(nitems, 4), cdiv(V / 4, 64)), dim3(256), 0, m->stream, in,
+                                   rows, items, nitems, m->dZu, pout, V, dsl, j);
+                continue;
+            }
             hipLaunchKernelGGL((segsum_rows<64, true, true, true>), dim3(cdiv(nitems, 4), cdiv(V / 4, 64)), dim3(256), 0,
                                m->stream, in, rows, items, nitems, m->dZu, pout, V, 1.0f,
                                (unsigned char*)nullptr, 1, (const float*)m->Zu,
@@ -472,7 +494,15 @@ static int dzu_from_dj(sert_model* m, const DataSplit& ds, int64_t batch_index) 
                                rows, items, nitems, m->dZu, pout, V, 1.0f, (unsigned char*)nullptr, 1);
         }
     }
-    if (V % 4 == 0 && bx.dense_cnt > 0) {
+    if (ll_heavy_fused && !ll_heavy_combined) {   // (no level 1: the combine alone)
+        PlusJobLL j = ll_job;
+        j.dense.n = bx.dense_cnt;
+        for (int h = 0; h < kHeavyMax; ++h) j.dense.slot[h] = h < bx.dense_cnt ? bx.dense_slot[h] : -2;
+        j.j.kind = 2; j.j.extra = bx.dense_cnt; j.j.src = m->hpart;
+        hipLaunchKernelGGL(segsum_rows_plus_ll, dim3(j.j.extra, cdiv(V / 4, 64)), dim3(256), 0, m->stream, (const float*)nullptr,
+                           (const int32_t*)nullptr, (const int4*)nullptr, 0, m->dZu, (float*)nullptr, V, j.dense, j);
+    }
+    if (V % 4 == 0 && bx.dense_cnt > 0 && !ll_heavy_fused) {
         // Heavy words: sum_i cnt[i][h] dJ[i, :] by ONE pass over dJ (262 MB at C2 dims) instead of one 4 kB
         // row fetch per occurrence -- a dozen words hold over half of a Zipfian batch's tokens
         const int B = m->cfg.batch_size, d4 = V / 4;
@@ -1080,6 +1110,9 @@ static bool ext_events() {
 // ends with a cache write-back): two per step instead of three.  SERT_FORK_LATE=0 restores the
 // fork right behind the NCE kernel with dW on the main stream.
 static bool side_heavy_mode(const sert_model* m);
+// Grid of dense_update_skip given the dense launches' grid for the same table (kOptBlocks, twice that from 2^24 elements).
+static int skip_grid(int nb_dense, size_t /*elements*/) { return nb_dense; }
+
 static bool fork_late_mode(const sert_model* m) {
     static const bool on = !(variant_knob("SERT_FORK_LATE") && atoi(variant_knob("SERT_FORK_LATE")) == 0);
     return on && !side_heavy_mode(m) && ext_events() && !is_dp(m) && !m->timing.enabled && m->nstreams == 2 &&
@@ -2087,6 +2120,7 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
                 // the LAZY form of the dense update (kernels_opt.h): rows neither this batch nor the announced next one
                 // touches are read (their share of sum(p^2)) but not written, except every kLazyK-th update
                 LazyArgs lz = lazy_args(m, m->step - 1, /*update=*/1);
+                int nb_skip = 0;    // (dense_update_skip's own grid, when it takes the launch)
                 lz.next_bits = next_bits;
                 lz.write_all = (next_bits == nullptr || m->step % kLazyK == 0) ? 1 : 0;
                 const unsigned d4 = (unsigned)c.word_dim / 4;
@@ -2109,6 +2143,13 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
                     }
                     m->rw_pred_ok = next_bits != nullptr;
                     const unsigned nrows = (unsigned)c.vocab_size;
+                    // (its own grid: a workgroup walks its rows one lane group per row, so shorter row ranges balance better --
+                    //  SERT_SKIP_BLOCKS in a variants build, tools/experiments/r05_skip_blocks.sh)
+                    static const int skip_blocks_knob = variant_knob("SERT_SKIP_BLOCKS") ? atoi(variant_knob("SERT_SKIP_BLOCKS")) : 0;
+                    const int nb_dense = nb;
+                    const int nb = std::max(1, std::min<int>(skip_blocks_knob > 0 ? std::min(skip_blocks_knob, 4 * kOptBlocks) : skip_grid(nb_dense, t.n),
+                                                             (int)cdiv(nrows, 8u)));
+                    nb_skip = nb;
 #define SERT_SKIP_LAUNCH(ADAM, LPR, CPL)                                                                                   \
     hipLaunchKernelGGL((dense_update_skip<ADAM, LPR, CPL>), dim3(nb), dim3(256), 0, m->stream, t.p, (const float*)t.g, t.s0, \
                        t.s1, nrows, aa, da, m->red_sq + n_sq, tf, (unsigned)c.word_dim, lz, sk)
@@ -2134,7 +2175,7 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
                 m->rw_last_cur ^= 1;
                 m->rw_stale = !lz.write_all;
                 m->rw_ready_batch = lz.write_all ? -1 : m->lazy_next;
-                n_sq += nb;
+                n_sq += nb_skip > 0 ? nb_skip : nb;
                 continue;
             }
             if (i == 0) m->rw_pred_ok = false;   // (a dense launch moves every row off its predicted trajectory)
@@ -3245,7 +3286,7 @@ int sert_upload_dataset(sert_model* m, int split, const void* x, const int32_t* 
             SERT_HIP(hipMemcpyAsync(d.idx_dense_words, hw.data(), hw.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
             SERT_HIP(hipStreamSynchronize(s));
             if (!m->hpart)
-                SERT_TRY(dmalloc(&m->hpart, (size_t)cdiv(B, is_vs(m) ? kHeavyRowsFused : kHeavyRowsPerBlock) * kHeavyMax *
+                SERT_TRY(dmalloc(&m->hpart, (size_t)cdiv(B, kHeavyRowsFused) * kHeavyMax *
                                                (size_t)(is_vs(m) ? m->cfg.word_dim : m->cfg.num_entities)));
         } else {
             for (auto& bxx : wi.batches) bxx.dense_cnt = 0;

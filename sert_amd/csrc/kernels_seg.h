@@ -32,6 +32,7 @@ struct XcdLists {
     int on;
     int off[8];
     int cnt[8];
+    int slot_is_row;    // level 0 of a sorted index (word_index.h: BatchIndex::slot_is_row): item.slot = the item's first source row
 };
 
 template <int LPI, bool DST_SLOT, bool LL_FINAL, bool SKIP_DENSE>
@@ -97,8 +98,12 @@ __device__ __forceinline__ void segsum_rows_body(const int bx_, const int by_, c
             const int cnt = min(LPI, len - base);
             int myr = it.x + base + min(l, cnt - 1);
             if (rows) {
-                myr = rows[myr];
-                if (rdiv > 1) myr /= rdiv;   // source row = entry / rdiv
+                if (!DST_SLOT && xl.slot_is_row && len == 1) {
+                    myr = it.w;              // (a one-entry item of a sorted index: its row number came with the descriptor)
+                } else {
+                    myr = rows[myr];
+                    if (rdiv > 1) myr /= rdiv;   // source row = entry / rdiv
+                }
             }
 #if defined(SERT_KO_SEG)   // timing knock-outs (wrong results; tools/experiments/r05_seg_ko.sh): where do level 0's 41 us go?
             if (rows && SERT_KO_SEG == 1) myr = (it.x + base + min(l, cnt - 1)) & 65535;   // 1: rows in entry order (perfect locality)
@@ -625,6 +630,7 @@ struct PlusJob {
     int nheavy;               // kind 2
     int nblocks;              // kind 2: row blocks of the partials
     int B;
+    int slot_is_row;          // the TREE's items: see XcdLists
 };
 
 __device__ __forceinline__ void heavy_rows_body(const int rblk, const int slab, const PlusJob& job, int d, float4 (*lds)[8][32]) {
@@ -722,8 +728,10 @@ __global__ __launch_bounds__(256) void segsum_rows_plus(const float* __restrict_
         else heavy_combine_body((int)blockIdx.x, (int)blockIdx.y, job, d, final_dst, divisor, plus_lds[0]);
         return;
     }
+    XcdLists xl = XcdLists();
+    xl.slot_is_row = job.slot_is_row;
     segsum_rows_body<32, false, false, false>((int)blockIdx.x - job.extra, (int)blockIdx.y, (int)gridDim.y, src, rows, items, nitems,
-                                              final_dst, partial_dst, d, divisor, nullptr, 1, nullptr, nullptr, DenseSlots(), XcdLists());
+                                              final_dst, partial_dst, d, divisor, nullptr, 1, nullptr, nullptr, DenseSlots(), xl);
 }
 
 // ... and the loglinear per-word dZ sums (V_e-wide rows, 64-lane items, gridDim.y = cdiv(V_e / 4, 64) column groups): the same

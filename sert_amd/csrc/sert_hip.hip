@@ -369,9 +369,15 @@ static int word_grad_segsum(sert_model* m, const DataSplit& ds, int64_t batch_in
         float* pout = m->wpart + (size_t)bx.part_off[l] * d;
         if (heavy_fused && l <= 1) {
             // level 0 + the heavy words' partial sums / level 1 + their combine: one launch each
-            const PlusJob j = l == 0 ? hjob : heavy_combine_job();
-            hipLaunchKernelGGL(segsum_rows_plus, dim3(j.extra + cdiv(nitems, 8), cdiv(d / 4, 32)), dim3(256), 0, m->stream, in, rows, items,
-                               nitems, m->g_rw, pout, d, divisor, j);
+            PlusJob j = l == 0 ? hjob : heavy_combine_job();
+            j.slot_is_row = (l == 0 && bx.slot_is_row) ? 1 : 0;
+            int ni = nitems;
+            // timing knock-outs (variants build, WRONG results; tools/experiments/r05_plus_ko.sh): 1 = the tree alone, 2 = the stream alone
+            static const int ko = variant_knob("SERT_KO_PLUS") ? atoi(variant_knob("SERT_KO_PLUS")) : 0;
+            if (ko == 1 && l == 0) j.extra = 0;
+            if (ko == 2 && l == 0) ni = 0;
+            hipLaunchKernelGGL(segsum_rows_plus, dim3(j.extra + cdiv(ni, 8), cdiv(d / 4, 32)), dim3(256), 0, m->stream, in, rows, items,
+                               ni, m->g_rw, pout, d, divisor, j);
             if (l == 1) heavy_combined = true;
             continue;
         }
@@ -389,6 +395,7 @@ static int word_grad_segsum(sert_model* m, const DataSplit& ds, int64_t batch_in
             const bool seg32y = ch > 64 && ch * (64 * cdiv(ch, 64)) > ch * (32 * cdiv(ch, 32));
             // row-grouped level 0: eight item lists, one per XCD (kernels_seg.h: XcdLists)
             XcdLists xl = XcdLists();
+            xl.slot_is_row = (l == 0 && bx.slot_is_row) ? 1 : 0;
             int longest = 0;
             if (l == 0 && bx.row_groups > 1) {
                 xl.on = 1;
@@ -3219,10 +3226,14 @@ int sert_upload_dataset(sert_model* m, int split, const void* x, const int32_t* 
         int row_groups = 1;
         if (is_vs(m) && m->cfg.word_dim % 4 == 0)
             if (const char* e = variant_knob("SERT_SEG_GROUPS")) row_groups = std::min(std::max(1, atoi(e)), std::max(1, B / 64));
+        // vectorspace: level 0 sorted by item length with the first row number in the descriptor (word_index.h: slot_is_row);
+        // not with bundles (they need the items in entry order); SERT_SEG_NO_SORT (variants build) for the A/B
+        const bool sort_level0 = is_vs(m) && row_groups == 1 && !(knob("SERT_SEG_BUNDLE") && atoi(knob("SERT_SEG_BUNDLE")) != 0) &&
+                                 !variant_knob("SERT_SEG_NO_SORT");
         bool ids_ok = true;
         SERT_ID_DISPATCH(m->cfg.id_bytes,
                          ids_ok = build_word_index<IdT>((const IdT*)x, nb, B, n, m->cfg.vocab_size, row_is_pos, wi,
-                                                        /*want_slots=*/!is_vs(m), /*dense_heavy=*/dense_heavy, row_groups));
+                                                        /*want_slots=*/!is_vs(m), /*dense_heavy=*/dense_heavy, row_groups, sort_level0));
         if (!ids_ok) SERT_FAIL("token id >= vocab_size in x");
         if (!is_vs(m) && !wi.slots.empty()) {
             const size_t V = (size_t)m->cfg.num_entities;

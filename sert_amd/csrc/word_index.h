@@ -72,6 +72,11 @@ struct BatchIndex {
     // values.  The items' entry ranges are consecutive, every item is still summed left to right: the same bits.
     int64_t bundle_off = 0;
     int32_t bundle_cnt = 0;
+    // level 0 SORTED by length, longest items first, and every level-0 item's `slot` = its FIRST source row
+    // (build_word_index: sort_level0; vectorspace only, where `slot` is otherwise unused): the eight items of a workgroup
+    // are then equally long -- a workgroup lasts as long as its longest item --, and a one-entry item (half of a Zipfian
+    // batch's words) fetches its row straight after the descriptor, one dependent round trip less
+    bool slot_is_row = false;
 };
 
 struct WordIndex {
@@ -113,7 +118,7 @@ struct WordIndex {
 template <typename IdT>
 bool build_word_index(const IdT* ids, int64_t num_batches, int B, int n, int vocab,
                       bool row_is_pos, WordIndex& out, bool want_slots = false, bool dense_heavy = false,
-                      int row_groups = 1) {
+                      int row_groups = 1, bool sort_level0 = false) {
     const int64_t T = (int64_t)B * n;
     if (want_slots || row_is_pos || row_groups < 1) row_groups = 1;
     const int rows_per_group = (B + row_groups - 1) / row_groups;
@@ -325,6 +330,14 @@ bool build_word_index(const IdT* ids, int64_t num_batches, int B, int n, int voc
         }
         bx.nlevels = level;
         bx.part_rows = part_base;
+        bx.slot_is_row = false;
+        if (sort_level0 && !want_slots && !row_is_pos && bx.row_groups == 1 && level >= 1 && bx.item_cnt[0] > 0) {
+            // (an item's destination -- a table row or a numbered partial row -- does not depend on where the item stands)
+            SegItem* l0 = out.items.data() + bx.item_off[0];
+            for (int32_t k = 0; k < bx.item_cnt[0]; ++k) l0[k].slot = rows[l0[k].begin];
+            std::stable_sort(l0, l0 + bx.item_cnt[0], [](const SegItem& a, const SegItem& b) { return a.end - a.begin > b.end - b.begin; });
+            bx.slot_is_row = true;
+        }
         bx.heavy_off = (int64_t)out.heavy.size() / 4;
         bx.heavy_cnt = 0;
         bx.fused_upper_ok = false;

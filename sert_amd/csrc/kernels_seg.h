@@ -612,14 +612,23 @@ __global__ __launch_bounds__(256) void segsum_heavy_combine(const float* __restr
 // is a STREAM (address-computable loads, no descriptor -> row numbers -> rows chain) and the tree's level 0 is bound by
 // exactly those chains -- side by side they use different things.  segsum_rows_plus is the tree's launch with `extra`
 // leading workgroups (x) that do the other job:
-//   kind 1 (beside level 0): the count-weighted partial sums of kHeavyRowsFused batch rows for the batch's <= 16 dense words.
+//   kind 1 (beside level 0): the count-weighted partial sums of PlusJob::rpb batch rows for the batch's <= 16 dense words.
 //       256 threads = 4 waves; waves 0, 1 take words 0-7, waves 2, 3 words 8-15 (eight float4 accumulators per lane: the
 //       launch keeps the tree's eight waves per SIMD); the four lane groups of a word half take every fourth row, four rows in
 //       flight per trip; their sums meet in the order (g0 + g1) + (g2 + g3) (lane permute, then 8 kB of LDS) and leave as
 //       part[row block][word][:] -- the layout of segsum_heavy, over smaller row blocks.
 //   kind 2 (beside level 1): segsum_heavy_combine's body, one workgroup per dense word (x) and 32-column slab (y).
 // The column slab of an extra workgroup is blockIdx.y: the launch must have gridDim.y == cdiv(d / 4, 32) (the LPI = 32 forms).
-constexpr int kHeavyRowsFused = 128;
+// Batch rows per extra workgroup of kind 1 (PlusJob::rpb, a multiple of 16): about one workgroup per CU -- fewer, longer ones leave
+// fewer partial rows to the combine (a chain of its own beside level 1), too few make the stream outlast level 0.  Measured
+// (tools/experiments/r05_heavy_rows.sh; 64 / 128 / 256 / 512 rows): C2 0.2398 / 0.2364 / 0.2353 / 0.2360 ms, C2 dims at 8192 rows
+// 0.0949 / 0.0961 / 0.1024 / 0.1166, C4 1.344 / 1.336 / 1.317 / 1.333, loglinear at batch 65536 0.923 / 0.904 / 0.893 / 1.02.
+constexpr int kHeavyRowsFusedMin = 64, kHeavyRowsFusedMax = 256;
+inline int heavy_rows_fused(int B) {
+    int r = kHeavyRowsFusedMin;
+    while (r < kHeavyRowsFusedMax && B / (2 * r) >= 256) r *= 2;
+    return r;
+}
 struct PlusJob {
     int kind;                 // 0: none, 1: heavy partial sums, 2: combine
     int extra;                // leading workgroups (x) that do it
@@ -631,6 +640,7 @@ struct PlusJob {
     int nblocks;              // kind 2: row blocks of the partials
     int B;
     int slot_is_row;          // the TREE's items: see XcdLists
+    int rpb;                  // kind 1: batch rows per extra workgroup
 };
 
 __device__ __forceinline__ void heavy_rows_body(const int rblk, const int slab, const PlusJob& job, int d, float4 (*lds)[8][32]) {
@@ -642,10 +652,10 @@ __device__ __forceinline__ void heavy_rows_body(const int rblk, const int slab, 
     f32x2 acc2[8][2];
 #pragma unroll
     for (int h = 0; h < 8; ++h) { acc2[h][0] = (f32x2)(0.f); acc2[h][1] = (f32x2)(0.f); }
-    const int row0 = rblk * kHeavyRowsFused + rs;
+    const int row0 = rblk * job.rpb + rs;
     const uint2* cnt8 = reinterpret_cast<const uint2*>(job.cnt16) + half;   // (this half's eight count bytes of row i: cnt8[2 i])
 #pragma unroll 1
-    for (int t = 0; t < kHeavyRowsFused / 16; ++t) {
+    for (int t = 0; t < job.rpb / 16; ++t) {
         uint2 c[4];
         float4 v[4];
 #pragma unroll
@@ -754,10 +764,10 @@ __device__ __forceinline__ void heavy_rows_body64(const int rblk, const int slab
     f32x2 acc2[8][2];
 #pragma unroll
     for (int h = 0; h < 8; ++h) { acc2[h][0] = (f32x2)(0.f); acc2[h][1] = (f32x2)(0.f); }
-    const int row0 = rblk * kHeavyRowsFused + rs;
+    const int row0 = rblk * job.rpb + rs;
     const uint2* cnt8 = reinterpret_cast<const uint2*>(job.cnt16) + half;
 #pragma unroll 1
-    for (int t = 0; t < kHeavyRowsFused / 8; ++t) {
+    for (int t = 0; t < job.rpb / 8; ++t) {
         uint2 c[4];
         float4 v[4];
 #pragma unroll

@@ -339,7 +339,7 @@ static int word_grad_segsum(sert_model* m, const DataSplit& ds, int64_t batch_in
         heavy_fused = !no_fuse && lpi32 && bx.nlevels >= 1 && bx.item_cnt[0] > 0 && bx.row_groups == 1 && !bundled;
         const uint4* cnt = ds.idx_dense_counts + (size_t)batch_index * B;
         if (heavy_fused) {
-            hjob.kind = 1; hjob.extra = cdiv(B, kHeavyRowsFused); hjob.src = src; hjob.cnt16 = cnt; hjob.part = m->hpart;
+            hjob.kind = 1; hjob.rpb = heavy_rows_fused(B); hjob.extra = cdiv(B, hjob.rpb); hjob.src = src; hjob.cnt16 = cnt; hjob.part = m->hpart;
             hjob.words = (const int32_t*)ds.idx_dense_words + (size_t)batch_index * kHeavyMax;
             hjob.nheavy = bx.dense_cnt; hjob.nblocks = hjob.extra; hjob.B = B;
         } else {
@@ -454,7 +454,7 @@ static int dzu_from_dj(sert_model* m, const DataSplit& ds, int64_t batch_index) 
     PlusJobLL ll_job = PlusJobLL();
     if (ll_heavy_fused) {
         const int B = m->cfg.batch_size;
-        ll_job.j.kind = 1; ll_job.j.extra = cdiv(B, kHeavyRowsFused); ll_job.j.src = m->J;
+        ll_job.j.kind = 1; ll_job.j.rpb = heavy_rows_fused(B); ll_job.j.extra = cdiv(B, ll_job.j.rpb); ll_job.j.src = m->J;
         ll_job.j.cnt16 = ds.idx_dense_counts + (size_t)batch_index * B; ll_job.j.part = m->hpart;
         ll_job.j.nheavy = bx.dense_cnt; ll_job.j.nblocks = ll_job.j.extra; ll_job.j.B = B;
         ll_job.logp = m->Zu; ll_job.rsum = m->ll_rsum;
@@ -3297,7 +3297,7 @@ int sert_upload_dataset(sert_model* m, int split, const void* x, const int32_t* 
             SERT_HIP(hipMemcpyAsync(d.idx_dense_words, hw.data(), hw.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
             SERT_HIP(hipStreamSynchronize(s));
             if (!m->hpart)
-                SERT_TRY(dmalloc(&m->hpart, (size_t)cdiv(B, kHeavyRowsFused) * kHeavyMax *
+                SERT_TRY(dmalloc(&m->hpart, (size_t)cdiv(B, kHeavyRowsFusedMin) * kHeavyMax *
                                                (size_t)(is_vs(m) ? m->cfg.word_dim : m->cfg.num_entities)));
         } else {
             for (auto& bxx : wi.batches) bxx.dense_cnt = 0;

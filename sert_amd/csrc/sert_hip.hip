@@ -2160,10 +2160,18 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
 #define SERT_SKIP_LAUNCH(ADAM, LPR, CPL)                                                                                   \
     hipLaunchKernelGGL((dense_update_skip<ADAM, LPR, CPL>), dim3(nb), dim3(256), 0, m->stream, t.p, (const float*)t.g, t.s0, \
                        t.s1, nrows, aa, da, m->red_sq + n_sq, tf, (unsigned)c.word_dim, lz, sk)
+                    // d_w = 300: 75 float4 per row are 3 x 32 lanes at 78 % or 2 x 64 at 59 % of the lanes, and eight rows per
+                    // workgroup instead of four.  Measured (tools/experiments/r05_skip_32x3.sh, three rounds, 64 x 2 -> 32 x 3):
+                    // product-search settings 0.1756 -> 0.1704 ms (the launch alone 68.5 us either way), W3C loglinear settings
+                    // 0.1922 -> 0.1894 (60.1 -> 57.5 us), C4's 150 M-element table 1.348 -> 1.344 (381 -> 387 us): taken below
+                    // 2^26 elements.  SERT_SKIP_32X3=0 / 1 (variants build) forces it off / on.
+                    static const int skip_32x3_knob = variant_knob("SERT_SKIP_32X3") ? atoi(variant_knob("SERT_SKIP_32X3")) : -1;
+                    const bool skip_32x3 = skip_32x3_knob >= 0 ? skip_32x3_knob != 0 : t.n < ((size_t)1 << 26);
 #define SERT_SKIP_SHAPE(ADAM)                                        \
     do {                                                             \
         if (d4 <= 32) SERT_SKIP_LAUNCH(ADAM, 32, 1);                 \
         else if (d4 <= 64) SERT_SKIP_LAUNCH(ADAM, 64, 1);            \
+        else if (d4 <= 96 && skip_32x3) SERT_SKIP_LAUNCH(ADAM, 32, 3); \
         else if (d4 <= 128) SERT_SKIP_LAUNCH(ADAM, 64, 2);           \
         else if (d4 <= 192) SERT_SKIP_LAUNCH(ADAM, 64, 3);           \
         else SERT_SKIP_LAUNCH(ADAM, 64, 4);                          \

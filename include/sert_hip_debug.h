@@ -35,7 +35,8 @@ int sert_debug_row_lists(const uint32_t* allbits, int world, int rank, int64_t n
  * autodiff of sert/models.py:180), built for ids[num_batches][B][n] and EVALUATED ON THE HOST the way the segmented-sum
  * kernels walk it: grad_out[vocab][d] = the word-table gradient of batch `batch` for source rows src[B][d] (dh), i.e.
  * sum over the occurrences of a word of src[row] / divisor.  row_groups > 1: level 0 cut into row ranges (XCD lists);
- * dense_heavy: the batch's heaviest words summed outside the tree.  stats[8] = {levels, items, partial rows, final items,
+ * dense_heavy: bit 0 = the batch's heaviest words summed outside the tree, bit 1 = level 0 sorted by item length with every
+ * item's first row number in its descriptor (what the vectorspace models upload).  stats[8] = {levels, items, partial rows, final items,
  * dense words, row groups, level-0 items, distinct words}. */
 int sert_debug_word_index_sum(const void* ids, int id_bytes, int64_t num_batches, int B, int n, int vocab, int row_groups,
                               int dense_heavy, int64_t batch, const float* src, int d, float divisor, float* grad_out,

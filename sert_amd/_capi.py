@@ -530,9 +530,10 @@ MEMBENCH_COPY, MEMBENCH_READ, MEMBENCH_GATHER, MEMBENCH_OPTIMIZER = 0, 1, 2, 3
 SEPARATE_ALLOCATIONS = ctypes.c_size_t(-1).value
 
 
-def debug_word_index_sum(ids, vocab, src, batch=0, row_groups=1, dense_heavy=False, divisor=1.0):
+def debug_word_index_sum(ids, vocab, src, batch=0, row_groups=1, dense_heavy=False, divisor=1.0, sort_level0=False):
     """Host only: the word-table gradient of one batch through the inverted index as the segmented-sum kernels walk it
-    (sert_debug_word_index_sum).  ids (num_batches, B, n) unsigned; src (B, d) float32.  Returns (grad (vocab, d), stats)."""
+    (sert_debug_word_index_sum).  ids (num_batches, B, n) unsigned; src (B, d) float32.  sort_level0: level 0 sorted by item
+    length with every item's first row number in its descriptor (what the vectorspace models upload).  Returns (grad (vocab, d), stats)."""
     lib = load()
     ids = np.ascontiguousarray(ids)
     assert ids.ndim == 3 and ids.dtype in (np.uint8, np.uint16, np.uint32), (ids.shape, ids.dtype)
@@ -545,7 +546,7 @@ def debug_word_index_sum(ids, vocab, src, batch=0, row_groups=1, dense_heavy=Fal
     lib.sert_debug_word_index_sum.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                               ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_float,
                                               ctypes.c_void_p, ctypes.c_void_p]
-    check(lib.sert_debug_word_index_sum(_addr(ids), ids.dtype.itemsize, nb, B, n, int(vocab), int(row_groups), int(bool(dense_heavy)),
+    check(lib.sert_debug_word_index_sum(_addr(ids), ids.dtype.itemsize, nb, B, n, int(vocab), int(row_groups), int(bool(dense_heavy)) | (2 if sort_level0 else 0),
                                         int(batch), _addr(src), d, float(divisor), _addr(out), _addr(stats)))
     keys = ('levels', 'items', 'partial_rows', 'final_items', 'dense_words', 'row_groups', 'level0_items', 'distinct_words')
     return out, dict(zip(keys, [int(x) for x in stats]))

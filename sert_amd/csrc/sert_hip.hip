@@ -4137,9 +4137,21 @@ int sert_debug_word_index_sum(const void* ids, int id_bytes, int64_t num_batches
     WordIndex wi;
     bool ok = true;
     SERT_ID_DISPATCH(id_bytes, ok = build_word_index<IdT>((const IdT*)ids, num_batches, B, n, vocab, /*row_is_pos=*/false, wi,
-                                                          /*want_slots=*/false, dense_heavy != 0, row_groups));
+                                                          /*want_slots=*/false, (dense_heavy & 1) != 0, row_groups,
+                                                          /*sort_level0=*/(dense_heavy & 2) != 0));
     if (!ok) SERT_FAIL("token id >= vocab");
     const BatchIndex& bx = wi.batches[(size_t)batch];
+    // (dense_heavy & 2: level 0 sorted by item length, first row number in the descriptor -- what sert_upload_dataset builds
+    //  for the vectorspace models; a row-grouped index is never sorted)
+    if (((dense_heavy & 2) != 0 && row_groups <= 1 && bx.nlevels >= 1 && bx.item_cnt[0] > 0) != bx.slot_is_row) SERT_FAIL("slot_is_row not as asked");
+    if (bx.slot_is_row) {
+        const SegItem* l0 = wi.items.data() + bx.item_off[0];
+        const int32_t* r0 = wi.rows.data() + bx.rows_off;
+        for (int32_t k = 0; k < bx.item_cnt[0]; ++k) {
+            if (l0[k].slot != r0[l0[k].begin]) SERT_FAIL("a level-0 item's slot is not its first row");
+            if (k > 0 && l0[k].end - l0[k].begin > l0[k - 1].end - l0[k - 1].begin) SERT_FAIL("level 0 is not sorted by length");
+        }
+    }
     std::fill(grad_out, grad_out + (size_t)vocab * d, 0.f);
     std::vector<float> part((size_t)std::max<int64_t>(1, bx.part_rows) * d, 0.f);
     int64_t items_total = 0, finals = 0;
@@ -4165,6 +4177,8 @@ int sert_debug_word_index_sum(const void* ids, int id_bytes, int64_t num_batches
             if (it.dst >= 0) ++finals;
             for (int c = 0; c < d; ++c) {
                 float a = 0.f;
+                if (l == 0 && bx.slot_is_row && it.end - it.begin == 1) a += in[(size_t)it.slot * d + c];   // (as segsum_rows does)
+                else
                 for (int32_t e = it.begin; e < it.end; ++e) a += in[(size_t)(rows ? rows[e] : e) * d + c];
                 dst[c] = it.dst >= 0 ? a / divisor : a;
             }

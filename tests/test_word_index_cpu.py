@@ -40,6 +40,28 @@ def test_tree_sum_equals_scatter_add(hip_lib, B, n, Vw, d, groups, dense, dtype)
         assert st['final_items'] == st['distinct_words'] - st['dense_words']
 
 
+@pytest.mark.parametrize('B,n,Vw,d,dense,dtype', [
+    (4096, 10, 2000, 8, False, np.uint16),      # three levels, Zipf: singletons, mid-size words, multi-chunk words
+    (20000, 5, 100, 4, True, np.uint8),         # with the dense heavy words out of the tree
+    (1000, 3, 50000, 4, False, np.uint32),      # nearly every item has one entry: the row comes from the descriptor
+    (3, 2, 7, 4, False, np.uint8),
+])
+def test_sorted_level0_equals_scatter_add(hip_lib, B, n, Vw, d, dense, dtype):
+    """Level 0 sorted by item length, every item's first row number in its descriptor (word_index.h: sort_level0 -- what the
+    vectorspace models upload since round 5): the host walk takes a one-entry item's row from the descriptor as the kernel
+    does, checks the order and the row numbers, and must still equal np.add.at; same item and level counts as unsorted."""
+    rng = np.random.RandomState(B + n + Vw)
+    ids = _zipf_ids(rng, 2, B, n, Vw, dtype)
+    src = rng.randint(-3, 4, size=(B, d)).astype(np.float32)
+    for batch in (0, 1):
+        got, st = C.debug_word_index_sum(ids, Vw, src, batch=batch, dense_heavy=dense, sort_level0=True)
+        _, st0 = C.debug_word_index_sum(ids, Vw, src, batch=batch, dense_heavy=dense)
+        ref = np.zeros((Vw, d), dtype=np.float32)
+        np.add.at(ref, ids[batch].astype(np.int64).ravel(), np.repeat(src, n, axis=0))
+        assert np.array_equal(got, ref), (batch, st)
+        assert st == st0
+
+
 def test_row_grouped_level0_item_count_and_single_item_words(hip_lib):
     """Row grouping multiplies the items (one per (range, word, <= 64 occurrences)) and lets words whose occurrences sit in
     one item skip the partial rows: the counts follow from the data."""

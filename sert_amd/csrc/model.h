@@ -32,6 +32,8 @@ struct DataSplit {
     uint32_t* idx_touched_bits = nullptr;   // per batch: bit w set iff word w occurs in it (word_index.h)
     uint4* idx_dense_counts = nullptr;      // per batch and row: occurrence counts of the batch's dense heavy words
     int32_t* idx_dense_words = nullptr;     // per batch: their word ids (kHeavyMax slots)
+    uint8_t* idx_tok_slot = nullptr;        // (vectorspace) per batch and token position: dense slot of its word or 255
+    std::vector<int32_t> dense_cnt_of;      // per batch: number of dense words (host copy for the forward's gather)
     int64_t bit_words = 0;                  // 32-bit words per batch in idx_touched_bits
     std::vector<BatchIndex> idx_batches;
 };

@@ -1076,6 +1076,15 @@ static int vs_project(sert_model* m, const DataSplit& ds, int64_t batch_index) {
         ScopedTimer t(m, TG_GATHER);
         SERT_ID_DISPATCH(c.id_bytes, {
             const IdT* X = (const IdT*)ds.x + row0 * n;
+            // the batch's hot rows from LDS (kernels_vs.h: vs_gather_mean_hot; training batches with an index and dense words).
+            // OPT-IN, SERT_GATHER_HOT=1: same h bit for bit; see profiles/r05_experiments.txt for what it measured.
+            static const bool hot_off = !(knob("SERT_GATHER_HOT") && atoi(knob("SERT_GATHER_HOT")) != 0);
+            const int nhot = (!hot_off && ds.idx_tok_slot && (size_t)batch_index < ds.dense_cnt_of.size()) ? ds.dense_cnt_of[(size_t)batch_index] : 0;
+            if (dw % 4 == 0 && nhot > 0 && (size_t)nhot * dw * sizeof(float) <= 48 * 1024)
+                hipLaunchKernelGGL((vs_gather_mean_hot<IdT>), dim3(std::min<int64_t>(grid_for((int64_t)B * dw / 4, 256, 1 << 20), 8 * m->num_cus)),
+                                   dim3(256), (size_t)nhot * dw * sizeof(float), m->stream, X, (const uint8_t*)ds.idx_tok_slot + row0 * n,
+                                   (const int32_t*)ds.idx_dense_words + (size_t)batch_index * kHeavyMax, nhot, (const float*)m->rw, m->H, B, n, dw);
+            else
             if (dw % 4 == 0)
                 hipLaunchKernelGGL((vs_gather_mean<IdT, 4>), dim3(grid_for((int64_t)B * dw / 4, 256, 1 << 20)),
                                    dim3(256), 0, m->stream, X, m->rw, m->H, B, n, dw);
@@ -2976,7 +2985,7 @@ static void free_split(DataSplit& d) {
     (void)hipFree(d.idx_bundles); d.idx_bundles = nullptr;
     (void)hipFree(d.idx_uwords); (void)hipFree(d.idx_slots); (void)hipFree(d.idx_rows_div);
     (void)hipFree(d.idx_touched_bits);
-    (void)hipFree(d.idx_dense_counts); (void)hipFree(d.idx_dense_words);
+    (void)hipFree(d.idx_dense_counts); (void)hipFree(d.idx_dense_words); (void)hipFree(d.idx_tok_slot);
     d.idx_uwords = nullptr; d.idx_slots = nullptr; d.idx_rows_div = nullptr;
     d = DataSplit();
 }
@@ -3301,6 +3310,12 @@ int sert_upload_dataset(sert_model* m, int split, const void* x, const int32_t* 
             std::vector<int32_t> hw((size_t)nb * kHeavyMax, 0);
             for (int64_t b = 0; b < nb; ++b)
                 for (int h = 0; h < wi.batches[(size_t)b].dense_cnt; ++h) hw[(size_t)b * kHeavyMax + h] = wi.batches[(size_t)b].dense_word[h];
+            if (!wi.dense_tok_slot.empty()) {
+                SERT_HIP(hipMalloc((void**)&d.idx_tok_slot, wi.dense_tok_slot.size()));
+                SERT_HIP(hipMemcpyAsync(d.idx_tok_slot, wi.dense_tok_slot.data(), wi.dense_tok_slot.size(), hipMemcpyHostToDevice, s));
+                d.dense_cnt_of.resize((size_t)nb);
+                for (int64_t b = 0; b < nb; ++b) d.dense_cnt_of[(size_t)b] = wi.batches[(size_t)b].dense_cnt;
+            }
             SERT_TRY(dmalloc(&d.idx_dense_words, hw.size()));
             SERT_HIP(hipMemcpyAsync(d.idx_dense_words, hw.data(), hw.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
             SERT_HIP(hipStreamSynchronize(s));

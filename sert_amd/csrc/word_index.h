@@ -101,6 +101,9 @@ struct WordIndex {
     // batch has any
     std::vector<uint8_t> dense_counts;    // [num_batches][B][kHeavyMax]
     bool any_dense = false;
+    // (vectorspace) per batch and token position: the dense slot of the position's word, 255 = none -- the forward's gather
+    // takes a dense word's row from LDS instead of fetching it once per occurrence (kernels_vs.h: vs_gather_mean_hot)
+    std::vector<uint8_t> dense_tok_slot;  // [num_batches][B * n]
 };
 
 // ids: (num_batches*B*n) token ids of the complete batches, IdT wide.
@@ -132,6 +135,7 @@ bool build_word_index(const IdT* ids, int64_t num_batches, int B, int n, int voc
     if (dense_heavy) {
         heavy_slot.assign((size_t)vocab, (int8_t)-1);
         out.dense_counts.assign((size_t)(num_batches * B) * kHeavyMax, (uint8_t)0);
+        if (!want_slots) out.dense_tok_slot.assign((size_t)(num_batches * T), (uint8_t)255);
     }
     out.rows.resize((size_t)(num_batches * T));
     out.batches.resize((size_t)num_batches);
@@ -181,9 +185,13 @@ bool build_word_index(const IdT* ids, int64_t num_batches, int B, int n, int voc
                 }
                 bx.dense_cnt = (int32_t)cand.size();
                 uint8_t* dc = out.dense_counts.data() + (size_t)(bi * B) * kHeavyMax;
+                uint8_t* ts = out.dense_tok_slot.empty() ? nullptr : out.dense_tok_slot.data() + (size_t)(bi * T);
                 for (int64_t p = 0; p < T; ++p) {
                     const int8_t h = heavy_slot[(size_t)x[p]];
-                    if (h >= 0) ++dc[(size_t)(p / n) * kHeavyMax + h];
+                    if (h >= 0) {
+                        ++dc[(size_t)(p / n) * kHeavyMax + h];
+                        if (ts) ts[p] = (uint8_t)h;
+                    }
                 }
                 out.any_dense = true;
             }

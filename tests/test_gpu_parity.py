@@ -137,6 +137,32 @@ def test_word_gradient_row_grouped_tree(hip_lib, monkeypatch, dims, groups, dens
 
 
 @pytest.mark.parametrize('dims', [
+    dict(B=20000, n=5, Vw=300, dw=128),      # three hot words, the rest through L1 / L2
+    dict(B=6100, n=8, Vw=3000, dw=300),      # 75 float4 per row, ragged last workgroup pass
+])
+def test_gather_with_hot_rows_in_lds_is_bit_identical(hip_lib, monkeypatch, dims):
+    """SERT_GATHER_HOT=1 (opt-in, kernels_vs.h: vs_gather_mean_hot): the forward's gather takes the rows of the batch's dense
+    heavy words from LDS instead of fetching them once per occurrence -- the same rows added in the same window order: h, the
+    loss and the word-table gradient of a step are the plain kernel's bit for bit."""
+    B, n, Vw, dw = dims['B'], dims['n'], dims['Vw'], dims['dw']
+    z, Ve, de = 3, 20, 32
+    p = U.make_vs_problem(17, B, n, z, Vw, Ve, dw, de, zipf=True)
+    neg = p['rng'].randint(0, Ve, size=(B, z)).astype(np.int64)
+    got = []
+    for hot in ('1', '0'):
+        monkeypatch.setenv('SERT_GATHER_HOT', hot)
+        eng = U.vs_engine(p, B, n, z, 0.01)
+        eng.upload_dataset(C.SPLIT_TRAIN, p['X'], y_int=p['y'], w=p['w'])
+        loss = eng.train_batch(0, neg)
+        got.append((loss, eng.get_tensor(C.T_ACT_H, (B, dw)).copy(), eng.get_tensor(C.T_GRAD_RW, (Vw, dw)).copy()))
+        eng.close()
+    assert got[0][0] == got[1][0]
+    assert np.array_equal(got[0][1], got[1][1]) and np.array_equal(got[0][2], got[1][2])
+    h64 = p['Rw'].astype(np.float64)[p['X'].astype(np.int64)].mean(axis=1)
+    assert U.rel_err(got[0][1], h64) < 2e-6
+
+
+@pytest.mark.parametrize('dims', [
     dict(B=20000, n=5, Vw=300, dw=128),      # C2's row width: a handful of words above 4096 occurrences, 157 row blocks (the last one ragged)
     dict(B=6100, n=8, Vw=3000, dw=300),      # d_w = 300: three 32-lane column groups (the extra workgroups' slab is blockIdx.y)
     dict(B=9000, n=12, Vw=20, dw=64, uniform=1),   # twenty words of ~5400 occurrences: sixteen dense, four stay in a three-level tree

@@ -1077,9 +1077,9 @@ static int vs_project(sert_model* m, const DataSplit& ds, int64_t batch_index) {
         SERT_ID_DISPATCH(c.id_bytes, {
             const IdT* X = (const IdT*)ds.x + row0 * n;
             // the batch's hot rows from LDS (kernels_vs.h: vs_gather_mean_hot; training batches with an index and dense words).
-            // OPT-IN, SERT_GATHER_HOT=1: same h bit for bit; see profiles/r05_experiments.txt for what it measured.
-            static const bool hot_off = !(knob("SERT_GATHER_HOT") && atoi(knob("SERT_GATHER_HOT")) != 0);
-            const int nhot = (!hot_off && ds.idx_tok_slot && (size_t)batch_index < ds.dense_cnt_of.size()) ? ds.dense_cnt_of[(size_t)batch_index] : 0;
+            // OPT-IN, SERT_GATHER_HOT=1 (read at upload: the slot bytes exist only then): same h bit for bit, measured SLOWER --
+            // profiles/r05_experiments.txt, item 32.
+            const int nhot = (ds.idx_tok_slot && (size_t)batch_index < ds.dense_cnt_of.size()) ? ds.dense_cnt_of[(size_t)batch_index] : 0;
             if (dw % 4 == 0 && nhot > 0 && (size_t)nhot * dw * sizeof(float) <= 48 * 1024)
                 hipLaunchKernelGGL((vs_gather_mean_hot<IdT>), dim3(std::min<int64_t>(grid_for((int64_t)B * dw / 4, 256, 1 << 20), 8 * m->num_cus)),
                                    dim3(256), (size_t)nhot * dw * sizeof(float), m->stream, X, (const uint8_t*)ds.idx_tok_slot + row0 * n,
@@ -3310,7 +3310,8 @@ int sert_upload_dataset(sert_model* m, int split, const void* x, const int32_t* 
             std::vector<int32_t> hw((size_t)nb * kHeavyMax, 0);
             for (int64_t b = 0; b < nb; ++b)
                 for (int h = 0; h < wi.batches[(size_t)b].dense_cnt; ++h) hw[(size_t)b * kHeavyMax + h] = wi.batches[(size_t)b].dense_word[h];
-            if (!wi.dense_tok_slot.empty()) {
+            // (only where the opt-in gather that reads it is switched on: a byte per token of the data set)
+            if (!wi.dense_tok_slot.empty() && knob("SERT_GATHER_HOT") && atoi(knob("SERT_GATHER_HOT")) != 0) {
                 SERT_HIP(hipMalloc((void**)&d.idx_tok_slot, wi.dense_tok_slot.size()));
                 SERT_HIP(hipMemcpyAsync(d.idx_tok_slot, wi.dense_tok_slot.data(), wi.dense_tok_slot.size(), hipMemcpyHostToDevice, s));
                 d.dense_cnt_of.resize((size_t)nb);

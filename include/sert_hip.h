@@ -307,12 +307,18 @@ int sert_synchronize(sert_model* m);
  * Enabled with sert_timing_enable(m, 1); while enabled the step runs fully serialised
  * on one stream (each kernel is measured alone) and every event record drains the
  * stream, so a timed step is slower than an untimed one: take throughput from
- * untimed steps.  Groups: sert_timing_count / sert_timing_name. */
+ * untimed steps.  Groups: sert_timing_count / sert_timing_name.
+ * sert_timing_enable(m, 2): IN-STEP timing -- the normal schedule (all streams, run-ahead of the announced batch), every
+ * plain kernel launch of a group bound to a (start, stop) event pair of its own (hipExtLaunchKernelGGL: the kernel's own
+ * dispatch timestamps, no barrier packets); sert_timing_avg_us then returns the group's kernel time per training step as
+ * it runs BESIDE the other queue's kernels, sert_timing_launches its timed launches per step.  Launches that carry a
+ * completion event of the schedule are not timed (their groups read low or 0). */
 int sert_timing_enable(sert_model* m, int on);
 int sert_timing_reset(sert_model* m);
 int sert_timing_count(sert_model* m);
 const char* sert_timing_name(sert_model* m, int i);
 double sert_timing_avg_us(sert_model* m, int i);
+double sert_timing_launches(sert_model* m, int i);
 
 #ifdef __cplusplus
 }

@@ -18,6 +18,21 @@
 extern "C" {
 #endif
 
+/* Launches of the word-table update (sert/models.py:548-549 applied to R_w) by kernel form since sert_create -- host
+ * counters, test hook: out[0] dense (adam_l2 / adadelta_l2), out[1] dense_update_lazy, out[2..7] dense_update_skip
+ * <32,1> <64,1> <32,3> <64,2> <64,3> <64,4> (lanes per row, float4 columns per lane), out[8] the dense_update_skip passes
+ * that read and wrote every row, out[9] its sparse passes.  n <= 10.  The tests assert through this that every template
+ * shape met the oracle (tests/test_gpu_skip_shapes.py). */
+int sert_debug_update_counts(sert_model* m, int64_t* out, int n);
+
+/* Test hook: overwrite the step's gradient scratch -- the flat buffer [g_Rw | g_Re | g_W | g_b | loss, sum of squares] with
+ * quiet NaNs, the per-entity sorted-run bounds behind it with the wrong run [0, 1) -- after waiting for the device.  A step
+ * whose negatives were drawn ahead launches NO prologue (nothing is zeroed): it relies on every value it reads having been
+ * written by this step's own kernels.  A run with this call between the steps must equal the run without it bit for bit
+ * (tests/test_gpu_parity.py::test_steps_read_nothing_stale_from_the_gradient_scratch).  Fails while a run-ahead step
+ * (sert_hint_next_batch) is in flight: its gradients live there. */
+int sert_debug_poison_scratch(sert_model* m);
+
 /* Host-only (no device is touched): the row-exchange lists rank `rank` of `world` derives for batch
  * `batch` from the touched-row bitmaps of ALL ranks, allbits[world][num_batches][bit_words] -- the
  * function sert_upload_dataset runs on the gathered bitmaps (csrc/kernels_xchg.h).  Lets the

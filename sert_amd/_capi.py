@@ -35,7 +35,8 @@ EXPORTS = [
     'sert_host_alloc', 'sert_host_free',
     'sert_comm_unique_id', 'sert_comm_init', 'sert_comm_init_host', 'sert_comm_destroy', 'sert_comm_stats',
     'sert_synchronize', 'sert_timing_enable', 'sert_timing_reset', 'sert_timing_count',
-    'sert_timing_name', 'sert_timing_avg_us', 'sert_bench_gemm', 'sert_debug_gemm', 'sert_debug_gemm_splitk', 'sert_debug_gemm_longk', 'sert_bench_memory', 'sert_debug_row_lists', 'sert_debug_word_index_sum',
+    'sert_timing_name', 'sert_timing_avg_us', 'sert_timing_launches', 'sert_bench_gemm', 'sert_debug_gemm', 'sert_debug_gemm_splitk', 'sert_debug_gemm_longk', 'sert_bench_memory', 'sert_debug_row_lists', 'sert_debug_word_index_sum',
+    'sert_debug_update_counts', 'sert_debug_poison_scratch',
     'sert_profile_range_push', 'sert_profile_range_pop',
 ]
 
@@ -139,6 +140,8 @@ def load():
     lib.sert_timing_name.restype = ctypes.c_char_p
     lib.sert_timing_avg_us.argtypes = [vp, ctypes.c_int]
     lib.sert_timing_avg_us.restype = ctypes.c_double
+    lib.sert_timing_launches.argtypes = [vp, ctypes.c_int]
+    lib.sert_timing_launches.restype = ctypes.c_double
     lib.sert_bench_gemm.argtypes = [ctypes.c_int] * 9 + [ctypes.POINTER(ctypes.c_double)]
     lib.sert_bench_memory.argtypes = [ctypes.c_int, ctypes.c_int, sz, sz, ctypes.c_int, ctypes.c_int, sz, ctypes.c_int,
                                       ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
@@ -358,10 +361,30 @@ class Engine(object):
         check(self._lib.sert_synchronize(self._h))
 
     def timing_enable(self, on=True):
-        check(self._lib.sert_timing_enable(self._h, 1 if on else 0))
+        """False / 0: off; True / 1: every kernel group alone on one queue; 2: in the step (see sert_hip.h)."""
+        check(self._lib.sert_timing_enable(self._h, int(on)))
+
+    def timing_launches(self):
+        """In-step mode: timed launches per training step and group."""
+        n = self._lib.sert_timing_count(self._h)
+        return {self._lib.sert_timing_name(self._h, i).decode():
+                self._lib.sert_timing_launches(self._h, i) for i in range(n)}
 
     def timing_reset(self):
         check(self._lib.sert_timing_reset(self._h))
+
+    def poison_scratch(self):
+        """sert_debug_poison_scratch (test hook): NaNs into the gradient scratch, wrong run bounds behind it."""
+        self._lib.sert_debug_poison_scratch.argtypes = [ctypes.c_void_p]
+        check(self._lib.sert_debug_poison_scratch(self._h))
+
+    def update_counts(self):
+        """sert_debug_update_counts (test hook): launches of the word-table update by kernel form since creation."""
+        v = (ctypes.c_int64 * 10)()
+        self._lib.sert_debug_update_counts.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_int]
+        check(self._lib.sert_debug_update_counts(self._h, v, 10))
+        names = ('dense', 'lazy', 'skip_32_1', 'skip_64_1', 'skip_32_3', 'skip_64_2', 'skip_64_3', 'skip_64_4', 'skip_full', 'skip_sparse')
+        return dict(zip(names, (int(x) for x in v)))
 
     def timings(self):
         n = self._lib.sert_timing_count(self._h)

@@ -27,12 +27,69 @@ inline void set_stop_event(hipEvent_t ev) { pending_stop_event() = ev; }
             hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);               \
     } while (0)
 
+// ---- in-step kernel timing -------------------------------------------------------------------------------------
+// sert_timing_enable(m, 2): the NORMAL schedule (all streams, run-ahead), with every plain kernel launch inside a timing
+// group bound to a (start, stop) event pair of its own through hipExtLaunchKernelGGL -- the kernel's own dispatch
+// timestamps, no barrier packets, no serialisation: what a kernel takes IN THE STEP, beside whatever the other queue runs
+// (mode 1 times every group alone on one queue).  The hook is thread-local and null outside a timing scope of a model
+// in that mode: one predictable branch per launch.  Launches that carry a completion event of the schedule (SERT_LAUNCH
+// with set_stop_event) keep it and are not timed.
+struct InStepHook {
+    void (*next)(void* ctx, hipEvent_t* start, hipEvent_t* stop);
+    void* ctx;
+};
+inline InStepHook& instep_hook() {
+    static thread_local InStepHook h = {nullptr, nullptr};
+    return h;
+}
+// (hip_ext.h's hipExtLaunchKernelGGL wants the call's argument types to BE the kernel's parameter types; the launches of
+//  this library rely on the implicit conversions and the default arguments that <<<>>> allows: so the timed launch converts
+//  the arguments to the kernel's own parameter types itself, and a call that leaves trailing parameters to their defaults
+//  -- which a function pointer does not carry -- is simply not timed)
+#include <tuple>
+#include <utility>
+template <typename... Formal, typename... Actual, size_t... I>
+inline bool sert_ext_launch_impl(void (*kernel)(Formal...), dim3 grid, dim3 block, unsigned shmem, hipStream_t stream,
+                                 hipEvent_t start, hipEvent_t stop, std::index_sequence<I...>, Actual&&... args) {
+    std::tuple<std::remove_cv_t<Formal>...> tup{static_cast<std::remove_cv_t<Formal>>(std::forward<Actual>(args))...};
+    void* ptrs[sizeof...(Formal) ? sizeof...(Formal) : 1] = {(void*)&std::get<I>(tup)...};
+    return hipExtLaunchKernel((const void*)kernel, grid, block, ptrs, shmem, stream, start, stop, 0) == hipSuccess;
+}
+template <typename... Formal, typename... Actual>
+inline bool sert_ext_launch(void (*kernel)(Formal...), dim3 grid, dim3 block, unsigned shmem, hipStream_t stream,
+                            hipEvent_t start, hipEvent_t stop, Actual&&... args) {
+    if constexpr (sizeof...(Formal) != sizeof...(Actual)) {
+        return false;
+    } else {
+        return sert_ext_launch_impl(kernel, grid, block, shmem, stream, start, stop, std::index_sequence_for<Formal...>{},
+                                    std::forward<Actual>(args)...);
+    }
+}
+template <typename... Formal, typename... Actual>
+constexpr bool sert_ext_arity_ok(void (*)(Formal...), Actual&&...) {
+    return sizeof...(Formal) == sizeof...(Actual);
+}
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)                                                      \
+    do {                                                                                                                 \
+        hipEvent_t sert_a_ = nullptr, sert_b_ = nullptr;                                                                 \
+        if (::instep_hook().next && ::sert_ext_arity_ok(kernel, __VA_ARGS__))                                            \
+            ::instep_hook().next(::instep_hook().ctx, &sert_a_, &sert_b_);                                               \
+        if (!(sert_a_ && ::sert_ext_launch(kernel, dim3(grid), dim3(block), (unsigned)(shmem), stream, sert_a_, sert_b_, \
+                                           __VA_ARGS__)))                                                                \
+            hipLaunchKernelGGLInternal((kernel), grid, block, shmem, stream, __VA_ARGS__);                               \
+    } while (0)
+
 // ---- environment switches -----------------------------------------------------------------------------------
-// The PRODUCT library reads nineteen documented variables, through knob(); each is exercised by a test
+// The PRODUCT library reads eighteen documented variables, through knob(); each is exercised by a test
 // ("Environment"):
 //   SERT_DP_EXCHANGE  SERT_AR_CHUNKS  SERT_STREAMS  SERT_SIDE_HEAVY  SERT_RE_DEFER  SERT_GEMM_FP32  SERT_NO_TOUCHED
 //   SERT_SCORE_MATERIALISE  SERT_SCORE_FP32  SERT_LL_NODEDUP  SERT_LL_DW_SIDE  SERT_DENSE_HEAVY  SERT_FS_TILE_ROWS
-//   SERT_EGRAD_SORT  SERT_ROCTX  SERT_SEG_BUNDLE  SERT_EVENT_FENCE  SERT_PROJ_FUSED  SERT_EGRAD_RANGES
+//   SERT_EGRAD_SORT  SERT_ROCTX  SERT_EVENT_FENCE  SERT_LAZY_SKIP (0: dense_update_lazy instead of dense_update_skip)
+//   SERT_LAZY_MAX (largest touched fraction of a batch whose word-table update is lazy; default 0.5 behind an announced
+//   next batch, min(that, 0.35) without one)
+// Round 6 moved the measured-and-lost opt-ins of round 5 behind variant_knob() and their kernels into csrc/variants/:
+// SERT_PROJ_FUSED, SERT_GATHER_HOT, SERT_EGRAD_RANGES, SERT_SEG_BUNDLE (and SERT_BWD_FUSED's kernel).
 // Everything else -- A/B variants that lost, cross-check paths of earlier rounds, tuning sweeps, timing
 // knock-outs -- is read through variant_knob(), which is the environment only in a library built with
 // -DSERT_VARIANTS (tools/build_variant.sh variants -DSERT_VARIANTS; run the suite against it with SERT_LIB=...)

@@ -68,6 +68,21 @@ struct Timing {
     int64_t samples[TG_COUNT] = {};
 };
 
+// sert_timing_enable(m, 2) (common.h: InStepHook): event pairs of the launches in flight, harvested when the ring is full
+// and when the averages are read
+struct InStep {
+    static constexpr int kRing = 1024;
+    bool on = false;
+    bool created = false;
+    hipEvent_t ev[kRing][2] = {};
+    int group[kRing] = {};
+    int64_t head = 0, tail = 0;        // pairs [head, tail) are pending
+    int cur_group = -1;                // the timing group the launching thread is inside (ScopedTimer)
+    double total_us[TG_COUNT] = {};
+    int64_t launches[TG_COUNT] = {};
+    int64_t steps = 0;
+};
+
 }  // namespace sert
 
 struct sert_model {
@@ -86,6 +101,7 @@ struct sert_model {
     bool fork_bound = false;         // ev_fork rides on the NCE kernel's completion signal (no record needed)
     bool egrad_ranges = false;       // SERT_EGRAD_RANGES=1 at sert_create: the one-launch range kernel for few pairs over a mid-size table (opt-in)
     bool egrad_force_sort = false;   // SERT_EGRAD_SORT=1 at sert_create: the sorted entity-gradient path whatever the shape
+    bool events_device_scope = false;  // the intra-model events carry hipEventDisableSystemFence (no communicator; sert_hip.hip: create_intra_events)
     bool lazy_join = false;          // this step: the main stream never waits for the entity chain
     int num_cus = 256;               // compute units of the device (persistent launches: one workgroup per CU)
     bool proj_fused = false;         // gather + mean-pool + projection in one launch where the shape allows (kernels_proj.h; opt-in, SERT_PROJ_FUSED=1)
@@ -123,6 +139,11 @@ struct sert_model {
     int64_t rw_pred_T = 0;         // the next update that reads every row
     bool lazy_skip = true;         // SERT_LAZY_SKIP=0: dense_update_lazy (reads every row every step)
     float lazy_max = 0.5f;         // SERT_LAZY_MAX: largest touched fraction of a batch whose word-table update is lazy
+    // launches of the word-table update by form since sert_create (host counters, read by sert_debug_update_counts -- the
+    // tests assert through them that every template shape of dense_update_skip was in front of the oracle):
+    // [0] dense (adam_l2 / adadelta_l2), [1] dense_update_lazy, [2..7] dense_update_skip <32,1> <64,1> <32,3> <64,2> <64,3>
+    // <64,4>, [8] of those the passes that read and write every row, [9] the sparse ones
+    int64_t upd_counts[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     int64_t projected_batch = -1;  // training batch whose forward projection already sits in H/T
     // hinted single-GPU steps go further: the whole forward + backward runs ahead
     int64_t spec_fb_batch = -1;    // forward + backward of this batch already ran (gradients ready) ...
@@ -293,6 +314,7 @@ struct sert_model {
     hipStream_t sq_stream = nullptr;                  // (the side stream the shard sum-of-squares runs on)
 
     sert::Timing timing;
+    sert::InStep instep;
 };
 
 struct sert_scorer {

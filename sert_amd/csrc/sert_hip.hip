@@ -14,8 +14,8 @@
 #include "common.h"
 #include "gemm.h"
 #include "gemm_x3.h"
-#include "gemm_bwd_fused.h"
-#ifdef SERT_VARIANTS   // opt-in GEMM variants that lost their A/B (csrc/variants/; tools/build_variant.sh -DSERT_VARIANTS)
+#ifdef SERT_VARIANTS   // opt-in variants that lost their A/B (csrc/variants/; tools/build_variant.sh -DSERT_VARIANTS)
+#include "variants/gemm_bwd_fused.h"
 #include "variants/gemm_big.h"
 #include "variants/gemm_x3_bres.h"
 #include "variants/score_filter_ring.h"
@@ -28,11 +28,16 @@
 #include "kernels_ll.h"
 #include "kernels_membench.h"
 #include "kernels_opt.h"
-#include "kernels_proj.h"
 #include "kernels_score.h"
 #include "kernels_seg.h"
 #include "kernels_sort.h"
 #include "kernels_vs.h"
+#ifdef SERT_VARIANTS
+#include "variants/kernels_gather_hot.h"
+#include "variants/kernels_seg_bundled.h"
+#include "variants/kernels_egrad_ranges.h"
+#include "variants/kernels_proj.h"   // (after kernels_vs.h / gemm_x3.h: gather + mean-pool + projection in one persistent launch, measured slower)
+#endif
 #include "model.h"
 
 namespace sert {
@@ -75,11 +80,45 @@ static bool roctx_groups() {
 }
 
 // ---- timing ----------------------------------------------------------------
+// in-step mode (sert_timing_enable(m, 2); common.h: InStepHook): a (start, stop) pair for the next launch of the group the
+// launching thread is inside
+static void instep_harvest(sert_model* m, bool all) {
+    InStep& t = m->instep;
+    while (t.head < t.tail && (all || t.tail - t.head >= InStep::kRing)) {
+        const int i = (int)(t.head % InStep::kRing);
+        float ms = 0.f;
+        if (hipEventSynchronize(t.ev[i][1]) == hipSuccess && hipEventElapsedTime(&ms, t.ev[i][0], t.ev[i][1]) == hipSuccess) {
+            t.total_us[t.group[i]] += 1000.0 * ms;
+            t.launches[t.group[i]] += 1;
+        }
+        ++t.head;
+    }
+}
+static void instep_next(void* ctx, hipEvent_t* a, hipEvent_t* b) {
+    sert_model* m = (sert_model*)ctx;
+    InStep& t = m->instep;
+    if (!t.on || t.cur_group < 0) return;
+    instep_harvest(m, false);
+    const int i = (int)(t.tail % InStep::kRing);
+    t.group[i] = t.cur_group;
+    *a = t.ev[i][0];
+    *b = t.ev[i][1];
+    ++t.tail;
+}
+
 struct ScopedTimer {
     sert_model* m;
     int g;
     hipStream_t s;
+    int instep_prev = -1;
+    InStepHook hook_prev = {nullptr, nullptr};
     ScopedTimer(sert_model* m_, int g_, hipStream_t s_ = nullptr) : m(m_), g(g_), s(s_ ? s_ : m_->stream) {
+        if (m->instep.on) {
+            instep_prev = m->instep.cur_group;
+            hook_prev = instep_hook();
+            m->instep.cur_group = g;
+            instep_hook() = InStepHook{instep_next, m};
+        }
         if (roctx_groups()) (void)g_roctx.push(kTimingNames[g]);
         // a group bracketed several times in one step spans first start .. last end
         if (m->timing.enabled && !m->timing.used[g]) {
@@ -92,6 +131,10 @@ struct ScopedTimer {
             m->timing.used[g] = true;
         }
         if (roctx_groups()) (void)g_roctx.pop();
+        if (m->instep.on) {
+            m->instep.cur_group = instep_prev;
+            instep_hook() = hook_prev;
+        }
     }
 };
 
@@ -383,11 +426,13 @@ static int word_grad_segsum(sert_model* m, const DataSplit& ds, int64_t batch_in
         }
         // level 0 in bundles of short items (kernels_seg.h: segsum_rows_bundled; opt-in, SERT_SEG_BUNDLE=1 at upload -- the
         // same sums bit for bit as one item per lane group, tests/test_gpu_parity.py::test_word_gradient_bundled_level0)
+#ifdef SERT_VARIANTS
         if (l == 0 && d % 4 == 0 && bx.bundle_cnt > 0 && ds.idx_bundles && bx.row_groups == 1) {
             hipLaunchKernelGGL(segsum_rows_bundled, dim3(cdiv(bx.bundle_cnt, 8), cdiv(d / 4, 32)), dim3(256), 0, m->stream, in, rows,
                                items, (const int32_t*)ds.idx_bundles + bx.bundle_off, (int)bx.bundle_cnt, m->g_rw, pout, d, divisor);
             continue;
         }
+#endif
         if (d % 4 == 0) {
             // lane groups of 32 or 64 float4 columns, whichever wastes fewer lanes (d = 300: 75 chunks are
             // 3 x 32 at 78 % instead of 2 x 64 at 59 %: 147 -> 143 us at C4; the sums do not depend on it)
@@ -1060,8 +1105,9 @@ static int vs_project(sert_model* m, const DataSplit& ds, int64_t batch_index) {
     const size_t row0 = (size_t)batch_index * B;
     // gather + mean-pool + projection in ONE launch where the shape allows it (kernels_proj.h: d_w, d_e <= 128, window <= 10):
     // the h and the t of the two launches below, bit for bit where they run gemm_x3.  OPT-IN, SERT_PROJ_FUSED=1 (read at
-    // sert_create): round 5 measured it slower than the two launches at C2 and equal at 8192 rows.  SERT_GEMM_FP32=1 (the
-    // fused kernel multiplies on the bf16 pipe) keeps the two launches too.
+    // sert_create, VARIANTS BUILD ONLY since round 6): round 5 measured it slower than the two launches at C2 and equal at 8192
+    // rows.  SERT_GEMM_FP32=1 (the fused kernel multiplies on the bf16 pipe) keeps the two launches too.
+#ifdef SERT_VARIANTS
     if (m->proj_fused && gemm_x3_enabled() && vs_project_fused_ok(B, n, dw, de, m->n_rw)) {
         if (m->T_alt) std::swap(m->T, m->T_alt);     // (see below: this projection goes to the other buffer)
         ScopedTimer t(m, TG_GATHER);
@@ -1072,19 +1118,22 @@ static int vs_project(sert_model* m, const DataSplit& ds, int64_t batch_index) {
         });
         return 0;
     }
+#endif
     {
         ScopedTimer t(m, TG_GATHER);
         SERT_ID_DISPATCH(c.id_bytes, {
             const IdT* X = (const IdT*)ds.x + row0 * n;
             // the batch's hot rows from LDS (kernels_vs.h: vs_gather_mean_hot; training batches with an index and dense words).
-            // OPT-IN, SERT_GATHER_HOT=1 (read at upload: the slot bytes exist only then): same h bit for bit, measured SLOWER --
+            // OPT-IN in a VARIANTS BUILD, SERT_GATHER_HOT=1 (read at upload: the slot bytes exist only then): same h bit for bit, measured SLOWER --
             // profiles/r05_experiments.txt, item 32.
+#ifdef SERT_VARIANTS
             const int nhot = (ds.idx_tok_slot && (size_t)batch_index < ds.dense_cnt_of.size()) ? ds.dense_cnt_of[(size_t)batch_index] : 0;
             if (dw % 4 == 0 && nhot > 0 && (size_t)nhot * dw * sizeof(float) <= 48 * 1024)
                 hipLaunchKernelGGL((vs_gather_mean_hot<IdT>), dim3(std::min<int64_t>(grid_for((int64_t)B * dw / 4, 256, 1 << 20), 8 * m->num_cus)),
                                    dim3(256), (size_t)nhot * dw * sizeof(float), m->stream, X, (const uint8_t*)ds.idx_tok_slot + row0 * n,
                                    (const int32_t*)ds.idx_dense_words + (size_t)batch_index * kHeavyMax, nhot, (const float*)m->rw, m->H, B, n, dw);
             else
+#endif
             if (dw % 4 == 0)
                 hipLaunchKernelGGL((vs_gather_mean<IdT, 4>), dim3(grid_for((int64_t)B * dw / 4, 256, 1 << 20)),
                                    dim3(256), 0, m->stream, X, m->rw, m->H, B, n, dw);
@@ -1262,19 +1311,26 @@ static bool bwd_fused_applies(const sert_model* m) {
     // opt-in (SERT_BWD_FUSED=1): measured EQUAL to the two gemm.h launches at C2 (57.5 us against 29.3 + 29.2;
     // step 0.3030 against 0.3046 ms, inside the run-to-run spread) -- the fused kernel keeps the matrix pipe as
     // busy as they do (48 %), it only saves a launch and half of the partial slabs
+#ifdef SERT_VARIANTS
     static const bool on = variant_knob("SERT_BWD_FUSED") && atoi(variant_knob("SERT_BWD_FUSED")) != 0;
     return on && m->cfg.kind == SERT_KIND_VECTORSPACE && m->cfg.word_dim == FB_D && m->cfg.entity_dim == FB_D &&
            m->cfg.batch_size >= 1024 && m->nstreams < 3 && (size_t)256 * (FB_D * FB_D + FB_D) <= m->part_count;
+#else
+    (void)m;
+    return false;      // (the kernel lives in csrc/variants/gemm_bwd_fused.h: not in the product library)
+#endif
 }
 
 // Few (pair, entity) keys over a table too large for the sort-free LDS path: the one-launch range kernel instead of
 // sort + chunked reduce + fix-up (eight launches).  The scan costs ranges x pairs id reads: capped at 64 M (~256 MB out of L2).
-// OPT-IN (SERT_EGRAD_RANGES=1 at sert_create): 32 us alone against 67 for the eight launches at the product-search settings,
+// OPT-IN in a VARIANTS BUILD (SERT_EGRAD_RANGES=1 at sert_create): 32 us alone against 67 for the eight launches at the product-search settings,
 // but the STEP does not move (0.202-0.207 against 0.199-0.203 ms: that chain is not what the step waits for; round 5).
+#ifdef SERT_VARIANTS
 static bool egrad_ranges_ok(const sert_model* m, int total) {
     const long long ranges = cdiv(m->cfg.num_entities, kERange);
     return m->egrad_ranges && !m->egrad_force_sort && !m->epart && m->cfg.entity_dim % 4 == 0 && total <= (1 << 20) && ranges * (long long)total <= (64ll << 20);
 }
+#endif
 
 static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) {
     const auto& c = m->cfg;
@@ -1284,7 +1340,11 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
     const bool fork_nce = fork_late && fork_at_nce(m);
     const bool side_heavy = side_heavy_mode(m);
     const bool fused_bwd = bwd_fused_applies(m) && !side_heavy;
+#ifdef SERT_VARIANTS
     const int fused_grid = std::min(256, cdiv(B, FB_ROWS));   // one workgroup per CU, or per strip if there are fewer
+#else
+    const int fused_grid = 0;
+#endif
     auto entity_grad = [&]() -> int {
         // fork: this chain only depends on the NCE kernel and is independent of the
         // GEMMs / word-table reduction below, so it runs on the side stream
@@ -1329,11 +1389,13 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
                 hipLaunchKernelGGL(egrad_group_sum, dim3(grid_for((int64_t)table4)), dim3(256), 0, st, m->epart, m->eg_groups,
                                    table4, m->g_re);
             }
+#ifdef SERT_VARIANTS
         } else if (egrad_ranges_ok(m, total)) {
-            // few pairs over a mid-size table: one workgroup per range of 128 entities, no sort (kernels_egrad.h: egrad_ranges)
+            // few pairs over a mid-size table: one workgroup per range of 32 entities, no sort (variants/kernels_egrad_ranges.h)
             ScopedTimer t(m, TG_EGRAD, st);
             hipLaunchKernelGGL(egrad_ranges, dim3(cdiv(V, kERange)), dim3(256), 0, st, (const int32_t*)m->cand, (const float*)m->coef,
                                (const float*)m->T, total, c.num_negatives + 1, de, V, m->g_re);
+#endif
         } else {
         // dR_e: stable sort of the (entity, pair) keys, chunked reduce, carry fix-up
         {
@@ -1392,6 +1454,7 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
             // (ev_dense below: the completion signal of this GEMM, not a barrier packet behind it)
             dense_bound = m->lazy_join && ext_events() && !strip && !fork_nce;
             if (dense_bound) set_stop_event(fork_late ? m->ev_fork : m->ev_dense);
+#ifdef SERT_VARIANTS
             if (fused_bwd) {
                 // dh, the per-workgroup partial slabs of dW and their column sums (db): one launch
                 static const bool attr_set = hipFuncSetAttribute((const void*)vs_bwd_fused, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1402,7 +1465,6 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
                 fa.stride = (size_t)FB_D * FB_D + FB_D;
                 SERT_LAUNCH(vs_bwd_fused, dim3(fused_grid), dim3(FB_THREADS), vs_bwd_fused_lds_bytes(), m->stream, fa);
             } else
-#ifdef SERT_VARIANTS
             if (strip)
                 launch_gemm_strip<true, EPI_STORE>(m->stream, m->DA, m->W, m->DH, nullptr, B, dw, de, de, de, dw);
             else
@@ -2176,26 +2238,29 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
                     // 2^26 elements.  SERT_SKIP_32X3=0 / 1 (variants build) forces it off / on.
                     static const int skip_32x3_knob = variant_knob("SERT_SKIP_32X3") ? atoi(variant_knob("SERT_SKIP_32X3")) : -1;
                     const bool skip_32x3 = skip_32x3_knob >= 0 ? skip_32x3_knob != 0 : t.n < ((size_t)1 << 26);
-#define SERT_SKIP_SHAPE(ADAM)                                        \
-    do {                                                             \
-        if (d4 <= 32) SERT_SKIP_LAUNCH(ADAM, 32, 1);                 \
-        else if (d4 <= 64) SERT_SKIP_LAUNCH(ADAM, 64, 1);            \
-        else if (d4 <= 96 && skip_32x3) SERT_SKIP_LAUNCH(ADAM, 32, 3); \
-        else if (d4 <= 128) SERT_SKIP_LAUNCH(ADAM, 64, 2);           \
-        else if (d4 <= 192) SERT_SKIP_LAUNCH(ADAM, 64, 3);           \
-        else SERT_SKIP_LAUNCH(ADAM, 64, 4);                          \
+#define SERT_SKIP_SHAPE(ADAM)                                                                   \
+    do {                                                                                        \
+        if (d4 <= 32) { SERT_SKIP_LAUNCH(ADAM, 32, 1); ++m->upd_counts[2]; }                    \
+        else if (d4 <= 64) { SERT_SKIP_LAUNCH(ADAM, 64, 1); ++m->upd_counts[3]; }               \
+        else if (d4 <= 96 && skip_32x3) { SERT_SKIP_LAUNCH(ADAM, 32, 3); ++m->upd_counts[4]; }  \
+        else if (d4 <= 128) { SERT_SKIP_LAUNCH(ADAM, 64, 2); ++m->upd_counts[5]; }              \
+        else if (d4 <= 192) { SERT_SKIP_LAUNCH(ADAM, 64, 3); ++m->upd_counts[6]; }              \
+        else { SERT_SKIP_LAUNCH(ADAM, 64, 4); ++m->upd_counts[7]; }                             \
+        ++m->upd_counts[sparse ? 9 : 8];                                                        \
     } while (0)
                     if (is_vs(m)) SERT_SKIP_SHAPE(true);
                     else SERT_SKIP_SHAPE(false);
 #undef SERT_SKIP_SHAPE
 #undef SERT_SKIP_LAUNCH
-                } else
+                } else {
+                ++m->upd_counts[1];
                 if (is_vs(m))
                     hipLaunchKernelGGL((dense_update_lazy<true>), dim3(nb), dim3(256), 0, m->stream, t.p, (const float*)t.g, t.s0, t.s1, t.n,
                                        aa, da, m->red_sq + n_sq, tf, (unsigned)c.word_dim, lz);
                 else
                     hipLaunchKernelGGL((dense_update_lazy<false>), dim3(nb), dim3(256), 0, m->stream, t.p, (const float*)t.g, t.s0, t.s1, t.n,
                                        aa, da, m->red_sq + n_sq, tf, (unsigned)c.word_dim, lz);
+                }
                 m->rw_last_cur ^= 1;
                 m->rw_stale = !lz.write_all;
                 m->rw_ready_batch = lz.write_all ? -1 : m->lazy_next;
@@ -2203,6 +2268,7 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
                 continue;
             }
             if (i == 0) m->rw_pred_ok = false;   // (a dense launch moves every row off its predicted trajectory)
+            if (i == 0) ++m->upd_counts[0];
             if (i == 0) SERT_TRY(ensure_rw_current(m, -1, m->step - 1));    // (a dense launch assumes every row is at the previous step; m->step is already this update's number)
             // (side_heavy: the entity table streams on the side stream, behind its gradient chain.  Loglinear with dW on the
             //  side stream: a W large enough to be a "big tensor" -- d x V_e >= 2^22, C4 -- is updated THERE, behind dW and
@@ -2571,6 +2637,7 @@ static int train_step_async(sert_model* m, int64_t batch_index, const int64_t* n
     if (m->comm_dead) SERT_FAIL("the communicator of this data-parallel model was destroyed");
     if (ds.N == 0) SERT_FAIL("no training data uploaded");
     if (batch_index < 0 || (batch_index + 1) * (int64_t)B > ds.N) SERT_FAIL("batch_index out of range");
+    if (m->instep.on) ++m->instep.steps;
     // what the previous call already ran ahead for this step (sert_hint_next_batch)
     const bool have_fb = negatives == nullptr && m->spec_fb_batch == batch_index && m->spec_fb_step == m->step &&
                          can_speculate_step(m);
@@ -2714,6 +2781,23 @@ static int sharded_state_io(sert_model* m, int i, int k, float* host_out, const 
     return rc;
 }
 
+// The events that order this model's own streams against each other.  device_scope: without the SYSTEM-scope release
+// (hipEventDisableSystemFence) -- right while every consumer is a kernel on this device.  A model with a communicator
+// (sert_comm_init / sert_comm_init_host) re-creates them with HIP's default flags: there ev_join / ev_dense / ev_fork also
+// stand in front of a D2H copy (host transport) or a collective whose readers are peers, and an agent-scope release does
+// not make the gradients visible to those (advisor, round 5).
+static int create_intra_events(sert_model* m, bool device_scope) {
+    hipEvent_t* evs[] = {&m->ev_word_opt, &m->ev_early, &m->ev_join3, &m->ev_step_done, &m->ev_neg, &m->ev_opt_fork,
+                         &m->ev_dense, &m->ev_small, &m->ev_re, &m->ev_fork, &m->ev_join};
+    const unsigned flags = hipEventDisableTiming | (device_scope ? (unsigned)hipEventDisableSystemFence : 0u);
+    for (hipEvent_t* e : evs) {
+        if (*e) { SERT_HIP(hipEventDestroy(*e)); *e = nullptr; }
+        SERT_HIP(hipEventCreateWithFlags(e, flags));
+    }
+    m->events_device_scope = device_scope;
+    return 0;
+}
+
 int sert_create(const sert_config* cfg, sert_model** out) {
     if (!cfg || !out) SERT_FAIL("null argument");
     if (cfg->struct_size != sizeof(sert_config)) SERT_FAIL("sert_config size mismatch (ABI)");
@@ -2802,7 +2886,7 @@ static int create_resources(sert_model* m) {
     // an agent-scope release already.  hipEventDisableSystemFence; SERT_EVENT_FENCE=system restores the default flags.
     // (ev_loss is waited on by the HOST and keeps them; so do the events of a communicator, whose consumers may be peers.)
     // (opt-in: measured SLOWER than the two launches at C2 -- 53 us against 25 + 25 -- and equal at 8192 rows; kernels_proj.h)
-    m->proj_fused = knob("SERT_PROJ_FUSED") && atoi(knob("SERT_PROJ_FUSED")) != 0;
+    m->proj_fused = variant_knob("SERT_PROJ_FUSED") && atoi(variant_knob("SERT_PROJ_FUSED")) != 0;
     m->lazy_skip = !(knob("SERT_LAZY_SKIP") && atoi(knob("SERT_LAZY_SKIP")) == 0);
     m->lazy_max = knob("SERT_LAZY_MAX") ? (float)atof(knob("SERT_LAZY_MAX")) : 0.5f;
     {
@@ -2811,19 +2895,8 @@ static int create_resources(sert_model* m) {
         m->num_cus = cus;
     }
     const char* fence_env = knob("SERT_EVENT_FENCE");
-    const unsigned dev_ev = hipEventDisableTiming | ((fence_env && !strcmp(fence_env, "system")) ? 0u : (unsigned)hipEventDisableSystemFence);
-    SERT_HIP(hipEventCreateWithFlags(&m->ev_word_opt, dev_ev));
-    SERT_HIP(hipEventCreateWithFlags(&m->ev_early, dev_ev));
-    SERT_HIP(hipEventCreateWithFlags(&m->ev_join3, dev_ev));
-    SERT_HIP(hipEventCreateWithFlags(&m->ev_step_done, dev_ev));
-    SERT_HIP(hipEventCreateWithFlags(&m->ev_neg, dev_ev));
-    SERT_HIP(hipEventCreateWithFlags(&m->ev_opt_fork, dev_ev));
-    SERT_HIP(hipEventCreateWithFlags(&m->ev_dense, dev_ev));
+    SERT_TRY(create_intra_events(m, !(fence_env && !strcmp(fence_env, "system"))));
     SERT_HIP(hipEventCreateWithFlags(&m->ev_loss, hipEventDisableTiming));
-    SERT_HIP(hipEventCreateWithFlags(&m->ev_small, dev_ev));
-    SERT_HIP(hipEventCreateWithFlags(&m->ev_re, dev_ev));
-    SERT_HIP(hipEventCreateWithFlags(&m->ev_fork, dev_ev));
-    SERT_HIP(hipEventCreateWithFlags(&m->ev_join, dev_ev));
     const size_t B = c.batch_size, n = c.window_size, dw = c.word_dim, V = c.num_entities;
     const bool vs = is_vs(m);
     const size_t de = vs ? c.entity_dim : 0;
@@ -2893,7 +2966,7 @@ static int create_resources(sert_model* m) {
                 // keeps the sorted path (cross-check knob)
                 const bool force_sort = knob("SERT_EGRAD_SORT") && atoi(knob("SERT_EGRAD_SORT")) != 0;   // (read per model)
                 m->egrad_force_sort = force_sort;
-                m->egrad_ranges = knob("SERT_EGRAD_RANGES") && atoi(knob("SERT_EGRAD_RANGES")) != 0;
+                m->egrad_ranges = variant_knob("SERT_EGRAD_RANGES") && atoi(variant_knob("SERT_EGRAD_RANGES")) != 0;
                 const size_t c1 = c.num_negatives + 1;
                 if (!force_sort && c.kind == SERT_KIND_VECTORSPACE && V <= 2048 && de % 4 == 0 && de <= 128 &&
                     total < ((size_t)1 << 27) && c1 <= (size_t)kElSubPairs) {
@@ -3037,6 +3110,9 @@ int sert_destroy(sert_model* m) {
     if (m->timing.created)
         for (int g = 0; g < TG_COUNT; ++g)
             for (int k = 0; k < 2; ++k) (void)hipEventDestroy(m->timing.ev[g][k]);
+    if (m->instep.created)
+        for (int i = 0; i < InStep::kRing; ++i)
+            for (int k = 0; k < 2; ++k) (void)hipEventDestroy(m->instep.ev[i][k]);
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     if (m->ev_join) (void)hipEventDestroy(m->ev_join);
     if (m->stream2) (void)hipStreamDestroy(m->stream2);
@@ -3230,7 +3306,7 @@ int sert_upload_dataset(sert_model* m, int split, const void* x, const int32_t* 
         if (is_vs(m) && m->cfg.word_dim % 4 == 0 && m->cfg.word_dim <= 512) {
             const int d4 = m->cfg.word_dim / 4;
             const bool lpi32 = d4 <= 32 || (d4 > 64 && 64 * cdiv(d4, 64) > 32 * cdiv(d4, 32));
-            const bool bundle_on = knob("SERT_SEG_BUNDLE") && atoi(knob("SERT_SEG_BUNDLE")) != 0;
+            const bool bundle_on = variant_knob("SERT_SEG_BUNDLE") && atoi(variant_knob("SERT_SEG_BUNDLE")) != 0;
             vs_heavy = knob("SERT_DENSE_HEAVY") ? atoi(knob("SERT_DENSE_HEAVY")) != 0 : (lpi32 && !bundle_on);
         }
         const bool dense_heavy = !variant_knob("SERT_NO_DENSE_HEAVY") && (is_vs(m) ? vs_heavy : (m->cfg.num_entities % 4 == 0));
@@ -3245,7 +3321,7 @@ int sert_upload_dataset(sert_model* m, int split, const void* x, const int32_t* 
             if (const char* e = variant_knob("SERT_SEG_GROUPS")) row_groups = std::min(std::max(1, atoi(e)), std::max(1, B / 64));
         // vectorspace: level 0 sorted by item length with the first row number in the descriptor (word_index.h: slot_is_row);
         // not with bundles (they need the items in entry order); SERT_SEG_NO_SORT (variants build) for the A/B
-        const bool sort_level0 = is_vs(m) && row_groups == 1 && !(knob("SERT_SEG_BUNDLE") && atoi(knob("SERT_SEG_BUNDLE")) != 0) &&
+        const bool sort_level0 = is_vs(m) && row_groups == 1 && !(variant_knob("SERT_SEG_BUNDLE") && atoi(variant_knob("SERT_SEG_BUNDLE")) != 0) &&
                                  !variant_knob("SERT_SEG_NO_SORT");
         bool ids_ok = true;
         SERT_ID_DISPATCH(m->cfg.id_bytes,
@@ -3288,7 +3364,7 @@ int sert_upload_dataset(sert_model* m, int split, const void* x, const int32_t* 
             // (round 5, profiles/r05_experiments.txt: C2 word-gradient group 59.5 us against 56.7, C4 150.9 against 145.0): the
             // short items are not what level 0 waits for -- with their lane groups leaving right after the descriptor load
             // (a knock-out) the group loses 7 of 57 us.
-            const bool bundle = knob("SERT_SEG_BUNDLE") && atoi(knob("SERT_SEG_BUNDLE")) != 0;
+            const bool bundle = variant_knob("SERT_SEG_BUNDLE") && atoi(variant_knob("SERT_SEG_BUNDLE")) != 0;
             if (!wi.bundles.empty() && bundle && is_vs(m)) {
                 SERT_TRY(dmalloc(&d.idx_bundles, wi.bundles.size()));
                 SERT_HIP(hipMemcpyAsync(d.idx_bundles, wi.bundles.data(), wi.bundles.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
@@ -3311,7 +3387,7 @@ int sert_upload_dataset(sert_model* m, int split, const void* x, const int32_t* 
             for (int64_t b = 0; b < nb; ++b)
                 for (int h = 0; h < wi.batches[(size_t)b].dense_cnt; ++h) hw[(size_t)b * kHeavyMax + h] = wi.batches[(size_t)b].dense_word[h];
             // (only where the opt-in gather that reads it is switched on: a byte per token of the data set)
-            if (!wi.dense_tok_slot.empty() && knob("SERT_GATHER_HOT") && atoi(knob("SERT_GATHER_HOT")) != 0) {
+            if (!wi.dense_tok_slot.empty() && variant_knob("SERT_GATHER_HOT") && atoi(variant_knob("SERT_GATHER_HOT")) != 0) {
                 SERT_HIP(hipMalloc((void**)&d.idx_tok_slot, wi.dense_tok_slot.size()));
                 SERT_HIP(hipMemcpyAsync(d.idx_tok_slot, wi.dense_tok_slot.data(), wi.dense_tok_slot.size(), hipMemcpyHostToDevice, s));
                 d.dense_cnt_of.resize((size_t)nb);
@@ -3321,7 +3397,10 @@ int sert_upload_dataset(sert_model* m, int split, const void* x, const int32_t* 
             SERT_HIP(hipMemcpyAsync(d.idx_dense_words, hw.data(), hw.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
             SERT_HIP(hipStreamSynchronize(s));
             if (!m->hpart)
-                SERT_TRY(dmalloc(&m->hpart, (size_t)cdiv(B, kHeavyRowsFusedMin) * kHeavyMax *
+                // (row blocks of the form that runs: the fused stream's heavy_rows_fused(B) rows or the two launches'
+                //  kHeavyRowsPerBlock -- sized for the smallest block, 64 rows, a loglinear model at batch 65536 and 100 k
+                //  entities asked for 6.5 GB where 1.6 GB is used)
+                SERT_TRY(dmalloc(&m->hpart, (size_t)std::max(cdiv(B, heavy_rows_fused(B)), cdiv(B, kHeavyRowsPerBlock)) * kHeavyMax *
                                                (size_t)(is_vs(m) ? m->cfg.word_dim : m->cfg.num_entities)));
         } else {
             for (auto& bxx : wi.batches) bxx.dense_cnt = 0;
@@ -4004,6 +4083,13 @@ static int exchange_slabs() {
     return std::max(1, std::min(want, (int)sert_model::kMaxArChunks));
 }
 
+// (see create_intra_events: a model that gets a communicator takes system-scope events; nothing is in flight afterwards)
+static int comm_scope_events(sert_model* m) {
+    if (!m->events_device_scope) return 0;
+    SERT_HIP(hipDeviceSynchronize());
+    return create_intra_events(m, false);
+}
+
 int sert_comm_unique_id(char id[SERT_COMM_ID_BYTES]) {
     SERT_TRY(rccl_load());
     SERT_NCCL(g_rccl.GetUniqueId(id));
@@ -4018,6 +4104,7 @@ int sert_comm_init(sert_model* m, const char id[SERT_COMM_ID_BYTES], int rank, i
     SERT_TRY(rccl_load());
     SERT_HIP(hipSetDevice(m->cfg.device));
     invalidate_speculation(m);
+    SERT_TRY(comm_scope_events(m));
     UniqueId uid;
     memcpy(uid.internal, id, SERT_COMM_ID_BYTES);
     for (int i = 0; i < 4; ++i)
@@ -4066,6 +4153,7 @@ int sert_comm_init_host(sert_model* m, int rank, int world, sert_alltoall_fn fn,
     m->rank = rank;
     m->world = world;
     invalidate_speculation(m);
+    SERT_TRY(comm_scope_events(m));
     m->ar_chunks = exchange_slabs();
     m->xr_mode = row_exchange_wanted(m);
     const int rc = shard_setup(m);
@@ -4115,6 +4203,29 @@ int sert_comm_stats(sert_model* m, double* out, int n) {
         }
     }
     for (int i = 0; i < n; ++i) out[i] = v[i];
+    return 0;
+}
+
+int sert_debug_poison_scratch(sert_model* m) {
+    if (!m) SERT_FAIL("null argument");
+    if (m->spec_fb_batch >= 0) SERT_FAIL("a run-ahead step is in flight (sert_hint_next_batch): its gradients live in the scratch");
+    SERT_HIP(hipSetDevice(m->cfg.device));
+    SERT_HIP(hipDeviceSynchronize());
+    if (!m->gflat) return 0;
+    // gradients, loss / sum-of-squares slots: quiet NaNs; the per-entity sorted-run bounds behind them: the in-range but wrong
+    // run [0, 1) (a fix-up that trusted a stale bound would add chunk 0's carry to an entity the reduce never met)
+    std::vector<uint32_t> h(m->gflat_alloc, 0x7fc00000u);
+    if (m->run_start) {
+        const size_t V4 = round_up((size_t)m->cfg.num_entities, 4);
+        for (size_t i = 0; i < V4; ++i) { h[m->gflat_count + i] = 0u; h[m->gflat_count + V4 + i] = 1u; }
+    }
+    SERT_HIP(hipMemcpy(m->gflat, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int sert_debug_update_counts(sert_model* m, int64_t* out, int n) {
+    if (!m || !out || n < 1 || n > 10) SERT_FAIL("bad argument");
+    for (int i = 0; i < n; ++i) out[i] = m->upd_counts[i];
     return 0;
 }
 
@@ -4238,19 +4349,53 @@ int sert_synchronize(sert_model* m) {
 
 int sert_timing_enable(sert_model* m, int on) {
     if (!m) SERT_FAIL("null model");
-    m->timing.enabled = on != 0;
+    if (on < 0 || on > 2) SERT_FAIL("timing mode: 0 = off, 1 = every group alone on one queue, 2 = in the step");
+    SERT_HIP(hipSetDevice(m->cfg.device));
+    if (m->instep.on && on != 2) {        // leaving the in-step mode: everything in flight is measured first
+        SERT_HIP(hipDeviceSynchronize());
+        instep_harvest(m, true);
+    }
+    if (on == 2 && !m->instep.created) {
+        for (int i = 0; i < InStep::kRing; ++i)
+            for (int k = 0; k < 2; ++k) SERT_HIP(hipEventCreate(&m->instep.ev[i][k]));
+        m->instep.created = true;
+    }
+    m->timing.enabled = on == 1;
+    m->instep.on = on == 2;
+    m->instep.cur_group = -1;
     return 0;
 }
 int sert_timing_reset(sert_model* m) {
     if (!m) SERT_FAIL("null model");
     for (int g = 0; g < TG_COUNT; ++g) { m->timing.total_us[g] = 0; m->timing.samples[g] = 0; m->timing.used[g] = false; }
+    if (m->instep.created) {
+        SERT_HIP(hipSetDevice(m->cfg.device));
+        SERT_HIP(hipDeviceSynchronize());
+        instep_harvest(m, true);
+        for (int g = 0; g < TG_COUNT; ++g) { m->instep.total_us[g] = 0; m->instep.launches[g] = 0; }
+        m->instep.steps = 0;
+    }
     return 0;
 }
 int sert_timing_count(sert_model*) { return TG_COUNT; }
 const char* sert_timing_name(sert_model*, int i) { return (i >= 0 && i < TG_COUNT) ? kTimingNames[i] : ""; }
 double sert_timing_avg_us(sert_model* m, int i) {
-    if (!m || i < 0 || i >= TG_COUNT || m->timing.samples[i] == 0) return 0.0;
+    if (!m || i < 0 || i >= TG_COUNT) return 0.0;
+    if (m->instep.steps > 0) {
+        // in-step mode: the group's kernel time per training step (sum of its timed launches' own durations)
+        if (m->instep.head < m->instep.tail) {
+            (void)hipSetDevice(m->cfg.device);
+            (void)hipDeviceSynchronize();
+            instep_harvest(m, true);
+        }
+        return m->instep.total_us[i] / (double)m->instep.steps;
+    }
+    if (m->timing.samples[i] == 0) return 0.0;
     return m->timing.total_us[i] / (double)m->timing.samples[i];
+}
+double sert_timing_launches(sert_model* m, int i) {
+    if (!m || i < 0 || i >= TG_COUNT || m->instep.steps == 0) return 0.0;
+    return (double)m->instep.launches[i] / (double)m->instep.steps;
 }
 
 int sert_bench_gemm(int device, int ta, int tb, int epi, int M, int N, int K, int splits, int iters,

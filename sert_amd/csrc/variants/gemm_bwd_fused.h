@@ -15,8 +15,8 @@
 // dW.  Per workgroup ONE partial dW slab + column sums (the step's tail launch combines them: 256 slabs
 // instead of the 512 of the split-K GEMM).  Deterministic: fixed strip order, fixed k order.
 #pragma once
-#include "common.h"
-#include "gemm.h"
+#include "../common.h"
+#include "../gemm.h"
 
 namespace sert {
 

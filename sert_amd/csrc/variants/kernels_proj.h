@@ -28,8 +28,8 @@
 // multiplying waves over two 32-row images: 60 us, one gathering wave per SIMD does not keep enough fetches in flight.)
 // Shapes: d_w % 16 == 0, d_w <= 128, d_e % 4 == 0, d_e <= 128 (one column tile); anything else takes the two launches.
 #pragma once
-#include "common.h"
-#include "gemm_x3.h"
+#include "../common.h"
+#include "../gemm_x3.h"
 
 namespace sert {
 

@@ -3,9 +3,12 @@ whatever the full record holds, and carries the contract's keys."""
 import copy
 import json
 import os
+import re
 
 import bench
 from tests import util as U
+
+ROOT = U.ROOT
 
 CONTRACT = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
             'dtype', 'data', 'config', 'roofline', 'cpu_baseline')
@@ -60,3 +63,52 @@ def test_line_without_optional_parts():
     rec = bench.compact_record(full)
     assert rec['cpu_baseline'] is None and rec['roofline']['traffic'] is None
     json.loads(json.dumps(rec))
+
+
+def _latest_kernel_summaries():
+    """(kind, path) of the newest committed rocprofv3 kernel summary per profiled configuration."""
+    import glob
+    out = []
+    for tag, kind in (('vs_c2', 'vectorspace'), ('c4', 'vectorspace'), ('ll_c2', 'loglinear')):
+        files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]*_%s_kernels.txt' % tag)))
+        if files:
+            out.append((kind, files[-1]))
+    return out
+
+
+def test_every_profiled_kernel_maps_to_a_group():
+    """bench.KERNELS_OF_GROUP names the HIP kernels of every timing group; traffic_by_group looks the PMC bytes of a group up
+    by those names.  Round 5 renamed the loglinear per-word dZ sums' kernel (segsum_rows_plus_ll) and the map kept the old
+    name: `loglinear.roofline.frac_counter` went out as 0.0.  Every kernel holding more than 1 % of the kernel time of the
+    newest committed summaries (profiles/rNN*_{vs_c2,c4,ll_c2}_kernels.txt) must map to a group of its model kind, or be one
+    of the micro-benchmarks' / the runtime's kernels."""
+    summaries = _latest_kernel_summaries()
+    assert len(summaries) == 3, summaries
+    for kind, path in summaries:
+        unknown, seen = [], 0
+        for line in open(path).read().splitlines()[1:]:
+            if line.startswith('total kernel time') or not line.strip():
+                continue
+            m = re.match(r'^(.*?)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s', line)
+            assert m, line
+            name, pct = m.group(1), float(m.group(7))
+            seen += 1
+            if pct > 1.0 and bench.group_of_kernel(kind, name) is None:
+                unknown.append((name, pct))
+        assert seen > 5 and not unknown, (path, unknown)
+    # the one that went stale
+    assert bench.group_of_kernel('loglinear', 'segsum_rows_plus_ll(float const*, int const*') == 'per_word_dz_sums'
+    assert bench.group_of_kernel('vectorspace', 'dense_update_skip<true, 64, 2>(float*') == 'optimizer_word_table'
+    assert bench.group_of_kernel('vectorspace', 'some_new_kernel(float*)') is None
+    assert bench.group_of_kernel('vectorspace', 'mb_stream_copy(HIP_vector_type') == ''
+
+
+def test_traffic_lookup_finds_the_dominant_loglinear_kernel_in_a_committed_counter_pass():
+    """The replay of round 5's failure: traffic_by_group over the committed counter pass of the loglinear record
+    (profiles/r05m_ll_c2_pmc.json, the rocpd_pmc per-kernel table the bench builds of its own --pmc passes) must find the
+    per-word dZ sums' kernel with its 1.98 GB per big launch -- not an empty record under a stale name."""
+    per_kernel = json.load(open(os.path.join(ROOT, 'profiles', 'r05m_ll_c2_pmc.json')))
+    tbg = bench.traffic_by_group(per_kernel, {'per_word_dz_sums': 287.0, 'loss': 198.0, 'gemm_fwd': 90.0}, 'loglinear')
+    assert tbg['per_word_dz_sums']['hip_kernel'].startswith('segsum_rows_plus_ll'), tbg['per_word_dz_sums']
+    assert tbg['per_word_dz_sums']['hbm_bytes'] > 1.5e9, tbg['per_word_dz_sums']
+    assert tbg['loss']['hip_kernel'].startswith('ll_row_wave') and tbg['gemm_fwd']['hip_kernel'].startswith('gemm_x3<false, false, 1')

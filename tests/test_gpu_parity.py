@@ -136,6 +136,7 @@ def test_word_gradient_row_grouped_tree(hip_lib, monkeypatch, dims, groups, dens
         assert U.rel_err(got[0][untouched], g64[1][untouched]) < 1e-6
 
 
+@pytest.mark.skipif(not VARIANTS_BUILD, reason='SERT_GATHER_HOT (csrc/variants/kernels_gather_hot.h, measured 10 % slower) is read only by a library built with -DSERT_VARIANTS since round 6')
 @pytest.mark.parametrize('dims', [
     dict(B=20000, n=5, Vw=300, dw=128),      # three hot words, the rest through L1 / L2
     dict(B=6100, n=8, Vw=3000, dw=300),      # 75 float4 per row, ragged last workgroup pass
@@ -210,6 +211,7 @@ def test_word_gradient_heavy_words_inside_the_tree_launches(hip_lib, monkeypatch
     assert not np.array_equal(got[0][heavy], got[2][heavy]), 'the dense pass did not run (same bits as the plain tree)'
 
 
+@pytest.mark.skipif(not VARIANTS_BUILD, reason='SERT_SEG_BUNDLE (csrc/variants/kernels_seg_bundled.h, measured slower) is read only by a library built with -DSERT_VARIANTS since round 6')
 @pytest.mark.parametrize('dims', [
     dict(B=64, n=4, Vw=300, dw=16),          # mostly singletons: bundles of eight one-entry items
     dict(B=1000, n=10, Vw=5000, dw=128),     # Zipf: singletons, mid-size words and multi-chunk words in one batch
@@ -276,6 +278,7 @@ def test_device_scope_events_change_nothing(hip_lib, monkeypatch, kind):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.skipif(not VARIANTS_BUILD, reason='SERT_PROJ_FUSED (csrc/variants/kernels_proj.h, measured slower) is read only by a library built with -DSERT_VARIANTS since round 6')
 @pytest.mark.parametrize('dims', [
     dict(B=20000, n=10, Vw=5000, dw=128, de=128, exact=True),    # the unfused projection runs gemm_x3 here: the same bits
     dict(B=16500, n=3, Vw=900, dw=64, de=96, exact=True),        # K = 64 (four k steps), 96 of the 128 tile columns
@@ -315,6 +318,7 @@ def test_fused_projection_equals_the_two_launches(hip_lib, monkeypatch, dims):
     assert np.abs(got[0][1] - f['t']).max() < 2e-6
 
 
+@pytest.mark.skipif(not VARIANTS_BUILD, reason='SERT_EGRAD_RANGES (csrc/variants/kernels_egrad_ranges.h, the step no faster) is read only by a library built with -DSERT_VARIANTS since round 6')
 @pytest.mark.parametrize('dims', [
     dict(B=512, n=4, z=10, Vw=300, Ve=32768, dw=32, de=128),        # the product-search table: 256 ranges, ~22 pairs each
     dict(B=300, n=3, z=5, Vw=200, Ve=2049, dw=16, de=36),           # just above the LDS path's 2048; last range of one entity
@@ -1194,3 +1198,40 @@ def test_loglinear_side_stream_does_not_change_a_bit(hip_lib, dims):
     for extra, o in zip(variants[1:], outs[1:]):
         assert o == outs[0], 'schedule variant %r changed the results' % (extra,)
     assert all(np.isfinite(outs[0]['losses']))
+
+
+@pytest.mark.parametrize('dims', [
+    dict(B=4096, n=4, z=6, Vw=3000, Ve=5000, dw=32, de=64),       # sorted entity chain (V_e > 2048): counting sort, chunked reduce, fix-up
+    dict(B=2048, n=3, z=10, Vw=2000, Ve=300, dw=64, de=128),      # sort-free chain (per-group partial tables)
+    dict(B=700, n=2, z=3, Vw=500, Ve=40000, dw=16, de=16),        # far more entities than pairs: most rows of dR_e come from the fix-up's zero fill
+])
+@pytest.mark.parametrize('ranges', [False, True])
+def test_steps_read_nothing_stale_from_the_gradient_scratch(hip_lib, monkeypatch, dims, ranges):
+    """A vectorspace step whose negatives were drawn at the end of the previous step launches NO prologue: nothing zeroes
+    the flat gradient buffer or the per-entity run bounds (sert_hip.hip: step_forward_backward, have_neg).  That is right only
+    while every value the step reads from there was written by the step's own kernels -- every row of dR_e by the entity
+    chain, the run bounds by the sort's first histogram pass, g_W / g_b by the split-K combine (advisor, round 5).  Checked
+    by force: quiet NaNs into the whole buffer and wrong bounds behind it between the steps (sert_debug_poison_scratch)
+    must change NOTHING -- losses, both tables, bit for bit."""
+    if ranges:
+        if not VARIANTS_BUILD:
+            pytest.skip('SERT_EGRAD_RANGES is read only by a library built with -DSERT_VARIANTS')
+        monkeypatch.setenv('SERT_EGRAD_RANGES', '1')
+    B, n, z, Vw, Ve, dw, de = (dims[k] for k in ('B', 'n', 'z', 'Vw', 'Ve', 'dw', 'de'))
+    p = U.make_vs_problem(29, 3 * B, n, z, Vw, Ve, dw, de, zipf=True)
+    outs = []
+    for poison in (False, True):
+        eng = U.vs_engine(p, B, n, z, 0.01, keep_grads=0, seed=5)
+        eng.upload_dataset(C.SPLIT_TRAIN, p['X'], y_int=p['y'], w=p['w'])
+        losses = []
+        for s in range(6):
+            losses.append(eng.train_batch(s % 3))          # (device-drawn negatives, no hint: no run-ahead in flight)
+            if poison:
+                eng.poison_scratch()
+        outs.append((losses, eng.get_tensor(C.T_RW).copy(), eng.get_tensor(C.T_RE).copy(), eng.get_tensor(C.T_W).copy(),
+                     eng.get_tensor(C.T_B).copy()))
+        eng.close()
+    assert all(np.isfinite(outs[1][0])), outs[1][0]
+    assert outs[0][0] == outs[1][0], (outs[0][0], outs[1][0])
+    for a, b in zip(outs[0][1:], outs[1][1:]):
+        assert np.array_equal(a, b)

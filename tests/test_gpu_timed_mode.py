@@ -67,7 +67,18 @@ CASES = {
     # the reference's product-search hyper-parameters (product-search.sh:121-133: batch 4096, d_w 300, d_e 128, z 10) on a
     # 100 k x 32 k vocabulary: lazy word-table update (12 % of the rows per batch), deferred entity-table update
     'product_search': dict(B=4096, n=10, Vw=100000, Ve=32768, dw=300, de=128, z=10, nb=6, steps=8, lazy=True),
+    # BASELINE.json configs[3] as bench.py's `c4` record runs it (round-5 verdict, "what's missing" 1): the 150 M-element
+    # word table takes dense_update_skip<true, 64, 2>, whose timed form -- hinted: full passes at updates 0, 4 and the
+    # unannounced last one, SPARSE launches (rows neither this nor the next batch touches neither read nor written) at
+    # 1, 2, 3, 5 -- had only met the HIP-vs-HIP repeat sweep; sorted entity chain, deferred 30 M-element entity update
+    'c4': dict(B=65536, n=10, Vw=500000, Ve=100000, dw=300, de=300, z=10, nb=4, steps=7, lazy=True,
+               counts=dict(skip_64_2=7, skip_full=3, skip_sparse=4, dense=0, lazy=0), float64=True),
 }
+# `b` (and `W`) take gradients that are sums over all 65536 batch rows of terms that largely cancel: the float32 oracle's own
+# sum is ~3e-4 off its float64 evaluation there (tests/test_gpu_fullbatch.py, same note), and Adam's first steps from b = 0
+# turn a relative gradient error into the same relative parameter error.  Where a case asks for it (`float64`) those tensors
+# are held to 3e-4 against the float32 oracle and to the 1e-4 of SURVEY 8-d against the SAME oracle run in float64.
+DENSE_SUM_TENSORS = ('b', 'W', 'm_W', 'v_W')
 
 
 @pytest.mark.parametrize('case', sorted(CASES))
@@ -85,6 +96,7 @@ def test_timed_mode_against_the_oracle(hip_lib, case):
     Rw0, Re0 = eng.get_tensor(C.T_RW).reshape(Vw, dw).copy(), eng.get_tensor(C.T_RE).reshape(Ve, de).copy()
     W0, b0 = eng.get_tensor(C.T_W).reshape(dw, de).copy(), eng.get_tensor(C.T_B).copy()
     ora = O.VectorSpaceOracle(B, n, z, Rw0, Re0, W0, b0, 0.01)
+    ora64 = O.VectorSpaceOracle(B, n, z, Rw0, Re0, W0, b0, 0.01, dtype=np.float64) if c.get('float64') else None
 
     # exactly bench.timed_steps' loop (hint, train_fn, per-step loss read-back), with the losses kept
     order = [(1 + i) % nb for i in range(steps)]
@@ -101,7 +113,13 @@ def test_timed_mode_against_the_oracle(hip_lib, case):
         neg = philox.training_negatives(seed, i, B, z, Ve)
         ref = float(ora.train_step(X[sl], y[sl], w[sl], neg))
         assert abs(losses[i] - ref) <= 1e-5 * abs(ref), (case, i, losses[i], ref)
+        if ora64 is not None:
+            ref64 = float(ora64.train_step(X[sl], y[sl], w[sl], neg))
+            assert abs(losses[i] - ref64) <= 1e-5 * abs(ref64), (case, i, losses[i], ref64)
     assert eng.get_step() == steps
+    # the kernel form that ran (sert_debug_update_counts: host counters of the word-table update's launches)
+    for k, v in c.get('counts', {}).items():
+        assert eng.update_counts()[k] == v, (case, k, eng.update_counts())
 
     got = {'R_w': eng.get_tensor(C.T_RW).reshape(Vw, dw), 'R_e': eng.get_tensor(C.T_RE).reshape(Ve, de),
            'W': eng.get_tensor(C.T_W).reshape(dw, de), 'b': eng.get_tensor(C.T_B),
@@ -113,7 +131,12 @@ def test_timed_mode_against_the_oracle(hip_lib, case):
             'm_Rw': ora.opt.m[1], 'v_Rw': ora.opt.v[1], 'm_Re': ora.opt.m[0], 'v_Re': ora.opt.v[0],
             'm_W': ora.opt.m[2], 'v_W': ora.opt.v[2]}
     for k in sorted(want):
-        assert U.rel_err(got[k], want[k]) < 1e-4, (case, k, U.rel_err(got[k], want[k]))
+        tol = 3e-4 if (ora64 is not None and k in DENSE_SUM_TENSORS) else 1e-4
+        assert U.rel_err(got[k], want[k]) < tol, (case, k, U.rel_err(got[k], want[k]))
+    if ora64 is not None:
+        want64 = {'b': ora64.b, 'W': ora64.W, 'm_W': ora64.opt.m[2], 'v_W': ora64.opt.v[2], 'R_w': ora64.R_w, 'R_e': ora64.R_e}
+        for k in sorted(want64):
+            assert U.rel_err(got[k], want64[k]) < 1e-4, (case, k, 'float64 oracle', U.rel_err(got[k], want64[k]))
     # row-wise: every row against its own norm (a row left one update behind, or updated once too often, shows here and
     # not in the whole-tensor bound); first moments of rows with cancelled sums get the documented floor
     for k in ('R_w', 'R_e', 'm_Rw', 'm_Re', 'v_Rw', 'v_Re'):
@@ -158,3 +181,35 @@ def test_timed_mode_loglinear_at_the_w3c_settings(hip_lib):
     err, row = U.row_err(got['R_w'], want['R_w'])
     assert err < 1e-4, (err, row)
     del model
+
+
+@pytest.mark.parametrize('kind', ['vectorspace', 'loglinear'])
+def test_in_step_timing_changes_nothing_and_times_the_update(hip_lib, kind):
+    """sert_timing_enable(m, 2) (bench.instep_pass: the durations `roofline.frac` is taken on): the normal schedule with every
+    plain launch bound to a HIP event pair of its own.  The steps' results are those of untimed steps bit for bit, every group
+    the step runs reports a time, the word-table update exactly one launch per step, and more launches than the event ring
+    holds (1024) are harvested on the way."""
+    B, n, Vw, Ve, d, nb, steps = 2048, 6, 40000, 300, 128, 4, 120
+    rng = np.random.RandomState(23)
+    X, y, w = bench.synth_data(rng, nb * B, n, Vw, Ve)
+    outs = []
+    for mode in (0, 2):
+        model = bench.build_model(kind, models, B, n, Vw, Ve, d, d, 5, X, y, w, seed=9)
+        eng = model._engine
+        eng.timing_enable(mode)
+        losses = []
+        for i in range(steps):
+            eng.hint_next_batch((i + 1) % nb if i + 1 < steps else None)
+            losses.append(float(model.train_fn(i % nb)))
+        eng.synchronize()
+        if mode == 2:
+            us, launches = eng.timings(), eng.timing_launches()
+            assert abs(launches['optimizer_word_table'] - 1.0) < 0.02, launches
+            assert 2.0 < us['optimizer_word_table'] < 500.0, us
+            assert us['gather'] > 0 and us['loss'] > 0 and us['word_grad_segsum'] > 0, us
+            assert sum(launches.values()) * steps > 1024, launches      # (the ring wrapped)
+        eng.timing_enable(0)
+        outs.append((losses, eng.get_tensor(C.T_RW).copy(), eng.get_tensor(C.T_W).copy()))
+        del model
+    assert outs[0][0] == outs[1][0]
+    assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])

@@ -7,6 +7,6 @@ set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 NAME=$1; shift
 mkdir -p $ROOT/sert_amd/variants
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -munsafe-fp-atomics -I$ROOT/include "$@" \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -I$ROOT/include "$@" \
     $ROOT/sert_amd/csrc/sert_hip.hip -o $ROOT/sert_amd/variants/libsert_$NAME.so -ldl
 echo $ROOT/sert_amd/variants/libsert_$NAME.so

@@ -67,8 +67,15 @@ struct X3Args {
 //  the split-K kernel)
 __device__ __forceinline__ int x3_off(int row, int half) { return row * 32 + ((half ^ (((row >> 2) ^ (row >> 3)) & 1)) << 4); }
 
-template <bool TA, bool TB, int EPI, bool CSB, int WAVES_M, int WAVES_N, int WMB, int WNB, bool VEC = true>
+// PF: k steps of HBM operand loads in flight per workgroup.  1 (rounds 4-5): the loads of step t + 1 are issued at the top of
+// step t.  2 (round 6, the 128 x 128-tile launches of the C2 step -- K = 128 is EIGHT steps, two workgroups per CU: 16 kB of A
+// in flight per CU where the HBM latency x the CU's share of the bandwidth asks for ~40): the loads of step t + 2 are issued
+// at the top of step t into the register set step t's operands left when they were stored during step t - 1.  Same k order,
+// same term order: bit-identical results.
+template <bool TA, bool TB, int EPI, bool CSB, int WAVES_M, int WAVES_N, int WMB, int WNB, bool VEC = true, int PF = 1>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N <= 4 ? 2 : 1)) void gemm_x3(const X3Args g) {
+    static_assert(PF == 1 || PF == 2, "one or two k steps of operand loads in flight");
+    static_assert(PF == 1 || WNB <= 2, "the deeper prefetch is written for the 128 x 128 tile");
     constexpr int THREADS = 64 * WAVES_M * WAVES_N;
     constexpr int TM = 32 * WMB * WAVES_M, TN = 32 * WNB * WAVES_N;
     constexpr int A_PLANE = TM * 32, B_PLANE = TN * 32;          // bytes
@@ -126,10 +133,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N <= 4 ? 2
     auto blk_b = [&](int i) { return WNB <= 2 ? WNB - 1 : (B_RC ? lim(2 + 2 * i, WNB - 1) : lim(WNB - 2 + i / 2, WNB - 1)); };
     auto blk_bl = [&](int i) { return WNB <= 2 ? 0 : lim(2 * i, WNB - 2); };
     static_assert(!B_RC || B_PIECES <= 2, "a row-contiguous B is staged through one set of eight registers");
-    float4 ra4[A_RC ? 1 : A_PIECES];
-    float ra8[A_RC ? A_PIECES : 1][8];
+    float4 ra4[PF][A_RC ? 1 : A_PIECES];
+    float ra8[PF][A_RC ? A_PIECES : 1][8];
     float4 rb4[B_RC ? 1 : B_PIECES];
-    float rb8[8];
+    float rb8[PF][8];
 
     // Eight row-strided dwords, no condition anywhere: a 128-bit buffer descriptor in SGPRs whose range ends with row
     // kend - 1 of the source + one 32-bit lane offset per load; k >= kend is out of range and loads zero.  A column
@@ -176,31 +183,33 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N <= 4 ? 2
         }
         return make_float4(e[0], e[1], e[2], e[3]);
     };
-    auto gload_a = [&](int k0) {
+    auto gload_a = [&](int k0, auto slot_tag) {
+        constexpr int S = decltype(slot_tag)::value;
 #pragma unroll
         for (int i = 0; i < A_PIECES; ++i) {
             const int p = tid + THREADS * i;
             if (!A_RC) {
                 const int row = p >> 2, q = p & 3;
-                ra4[i] = load_piece(g.A, row < TM && m0 + row < g.M, (unsigned)(m0 + row) * (unsigned)g.lda, k0 + 4 * q);
+                ra4[S][i] = load_piece(g.A, row < TM && m0 + row < g.M, (unsigned)(m0 + row) * (unsigned)g.lda, k0 + 4 * q);
             } else {
                 const int row = p % TM, h = p / TM;
-                load8(g.A, g.lda, k0 + 8 * h, m0 + row, ra8[i]);
+                load8(g.A, g.lda, k0 + 8 * h, m0 + row, ra8[S][i]);
             }
         }
     };
-    auto lstore_a = [&](int buf, int k0, int i) {
+    auto lstore_a = [&](int buf, int k0, int i, auto slot_tag) {
+        constexpr int S = decltype(slot_tag)::value;
         unsigned char* As = lds + buf * BUF;
         const int p = tid + THREADS * i;
         if (!A_RC) {
             const int row = p >> 2, q = p & 3;
             const bool ok = m0 + row < g.M && k0 + 4 * q < kend, mine = TM * 4 % THREADS == 0 || row < TM;
             store4(mine ? As : sink, mine ? A_PLANE : 0, mine ? x3_off(row, q >> 1) + ((q & 1) << 3) : 0,
-                   ok ? ra4[i] : make_float4(0.f, 0.f, 0.f, 0.f));
+                   ok ? ra4[S][i] : make_float4(0.f, 0.f, 0.f, 0.f));
         } else {
             const int row = p % TM, h = p / TM;
             const bool mine = TM * 2 % THREADS == 0 || h < 2;
-            store8(mine ? As : sink, mine ? A_PLANE : 0, mine ? x3_off(row, h) : 0, ra8[i]);
+            store8(mine ? As : sink, mine ? A_PLANE : 0, mine ? x3_off(row, h) : 0, ra8[S][i]);
         }
     };
     // k-contiguous B: every piece at once
@@ -219,42 +228,60 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N <= 4 ? 2
                ok ? rb4[i] : make_float4(0.f, 0.f, 0.f, 0.f));
     };
     // row-contiguous B: piece i
-    auto gload_b8 = [&](int k0, int i) {
+    static_assert(PF == 1 || !B_RC || B_PIECES == 1, "two steps in flight: one piece of a row-contiguous B per thread and step");
+    auto gload_b8 = [&](int k0, int i, auto slot_tag) {
+        constexpr int S = decltype(slot_tag)::value;
         const int p = tid + THREADS * i, row = p % TN, h = p / TN;
-        load8(g.B, g.ldb, k0 + 8 * h, n0 + row, rb8);
+        load8(g.B, g.ldb, k0 + 8 * h, n0 + row, rb8[S]);
     };
     float csum = 0.f;   // CSB: this thread's share of a column sum of B (its column, its half of every 16 k)
-    auto lstore_b8 = [&](int buf, int i) {
+    auto lstore_b8 = [&](int buf, int i, auto slot_tag) {
+        constexpr int S = decltype(slot_tag)::value;
         unsigned char* Bs = lds + buf * BUF + 3 * A_PLANE;
         const int p = tid + THREADS * i, row = p % TN, h = p / TN;
         const bool mine = TN * 2 % THREADS == 0 || h < 2;
-        if (CSB) csum += ((rb8[0] + rb8[1]) + (rb8[2] + rb8[3])) + ((rb8[4] + rb8[5]) + (rb8[6] + rb8[7]));
-        store8(mine ? Bs : sink, mine ? B_PLANE : 0, mine ? x3_off(row, h) : 0, rb8);
+        if (CSB) csum += ((rb8[S][0] + rb8[S][1]) + (rb8[S][2] + rb8[S][3])) + ((rb8[S][4] + rb8[S][5]) + (rb8[S][6] + rb8[S][7]));
+        store8(mine ? Bs : sink, mine ? B_PLANE : 0, mine ? x3_off(row, h) : 0, rb8[S]);
     };
 
     // fragment of a 32 x 16 block: lane -> row li, k = 8 lh .. 8 lh + 7 (16 bytes)
     const int a_frag = x3_off(wm * (WMB * 32) + li, lh);
     const int b_frag = x3_off(wn * (WNB * 32) + li, lh);
 
-    gload_a(kbeg);
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, PF - 1>;      // (PF = 1: the one register set)
+    gload_a(kbeg, S0{});
+    if (PF == 2) gload_a(kbeg + X3_KC, S1{});            // (beyond kend: zeros / a clamped address, never stored)
     if (!B_RC) {
         gload_b4(kbeg);
 #pragma unroll
         for (int i = 0; i < B_PIECES; ++i) lstore_b4(0, kbeg, i);
+    } else if (PF == 2) {
+        gload_b8(kbeg, 0, S0{});
+        gload_b8(kbeg + X3_KC, 0, S1{});
+        lstore_b8(0, 0, S0{});
     } else {
 #pragma unroll
-        for (int i = 0; i < B_PIECES; ++i) { gload_b8(kbeg, i); lstore_b8(0, i); }
+        for (int i = 0; i < B_PIECES; ++i) { gload_b8(kbeg, i, S0{}); lstore_b8(0, i, S0{}); }
     }
 #pragma unroll
-    for (int i = 0; i < A_PIECES; ++i) lstore_a(0, kbeg, i);
+    for (int i = 0; i < A_PIECES; ++i) lstore_a(0, kbeg, i, S0{});
     __syncthreads();
     // One k step.  MORE (a compile-time flag: the last step is peeled) -- with a run-time `more` the compiler has to
     // assume a staged load may still be pending from a path on which its store was skipped, and puts a vmcnt(0) in
     // front of every batch of loads: the full HBM latency of A, once per step.
-    auto step = [&](int t, auto more_tag) {
-        constexpr bool MORE = decltype(more_tag)::value;
+    // LOAD: there is a step t + PF, whose operands are requested at the top of this one into register set SLOT (= t % PF, a
+    // compile-time constant: the loop below is unrolled by PF); the operands of step t + 1 are split and stored from set
+    // (SLOT + 1) % PF.  PF = 1: LOAD = MORE, one set.
+    auto step = [&](int t, auto more_tag, auto load_tag, auto slot_tag) {
+        constexpr bool MORE = decltype(more_tag)::value, LOAD = decltype(load_tag)::value;
+        using SL = std::integral_constant<int, decltype(slot_tag)::value>;           // loads of step t + PF
+        using SS = std::integral_constant<int, (decltype(slot_tag)::value + 1) % PF>;   // stores of step t + 1
         const int k0 = kbeg + t * X3_KC;
-        if (MORE) gload_a(k0 + X3_KC);   // (from HBM: a whole step ahead of its split)
+        if (LOAD) {
+            gload_a(k0 + PF * X3_KC, SL{});   // (from HBM: PF whole steps ahead of its split)
+            if (PF == 2 && B_RC) gload_b8(k0 + PF * X3_KC, 0, SL{});
+        }
         const unsigned char* As = lds + (t & 1) * BUF;
         const unsigned char* Bs = As + 3 * A_PLANE;
         x3_bf16x8 a[WMB][3];
@@ -285,17 +312,19 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N <= 4 ? 2
                 const int nb = (t + 1) & 1, kn = k0 + X3_KC;
 #pragma unroll
                 for (int i = 0; i < A_PIECES; ++i)
-                    if (j == blk_a(i)) { lstore_a(nb, kn, i); valu += A_RC ? 80 : 40; }
+                    if (j == blk_a(i)) { lstore_a(nb, kn, i, SS{}); valu += A_RC ? 80 : 40; }
                 if (!B_RC) {
                     if (j == 0) gload_b4(kn);
 #pragma unroll
                     for (int i = 0; i < B_PIECES; ++i)
                         if (j == blk_b(i)) { lstore_b4(nb, kn, i); valu += 40; }
+                } else if (PF == 2) {
+                    if (j == blk_b(0)) { lstore_b8(nb, 0, SS{}); valu += 80; }
                 } else {
 #pragma unroll
                     for (int i = 0; i < B_PIECES; ++i) {
-                        if (j == blk_b(i)) { lstore_b8(nb, i); valu += 80; }
-                        if (j == blk_bl(i)) gload_b8(kn, i);
+                        if (j == blk_b(i)) { lstore_b8(nb, i, SS{}); valu += 80; }
+                        if (j == blk_bl(i)) gload_b8(kn, i, SS{});
                     }
                 }
             }
@@ -313,10 +342,29 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, (WAVES_M * WAVES_N <= 4 ? 2
         }
         if (MORE) __syncthreads();
     };
-    for (int t = 0; t + 1 < steps; ++t) step(t, std::true_type{});
     // (an EMPTY k range -- kbeg >= K, a caller's (splits, kper) with more ranges than K holds: steps <= 0 -- reads the image
     //  the prologue stored, which is all zeros then: the slab receives zeros instead of whatever buffer 1 held)
-    step(steps > 0 ? steps - 1 : 0, std::false_type{});
+    if (PF == 1) {
+        for (int t = 0; t + 1 < steps; ++t) step(t, std::true_type{}, std::true_type{}, S0{});
+        step(steps > 0 ? steps - 1 : 0, std::false_type{}, std::false_type{}, S0{});
+    } else {
+        int t = 0;
+        for (; t + 3 < steps; t += 2) {
+            step(t, std::true_type{}, std::true_type{}, S0{});
+            step(t + 1, std::true_type{}, std::true_type{}, S1{});
+        }
+        const int rest = steps - t;      // t even: <= 3 steps left, the first of them on set 0
+        if (rest == 3) {
+            step(t, std::true_type{}, std::true_type{}, S0{});
+            step(t + 1, std::true_type{}, std::false_type{}, S1{});
+            step(t + 2, std::false_type{}, std::false_type{}, S0{});
+        } else if (rest == 2) {
+            step(t, std::true_type{}, std::false_type{}, S0{});
+            step(t + 1, std::false_type{}, std::false_type{}, S1{});
+        } else {
+            step(steps > 0 ? t : 0, std::false_type{}, std::false_type{}, S0{});
+        }
+    }
 
     // ---- epilogue.  C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5): a store instruction
     // writes two 128-byte row segments.  (Computing the blocks transposed, so that a lane holds four consecutive
@@ -408,6 +456,17 @@ inline bool x3_shape_ok(bool ta, bool tb, const float* A, const float* B, int M,
     return in_range && N <= (1 << 20) && (K <= 4096 || splits > 1) && (big || x3_mid_size(M, N, K, splits, a_vec && b_vec));
 }
 
+// Two k steps of operand loads in flight for the 128 x 128-tile launches: MEASURED EQUAL OR SLOWER (round 6,
+// profiles/r06_experiments.txt item 2: the three C2 GEMMs alone 24.9 / 22.3 / 21.3 us against 24.1 / 22.0 / 22.0, the step
+// 0.2410-0.2421 against 0.2382-0.2404 ms) -- the launches are not waiting for more bytes in flight.  The instantiations exist
+// in a -DSERT_VARIANTS build only (SERT_X3_PF=2).
+#ifdef SERT_VARIANTS
+inline bool x3_pf2() {
+    static const bool on = variant_knob("SERT_X3_PF") && atoi(variant_knob("SERT_X3_PF")) == 2;
+    return on;
+}
+#endif
+
 template <bool TB, int EPI>
 inline void launch_gemm_x3(hipStream_t s, const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
                            int lda, int ldb, int ldc, int splits, int kper, size_t c_split_stride) {
@@ -428,6 +487,10 @@ inline void launch_gemm_x3(hipStream_t s, const float* A, const float* B, float*
     const bool big = vec && x3_big_size(M, N, K, g.splits);
     if (N <= 128 || !big) {
         g.tiles_m = cdiv(M, 128); g.tiles_n = cdiv(N, 128);
+#ifdef SERT_VARIANTS
+        if (vec && x3_pf2()) SERT_LAUNCH((gemm_x3<false, TB, EPI, false, 2, 2, 2, 2, true, 2>), dim3(g.tiles_m * g.tiles_n * g.splits), dim3(256), 0, s, g);
+        else
+#endif
         if (vec) SERT_LAUNCH((gemm_x3<false, TB, EPI, false, 2, 2, 2, 2>), dim3(g.tiles_m * g.tiles_n * g.splits), dim3(256), 0, s, g);
         else     SERT_LAUNCH((gemm_x3<false, TB, EPI, false, 2, 2, 2, 2, false>), dim3(g.tiles_m * g.tiles_n * g.splits), dim3(256), 0, s, g);
     } else if (x3_tile_cols(N) == 256) {
@@ -449,6 +512,10 @@ inline void launch_gemm_x3_ta(hipStream_t s, const float* A, const float* B, flo
     g.tiles_m = 1;
     if (M <= 128 && N <= 128) {
         g.tiles_n = 1;
+#ifdef SERT_VARIANTS
+        if (x3_pf2()) SERT_LAUNCH((gemm_x3<true, false, EPI_STORE, CSB, 2, 2, 2, 2, true, 2>), dim3(splits == 1 ? 1 : 8 * cdiv(splits, 8)), dim3(256), 0, s, g);
+        else
+#endif
         SERT_LAUNCH((gemm_x3<true, false, EPI_STORE, CSB, 2, 2, 2, 2>), dim3(splits == 1 ? 1 : 8 * cdiv(splits, 8)), dim3(256), 0, s, g);
     } else if (M <= 320 && M > 128) {
         // 320 x 160 tiles, ten waves of 32 x 160 (80 accumulator registers: three waves fit a SIMD)

@@ -259,9 +259,12 @@ __device__ __forceinline__ float4 clip4(float4 t) {
 
 // er_shift: er = 1 << er_shift entities per range (<= 16).  sub_rows rows per sub-group,
 // sub_rows * c1 <= kElSubPairs.  entries: (B*c1) ints, offs: (num_sub, num_ranges + 1) ints.
+// y / neg != nullptr: the keys straight from the labels and the negatives -- cand[i, j] = j ? neg[i, j - 1] : y[i] is what the
+// loss kernel writes (kernels_vs.h) -- so that the partition can run BEFORE the loss kernel, beside the forward (round 6).
 __global__ __launch_bounds__(512) void egrad_bucket(const int32_t* __restrict__ cand, int B, int c1, int sub_rows,
                                                     int er_shift, int num_ranges, int32_t* __restrict__ entries,
-                                                    int32_t* __restrict__ offs) {
+                                                    int32_t* __restrict__ offs, const int32_t* __restrict__ y = nullptr,
+                                                    const int32_t* __restrict__ neg = nullptr) {
     constexpr int NW = 8;                        // waves per workgroup
     __shared__ int32_t wh[NW][kElMaxRanges];    // per-wave range counts -> start positions
     __shared__ int32_t base[kElMaxRanges + 1];
@@ -280,7 +283,13 @@ __global__ __launch_bounds__(512) void egrad_bucket(const int32_t* __restrict__ 
 #pragma unroll
     for (int k = 0; k < KPL; ++k) {
         const int i = w_lo + k * 64 + lane;
-        key[k] = cand[p_lo + min(i, max(npairs - 1, 0))];
+        const int p = p_lo + min(i, max(npairs - 1, 0));
+        if (y) {
+            const int row = p / c1, j = p - row * c1;
+            key[k] = j ? neg[(size_t)row * (c1 - 1) + (j - 1)] : y[row];
+        } else {
+            key[k] = cand[p];
+        }
     }
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     volatile int32_t* mine = wh[w];

@@ -125,6 +125,8 @@ struct sert_model {
     // 3 = + dW on a third (0.403: every cross-queue dependency costs 15-25 us of idle GPU)
     int nstreams = 2;
     int64_t hint_next = -1;        // sert_hint_next_batch
+    bool neg_side_ready = false;   // this step's negatives were drawn on the side stream during the previous step
+    bool bucket_early = false;     // this step's egrad_bucket ran in front of the fork (sert_hip.hip: vs_backward)
     // lazy dense update of the word table (kernels_opt.h: dense_update_lazy)
     int32_t* rw_last[2] = {nullptr, nullptr};   // per word row: updates applied to its stored (p, state0, state1)
     int rw_last_cur = 0;           // which of the two holds the current values

@@ -1366,10 +1366,11 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
             const int de4 = de / 4, c1 = c.num_negatives + 1;
             const size_t lds = (size_t)4 * 16 * de * sizeof(float);
             const int grid = 8 * cdiv(m->eg_groups, 8) * m->eg_ranges;
-            {
+            if (!m->bucket_early) {     // (else: the partition ran beside the forward, see dh_gemm below)
                 ScopedTimer t(m, TG_SORT, st);
                 hipLaunchKernelGGL(egrad_bucket, dim3(m->eg_num_sub), dim3(512), 0, st, m->cand, B, c1, m->eg_sub_rows,
-                                   m->eg_er_shift, m->eg_ranges, m->eg_entries, m->eg_offs);
+                                   m->eg_er_shift, m->eg_ranges, m->eg_entries, m->eg_offs, (const int32_t*)nullptr,
+                                   (const int32_t*)nullptr);
             }
             {
                 ScopedTimer t(m, TG_EGRAD, st);
@@ -1489,6 +1490,27 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
             hipLaunchKernelGGL(vs_sample_negatives, dim3(grid_for((count + 3) / 4)), dim3(256), 0, m->stream2, m->neg_alt, count,
                                (int64_t)m->rank * count, (uint32_t)c.num_entities, c.seed, (uint64_t)(m->step + 1) * 2);
             m->neg_alt_step = m->step + 1;
+        }
+        // Round 6: the PARTITION of this step's (pair, entity) keys by entity range (egrad_bucket, 19 us at C2) needs the
+        // labels and the negatives only -- not the loss kernel's coefficients -- and this step's negatives were drawn on this
+        // very stream during the previous step (neg_side_ready): it goes out in front of the fork as well and runs beside
+        // gather / projection / loss.  The chain behind the fork is then egrad_acc alone: it starts 19 us earlier and ends
+        // that much earlier beside the word table's update (profiles/r06_experiments.txt, item 1).
+        static const bool no_early_bucket = variant_knob("SERT_NO_EARLY_BUCKET") != nullptr;
+        m->bucket_early = false;
+        // Measured (tools/experiments/r06_early_bucket.sh, three rounds on one box, ms/step early / behind the fork): batch 32768
+        // 0.1458-0.1466 / 0.1545-0.1552 (-5.8 %), 65536 0.2406-0.2426 / 0.2404-0.2414 (equal: egrad_acc ends 29 us earlier, the
+        // tree beside it stretches by 5), 8192 0.0977-0.0987 / 0.0962-0.0966 (+1.5 %: there the partition beside the forward
+        // delays the loss kernel): from batch 16384.  SERT_EARLY_BUCKET=0 / 1 (variants build) forces it off / on.
+        static const int early_knob = variant_knob("SERT_EARLY_BUCKET") ? atoi(variant_knob("SERT_EARLY_BUCKET")) : -1;
+        const bool early_bucket = early_knob >= 0 ? early_knob != 0 : B >= 16384;
+        if (!no_early_bucket && early_bucket && fork_late && !fork_nce && !is_dp(m) && !m->timing.enabled && m->epart && c.kind == SERT_KIND_VECTORSPACE &&
+            c.num_negatives > 0 && m->neg_side_ready && ds.y) {
+            ScopedTimer t(m, TG_SORT, m->stream2);
+            hipLaunchKernelGGL(egrad_bucket, dim3(m->eg_num_sub), dim3(512), 0, m->stream2, (const int32_t*)nullptr, B, c.num_negatives + 1,
+                               m->eg_sub_rows, m->eg_er_shift, m->eg_ranges, m->eg_entries, m->eg_offs,
+                               (const int32_t*)ds.y + row0, (const int32_t*)m->neg);
+            m->bucket_early = true;
         }
         if (fork_late && !fork_nce) SERT_HIP(hipStreamWaitEvent(m->stream2, m->ev_fork, 0));
         if (fork_late && dw_third_queue(m)) SERT_HIP(hipStreamWaitEvent(m->stream3, m->ev_fork, 0));
@@ -2552,6 +2574,7 @@ static int step_forward_backward(sert_model* m, const DataSplit& ds, int64_t bat
         std::swap(m->neg, m->neg_alt);
         m->neg_alt_step = -1;
     }
+    m->neg_side_ready = have_neg;      // (this step's negatives are complete in the side stream's order: vs_backward)
     const bool fused_pre = side_pre && negatives == nullptr && fused_prologue_applies(m);
     hipStream_t pre = (side_pre && !fused_pre) ? m->stream2 : m->stream;
     *fused_pre_out = (pre == m->stream);   // no side-stream prologue: no end-of-step event needed

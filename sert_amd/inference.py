@@ -24,125 +24,94 @@ import numpy as np
 def create(predict_fn, word_representations,
            batch_size, window_size, vocabulary_size,
            result_callback, batched=False):
+    """The front end that fits the callback: callbacks that want the pooled query vector (vectorspace) get a mapper,
+    the others (loglinear: per-token distributions) the fixed-shape batcher (sert/inference.py:5-25)."""
     assert result_callback is not None
-
-    # id width of the packed batches (inference.py:10)
-    instance_dtype = np.min_scalar_type(vocabulary_size - 1)
-    logging.info('Instance elements will be stored using %s.', instance_dtype)
-
-    if result_callback.should_average_input():
-        if batched and hasattr(result_callback, 'process_batch'):
-            return BatchedEmbeddingMapper(
-                predict_fn, word_representations, result_callback)
-        return EmbeddingMapper(
-            predict_fn, word_representations, result_callback)
-
-    return WordBatcher(
-        predict_fn, batch_size, window_size, instance_dtype, result_callback)
+    if not result_callback.should_average_input():
+        ids = np.min_scalar_type(vocabulary_size - 1)          # id width of the packed batches (inference.py:10)
+        logging.info('Instance elements will be stored using %s.', ids)
+        return WordBatcher(predict_fn, batch_size, window_size, ids, result_callback)
+    mapper = BatchedEmbeddingMapper if batched and hasattr(result_callback, 'process_batch') else EmbeddingMapper
+    return mapper(predict_fn, word_representations, result_callback)
 
 
 class WordBatcher(object):
-    """Fixed-shape batches for the loglinear predict_fn, which only accepts
-    exactly (batch_size, window_size) inputs (models.py:830-856)."""
+    """Queries in front of the loglinear predict_fn, which takes exactly (batch_size, window_size) ids + an int8 mask
+    (models.py:830-856).  Same surface and same batches as the reference's batcher (sert/inference.py:28-143, pinned by
+    tests/test_golden_host.py), built differently: ``submit`` only QUEUES a query and books its rows; the id batch and the
+    mask are filled for all queued queries at once when the batch goes out -- a query of T tokens that starts at row r
+    owns the flat slots [r n, r n + T) of the row-major batch (that is what "long queries spill over several rows" means,
+    inference.py:115-117, 132-143), so packing is one scatter of the concatenated tokens and a query's per-token
+    distributions are one contiguous slice of the flattened result (inference.py:89-94)."""
 
     OVERFLOW, TRUNCATE = range(5, 7)
 
-    def __init__(self, predict_fn,
-                 batch_size, window_size, instance_dtype,
-                 result_callback=None,
-                 overflow_mode=OVERFLOW):
+    def __init__(self, predict_fn, batch_size, window_size, instance_dtype, result_callback=None, overflow_mode=OVERFLOW):
         assert overflow_mode in (WordBatcher.OVERFLOW, WordBatcher.TRUNCATE)
-        if result_callback is not None:
-            assert hasattr(result_callback, '__call__')
-
-        self.predict_fn = predict_fn
-        self.batch_size = batch_size
-        self.window_size = window_size
-        self.overflow_mode = overflow_mode
-        self.callback = result_callback
-
-        self.batch = np.zeros((batch_size, window_size), dtype=instance_dtype)
+        assert result_callback is None or callable(result_callback)
+        self.predict_fn, self.callback = predict_fn, result_callback
+        self.batch_size, self.window_size, self.overflow_mode = batch_size, window_size, overflow_mode
+        self.batch = np.zeros((batch_size, window_size), dtype=instance_dtype)     # (padding slots carry token id 0)
         self.mask = np.zeros((batch_size, window_size), dtype=np.int8)
+        self._queue = []            # (first row, tokens, kwargs) of the queries waiting for the next predict_fn call
+        self._rows = 0              # rows booked by them
 
-        self._empty_batch()
-
-    def _empty_batch(self):
-        self.batch.fill(0)     # padding rows/slots carry token id 0
-        self.mask.fill(0)
-        self.num_used_instances = 0
-        self.requests = []
-
-    def _rows_needed(self, num_tokens):
-        return -(-num_tokens // self.window_size)
+    @property
+    def num_used_instances(self):
+        return self._rows
 
     def submit(self, query_tokens, **kwargs):
         assert len(query_tokens) > 0
-
-        if self.overflow_mode == WordBatcher.TRUNCATE and \
-                len(query_tokens) > self.window_size:
-            logging.error('Truncated query "%s" as it exceeded '
-                          'the window size.', query_tokens)
+        if self.overflow_mode == WordBatcher.TRUNCATE and len(query_tokens) > self.window_size:
+            logging.error('Truncated query "%s" as it exceeded the window size.', query_tokens)
             query_tokens = query_tokens[:self.window_size]
+        rows = -(-len(query_tokens) // self.window_size)
+        if rows > self.batch_size:
+            raise RuntimeError()        # (more tokens than one batch holds: inference.py:124-125)
+        if self._rows + rows > self.batch_size:
+            self.process()              # (no room left: the batch goes out first, inference.py:126-128)
+        self._queue.append((self._rows, query_tokens, kwargs))
+        self._rows += rows
 
-        num_instances = self._rows_needed(len(query_tokens))
-
-        if num_instances > self.batch_size:
-            # a query longer than batch_size * window_size tokens cannot be
-            # scored (inference.py:124-125)
-            raise RuntimeError()
-        if num_instances > self.batch_size - self.num_used_instances:
-            self.process()
-
-        self.requests.append((num_instances, query_tokens, kwargs))
-
-        # long queries spill row-major over several rows (inference.py:132-143)
-        first = self.num_used_instances
-        flat = np.asarray(query_tokens)
-        for r in range(num_instances):
-            piece = flat[r * self.window_size:(r + 1) * self.window_size]
-            self.batch[first + r, :len(piece)] = piece
-            self.mask[first + r, :len(piece)] = 1
-        self.num_used_instances += num_instances
+    def _pack(self):
+        """Fill batch / mask from the queue: one scatter into the flattened arrays."""
+        lengths = np.fromiter((len(q) for _, q, _ in self._queue), dtype=np.int64, count=len(self._queue))
+        starts = np.fromiter((r for r, _, _ in self._queue), dtype=np.int64, count=len(self._queue)) * self.window_size
+        ends = np.cumsum(lengths)
+        # flat slot of every queued token: its query's first slot + its position in the query
+        slots = np.repeat(starts - (ends - lengths), lengths) + np.arange(int(ends[-1]))
+        self.batch.fill(0)
+        self.mask.fill(0)
+        self.batch.reshape(-1)[slots] = np.concatenate([np.asarray(q) for _, q, _ in self._queue])
+        self.mask.reshape(-1)[slots] = 1
+        return starts, lengths
 
     def process(self):
-        if len(self.requests) == 0:
+        if not self._queue:
             return
-        logging.debug('Processing batch (batch size=%d, current batch=%d).',
-                      self.batch_size, self.num_used_instances)
-        results = self.predict_fn(self.batch, self.mask)   # (B, n, V_e)
-
-        row = 0
-        for num_instances, payload, kwargs in self.requests:
-            # the request's rows, flattened to one distribution per token and
-            # cut back to the real token count (inference.py:89-94)
-            result = results[row:row + num_instances]
-            result = result.reshape((-1, result.shape[-1]))[:len(payload)]
-            assert result.ndim == 2 and result.shape[0] == len(payload)
-
-            self.callback(payload, result, **kwargs)
-            row += num_instances
-
-        self._empty_batch()
+        logging.debug('Processing batch (batch size=%d, current batch=%d).', self.batch_size, self._rows)
+        starts, lengths = self._pack()
+        out = self.predict_fn(self.batch, self.mask)            # (B, n, V_e)
+        per_token = out.reshape((-1, out.shape[-1]))
+        for (_, payload, kwargs), s0, T in zip(self._queue, starts, lengths):
+            self.callback(payload, per_token[s0:s0 + T], **kwargs)
+        self._queue, self._rows = [], 0
 
 
 class EmbeddingMapper(object):
     """One query at a time: mean word vector -> predict_fn -> callback."""
 
     def __init__(self, predict_fn, word_representations, result_callback):
-        if result_callback is not None:
-            assert hasattr(result_callback, '__call__')
-
-        self.predict_fn = predict_fn
+        assert result_callback is None or callable(result_callback)
+        self.predict_fn, self.callback = predict_fn, result_callback
         self.word_representations = word_representations
-        self.callback = result_callback
-
-    def process(self):
-        return None   # (nothing is queued: submit() answers immediately)
 
     def submit(self, query_tokens, **kwargs):
-        pooled = self.word_representations[query_tokens, :].mean(axis=0)
-        projection = self.predict_fn(pooled)
-        self.callback(query_tokens, projection, **kwargs)
+        # (sert/inference.py:161-167: the query is the mean of its words' rows)
+        self.callback(query_tokens, self.predict_fn(self.word_representations[query_tokens, :].mean(axis=0)), **kwargs)
+
+    def process(self):
+        """Nothing is ever queued: submit() answers immediately."""
 
 
 class BatchedEmbeddingMapper(object):
@@ -176,19 +145,24 @@ class BatchedEmbeddingMapper(object):
         self.pending = []
 
 
+def _product_skipping_zeros(distribution, axis):
+    # multiplied in log space with log(0) counted as 0: a zero entry is skipped, it does not annihilate the product
+    return np.exp(np.ma.log(distribution).filled(0).sum(axis=axis))
+
+
+_AGGREGATORS = {
+    'sum': lambda dist, axis: np.mean(dist, axis=axis),              # (sic: the reference's 'sum' is the mean)
+    'product': _product_skipping_zeros,
+    'last': lambda dist, axis: np.take(dist, indices=dist.shape[axis] - 1, axis=axis),
+    'max': lambda dist, axis: np.max(dist, axis=axis),
+    'identity': lambda dist, axis: dist,
+}
+
+
 def aggregate_distribution(distribution, mode, axis):
-    """inference.py:170-183.  'product' multiplies in log space with log(0)
-    treated as 0, i.e. zero entries are skipped, not annihilating."""
-    if mode == 'sum':
-        return np.mean(distribution, axis=axis)
-    if mode == 'product':
-        logs = np.ma.log(distribution).filled(0)
-        return np.exp(np.sum(logs, axis=axis))
-    if mode == 'last':
-        return np.take(distribution, axis=axis,
-                       indices=distribution.shape[axis] - 1)
-    if mode == 'max':
-        return np.max(distribution, axis=axis)
-    if mode == 'identity':
-        return distribution
-    raise NotImplementedError()
+    """Per-token distributions -> one (sert/inference.py:170-183); unknown modes raise NotImplementedError."""
+    try:
+        fn = _AGGREGATORS[mode]
+    except KeyError:
+        raise NotImplementedError()
+    return fn(distribution, axis)

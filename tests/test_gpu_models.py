@@ -394,6 +394,49 @@ def test_cli_train_then_query(hip_lib, tmp_path, kind):
 
 
 @pytest.mark.parametrize('kind', ['vectorspace', 'loglinear'])
+def test_cli_train_with_a_representation_initializer(hip_lib, tmp_path, kind):
+    """bin/train.py --representation_initializer <word2vec binary> (reference bin/train.py:131-151), end to end on the GPU:
+    the dump taken BEFORE the first epoch (model_0.bin, train.py:289-300) carries the pre-trained vectors in the rows of the
+    words the file knows -- looked up lower-cased, the last duplicate wins -- and Glorot rows elsewhere; one epoch of training
+    moves both kinds of rows, and bin/query.py reads the result."""
+    from sert_amd import training
+    from sert_amd.utils import embedding_utils as EU
+    _write_tiny_corpus(tmp_path, kind)
+    dim = 16
+    rng = np.random.RandomState(3)
+    known = ['w%d' % i for i in range(0, 120, 2)]                  # every second word of the vocabulary ...
+    names = known + ['not-in-the-vocabulary', 'w4']                 # ... an unknown one, and w4 a second time (the last one wins)
+    vecs = rng.uniform(-0.5, 0.5, (len(names), dim)).astype(np.float32)
+    EU.save_binary_representations(str(tmp_path / 'pre.bin'), names, vecs)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    cmd = [sys.executable, os.path.join(ROOT, 'bin', 'train.py'), '--data', str(tmp_path / 'data.npz'),
+           '--meta', str(tmp_path / 'meta'), '--type', kind, '--iterations', '1', '--batch_size', '32',
+           '--word_representation_size', str(dim), '--representation_initializer', str(tmp_path / 'pre.bin'),
+           '--model_output', str(tmp_path / 'model'), '--seed', '2', '--loglevel', 'WARNING']
+    if kind == 'vectorspace':
+        cmd += ['--num_negative_samples', '5', '--one_hot_classes', '--entity_representation_size', '12']
+    subprocess.check_call(cmd, env=env)
+    Rw0 = training.read_checkpoint(str(tmp_path / 'model_0.bin'))['tables'][0]
+    Rw1 = training.read_checkpoint(str(tmp_path / 'model_1.bin'))['tables'][0]
+    assert Rw0.shape == (120, dim) and Rw0.dtype == np.float32
+    want = {w: v for w, v in zip(names, vecs)}                      # (dict: the later 'w4' overrides the earlier one)
+    for i in range(120):
+        if 'w%d' % i in want:
+            assert np.array_equal(Rw0[i], want['w%d' % i]), i
+        else:
+            # a Glorot row: inside +-sqrt(6 / (rows + cols)) and not one of the file's vectors
+            assert np.abs(Rw0[i]).max() <= np.sqrt(6.0 / (120 + dim)) + 1e-6 and not (vecs == Rw0[i]).all(axis=1).any(), i
+    assert not np.array_equal(Rw0[4], vecs[2]) and np.array_equal(Rw0[4], vecs[-1])
+    moved = np.abs(Rw1 - Rw0).max(axis=1)
+    assert (moved[0::2] > 0).all() and (moved[1::2] > 0).all()      # training moved pre-trained and random rows alike
+    cmdq = [sys.executable, os.path.join(ROOT, 'bin', 'query.py'), '--meta', str(tmp_path / 'meta'),
+            '--model', str(tmp_path / 'model_1.bin'), '--topics', str(tmp_path / 'topics'),
+            '--run_out', str(tmp_path / 'run'), '--loglevel', 'WARNING']
+    subprocess.check_call(cmdq + (['--top', '5'] if kind == 'vectorspace' else []), env=env)
+    assert os.path.getsize(str(tmp_path / 'run_ef')) > 0
+
+
+@pytest.mark.parametrize('kind', ['vectorspace', 'loglinear'])
 def test_resumed_run_equals_uninterrupted_run(hip_lib, tmp_path, kind):
     """bin/train.py --iterations 2  ==  --iterations 1, then --resume model_1.bin --iterations 2:
     parameters, optimiser tensors and step, sampler positions and the batch shuffle continue

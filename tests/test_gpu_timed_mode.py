@@ -206,7 +206,9 @@ def test_in_step_timing_changes_nothing_and_times_the_update(hip_lib, kind):
             us, launches = eng.timings(), eng.timing_launches()
             assert abs(launches['optimizer_word_table'] - 1.0) < 0.02, launches
             assert 2.0 < us['optimizer_word_table'] < 500.0, us
-            assert us['gather'] > 0 and us['loss'] > 0 and us['word_grad_segsum'] > 0, us
+            # (vectorspace: gather, loss, the word gradient's tree; loglinear: gather of the distinct words, loss, and the
+            #  per-word dZ sums, which reuse the entity_grad_reduce slot)
+            assert us['gather'] > 0 and us['loss'] > 0 and us['word_grad_segsum' if kind == 'vectorspace' else 'entity_grad_reduce'] > 0, us
             assert sum(launches.values()) * steps > 1024, launches      # (the ring wrapped)
         eng.timing_enable(0)
         outs.append((losses, eng.get_tensor(C.T_RW).copy(), eng.get_tensor(C.T_W).copy()))

@@ -256,6 +256,16 @@ int p2p(bool is_send, void* buf, size_t count, int datatype, int peer, Comm* c, 
     return ncclSuccess;
 }
 
+// Fault injection (tests/test_gpu_rccl_stub.py::test_a_failing_collective_is_a_clean_error): RCCL_STUB_FAIL_SEQ=N makes the
+// N-th collective of the communicator (1-based, counted as the product issues them: all-reduce, reduce-scatter, all-gather,
+// a group of sends / receives) RETURN ncclSystemError instead of enqueueing anything -- on the rank RCCL_STUB_FAIL_RANK names,
+// or on every rank when that is unset.  What a node sees when a link or a peer goes away under a collective.
+bool inject_failure(Comm* c, uint64_t seq) {
+    static const long fail_seq = getenv("RCCL_STUB_FAIL_SEQ") ? atol(getenv("RCCL_STUB_FAIL_SEQ")) : 0;
+    static const int fail_rank = getenv("RCCL_STUB_FAIL_RANK") ? atoi(getenv("RCCL_STUB_FAIL_RANK")) : -1;
+    return fail_seq > 0 && (long)seq >= fail_seq && (fail_rank < 0 || fail_rank == c->rank);
+}
+
 }  // namespace
 
 extern "C" {
@@ -328,6 +338,7 @@ int ncclCommDestroy(void* comm) {
 int ncclAllReduce(const void* send, void* recv, size_t count, int datatype, int op, void* comm, hipStream_t st) {
     Comm* c = static_cast<Comm*>(comm);
     if (datatype != ncclFloat32 || op != ncclSum) return fail(ncclInvalidArgument, "the stub sums float32 only");
+    if (inject_failure(c, c->seq + 1)) return fail(ncclSystemError, "ncclAllReduce: injected failure (RCCL_STUB_FAIL_SEQ)");
     Op* o = new Op();
     o->c = c; o->kind = OP_ALLREDUCE; o->seq = ++c->seq; o->send_count = count; o->recv_count = count;
     return enqueue(c, o, {Segment{const_cast<void*>(send), count, 0}}, {0}, {Segment{recv, count, 0}}, {0}, st);
@@ -336,6 +347,7 @@ int ncclAllReduce(const void* send, void* recv, size_t count, int datatype, int 
 int ncclReduceScatter(const void* send, void* recv, size_t recvcount, int datatype, int op, void* comm, hipStream_t st) {
     Comm* c = static_cast<Comm*>(comm);
     if (datatype != ncclFloat32 || op != ncclSum) return fail(ncclInvalidArgument, "the stub sums float32 only");
+    if (inject_failure(c, c->seq + 1)) return fail(ncclSystemError, "ncclReduceScatter: injected failure (RCCL_STUB_FAIL_SEQ)");
     Op* o = new Op();
     o->c = c; o->kind = OP_REDUCESCATTER; o->seq = ++c->seq; o->send_count = recvcount * (size_t)c->world; o->recv_count = recvcount;
     return enqueue(c, o, {Segment{const_cast<void*>(send), o->send_count, 0}}, {0}, {Segment{recv, recvcount, 0}}, {0}, st);
@@ -344,6 +356,7 @@ int ncclReduceScatter(const void* send, void* recv, size_t recvcount, int dataty
 int ncclAllGather(const void* send, void* recv, size_t sendcount, int datatype, void* comm, hipStream_t st) {
     Comm* c = static_cast<Comm*>(comm);
     if (datatype != ncclFloat32) return fail(ncclInvalidArgument, "the stub moves float32 only");
+    if (inject_failure(c, c->seq + 1)) return fail(ncclSystemError, "ncclAllGather: injected failure (RCCL_STUB_FAIL_SEQ)");
     Op* o = new Op();
     o->c = c; o->kind = OP_ALLGATHER; o->seq = ++c->seq; o->send_count = sendcount; o->recv_count = sendcount * (size_t)c->world;
     return enqueue(c, o, {Segment{const_cast<void*>(send), sendcount, 0}}, {0}, {Segment{recv, o->recv_count, 0}}, {0}, st);
@@ -362,6 +375,10 @@ int ncclGroupStart() { g_group.depth += 1; return ncclSuccess; }
 int ncclGroupEnd() {
     if (g_group.depth <= 0) return fail(ncclInvalidArgument, "ncclGroupEnd without ncclGroupStart");
     if (--g_group.depth > 0) return ncclSuccess;
+    if (g_group.comm && inject_failure(g_group.comm, g_group.comm->seq + 1)) {
+        g_group = GroupState();
+        return fail(ncclSystemError, "ncclGroupEnd: injected failure (RCCL_STUB_FAIL_SEQ)");
+    }
     return flush_group();
 }
 

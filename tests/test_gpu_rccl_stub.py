@@ -85,3 +85,32 @@ def test_async_branch_at_c2_size_with_two_ranks(hip_lib, tmp_path):
         assert abs(float(res[key]) - float(one[key])) <= 2e-5 * abs(float(one[key])), key
     for key in ('Rw', 'Re', 'W', 'b', 'opt_state0_rw', 'opt_state1_rw'):
         assert U.rel_err(res[key], one[key]) < 2e-5, key
+
+
+@pytest.mark.parametrize('world,fail_rank,exchange', [(2, None, 'rows'), (4, 1, 'rows'), (2, 0, 'zero1')])
+def test_a_failing_collective_is_a_clean_error(hip_lib, tmp_path, world, fail_rank, exchange):
+    """First contact with a real communicator will meet failures the single-GPU box never shows: here the stand-in
+    makes the N-th collective of a run RETURN ncclSystemError (RCCL_STUB_FAIL_SEQ) -- on every rank, or on one rank
+    while its peers sit in that collective.  Required: the failing rank raises SertError naming the RCCL call (no crash,
+    no hang), the launcher takes the peers down, and the whole run ends with a non-zero exit code well inside the
+    collective's own deadline -- never a hang of the box."""
+    import time
+    from tests import rccl_stub
+    env = rccl_stub.env_with_stub(dict(os.environ, OMP_NUM_THREADS='1', SERT_DP_EXCHANGE=exchange, RCCL_STUB_TIMEOUT='60',
+                                       RCCL_STUB_FAIL_SEQ='9'))
+    if fail_rank is not None:
+        env['RCCL_STUB_FAIL_RANK'] = str(fail_rank)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'SERT_RDZV_DIR', 'SERT_COMM'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'sert_amd.distributed', str(world), os.path.join(U.ROOT, 'tests', 'dp_worker.py'),
+           'vectorspace', str(tmp_path / 'dp.npz')]
+    t0 = time.time()
+    r = subprocess.run(cmd, env=env, cwd=U.ROOT, timeout=600, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    took = time.time() - t0
+    err = r.stderr.decode(errors='replace')
+    assert r.returncode != 0, 'the run must fail'
+    assert r.returncode not in (97, 124), (r.returncode, err[-2000:])     # (97: the stand-in's own deadline; 124: a launcher timeout)
+    assert 'SertError' in err and 'injected failure' in err, err[-3000:]
+    assert 'Segmentation fault' not in err and 'core dumped' not in err
+    assert took < 240, took
+    assert not os.path.exists(str(tmp_path / 'dp.npz'))

@@ -1345,6 +1345,32 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
 #else
     const int fused_grid = 0;
 #endif
+    m->bucket_early = false;
+    auto early_bucket = [&]() -> int {
+        // Round 6: the PARTITION of this step's (pair, entity) keys by entity range (egrad_bucket, 19 us at C2) needs the
+        // labels and the negatives only -- not the loss kernel's coefficients -- and this step's negatives were drawn on this
+        // very stream during the previous step (neg_side_ready): it goes out in front of the fork as well and runs beside
+        // gather / projection / loss.  The chain behind the fork is then egrad_acc alone: it starts 19 us earlier and ends
+        // that much earlier beside the word table's update (profiles/r06_experiments.txt, item 1).
+        static const bool no_early_bucket = variant_knob("SERT_NO_EARLY_BUCKET") != nullptr;
+        m->bucket_early = false;
+        // Measured (tools/experiments/r06_early_bucket.sh, r06_fork_nce_early.sh; three rounds each on one box, ms/step early / behind
+        // the fork): batch 32768 0.1426-0.1466 / 0.1515-0.1552 (-5.5 %), 65536 0.2404-0.2427 / 0.2404-0.2426 (equal: egrad_acc ends
+        // 29 us earlier, the tree beside it stretches by 5), 16384 0.1182-0.1213 / 0.1170-0.1184 (+1.5 %), 8192 0.0977-0.1000 /
+        // 0.0938-0.0966 (+3-5 %: there the partition beside the forward delays the loss kernel and the update): from batch 32768.
+        // SERT_EARLY_BUCKET=0 / 1 (variants build) forces it off / on.
+        static const int early_knob = variant_knob("SERT_EARLY_BUCKET") ? atoi(variant_knob("SERT_EARLY_BUCKET")) : -1;
+        const bool want_early = early_knob >= 0 ? early_knob != 0 : B >= 32768;
+        if (!no_early_bucket && want_early && fork_late && !is_dp(m) && !m->timing.enabled && m->epart && c.kind == SERT_KIND_VECTORSPACE &&
+            c.num_negatives > 0 && m->neg_side_ready && ds.y) {
+            ScopedTimer t(m, TG_SORT, m->stream2);
+            hipLaunchKernelGGL(egrad_bucket, dim3(m->eg_num_sub), dim3(512), 0, m->stream2, (const int32_t*)nullptr, B, c.num_negatives + 1,
+                               m->eg_sub_rows, m->eg_er_shift, m->eg_ranges, m->eg_entries, m->eg_offs,
+                               (const int32_t*)ds.y + row0, (const int32_t*)m->neg);
+            m->bucket_early = true;
+        }
+        return 0;
+    };
     auto entity_grad = [&]() -> int {
         // fork: this chain only depends on the NCE kernel and is independent of the
         // GEMMs / word-table reduction below, so it runs on the side stream
@@ -1491,27 +1517,7 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
                                (int64_t)m->rank * count, (uint32_t)c.num_entities, c.seed, (uint64_t)(m->step + 1) * 2);
             m->neg_alt_step = m->step + 1;
         }
-        // Round 6: the PARTITION of this step's (pair, entity) keys by entity range (egrad_bucket, 19 us at C2) needs the
-        // labels and the negatives only -- not the loss kernel's coefficients -- and this step's negatives were drawn on this
-        // very stream during the previous step (neg_side_ready): it goes out in front of the fork as well and runs beside
-        // gather / projection / loss.  The chain behind the fork is then egrad_acc alone: it starts 19 us earlier and ends
-        // that much earlier beside the word table's update (profiles/r06_experiments.txt, item 1).
-        static const bool no_early_bucket = variant_knob("SERT_NO_EARLY_BUCKET") != nullptr;
-        m->bucket_early = false;
-        // Measured (tools/experiments/r06_early_bucket.sh, three rounds on one box, ms/step early / behind the fork): batch 32768
-        // 0.1458-0.1466 / 0.1545-0.1552 (-5.8 %), 65536 0.2406-0.2426 / 0.2404-0.2414 (equal: egrad_acc ends 29 us earlier, the
-        // tree beside it stretches by 5), 8192 0.0977-0.0987 / 0.0962-0.0966 (+1.5 %: there the partition beside the forward
-        // delays the loss kernel): from batch 16384.  SERT_EARLY_BUCKET=0 / 1 (variants build) forces it off / on.
-        static const int early_knob = variant_knob("SERT_EARLY_BUCKET") ? atoi(variant_knob("SERT_EARLY_BUCKET")) : -1;
-        const bool early_bucket = early_knob >= 0 ? early_knob != 0 : B >= 16384;
-        if (!no_early_bucket && early_bucket && fork_late && !fork_nce && !is_dp(m) && !m->timing.enabled && m->epart && c.kind == SERT_KIND_VECTORSPACE &&
-            c.num_negatives > 0 && m->neg_side_ready && ds.y) {
-            ScopedTimer t(m, TG_SORT, m->stream2);
-            hipLaunchKernelGGL(egrad_bucket, dim3(m->eg_num_sub), dim3(512), 0, m->stream2, (const int32_t*)nullptr, B, c.num_negatives + 1,
-                               m->eg_sub_rows, m->eg_er_shift, m->eg_ranges, m->eg_entries, m->eg_offs,
-                               (const int32_t*)ds.y + row0, (const int32_t*)m->neg);
-            m->bucket_early = true;
-        }
+        SERT_TRY(early_bucket());
         if (fork_late && !fork_nce) SERT_HIP(hipStreamWaitEvent(m->stream2, m->ev_fork, 0));
         if (fork_late && dw_third_queue(m)) SERT_HIP(hipStreamWaitEvent(m->stream3, m->ev_fork, 0));
         return 0;
@@ -1645,6 +1651,7 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         SERT_TRY(entity_grad());       // side, behind dW
         SERT_TRY(word_table_sum());    // main
     } else if (fork_nce) {
+        SERT_TRY(early_bucket());      // (side, in front of the fork wait: beside the forward)
         SERT_TRY(entity_grad());       // side, forked on the NCE kernel's completion
         SERT_TRY(dh_gemm());
         SERT_TRY(dense_grad());

@@ -2650,11 +2650,20 @@ static int step_forward_backward(sert_model* m, const DataSplit& ds, int64_t bat
 }
 
 // May the forward + backward of a hinted next batch run ahead of the host (before the loss
-// of the current step has been read)?  Single GPU, product settings, device sampler only:
-// there it touches nothing but activations and gradient scratch, and the data-parallel
-// exchange (a collective) is never issued speculatively.
+// of the current step has been read)?  It touches nothing but activations and gradient scratch.
+// Single GPU: product settings, device sampler.  Data parallel (round 6): as well -- the run-ahead then includes the
+// collectives of the backward (the gradient rows' all-to-all / the reduce-scatter), which is safe because every rank
+// sees the same sequence of hints and batches (the global batch order is rank-invariant) and therefore
+// issues, keeps or discards the same run-ahead; the parameter fetch of the hinted batch was already issued this way.
+// Without it the data-parallel step was HOST-bound: its ~45 runtime calls only started when the previous loss had
+// arrived (world of one, 8192 rows: 0.174 ms against 0.096 on one GPU; profiles/r06_experiments.txt item 4).
+// SERT_DP_RUN_AHEAD=0 (variants build) restores the round-5 behaviour.
 static bool can_speculate_step(const sert_model* m) {
-    if (is_dp(m) || m->timing.enabled || m->cfg.keep_grads) return false;
+    if (m->timing.enabled || m->cfg.keep_grads) return false;
+    if (is_dp(m)) {
+        static const bool dp_off = variant_knob("SERT_DP_RUN_AHEAD") && atoi(variant_knob("SERT_DP_RUN_AHEAD")) == 0;
+        return !dp_off && is_vs(m) && !is_fs(m);
+    }
     if (is_vs(m) && !is_fs(m)) return use_touched_now(m) && fused_prologue_applies_with(m, true);
     return true;   // loglinear / full-softmax: the whole step lives on the main stream
 }

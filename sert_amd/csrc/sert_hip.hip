@@ -1517,7 +1517,6 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
                                (int64_t)m->rank * count, (uint32_t)c.num_entities, c.seed, (uint64_t)(m->step + 1) * 2);
             m->neg_alt_step = m->step + 1;
         }
-        SERT_TRY(early_bucket());
         if (fork_late && !fork_nce) SERT_HIP(hipStreamWaitEvent(m->stream2, m->ev_fork, 0));
         if (fork_late && dw_third_queue(m)) SERT_HIP(hipStreamWaitEvent(m->stream3, m->ev_fork, 0));
         return 0;
@@ -1628,9 +1627,16 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
     // (!pt_big[2]: a projection matrix large enough for a streaming update of its own is updated on the main stream, which
     //  would then have to wait for the side stream's dW)
     const bool fork_nce_dw = fork_nce && fork_at_nce_dw(m) && !side_heavy && m->lazy_join && !fused_bwd && !m->pt_big[2] && m->nstreams == 2;
+    // Round 6: the entity keys' partition goes out first of all on the side stream, in front of the fork wait (early_bucket above) --
+    // and where it does, dW / db first on the side stream pays at EVERY batch size: the chain behind the fork is then dW + egrad_acc,
+    // the main stream goes from dh straight into the tree.  tools/experiments/r06_dw_first_again.sh, three rounds on one box, ms/step,
+    // dW on the main stream / first on the side stream: batch 65536 0.2375-0.2390 / 0.2244-0.2261 (-5.4 %; with the partition behind the
+    // fork, as in round 5: 0.2381-0.2404 / 0.2346-0.2360), 131072 0.4190-0.4222 / 0.4040-0.4142.
+    SERT_TRY(early_bucket());
     m->dw_side_first = fork_nce_dw ||
                        (!dw_first_off && fork_late && !fork_nce && !side_heavy && m->lazy_join && !fused_bwd && !dw_third_queue(m) &&
-                        !m->pt_big[2] && c.kind == SERT_KIND_VECTORSPACE && (dw_first_always || ((size_t)B * dw * sizeof(float) <= ((size_t)24 << 20) && m->epart)));
+                        !m->pt_big[2] && c.kind == SERT_KIND_VECTORSPACE &&
+                        (dw_first_always || (((size_t)B * dw * sizeof(float) <= ((size_t)24 << 20) || m->bucket_early) && m->epart)));
     // (m->epart: the sort-free entity chain of small entity tables.  Behind the counting sort of a larger one the side stream is
     //  the longer of the two already: the reference's product-search settings, V_e = 32768, 205.8 -> 214.5 us with dW in front)
     static const int dp_late_mode = variant_knob("SERT_DP_LATE") ? atoi(variant_knob("SERT_DP_LATE")) : 1;   // 0: off; 2: dW behind the chain
@@ -1651,7 +1657,6 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         SERT_TRY(entity_grad());       // side, behind dW
         SERT_TRY(word_table_sum());    // main
     } else if (fork_nce) {
-        SERT_TRY(early_bucket());      // (side, in front of the fork wait: beside the forward)
         SERT_TRY(entity_grad());       // side, forked on the NCE kernel's completion
         SERT_TRY(dh_gemm());
         SERT_TRY(dense_grad());
@@ -2477,8 +2482,13 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
         const float* lp = is_dp(m) ? m->g_loss : (m->loss_from_rows ? m->rowloss : m->red_loss);
         const int nl = is_dp(m) ? 1 : n_loss_partials;
         unsigned* flag = publish ? reinterpret_cast<unsigned*>(loss_dst + 4) : nullptr;
+        // timing knock-out (variants build, WRONG loss: the sums of squares of the word table are read while its update runs):
+        // the tail on the SIDE stream behind the entity chain -- what taking it off the main queue would buy (r06 experiments, item 6)
+        static const bool ko_tail_side = variant_knob("SERT_KO_TAIL_SIDE") != nullptr;
+        const bool tail_side = ko_tail_side && tail_splits > 0 && m->dw_side_first && defer_small && side_small;
+        hipStream_t ts = tail_side ? ss : m->stream;
         if (tail_splits > 0) {
-            if (m->dw_side_first) SERT_HIP(hipStreamWaitEvent(m->stream, m->ev_dense, 0));   // (dW / db slabs: side stream)
+            if (m->dw_side_first && !tail_side) SERT_HIP(hipStreamWaitEvent(m->stream, m->ev_dense, 0));   // (dW / db slabs: side stream)
             TailArgs ta;
             ta.part = m->part; ta.splits = tail_splits; ta.stride = m->tail_stride;
             ta.W = m->W; ta.b = m->b; ta.s0_w = m->s0_w; ta.s1_w = m->s1_w; ta.s0_b = m->s0_b; ta.s1_b = m->s1_b;
@@ -2497,8 +2507,13 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
             if (++m->tail_launch_seq == 0) ++m->tail_launch_seq;   // (0 = "never written")
             ta.launch_seq = m->tail_launch_seq;
             const int nb = cdiv((int64_t)(m->n_w + m->n_b), 64);
-            if (c.keep_grads) hipLaunchKernelGGL((vs_tail<true>), dim3(nb), dim3(1024), 0, m->stream, ta);
-            else              hipLaunchKernelGGL((vs_tail<false>), dim3(nb), dim3(1024), 0, m->stream, ta);
+            if (c.keep_grads) hipLaunchKernelGGL((vs_tail<true>), dim3(nb), dim3(1024), 0, ts, ta);
+            else              hipLaunchKernelGGL((vs_tail<false>), dim3(nb), dim3(1024), 0, ts, ta);
+            if (tail_side) {     // (the next projection reads W: it waits for this, see step_forward_backward)
+                SERT_HIP(hipEventRecord(m->ev_re, ss));
+                m->re_pending = true;
+                m->w_pending = true;
+            }
         } else
         hipLaunchKernelGGL(finalize_loss, dim3(1), dim3(256), 0, m->stream, lp, nl, m->red_sq,
                            n_sq, inv_batch, reg_scale, loss_dst, flag, publish ? ++m->loss_seq : 0u,
@@ -2599,6 +2614,7 @@ static int step_forward_backward(sert_model* m, const DataSplit& ds, int64_t bat
     // the main stream's first kernels go out BEFORE the prologue's host calls: the GPU
     // starts on gather + projection while the host is still enqueueing
     if (is_vs(m) && !is_fs(m)) {
+        if (m->w_pending) { SERT_TRY(settle_entity_update(m)); m->w_pending = false; }   // (W, b updated on the side stream)
         if (m->projected_batch != batch_index) SERT_TRY(vs_project(m, ds, batch_index));
         m->projected_batch = -1;
     }

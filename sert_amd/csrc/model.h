@@ -115,6 +115,7 @@ struct sert_model {
     // the previous step's launch (re_sq[k]: partials of the updated table, for optimiser step re_sq_for[k])
     hipEvent_t ev_re = nullptr;
     bool re_pending = false;
+    bool tail_early = false, w_early_pending = false;   // (knock-out SERT_KO_TAIL_EARLY: see sert_hip.hip)
     bool w_pending = false;          // W, b were updated on the side stream too (same event): the next projection waits
     float* re_sq = nullptr;          // [2][2 * kOptBlocks]
     int64_t re_sq_for[2] = {-1, -1};

@@ -1601,6 +1601,31 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         }
         // the loss partials only depend on the NCE kernel too
         SERT_TRY(reduce_rowloss(m, sd));
+        // timing knock-out (variants build, WRONG loss; r06 experiments item 9): the dW combine + W, b update right behind dW on the side
+        // stream, the loss left to a one-workgroup launch behind the word table's update -- what splitting the tail that way would buy
+        static const bool ko_tail_early = variant_knob("SERT_KO_TAIL_EARLY") != nullptr;
+        m->tail_early = false;
+        if (ko_tail_early && m->tail_splits > 0 && m->dw_side_first && sd == m->stream2 && !c.keep_grads && !m->timing.enabled) {
+            AdamArgs aa2; AdadeltaArgs da2;
+            optimizer_args(m, m->step + 1, &aa2, &da2);
+            TailArgs ta;
+            ta.part = m->part; ta.splits = m->tail_splits; ta.stride = m->tail_stride;
+            ta.W = m->W; ta.b = m->b; ta.s0_w = m->s0_w; ta.s1_w = m->s1_w; ta.s0_b = m->s0_b; ta.s1_b = m->s1_b;
+            ta.g_w = m->g_w; ta.g_b = m->g_b;
+            ta.n_w = (unsigned)m->n_w; ta.n_b = (unsigned)m->n_b;
+            ta.aa = aa2;
+            ta.loss_partials = m->red_loss; ta.n_loss = 0;
+            ta.sq_partials = m->red_sq; ta.n_sq = 0;
+            ta.sq_alt = nullptr; ta.sq_alt_lo = 0; ta.sq_alt_hi = 0;
+            ta.inv_batch = 1.f; ta.reg_scale = 0.f;
+            ta.out = m->d_loss; ta.host_flag = nullptr; ta.seq = 0u;
+            ta.blk = m->tail_blk;
+            if (++m->tail_launch_seq == 0) ++m->tail_launch_seq;
+            ta.launch_seq = m->tail_launch_seq;
+            const int nbt = cdiv((int64_t)(m->n_w + m->n_b), 64);
+            hipLaunchKernelGGL((vs_tail<false>), dim3(nbt), dim3(1024), 0, sd, ta);
+            m->tail_early = true;
+        }
         if (m->dw_side_first) SERT_HIP(hipEventRecord(m->ev_dense, sd));   // (the tail waits for this, not for the chain behind it)
         if (sd != m->stream && sd != m->stream2 && !fork_late) SERT_HIP(hipEventRecord(m->ev_join3, sd));
         return 0;
@@ -2487,6 +2512,12 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
         static const bool ko_tail_side = variant_knob("SERT_KO_TAIL_SIDE") != nullptr;
         const bool tail_side = ko_tail_side && tail_splits > 0 && m->dw_side_first && defer_small && side_small;
         hipStream_t ts = tail_side ? ss : m->stream;
+        if (tail_splits > 0 && m->tail_early) {
+            // (knock-out: W and b were updated behind dW on the side stream; only the loss is left -- the next projection waits for ev_dense)
+            hipLaunchKernelGGL(finalize_loss, dim3(1), dim3(256), 0, m->stream, lp, nl, m->red_sq, n_sq, inv_batch, reg_scale, loss_dst, flag,
+                               publish ? ++m->loss_seq : 0u, (const float*)nullptr);
+            m->w_early_pending = true;
+        } else
         if (tail_splits > 0) {
             if (m->dw_side_first && !tail_side) SERT_HIP(hipStreamWaitEvent(m->stream, m->ev_dense, 0));   // (dW / db slabs: side stream)
             TailArgs ta;
@@ -2615,6 +2646,7 @@ static int step_forward_backward(sert_model* m, const DataSplit& ds, int64_t bat
     // starts on gather + projection while the host is still enqueueing
     if (is_vs(m) && !is_fs(m)) {
         if (m->w_pending) { SERT_TRY(settle_entity_update(m)); m->w_pending = false; }   // (W, b updated on the side stream)
+        if (m->w_early_pending) { SERT_HIP(hipStreamWaitEvent(m->stream, m->ev_dense, 0)); m->w_early_pending = false; }
         if (m->projected_batch != batch_index) SERT_TRY(vs_project(m, ds, batch_index));
         m->projected_batch = -1;
     }

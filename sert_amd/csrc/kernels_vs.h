@@ -73,6 +73,18 @@ __device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uin
         k1 += 0xBB67AE85u;
     }
 }
+// The (pair, entity) keys of a batch as the loss kernel writes them -- cand[i, j] = j ? neg[i, j - 1] : y[i] -- from the labels and the
+// negatives alone: the stable sort of the entity-gradient chain (V_e > 2048) can then run BEFORE the loss kernel, beside the forward
+// (round 6; sert_hip.hip: vs_backward, early_sort).
+__global__ __launch_bounds__(256) void vs_build_cand(const int32_t* __restrict__ y, const int32_t* __restrict__ neg, int B, int z,
+                                                     int32_t* __restrict__ cand) {
+    const int c1 = z + 1, total = B * c1;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int row = i / c1, j = i - row * c1;
+        cand[i] = j ? neg[(size_t)row * z + (j - 1)] : y[row];
+    }
+}
+
 // zero_f / zero_b (optional): the step's other prologue work rides along -- zero `nzf4`
 // float4 of small gradient buffers and `nzb16` 16-byte words of row flags -- so that a
 // training step needs ONE prologue launch on the main stream instead of two memsets and

@@ -128,6 +128,7 @@ struct sert_model {
     int nstreams = 2;
     int64_t hint_next = -1;        // sert_hint_next_batch
     bool neg_side_ready = false;   // this step's negatives were drawn on the side stream during the previous step
+    bool sort_early = false;       // this step's entity keys were sorted in front of the fork (sert_hip.hip: vs_backward, early_sort)
     bool bucket_early = false;     // this step's egrad_bucket ran in front of the fork (sert_hip.hip: vs_backward)
     // lazy dense update of the word table (kernels_opt.h: dense_update_lazy)
     int32_t* rw_last[2] = {nullptr, nullptr};   // per word row: updates applied to its stored (p, state0, state1)
@@ -187,6 +188,7 @@ struct sert_model {
     int64_t* neg_stage = nullptr; // (B, z) int64 staging for host-supplied negatives
     // entity-gradient machinery (kernels_egrad.h), all (B*(1+z)) long
     int32_t *cand = nullptr, *cand_sorted = nullptr, *pair_sorted = nullptr;
+    int32_t* cand_early = nullptr;   // the same keys built from labels + negatives in front of the loss kernel (early_sort)
     float* coef = nullptr;
     float *ehead = nullptr, *etail = nullptr;  // (chunks, d_e) carries
     // small entity vocabularies: the sort-free path (egrad_lds, kernels_egrad.h)

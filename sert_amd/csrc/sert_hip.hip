@@ -579,12 +579,12 @@ static int dzu_from_dj(sert_model* m, const DataSplit& ds, int64_t batch_index) 
 
 // Stable sort of the (entity id, pair index) keys of this step: cand -> cand_sorted,
 // iota -> pair_sorted (kernels_sort.h), LSD over ceil(bits/11) digits.
-static int entity_key_sort(sert_model* m, int total, hipStream_t st) {
+static int entity_key_sort(sert_model* m, int total, hipStream_t st, const int32_t* keys = nullptr) {
     const int tiles = cdiv(total, kSortTile);
     const int bits = m->sort_bits;
     const int passes = cdiv(bits, kSortMaxBits);
     const int width = cdiv(bits, passes);
-    const int32_t* kin = m->cand;
+    const int32_t* kin = keys ? keys : m->cand;
     const int32_t* vin = nullptr;  // value of element i is i
     for (int p = 0; p < passes; ++p) {
         const int shift = p * width;
@@ -1371,6 +1371,35 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
         }
         return 0;
     };
+    // ... and the same for the SORTED entity chain of a larger entity table (V_e > 2048: the reference's product-search settings, C4):
+    // the stable counting sort of the (entity, pair) keys -- six of the chain's eight launches -- needs the labels and the negatives
+    // only.  With the negatives drawn ahead on this stream it goes out in front of the fork wait and runs beside gather / projection /
+    // loss; behind the fork the chain is the chunked reduce + the fix-up.  (The first histogram pass also clears the per-entity run
+    // bounds: nothing of the previous step reads them any more -- its fix-up precedes this in the stream.)
+    m->sort_early = false;
+    auto early_sort = [&]() -> int {
+        // Measured (tools/experiments/r06_early_sort.sh, r06_early_sort_sizes.sh; two to three rounds each on one box; ms/step beside the
+        // forward / inside the chain): the reference's product-search settings (batch 4096, V_e 32768, d_w 300) 0.1669-0.1689 / 0.1696-0.1727,
+        // the same at batch 1024 0.1434-0.1443 / 0.1513-0.1527; d = 128, V_e 32768: batch 16384 0.1514-0.1529 / 0.1717-0.1727 (-12 %), 32768
+        // 0.2034-0.2049 / 0.2255-0.2279, 65536 0.3227-0.3253 / 0.3434-0.3457; V_e 100000: batch 65536 at d = 128 0.4099-0.4140 / 0.4319-0.4355,
+        // d = 300: batch 16384 0.705-0.714 / 0.709-0.717, 32768 0.865-0.920 / 0.906-0.954 -- but C4 itself (batch 65536, d = 300) 1.404-1.411 /
+        // 1.360-1.364: there the chunked reduce (865 MB of row fetches) then starts beside the word gradient's tree (680 MB of them) instead of
+        // beside the update, and the tree takes 389 us instead of 125.  Taken while dh, the tree's source, is below 64 MB.
+        // SERT_EARLY_SORT=1 (variants build) forces it, SERT_NO_EARLY_SORT=1 switches it off.
+        static const bool off = variant_knob("SERT_NO_EARLY_SORT") != nullptr;
+        static const bool force = variant_knob("SERT_EARLY_SORT") && atoi(variant_knob("SERT_EARLY_SORT")) != 0;
+        if (!force && (size_t)B * dw * sizeof(float) >= ((size_t)64 << 20)) return 0;
+        if (off || m->epart || !m->cand_early || is_dp(m) || m->timing.enabled || m->nstreams < 2 || c.kind != SERT_KIND_VECTORSPACE ||
+            c.num_negatives <= 0 || !m->neg_side_ready || !ds.y || c.num_entities <= 0)
+            return 0;
+        const int total = B * (c.num_negatives + 1);
+        ScopedTimer t(m, TG_SORT, m->stream2);
+        hipLaunchKernelGGL(vs_build_cand, dim3(grid_for(total)), dim3(256), 0, m->stream2, (const int32_t*)ds.y + row0, (const int32_t*)m->neg, B,
+                           c.num_negatives, m->cand_early);
+        SERT_TRY(entity_key_sort(m, total, m->stream2, m->cand_early));
+        m->sort_early = true;
+        return 0;
+    };
     auto entity_grad = [&]() -> int {
         // fork: this chain only depends on the NCE kernel and is independent of the
         // GEMMs / word-table reduction below, so it runs on the side stream
@@ -1425,7 +1454,7 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
 #endif
         } else {
         // dR_e: stable sort of the (entity, pair) keys, chunked reduce, carry fix-up
-        {
+        if (!m->sort_early) {       // (else: the keys were sorted beside the forward, see early_sort below)
             ScopedTimer t(m, TG_SORT, st);
             SERT_TRY(entity_key_sort(m, total, st));
         }
@@ -1658,6 +1687,7 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
     // dW on the main stream / first on the side stream: batch 65536 0.2375-0.2390 / 0.2244-0.2261 (-5.4 %; with the partition behind the
     // fork, as in round 5: 0.2381-0.2404 / 0.2346-0.2360), 131072 0.4190-0.4222 / 0.4040-0.4142.
     SERT_TRY(early_bucket());
+    SERT_TRY(early_sort());
     m->dw_side_first = fork_nce_dw ||
                        (!dw_first_off && fork_late && !fork_nce && !side_heavy && m->lazy_join && !fused_bwd && !dw_third_queue(m) &&
                         !m->pt_big[2] && c.kind == SERT_KIND_VECTORSPACE &&
@@ -3078,6 +3108,7 @@ static int create_resources(sert_model* m) {
                 }
             }
             SERT_TRY(dzalloc(&m->cand, total, s));        SERT_TRY(dzalloc(&m->cand_sorted, total + 1, s));
+            SERT_TRY(dzalloc(&m->cand_early, total, s));
             SERT_TRY(dzalloc(&m->pair_sorted, total, s));
             SERT_TRY(dzalloc(&m->coef, total, s));
             const size_t chunks = (total + kEChunk - 1) / kEChunk;
@@ -3186,7 +3217,7 @@ int sert_destroy(sert_model* m) {
     (void)hipFree(m->Zu); (void)hipFree(m->dZu); (void)hipFree(m->zpart);
     (void)hipFree(m->neg); (void)hipFree(m->neg_alt); (void)hipFree(m->neg_stage);
     (void)hipFree(m->pred_a); (void)hipFree(m->pred_b); (void)hipFree(m->pred_ids);
-    (void)hipFree(m->cand); (void)hipFree(m->cand_sorted); 
+    (void)hipFree(m->cand); (void)hipFree(m->cand_sorted); (void)hipFree(m->cand_early);
     (void)hipFree(m->pair_sorted); (void)hipFree(m->coef); (void)hipFree(m->ehead);
     (void)hipFree(m->etail); (void)hipFree(m->epart); (void)hipFree(m->eg_entries); (void)hipFree(m->eg_offs); (void)hipFree(m->sort_hist); (void)hipFree(m->sort_bin_total);
     (void)hipFree(m->sort_k_tmp); (void)hipFree(m->sort_v_tmp);

@@ -1142,7 +1142,7 @@ def test_schedule_variants_do_not_change_a_bit(hip_lib):
         variants += ({'SERT_FORK_LATE': '0'}, {'SERT_EXT_EVENTS': '0'}, {'SERT_EGRAD_GROUP_SUM': '1'}, {'SERT_FORK_AT': 'nce'}, {'SERT_FORK_AT': 'nce_dw'},
                      {'SERT_DW_FIRST': '0'},      # (dW / db on the main stream instead of first on the side stream)
                      {'SERT_SEG_NO_FUSED_UPPER': '1'}, {'SERT_NO_TAIL': '1'},
-                     {'SERT_NO_EARLY_BUCKET': '1'})    # (round 6: the entity keys' partition behind the fork again instead of beside the forward)
+                     {'SERT_NO_EARLY_BUCKET': '1'}, {'SERT_NO_EARLY_SORT': '1'})    # (round 6: the entity keys' partition behind the fork again instead of beside the forward)
     outs = []
     for extra in variants:
         r = subprocess.run([sys.executable, '-c', code], check=True, env=dict(os.environ, **extra),

@@ -1688,6 +1688,7 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
     // fork, as in round 5: 0.2381-0.2404 / 0.2346-0.2360), 131072 0.4190-0.4222 / 0.4040-0.4142.
     SERT_TRY(early_bucket());
     SERT_TRY(early_sort());
+    static const bool chain_behind_tree = variant_knob("SERT_CHAIN_BEHIND_TREE") != nullptr;
     m->dw_side_first = fork_nce_dw ||
                        (!dw_first_off && fork_late && !fork_nce && !side_heavy && m->lazy_join && !fused_bwd && !dw_third_queue(m) &&
                         !m->pt_big[2] && c.kind == SERT_KIND_VECTORSPACE &&
@@ -1698,7 +1699,15 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
     const bool dp_late = dp_late_mode != 0 && is_dp(m) && !m->host_ar && m->comm && !m->timing.enabled && m->nstreams == 2 && !side_heavy && !fork_nce &&
                          !fork_late;
     m->dp_late_join = dp_late;
-    if (side_heavy) {
+    if (side_heavy && chain_behind_tree && m->sort_early) {
+        // (experiment, round 6 item 13: with the key sort beside the forward, the rest of the sorted entity chain -- chunked reduce, fix-up, then
+        //  dW -- forked behind the word gradient's TREE instead of behind the loss kernel: beside the update, not beside the tree)
+        SERT_TRY(dh_gemm());
+        SERT_TRY(word_table_sum());
+        m->fork_bound = false;         // (not the loss kernel's completion signal: a record behind the tree)
+        SERT_TRY(entity_grad());       // (records its fork on the main stream HERE: behind the tree)
+        SERT_TRY(dense_grad());
+    } else if (side_heavy) {
         SERT_TRY(entity_grad());       // side, forked on the loss kernel's completion
         SERT_TRY(dh_gemm());           // main (its completion is ev_dense)
         SERT_TRY(word_table_sum());    // main

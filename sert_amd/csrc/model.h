@@ -239,6 +239,7 @@ struct sert_model {
     // single-GPU vectorspace step: split-K combine + W, b update + loss finalisation as one launch
     // (kernels_opt.h: vs_tail).  tail_splits > 0: this step's dW / db still sit in `part` as that
     // many partial slabs, tail_stride elements apart
+    const float* tail_part = nullptr;   // where the tail finds dW | db: the split-K slabs, or their sums (combined on the side stream)
     unsigned long long* tail_blk = nullptr;
     unsigned tail_launch_seq = 0;
     int tail_splits = 0;

@@ -1623,6 +1623,21 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
             mn + de < ((size_t)1 << 31)) {
             m->tail_splits = splits;
             m->tail_stride = stride;
+            m->tail_part = m->part;
+            // Experiment (round 6 item 14, variants build: SERT_COMBINE_SIDE=1): with dW / db first on the SIDE stream their split-K combine
+            // there too, right behind the GEMM (the tail's own summation order: reduce_partials_g<16>), so that the tail reads 66 kB of sums
+            // instead of the slabs.  Bit-identical and SLOWER at every batch size (C2 0.2294-0.2304 against 0.2226-0.2229 ms): the tail is a
+            // latency-bound launch whatever it reads, and the combine lengthens the side chain.
+            static const bool combine_side_off = !(variant_knob("SERT_COMBINE_SIDE") && atoi(variant_knob("SERT_COMBINE_SIDE")) == 1);
+            if (!combine_side_off && m->dw_side_first && sd == m->stream2 && splits > 1 && !c.keep_grads) {
+                ScopedTimer t(m, TG_SPLITK, sd);
+                const size_t count = stride;
+                hipLaunchKernelGGL((reduce_partials_g<16>), dim3((unsigned)((count + 63) / 64)), dim3(1024), 0, sd, (const float*)m->part, splits, stride,
+                                   count, m->g_w, mn, m->g_b, (const int32_t*)nullptr, 0);
+                m->tail_splits = 1;
+                m->tail_part = m->g_w;         // (g_w | g_b are adjacent in the flat gradient buffer: one "slab" of mn + de sums)
+                if (m->g_b != m->g_w + mn) SERT_FAIL("internal: g_W and g_b are not adjacent");
+            }
         } else {
             ScopedTimer t(m, TG_SPLITK);
             launch_reduce_partials(sd, m->part,
@@ -1638,7 +1653,7 @@ static int vs_backward(sert_model* m, const DataSplit& ds, int64_t batch_index) 
             AdamArgs aa2; AdadeltaArgs da2;
             optimizer_args(m, m->step + 1, &aa2, &da2);
             TailArgs ta;
-            ta.part = m->part; ta.splits = m->tail_splits; ta.stride = m->tail_stride;
+            ta.part = m->tail_part ? m->tail_part : m->part; ta.splits = m->tail_splits; ta.stride = m->tail_stride;
             ta.W = m->W; ta.b = m->b; ta.s0_w = m->s0_w; ta.s1_w = m->s1_w; ta.s0_b = m->s0_b; ta.s1_b = m->s1_b;
             ta.g_w = m->g_w; ta.g_b = m->g_b;
             ta.n_w = (unsigned)m->n_w; ta.n_b = (unsigned)m->n_b;
@@ -2560,7 +2575,7 @@ static int optimizer_and_loss(sert_model* m, float* loss_dst, bool publish = fal
         if (tail_splits > 0) {
             if (m->dw_side_first && !tail_side) SERT_HIP(hipStreamWaitEvent(m->stream, m->ev_dense, 0));   // (dW / db slabs: side stream)
             TailArgs ta;
-            ta.part = m->part; ta.splits = tail_splits; ta.stride = m->tail_stride;
+            ta.part = m->tail_part ? m->tail_part : m->part; ta.splits = tail_splits; ta.stride = m->tail_stride;
             ta.W = m->W; ta.b = m->b; ta.s0_w = m->s0_w; ta.s1_w = m->s1_w; ta.s0_b = m->s0_b; ta.s1_b = m->s1_b;
             ta.g_w = m->g_w; ta.g_b = m->g_b;
             ta.n_w = (unsigned)m->n_w; ta.n_b = (unsigned)m->n_b;

@@ -1003,7 +1003,7 @@ def measure_record(kind, models, _capi, dist, dims, steps, warmup, seed, live_pm
     ceil = ceilings_for(_capi, work, device=m._engine.cfg.device)
     _, tm, _ = timed_steps(m, dist, num_batches, steps, 1, timing=True)
     dt, _, loss = timed_steps(m, dist, num_batches, steps, warmup, timing=False)
-    us_in, launches_in = instep_pass(m, num_batches, steps)
+    us_in, launches_in = instep_pass(m, num_batches, max(steps, 40))
     del m
     per_kernel, source, tbg = None, None, {}
     if live_pmc:
@@ -1273,7 +1273,9 @@ def main():
     dt, _, last_loss = timed_steps(model, dist, args.num_batches, args.steps, args.warmup, timing=False)
     value = args.steps * Bg / dt
     # (behind the number: the same K steps once more with every kernel's own dispatch timed IN the step)
-    us_instep, launches_instep = instep_pass(model, args.num_batches, args.steps) if N == 1 else ({}, {})
+    # (its own step count: a 20-step run holds five or six passes of the lazy update that read everything among its launches, a 100-step one
+    #  a quarter -- the in-step average is taken over at least 100 steps whatever K is)
+    us_instep, launches_instep = instep_pass(model, args.num_batches, max(args.steps, 100)) if N == 1 else ({}, {})
 
     # pass 3 (extra, not the headline): the same steps with the loss read-back deferred
     # (sert_train_batches: 25 batches per host synchronisation) -- what the per-step

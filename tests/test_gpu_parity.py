@@ -327,8 +327,8 @@ def test_fused_projection_equals_the_two_launches(hip_lib, monkeypatch, dims):
     dict(B=9000, n=2, z=0, Vw=50, Ve=3000, dw=8, de=8, skew=True),  # z = 0, 9000 pairs in one range: beyond the list, the slow walk
 ])
 def test_entity_gradient_of_few_pairs_over_a_mid_size_table(hip_lib, monkeypatch, dims):
-    """kernels_egrad.h: egrad_ranges -- few (pair, entity) keys over a table above the LDS path's 2048 entities (the reference's
-    product-search regime): one launch, one workgroup per range of 128 entities (scan, LDS list, bitonic sort, one chain per
+    """csrc/variants/kernels_egrad_ranges.h: egrad_ranges -- few (pair, entity) keys over a table above the LDS path's 2048 entities (the reference's
+    product-search regime): one launch, one workgroup per range of 32 entities (scan, LDS list, bitonic sort, one chain per
     entity in pair order) instead of counting sort + chunked reduce + fix-up.  Row by row against the float64 oracle,
     bit-identical run to run, equal to the sorted path (the default: the range kernel is an opt-in, SERT_EGRAD_RANGES=1 --
     twice as fast alone, no faster as a step) up to fp32 reassociation; a range with more pairs than its list holds takes the

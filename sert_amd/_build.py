@@ -18,6 +18,9 @@ def _stale():
     vdir = os.path.join(CSRC, 'variants')                                             # (... and of csrc/variants/)
     if os.path.isdir(vdir):
         deps += [os.path.join(vdir, f) for f in os.listdir(vdir) if f.endswith('.h')]
+    hdir = os.path.join(CSRC, 'host')                                                 # (... and the host-side parts of sert_hip.hip)
+    if os.path.isdir(hdir):
+        deps += [os.path.join(hdir, f) for f in os.listdir(hdir) if f.endswith('.inc')]
     deps.append(os.path.join(INCLUDE, 'sert_hip.h'))
     deps.append(os.path.join(INCLUDE, 'sert_hip_debug.h'))
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))

@@ -116,6 +116,10 @@ struct sert_model {
     hipEvent_t ev_re = nullptr;
     bool re_pending = false;
     bool tail_early = false, w_early_pending = false;   // (knock-out SERT_KO_TAIL_EARLY: see sert_hip.hip)
+    hipStream_t tail_stream = nullptr;   // the step's tail on a queue of its own (optimizer_and_loss: tail_queue)
+    hipEvent_t ev_tail_go = nullptr, ev_tail_done = nullptr;
+    bool tail_pending = false;
+    int tail_queue_min_batch = 0;
     bool w_pending = false;          // W, b were updated on the side stream too (same event): the next projection waits
     float* re_sq = nullptr;          // [2][2 * kOptBlocks]
     int64_t re_sq_for[2] = {-1, -1};

@@ -247,8 +247,10 @@ static void discard_run_ahead(sert_model* m) {
 }
 static int ensure_rw_current(sert_model* m, int64_t batch, int64_t t_applied = -1);
 static bool egrad_writes_every_row(const sert_model* m);
+static int settle_tail(sert_model* m);
 static void invalidate_speculation(sert_model* m) {
     discard_run_ahead(m);
+    (void)settle_tail(m);
     (void)ensure_rw_current(m, -1);   // (whatever comes next -- new parameters, another step counter, new data -- sees every row current)
     if (m->re_pending) {       // (a deferred entity-table update: see settle_entity_update)
         (void)hipStreamWaitEvent(m->stream, m->ev_re, 0);
